@@ -1,0 +1,185 @@
+"""The oracle (oracle/hsimae_oracle.py) against fixtures recorded from the reference."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hsimae_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_pos_embed_tables():
+    z = np.load(os.path.join(G, "pos_embed.npz"))
+    for k in z.files:
+        D, T = (int(s[1:]) for s in k.split("_"))
+        np.testing.assert_allclose(O.sincos_pos_embed_3d(D, T, 3), z[k], rtol=0, atol=1e-6)
+
+
+def test_masking_bit_exact_and_candidates():
+    z = np.load(os.path.join(G, "masking.npz"))
+    meta = json.load(open(os.path.join(G, "masking.json")))
+    for c in meta["cases"]:
+        k = c["key"]
+        cands = O.grid_candidates(c["T"], c["L"], c["ratio"])
+        assert [list(x) for x in cands] == c["candidates"]
+        random.seed(c["seed"])
+        assert list(O.choose_grid(c["T"], c["L"], c["ratio"], random)) == [c["len_t"], c["len_l"]]
+        keep, restore, mask = O.mask_from_noise(z[k + "_n1"], z[k + "_n2"], c["len_t"], c["len_l"])
+        assert np.array_equal(keep, z[k + "_keep"].astype(np.int64))
+        assert np.array_equal(restore, z[k + "_restore"].astype(np.int64))
+        assert np.array_equal(mask, z[k + "_mask"].astype(np.float32))
+        k2, r2, m2 = O.mask_from_noise_literal(torch.from_numpy(z[k + "_n1"]), torch.from_numpy(z[k + "_n2"]),
+                                               c["len_t"], c["len_l"])
+        assert np.array_equal(k2, keep) and np.array_equal(r2, restore) and np.array_equal(m2, mask)
+
+
+def test_python_random_draw_sequence():
+    meta = json.load(open(os.path.join(G, "masking.json")))
+    for seed, seq in meta["draws"].items():
+        random.seed(int(seed))
+        got = [list(O.choose_grid(12, 9, 0.75, random)) for _ in range(len(seq))]
+        assert got == seq
+
+
+def test_mask_ties_lower_index_wins():
+    n1 = np.array([[0.5, 0.5, 0.1, 0.5]], dtype=np.float32)
+    n2 = np.array([[0.3] * 9], dtype=np.float32)
+    keep, restore, mask = O.mask_from_noise(n1, n2, 2, 3)
+    assert keep.tolist() == [[0, 1, 2, 18, 19, 20]]
+    assert mask.sum() == 36 - 6
+    assert sorted(restore[0].tolist()) == list(range(36))
+
+
+@pytest.mark.parametrize("tag", ["r50", "r75"])
+def test_tiny_model_all_stages_and_grads(tag):
+    z = np.load(os.path.join(G, f"tiny_model_{tag}.npz"))
+    cfg = O.OracleConfig(bands=32, embed_dim=32, depth=3, num_heads=2, s_depth=2, decoder_embed_dim=16,
+                         decoder_depth=1, decoder_num_heads=2)
+    P = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_")}
+    x = torch.from_numpy(z["x"])
+    lt, ll = (int(v) for v in z["len_tl"])
+    taps = {}
+    loss, pred, mask, grads = O.forward_backward(P, cfg, x, z["noise_1"], z["noise_2"], lt, ll, taps)
+    assert abs(loss.item() - float(z["loss"])) <= 1e-6 * abs(float(z["loss"]))
+    assert np.array_equal(taps["ids_keep"].numpy(), z["tap_ids_keep"].astype(np.int64))
+    assert np.array_equal(taps["ids_restore"].numpy(), z["tap_ids_restore"].astype(np.int64))
+    assert np.array_equal(taps["mask"].numpy(), z["tap_mask"])
+    N, K, D = x.shape[0], lt * ll, 32
+
+    def close(a, b, tol=1e-5):
+        a = a.detach().numpy() if isinstance(a, torch.Tensor) else a
+        denom = max(1e-6, float(np.abs(b).max()))
+        assert float(np.abs(a - b).max()) / denom <= tol
+
+    close(taps["patch_embed"].reshape(N, cfg.T, cfg.L, D), z["tap_patch_embed"])
+    close(taps["enc_in"].reshape(N * lt, ll, D), z["tap_enc_in_seq"])
+    close(taps["x1"].reshape(N * lt, ll, D), z["tap_x1_seq"])
+    close(taps["x2"].reshape(N, lt, ll, D).permute(0, 2, 1, 3).reshape(N * ll, lt, D), z["tap_x2_seq"])
+    for k in ("fused", "latent", "dec_in", "dec_out", "pred"):
+        close(taps[k], z["tap_" + k])
+    close(pred, z["pred_img"])
+    assert np.array_equal(mask.numpy().astype(np.uint8), z["mask_img"])
+    gnames = [k[5:] for k in z.files if k.startswith("grad_")]
+    assert sorted(gnames) == sorted(grads.keys())
+    assert set(z["no_grad_names"].tolist()) == {"pos_embed", "mask_token", "decoder_pos_embed"}
+    for k in gnames:
+        close(grads[k], z["grad_" + k], 2e-5)
+
+
+def test_strided_band_fastest_input_is_value_equivalent():
+    z = np.load(os.path.join(G, "tiny_model_r50.npz"))
+    cfg = O.OracleConfig(bands=32, embed_dim=32, depth=3, num_heads=2, s_depth=2, decoder_embed_dim=16,
+                         decoder_depth=1, decoder_num_heads=2)
+    x = torch.from_numpy(z["x"])
+    xs = x[:, 0].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2).unsqueeze(1)
+    assert not xs.is_contiguous()
+    assert torch.equal(O.patchify(xs, cfg), O.patchify(x, cfg))
+
+
+def _rebuild_perturbed_state(names_shapes, cfg, seed, std=0.2):
+    """Same generator walk as tests/golden/make_golden.py::perturb (values only, no reference code)."""
+    g = torch.Generator().manual_seed(seed)
+    P = {}
+    for n, shape in names_shapes:
+        if n == "pos_embed":
+            P[n] = torch.from_numpy(O.sincos_pos_embed_3d(cfg.embed_dim, cfg.T, cfg.grid)).unsqueeze(0)
+        elif n == "decoder_pos_embed":
+            P[n] = torch.from_numpy(O.sincos_pos_embed_3d(cfg.decoder_embed_dim, cfg.T, cfg.grid)).unsqueeze(0)
+        elif n == "mask_token":
+            P[n] = torch.zeros(shape)
+        elif "norm" in n and n.endswith("weight"):
+            P[n] = 1 + 0.1 * torch.randn(shape, generator=g)
+        elif n.endswith("bias"):
+            P[n] = 0.1 * torch.randn(shape, generator=g)
+        elif n == "patch_embed.proj.weight":
+            P[n] = 0.5 * torch.randn(shape, generator=g)
+        else:
+            P[n] = std * torch.randn(shape, generator=g) / (shape[1] ** 0.5) * 4
+    return P
+
+
+def test_c1_summary_base48_loss_stats_gradnorms():
+    s = json.load(open(os.path.join(G, "c1_summary.json")))
+    z = np.load(os.path.join(G, "c1_summary.npz"))
+    man = json.load(open(os.path.join(G, "manifest.json")))
+    cfg = O.OracleConfig(bands=48)
+    assert s["candidates"] == [[2, 7]] and (s["len_t"], s["len_l"]) == (2, 7)
+    keep, _, mask = O.mask_from_noise(z["noise_1"], z["noise_2"], 2, 7)
+    assert np.array_equal(keep, z["ids_keep"].astype(np.int64))
+    assert mask.sum() * cfg.patch_dim == s["mask_img_sum"]
+    assert abs(s["loss_fp32"] - s["loss_fp64"]) / s["loss_fp64"] < 1e-6
+    assert len(s["grad_l2"]) == 532
+    names_shapes = [(k, tuple(sh)) for k, sh, _ in man["C1_base48"]]
+    order = {k: i for i, k in enumerate(man["named_parameters_C2"])}
+    names_shapes.sort(key=lambda ks: order[ks[0]])            # perturb walks named_parameters() order
+    P = _rebuild_perturbed_state(names_shapes, cfg, s["perturb_seed"])
+    torch.manual_seed(s["x_seed"])
+    x = torch.rand(s["N"], 1, 48, 9, 9)
+    taps = {}
+    loss, pred, mimg, grads = O.forward_backward(P, cfg, x, z["noise_1"], z["noise_2"], 2, 7, taps)
+    assert abs(loss.item() - s["loss_fp32"]) <= 2e-6 * s["loss_fp32"]
+    np.testing.assert_allclose(taps["latent"][:4].detach().numpy(), z["latent"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(taps["pred"][:2].detach().numpy(), z["pred"], rtol=0, atol=2e-5)
+    for k in ("fused", "latent", "dec_in", "dec_out", "pred"):
+        got = taps[k].detach().double()
+        ref = s["taps"][k]
+        assert abs(float(got.pow(2).sum().sqrt()) - ref[2]) <= 1e-5 * ref[2]
+        assert abs(float(got.abs().sum()) - ref[1]) <= 1e-5 * ref[1]
+    for k, ref in s["grad_l2"].items():
+        assert abs(float(grads[k].double().norm()) - ref) <= 1e-4 * max(ref, 1e-6), k
+    # fp64 oracle against the reference's fp64 loss
+    P64 = {k: v.double() for k, v in P.items()}
+    l64, _, _ = O.forward(P64, cfg, x.double(), z["noise_1"], z["noise_2"], 2, 7)
+    assert abs(l64.item() - s["loss_fp64"]) <= 1e-10 * s["loss_fp64"]
+
+
+def test_flop_model_matches_survey():
+    vals = {(48, 128, 2, 7): 0.5014, (96, 128, 3, 9): 1.0163, (96, 256, 3, 9): 3.0360}
+    for (b, d, t, l), g in vals.items():
+        cfg = O.OracleConfig(bands=b, embed_dim=d, num_heads=d // 16)
+        assert abs(O.flops_per_sample(cfg, t, l) / 1e9 - g) < 5e-4
+
+
+def test_trajectory_10_adamw_steps():
+    z = np.load(os.path.join(G, "trajectory.npz"))
+    meta = json.load(open(os.path.join(G, "trajectory.json")))
+    cfg = O.OracleConfig(**meta["cfg"])
+    P = {k[3:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith("sd_")}
+    x = torch.from_numpy(z["x"])
+    nd = ["bias", "norm"]
+    names = list(P.keys())
+    params = {k: torch.nn.Parameter(P[k]) for k in names}
+    for k in ("pos_embed", "decoder_pos_embed"):
+        params[k].requires_grad_(False)
+    groups = [{"params": [params[n] for n in names if not any(k in n for k in nd)], "weight_decay": meta["wd"]},
+              {"params": [params[n] for n in names if any(k in n for k in nd)], "weight_decay": 0.0}]
+    opt = torch.optim.AdamW(groups, lr=meta["lr"], weight_decay=meta["wd"], betas=tuple(meta["betas"]))
+    for i, ref in enumerate(meta["losses"]):
+        lt, ll = meta["grids"][i]
+        loss, _, _ = O.forward(params, cfg, x, z[f"n1_{i}"], z[f"n2_{i}"], lt, ll)
+        opt.zero_grad(); loss.backward(); opt.step()
+        assert abs(loss.item() - ref) <= 1e-5 * abs(ref), (i, loss.item(), ref)
