@@ -1,0 +1,8 @@
+"""hsimae_amd — MI355X-native (gfx950) HSIMAE masked-autoencoder pretraining path.
+
+`HSIMAE` mirrors the reference `Models.HSIMAE` module surface; the arithmetic lives in
+`libhsimae_hip.so` (hand-written HIP kernels, C ABI in include/hsimae_hip.h).
+"""
+from .model import HSIMAE, swiglu_hidden, sincos_table  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,147 @@
+"""ctypes binding of libhsimae_hip.so (include/hsimae_hip.h).
+
+The shared library is the product's only compute path: if it is missing this module raises at
+import of the symbol table, and every wrapper raises RuntimeError on a non-zero return code.
+There is no CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhsimae_hip.so")
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class Config(C.Structure):
+    _fields_ = [("bands", i32), ("embed_dim", i32), ("depth", i32), ("s_depth", i32), ("num_heads", i32),
+                ("dec_dim", i32), ("dec_depth", i32), ("dec_heads", i32), ("hidden", i32), ("dec_hidden", i32),
+                ("norm_pix_loss", i32)]
+
+
+class IO(C.Structure):
+    _fields_ = [("x", vp), ("sn", i64), ("sb", i64), ("sh", i64), ("sw", i64),
+                ("N", i32), ("len_t", i32), ("len_l", i32),
+                ("noise1", vp), ("noise2", vp), ("params", vp), ("wpk", vp),
+                ("workspace", vp), ("workspace_bytes", i64),
+                ("grad_scale", f32), ("want_recons", i32),
+                ("loss", vp), ("pred_img", vp), ("mask_img", vp), ("mask", vp),
+                ("ids_keep", vp), ("ids_restore", vp), ("latent", vp), ("pred", vp)]
+
+
+class MaskParams(C.Structure):
+    _fields_ = [("noise1", vp), ("noise2", vp), ("N", i32), ("T", i32), ("L", i32), ("len_t", i32), ("len_l", i32),
+                ("ids_keep", vp), ("ids_restore", vp), ("mask", vp)]
+
+
+class PatchParams(C.Structure):
+    _fields_ = [("x", vp), ("sn", i64), ("sb", i64), ("sh", i64), ("sw", i64), ("N", i32), ("T", i32), ("K", i32),
+                ("ids_keep", vp), ("out", vp), ("pos_ids", vp)]
+
+
+class GemmParams(C.Structure):
+    _fields_ = [("A", vp), ("lda", i32), ("M", i32), ("N", i32), ("K", i32), ("n_valid", i32),
+                ("W", vp), ("W2", vp), ("bias", vp), ("bias2", vp), ("gamma", vp), ("beta", vp),
+                ("stats", vp), ("u_out", vp), ("ldu", i32), ("out", vp), ("ldo", i32),
+                ("res", vp), ("res2", vp), ("ldr", i32), ("pos", vp), ("ids", vp), ("ldpos", i32),
+                ("h13", vp), ("ldh", i32), ("hoff", i32)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("src", vp), ("rows", i32), ("cols", i32), ("transpose", i32), ("n_off", i32), ("k_off", i32),
+                ("KS", i32), ("dst", vp)]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [("qkv", vp), ("ld", i32), ("d", i32), ("heads", i32), ("hd", i32), ("Ts", i32), ("nsamples", i32),
+                ("mode", i32), ("len_l", i32), ("o", vp), ("ldo", i32), ("lse", vp), ("dout", vp), ("lddo", i32),
+                ("dqkv", vp)]
+
+
+class WgradTask(C.Structure):
+    _fields_ = [("dO", vp), ("dO_f32", i32), ("ldo", i32), ("A", vp), ("lda", i32), ("N", i32), ("K", i32),
+                ("dW", vp), ("ldw", i32), ("db", vp)]
+
+
+class WgradParams(C.Structure):
+    _fields_ = [("t", WgradTask * 8), ("ntasks", i32), ("M", i32), ("msplit", i32)]
+
+
+class LnBwdParams(C.Structure):
+    _fields_ = [("du", vp), ("x", vp), ("stats", vp), ("gamma", vp), ("dres", vp), ("dx", vp), ("accumulate", i32),
+                ("dgamma", vp), ("dbeta", vp), ("M", i32), ("d", i32)]
+
+
+class AssembleParams(C.Structure):
+    _fields_ = [("y", vp), ("N", i32), ("K", i32), ("TL", i32), ("Dd", i32), ("ids_restore", vp), ("pos", vp),
+                ("yfull", vp), ("dyfull", vp), ("dy", vp)]
+
+
+class LossParams(C.Structure):
+    _fields_ = [("x", vp), ("sn", i64), ("sb", i64), ("sh", i64), ("sw", i64), ("N", i32), ("T", i32),
+                ("pred", vp), ("mask", vp), ("norm_pix", i32), ("inv_scale", f32), ("partial", vp), ("loss", vp),
+                ("sum_mask", f32), ("dpred", vp), ("pred_img", vp), ("mask_img", vp)]
+
+
+BUCKET_CB = C.CFUNCTYPE(None, i32, i64, i64, vp)
+
+# name -> (restype, argtypes); also the list the CPU test checks against include/hsimae_hip.h
+SYMBOLS = {
+    "hsimae_version": (C.c_int, []),
+    "hsimae_strerror": (C.c_char_p, [C.c_int]),
+    "hsimae_param_layout": (C.c_int, [C.POINTER(Config), C.POINTER(i64), C.POINTER(i64), C.c_int]),
+    "hsimae_wpk_elems": (i64, [C.POINTER(Config)]),
+    "hsimae_pack_table_bytes": (i64, [C.POINTER(Config)]),
+    "hsimae_build_pack_table": (C.c_int, [C.POINTER(Config), vp, vp, vp]),
+    "hsimae_pack_params": (C.c_int, [C.POINTER(Config), vp, vp]),
+    "hsimae_workspace_bytes": (i64, [C.POINTER(Config), i32, i32, i32]),
+    "hsimae_forward": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp]),
+    "hsimae_backward": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp, BUCKET_CB, vp, vp]),
+    "hsimae_mask_from_noise": (C.c_int, [C.POINTER(MaskParams), vp]),
+    "hsimae_patch_gather": (C.c_int, [C.POINTER(PatchParams), vp]),
+    "hsimae_gemm": (C.c_int, [C.POINTER(GemmParams), i32, i32, vp]),
+    "hsimae_pack_matrix": (C.c_int, [vp, i32, i32, vp]),
+    "hsimae_attn_fwd": (C.c_int, [C.POINTER(AttnParams), vp]),
+    "hsimae_attn_bwd": (C.c_int, [C.POINTER(AttnParams), vp]),
+    "hsimae_wgrad": (C.c_int, [C.POINTER(WgradParams), vp]),
+    "hsimae_ln_bwd": (C.c_int, [C.POINTER(LnBwdParams), vp]),
+    "hsimae_ln_fwd": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
+    "hsimae_assemble_fwd": (C.c_int, [C.POINTER(AssembleParams), vp]),
+    "hsimae_assemble_bwd": (C.c_int, [C.POINTER(AssembleParams), vp]),
+    "hsimae_loss_partials": (C.c_int, [i32, i32]),
+    "hsimae_loss": (C.c_int, [C.POINTER(LossParams), vp]),
+}
+
+A_BF16, A_F32, A_F32_LN = 0, 1, 2
+E_BF16, E_F32, E_RES_F32, E_POS_F32, E_SWIGLU, E_SWIGLU_BWD = 0, 1, 2, 3, 4, 5
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the in-tree shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m hsimae_amd.build` (hipcc --offload-arch=gfx950). "
+                "hsimae_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(code: int, what: str = "hsimae") -> None:
+    if code != 0:
+        msg = load().hsimae_strerror(code)
+        raise RuntimeError(f"{what} failed with code {code}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

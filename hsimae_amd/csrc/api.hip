@@ -1,0 +1,569 @@
+// C ABI of libhsimae_hip.so (include/hsimae_hip.h): geometry/layout helpers, per-kernel entry points and
+// the whole-pass forward / backward schedules of the HSIMAE pretraining path.
+#include "common.h"
+#include "kernels.h"
+#include <vector>
+#include <algorithm>
+#include <cstring>
+
+namespace {
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------ parameter layout (flat fp32, registration order)
+struct BlkOff { int64_t n1w, n1b, qw, qb, kw, kb, vw, vb, pw, pb, n2w, n2b, w1w, w1b, w2w, w2b, w3w, w3b, end; };
+
+struct Geo {
+    int B, T, TL, D, H, hd, h, hp, Dd, Hd, hdd, hdec, hpd, depth, sdepth, nfus, ddepth, norm_pix;
+    bool has_axis, has_fus;
+};
+
+int make_geo(const hsimae_config* c, Geo& g) {
+    if (!c) return HSIMAE_ENULL;
+    if (c->bands <= 0 || c->bands % 8) return HSIMAE_EDIMS;
+    g.B = c->bands; g.T = c->bands / 8; g.TL = g.T * 9;
+    g.D = c->embed_dim; g.H = c->num_heads; g.Dd = c->dec_dim; g.Hd = c->dec_heads;
+    if (g.D <= 0 || g.Dd <= 0 || g.H <= 0 || g.Hd <= 0 || g.D % g.H || g.Dd % g.Hd) return HSIMAE_EDIMS;
+    g.hd = g.D / g.H; g.hdd = g.Dd / g.Hd;
+    g.h = c->hidden; g.hdec = c->dec_hidden; g.hp = rup(g.h, 32); g.hpd = rup(g.hdec, 32);
+    g.depth = c->depth; g.sdepth = c->s_depth; g.ddepth = c->dec_depth;
+    g.has_axis = g.sdepth > 0;
+    g.has_fus = g.sdepth < 12;                     // Models.py:385 (hard-coded 12)
+    g.nfus = g.has_fus ? std::max(0, g.depth - g.sdepth) : 0;
+    g.norm_pix = c->norm_pix_loss;
+    if (g.D % 32 || g.Dd % 32 || g.D > 512 || g.Dd > 512) return HSIMAE_EUNSUPPORTED;
+    if ((g.hd != 8 && g.hd != 16) || (g.hdd != 8 && g.hdd != 16)) return HSIMAE_EUNSUPPORTED;
+    if (g.h <= 0 || g.hdec <= 0 || g.h % 4 || g.hdec % 4 || g.T > 64 || g.ddepth < 1) return HSIMAE_EUNSUPPORTED;
+    return HSIMAE_OK;
+}
+
+struct PLayout {
+    int64_t pos, mask_token, dpos, pew, peb, nw, nb, dew, deb, dnw, dnb, dpw, dpb, total;
+    std::vector<BlkOff> b1, b2, bf, bd;
+    std::vector<int64_t> offs, sizes;
+};
+
+void make_playout(const Geo& g, PLayout& L) {
+    int64_t cur = 0;
+    auto add = [&](int64_t n) { int64_t o = cur; L.offs.push_back(o); L.sizes.push_back(n); cur += n; return o; };
+    auto blk = [&](int d, int h) {
+        BlkOff b;
+        b.n1w = add(d); b.n1b = add(d);
+        b.qw = add((int64_t)d * d); b.qb = add(d);
+        b.kw = add((int64_t)d * d); b.kb = add(d);
+        b.vw = add((int64_t)d * d); b.vb = add(d);
+        b.pw = add((int64_t)d * d); b.pb = add(d);
+        b.n2w = add(d); b.n2b = add(d);
+        b.w1w = add((int64_t)h * d); b.w1b = add(h);
+        b.w2w = add((int64_t)d * h); b.w2b = add(d);
+        b.w3w = add((int64_t)h * d); b.w3b = add(h);
+        b.end = cur;
+        return b;
+    };
+    L.pos = add((int64_t)g.TL * g.D);
+    L.mask_token = add(g.Dd);
+    L.dpos = add((int64_t)g.TL * g.Dd);
+    L.pew = add((int64_t)g.D * 72);
+    L.peb = add(g.D);
+    if (g.has_axis) {
+        for (int i = 0; i < g.sdepth; ++i) L.b1.push_back(blk(g.D, g.h));
+        for (int i = 0; i < g.sdepth; ++i) L.b2.push_back(blk(g.D, g.h));
+    }
+    for (int i = 0; i < g.nfus; ++i) L.bf.push_back(blk(g.D, g.h));
+    L.nw = add(g.D); L.nb = add(g.D);
+    L.dew = add((int64_t)g.Dd * g.D); L.deb = add(g.Dd);
+    for (int i = 0; i < g.ddepth; ++i) L.bd.push_back(blk(g.Dd, g.hdec));
+    L.dnw = add(g.Dd); L.dnb = add(g.Dd);
+    L.dpw = add((int64_t)72 * g.Dd); L.dpb = add(72);
+    L.total = cur;
+}
+
+// ------------------------------------------------------------------ packed-weight layout (bf16 images + fp32 bias packs)
+struct BlkW { int64_t qkv, p, w1, w3, w2, qkvT, pT, w13T, w2T; int64_t bqkv; };   // element offsets (bf16) / float offsets
+struct WLayout {
+    int64_t pe, de, deT, dp, dpT;
+    std::vector<BlkW> b1, b2, bf, bd;
+    int64_t bf16_elems;      // bf16 region size (elements), multiple of 8
+    int64_t f32_elems;       // fp32 region (bias packs)
+    int64_t total_elems;     // in bf16 units
+};
+
+void make_wlayout(const Geo& g, WLayout& W) {
+    int64_t cur = 0, fcur = 0;
+    auto img = [&](int N, int K) { int64_t o = cur; cur += (int64_t)N * K; return o; };
+    auto blk = [&](int d, int hp) {
+        BlkW b;
+        b.qkv = img(3 * d, d); b.p = img(d, d); b.w1 = img(hp, d); b.w3 = img(hp, d); b.w2 = img(d, hp);
+        b.qkvT = img(d, 3 * d); b.pT = img(d, d); b.w13T = img(d, 2 * hp); b.w2T = img(hp, d);
+        b.bqkv = fcur; fcur += 3 * d;
+        return b;
+    };
+    W.pe = img(g.D, 96);
+    if (g.has_axis) {
+        for (int i = 0; i < g.sdepth; ++i) W.b1.push_back(blk(g.D, g.hp));
+        for (int i = 0; i < g.sdepth; ++i) W.b2.push_back(blk(g.D, g.hp));
+    }
+    for (int i = 0; i < g.nfus; ++i) W.bf.push_back(blk(g.D, g.hp));
+    W.de = img(g.Dd, g.D); W.deT = img(g.D, g.Dd);
+    for (int i = 0; i < g.ddepth; ++i) W.bd.push_back(blk(g.Dd, g.hpd));
+    W.dp = img(80, g.Dd); W.dpT = img(g.Dd, 96);
+    W.bf16_elems = (cur + 7) & ~7ll;
+    W.f32_elems = fcur;
+    W.total_elems = W.bf16_elems + 2 * W.f32_elems;
+}
+
+void pack_descs(const Geo& g, const PLayout& L, const WLayout& W, const float* P, hs_bf16* wpk,
+                std::vector<PackDesc>& out) {
+    float* fbase = reinterpret_cast<float*>(wpk + W.bf16_elems);
+    auto mat = [&](int64_t src, int rows, int cols, int tr, int n_off, int k_off, int K_img, int64_t dst) {
+        PackDesc d; d.src = P + src; d.rows = rows; d.cols = cols; d.transpose = tr; d.n_off = n_off; d.k_off = k_off;
+        d.KS = K_img / 32; d.dst = wpk + dst; out.push_back(d);
+    };
+    auto fcopy = [&](int64_t src, int n, int64_t dst_f, int off) {
+        PackDesc d; d.src = P + src; d.rows = 1; d.cols = n; d.transpose = 0; d.n_off = off; d.k_off = 0; d.KS = 0;
+        d.dst = reinterpret_cast<hs_bf16*>(fbase + dst_f); out.push_back(d);
+    };
+    auto blk = [&](const BlkOff& b, const BlkW& w, int d, int h, int hp) {
+        mat(b.qw, d, d, 0, 0, 0, d, w.qkv); mat(b.kw, d, d, 0, d, 0, d, w.qkv); mat(b.vw, d, d, 0, 2 * d, 0, d, w.qkv);
+        mat(b.pw, d, d, 0, 0, 0, d, w.p);
+        mat(b.w1w, h, d, 0, 0, 0, d, w.w1); mat(b.w3w, h, d, 0, 0, 0, d, w.w3);
+        mat(b.w2w, d, h, 0, 0, 0, hp, w.w2);
+        // transposed images for the data gradients
+        mat(b.qw, d, d, 1, 0, 0, 3 * d, w.qkvT); mat(b.kw, d, d, 1, 0, d, 3 * d, w.qkvT); mat(b.vw, d, d, 1, 0, 2 * d, 3 * d, w.qkvT);
+        mat(b.pw, d, d, 1, 0, 0, d, w.pT);
+        mat(b.w1w, h, d, 1, 0, 0, 2 * hp, w.w13T); mat(b.w3w, h, d, 1, 0, hp, 2 * hp, w.w13T);
+        mat(b.w2w, d, h, 1, 0, 0, d, w.w2T);
+        fcopy(b.qb, d, w.bqkv, 0); fcopy(b.kb, d, w.bqkv, d); fcopy(b.vb, d, w.bqkv, 2 * d);
+    };
+    mat(L.pew, g.D, 72, 0, 0, 0, 96, W.pe);
+    for (size_t i = 0; i < L.b1.size(); ++i) blk(L.b1[i], W.b1[i], g.D, g.h, g.hp);
+    for (size_t i = 0; i < L.b2.size(); ++i) blk(L.b2[i], W.b2[i], g.D, g.h, g.hp);
+    for (size_t i = 0; i < L.bf.size(); ++i) blk(L.bf[i], W.bf[i], g.D, g.h, g.hp);
+    mat(L.dew, g.Dd, g.D, 0, 0, 0, g.D, W.de); mat(L.dew, g.Dd, g.D, 1, 0, 0, g.Dd, W.deT);
+    for (size_t i = 0; i < L.bd.size(); ++i) blk(L.bd[i], W.bd[i], g.Dd, g.hdec, g.hpd);
+    mat(L.dpw, 72, g.Dd, 0, 0, 0, g.Dd, W.dp); mat(L.dpw, 72, g.Dd, 1, 0, 0, 96, W.dpT);
+}
+
+// ------------------------------------------------------------------ workspace
+struct BlkBuf { hs_bf16* u; hs_bf16* qkv; float* lse; hs_bf16* o; float* x1; hs_bf16* u2; hs_bf16* h13; hs_bf16* g; float* x2; };
+
+struct Ws {
+    hs_bf16* a_pe; float* x0;
+    std::vector<BlkBuf> b1, b2, bf, bd;
+    hs_bf16* lat; float* y; float* yfull; hs_bf16* zn; float* pred; hs_bf16* dpred; float* partial;
+    float *G0, *G1, *G2, *du; hs_bf16 *dh13, *dob, *dqkv, *dyb;
+    int64_t bytes;
+};
+
+void carve(const Geo& g, int N, int K, char* base, Ws& w) {
+    int64_t cur = 0;
+    auto take = [&](int64_t bytes) { char* p = base ? base + cur : nullptr; cur += (bytes + 255) & ~255ll; return p; };
+    const int64_t Me = (int64_t)N * K, Md = (int64_t)N * g.TL;
+    auto blk = [&](int64_t M, int d, int heads, int hp) {
+        BlkBuf b;
+        b.u = (hs_bf16*)take(M * d * 2); b.qkv = (hs_bf16*)take(M * 3 * d * 2); b.lse = (float*)take(M * heads * 4);
+        b.o = (hs_bf16*)take(M * d * 2); b.x1 = (float*)take(M * d * 4); b.u2 = (hs_bf16*)take(M * d * 2);
+        b.h13 = (hs_bf16*)take(M * 2 * hp * 2); b.g = (hs_bf16*)take(M * hp * 2); b.x2 = (float*)take(M * d * 4);
+        return b;
+    };
+    w.a_pe = (hs_bf16*)take(Me * 96 * 2);
+    w.x0 = (float*)take(Me * g.D * 4);
+    w.b1.clear(); w.b2.clear(); w.bf.clear(); w.bd.clear();
+    if (g.has_axis) {
+        for (int i = 0; i < g.sdepth; ++i) w.b1.push_back(blk(Me, g.D, g.H, g.hp));
+        for (int i = 0; i < g.sdepth; ++i) w.b2.push_back(blk(Me, g.D, g.H, g.hp));
+    }
+    for (int i = 0; i < g.nfus; ++i) w.bf.push_back(blk(Me, g.D, g.H, g.hp));
+    w.lat = (hs_bf16*)take(Me * g.D * 2);
+    w.y = (float*)take(Me * g.Dd * 4);
+    w.yfull = (float*)take(Md * g.Dd * 4);
+    for (int i = 0; i < g.ddepth; ++i) w.bd.push_back(blk(Md, g.Dd, g.Hd, g.hpd));
+    w.zn = (hs_bf16*)take(Md * g.Dd * 2);
+    w.pred = (float*)take(Md * 72 * 4);
+    w.dpred = (hs_bf16*)take(Md * 96 * 2);
+    w.partial = (float*)take((int64_t)hs_loss_partials(N, g.T) * 4);
+    const int64_t gmax = std::max(Me * g.D, Md * g.Dd);
+    w.G0 = (float*)take(gmax * 4); w.G1 = (float*)take(gmax * 4); w.G2 = (float*)take(gmax * 4); w.du = (float*)take(gmax * 4);
+    w.dh13 = (hs_bf16*)take(std::max(Me * 2 * g.hp, Md * 2 * g.hpd) * 2);
+    w.dob = (hs_bf16*)take(gmax * 2);
+    w.dqkv = (hs_bf16*)take(gmax * 3 * 2);
+    w.dyb = (hs_bf16*)take(Me * g.Dd * 2);
+    w.bytes = cur;
+}
+
+struct BlkP {            // resolved pointers of one block
+    const float *n1w, *n1b, *bqkv, *pb, *n2w, *n2b, *w1b, *w3b, *w2b;
+    const hs_bf16 *qkv, *p, *w1, *w3, *w2, *qkvT, *pT, *w13T, *w2T;
+};
+
+BlkP resolve(const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk, const WLayout& WL) {
+    const float* fbase = reinterpret_cast<const float*>(wpk + WL.bf16_elems);
+    BlkP b;
+    b.n1w = P + o.n1w; b.n1b = P + o.n1b; b.bqkv = fbase + w.bqkv; b.pb = P + o.pb; b.n2w = P + o.n2w; b.n2b = P + o.n2b;
+    b.w1b = P + o.w1b; b.w3b = P + o.w3b; b.w2b = P + o.w2b;
+    b.qkv = wpk + w.qkv; b.p = wpk + w.p; b.w1 = wpk + w.w1; b.w3 = wpk + w.w3; b.w2 = wpk + w.w2;
+    b.qkvT = wpk + w.qkvT; b.pT = wpk + w.pT; b.w13T = wpk + w.w13T; b.w2T = wpk + w.w2T;
+    return b;
+}
+
+#define CK(expr) do { int _e = (expr); if (_e) return _e; } while (0)
+
+GemmParams gp() { GemmParams p; std::memset(&p, 0, sizeof(p)); return p; }
+
+// One transformer Block forward (Models.py:303-306): 5 launches.
+int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int d, int heads, int h, int hp, int Ts,
+              int nsamples, int mode, int len_l, const float* res2, hipStream_t s) {
+    GemmParams p = gp();
+    p.A = x_in; p.lda = d; p.M = (int)M; p.N = 3 * d; p.K = d; p.n_valid = 3 * d; p.W = P.qkv; p.bias = P.bqkv;
+    p.gamma = P.n1w; p.beta = P.n1b; p.u_out = b.u; p.ldu = d; p.out = b.qkv; p.ldo = 3 * d;
+    CK(hs_gemm(p, A_F32_LN, E_BF16, s));
+    AttnParams a; std::memset(&a, 0, sizeof(a));
+    a.qkv = b.qkv; a.ld = 3 * d; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
+    a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = d; a.lse = b.lse;
+    CK(hs_attn_fwd(a, s));
+    p = gp();
+    p.A = b.o; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d; p.W = P.p; p.bias = P.pb;
+    p.res = x_in; p.ldr = d; p.out = b.x1; p.ldo = d;
+    CK(hs_gemm(p, A_BF16, E_RES_F32, s));
+    p = gp();
+    p.A = b.x1; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = h; p.W = P.w1; p.W2 = P.w3; p.bias = P.w1b;
+    p.bias2 = P.w3b; p.gamma = P.n2w; p.beta = P.n2b; p.u_out = b.u2; p.ldu = d; p.out = b.g; p.ldo = hp;
+    p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp;
+    CK(hs_gemm(p, A_F32_LN, E_SWIGLU, s));
+    p = gp();
+    p.A = b.g; p.lda = hp; p.M = (int)M; p.N = d; p.K = hp; p.n_valid = d; p.W = P.w2; p.bias = P.w2b;
+    p.res = b.x1; p.res2 = res2; p.ldr = d; p.out = b.x2; p.ldo = d;
+    CK(hs_gemm(p, A_BF16, E_RES_F32, s));
+    return HSIMAE_OK;
+}
+
+int wgrad_msplit(int tiles, int64_t M) {
+    const int chunks = (int)((M + 63) / 64);
+    int ms = std::max(1, 640 / std::max(1, tiles));
+    return std::min(ms, chunks);
+}
+
+// One Block backward: data grads (7 launches) + all weight/bias grads of the block (1 launch).
+int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, const BlkBuf& b, int64_t M, int d,
+              int heads, int h, int hp, int Ts, int nsamples, int mode, int len_l, float* G0, float* G1, const Ws& w,
+              float* dx_out, int accumulate, hipStream_t s) {
+    GemmParams p = gp();
+    p.A = G0; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = hp; p.W = P.w2T; p.out = w.dh13; p.ldo = 2 * hp;
+    p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp;
+    CK(hs_gemm(p, A_F32, E_SWIGLU_BWD, s));
+    p = gp();
+    p.A = w.dh13; p.lda = 2 * hp; p.M = (int)M; p.N = d; p.K = 2 * hp; p.n_valid = d; p.W = P.w13T; p.out = w.du; p.ldo = d;
+    CK(hs_gemm(p, A_BF16, E_F32, s));
+    LnBwdParams l; std::memset(&l, 0, sizeof(l));
+    l.du = w.du; l.x = b.x1; l.gamma = P.n2w; l.dres = G0; l.dx = G1; l.accumulate = 0;
+    l.dgamma = grads + o.n2w; l.dbeta = grads + o.n2b; l.M = (int)M; l.d = d;
+    CK(hs_ln_bwd(l, s));
+    p = gp();
+    p.A = G1; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d; p.W = P.pT; p.out = w.dob; p.ldo = d;
+    CK(hs_gemm(p, A_F32, E_BF16, s));
+    AttnParams a; std::memset(&a, 0, sizeof(a));
+    a.qkv = b.qkv; a.ld = 3 * d; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
+    a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = d; a.lse = b.lse; a.dout = w.dob; a.lddo = d; a.dqkv = w.dqkv;
+    CK(hs_attn_bwd(a, s));
+    p = gp();
+    p.A = w.dqkv; p.lda = 3 * d; p.M = (int)M; p.N = d; p.K = 3 * d; p.n_valid = d; p.W = P.qkvT; p.out = w.du; p.ldo = d;
+    CK(hs_gemm(p, A_BF16, E_F32, s));
+
+    WgradParams g; std::memset(&g, 0, sizeof(g));
+    auto task = [&](const void* dO, int f32, int ldo, const hs_bf16* A, int lda, int N, int K, int64_t dW, int64_t db) {
+        WgradTask& t = g.t[g.ntasks++];
+        t.dO = dO; t.dO_f32 = f32; t.ldo = ldo; t.A = A; t.lda = lda; t.N = N; t.K = K; t.dW = grads + dW; t.ldw = K;
+        t.db = grads + db;
+    };
+    task(w.dqkv, 0, 3 * d, b.u, d, d, d, o.qw, o.qb);
+    task(w.dqkv + d, 0, 3 * d, b.u, d, d, d, o.kw, o.kb);
+    task(w.dqkv + 2 * d, 0, 3 * d, b.u, d, d, d, o.vw, o.vb);
+    task(G1, 1, d, b.o, d, d, d, o.pw, o.pb);
+    task(w.dh13, 0, 2 * hp, b.u2, d, h, d, o.w1w, o.w1b);
+    task(w.dh13 + hp, 0, 2 * hp, b.u2, d, h, d, o.w3w, o.w3b);
+    task(G0, 1, d, b.g, hp, d, h, o.w2w, o.w2b);
+    g.M = (int)M;
+    int tiles = 0;
+    for (int i = 0; i < g.ntasks; ++i) tiles += ((g.t[i].N + 127) / 128) * ((g.t[i].K + 127) / 128);
+    g.msplit = wgrad_msplit(tiles, M);
+    CK(hs_wgrad(g, s));
+
+    l.du = w.du; l.x = x_in; l.gamma = P.n1w; l.dres = G1; l.dx = dx_out; l.accumulate = accumulate;
+    l.dgamma = grads + o.n1w; l.dbeta = grads + o.n1b;
+    CK(hs_ln_bwd(l, s));
+    return HSIMAE_OK;
+}
+
+struct Ctx {
+    Geo g; PLayout L; WLayout W; Ws w;
+    int N, K, len_t, len_l;
+    int64_t Me, Md;
+};
+
+int make_ctx(const hsimae_config* cfg, const hsimae_io* io, Ctx& c, bool need_ws) {
+    CK(make_geo(cfg, c.g));
+    if (!io) return HSIMAE_ENULL;
+    c.N = io->N; c.len_t = io->len_t; c.len_l = io->len_l;
+    if (c.N <= 0 || c.len_t < 1 || c.len_t > c.g.T || c.len_l < 1 || c.len_l > 9) return HSIMAE_EDIMS;
+    c.K = c.len_t * c.len_l;
+    c.Me = (int64_t)c.N * c.K; c.Md = (int64_t)c.N * c.g.TL;
+    if (c.Md * 96 >= (1ll << 31) || c.Me * 3 * c.g.D >= (1ll << 31)) return HSIMAE_EUNSUPPORTED;   // 32-bit row math in kernels
+    make_playout(c.g, c.L);
+    make_wlayout(c.g, c.W);
+    if (need_ws) {
+        if (!io->workspace || !io->params || !io->wpk) return HSIMAE_ENULL;
+        if (reinterpret_cast<uintptr_t>(io->workspace) % 256) return HSIMAE_EALIGN;
+        carve(c.g, c.N, c.K, reinterpret_cast<char*>(io->workspace), c.w);
+        if (c.w.bytes > io->workspace_bytes) return HSIMAE_EDIMS;
+    }
+    return HSIMAE_OK;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+int hsimae_version(void) { return 100; }
+
+const char* hsimae_strerror(int code) {
+    switch (code) {
+        case HSIMAE_OK: return "ok";
+        case HSIMAE_EDIMS: return "bad dimensions or strides";
+        case HSIMAE_EUNSUPPORTED: return "configuration not supported by the gfx950 kernels";
+        case HSIMAE_EALIGN: return "misaligned pointer";
+        case HSIMAE_ENULL: return "required pointer is NULL";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+int hsimae_param_layout(const hsimae_config* cfg, int64_t* offsets, int64_t* sizes, int max_entries) {
+    Geo g; int e = make_geo(cfg, g); if (e) return e;
+    PLayout L; make_playout(g, L);
+    const int n = (int)L.offs.size();
+    for (int i = 0; i < n && i < max_entries; ++i) {
+        if (offsets) offsets[i] = L.offs[i];
+        if (sizes) sizes[i] = L.sizes[i];
+    }
+    return n;
+}
+
+int64_t hsimae_wpk_elems(const hsimae_config* cfg) {
+    Geo g; if (make_geo(cfg, g)) return -1;
+    WLayout W; make_wlayout(g, W);
+    return W.total_elems;
+}
+
+int64_t hsimae_pack_table_bytes(const hsimae_config* cfg) {
+    Geo g; if (make_geo(cfg, g)) return -1;
+    PLayout L; make_playout(g, L); WLayout W; make_wlayout(g, W);
+    std::vector<PackDesc> d; pack_descs(g, L, W, nullptr, nullptr, d);
+    return (int64_t)d.size() * sizeof(PackDesc);
+}
+
+int hsimae_build_pack_table(const hsimae_config* cfg, const float* params_dev, hs_bf16* wpk_dev, void* table_host) {
+    Geo g; CK(make_geo(cfg, g));
+    if (!params_dev || !wpk_dev || !table_host) return HSIMAE_ENULL;
+    PLayout L; make_playout(g, L); WLayout W; make_wlayout(g, W);
+    std::vector<PackDesc> d; pack_descs(g, L, W, params_dev, wpk_dev, d);
+    std::memcpy(table_host, d.data(), d.size() * sizeof(PackDesc));
+    return HSIMAE_OK;
+}
+
+int hsimae_pack_params(const hsimae_config* cfg, const void* table_dev, void* stream) {
+    Geo g; CK(make_geo(cfg, g));
+    if (!table_dev) return HSIMAE_ENULL;
+    const int n = (int)(hsimae_pack_table_bytes(cfg) / (int64_t)sizeof(PackDesc));
+    const int maxe = std::max({g.D * g.D, g.h * g.D, g.Dd * g.Dd, g.hdec * g.Dd, g.D * g.Dd, g.D * 72});
+    return hs_pack(reinterpret_cast<const PackDesc*>(table_dev), n, maxe, S(stream));
+}
+
+int64_t hsimae_workspace_bytes(const hsimae_config* cfg, int32_t N, int32_t len_t, int32_t len_l) {
+    Geo g; if (make_geo(cfg, g)) return -1;
+    if (N <= 0 || len_t < 1 || len_l < 1) return -1;
+    Ws w; carve(g, N, len_t * len_l, nullptr, w);
+    return w.bytes;
+}
+
+int hsimae_forward(const hsimae_config* cfg, const hsimae_io* io, void* stream) {
+    Ctx c; CK(make_ctx(cfg, io, c, true));
+    if (!io->x || !io->noise1 || !io->noise2 || !io->loss || !io->mask || !io->ids_keep || !io->ids_restore) return HSIMAE_ENULL;
+    if (io->want_recons && (!io->pred_img || !io->mask_img)) return HSIMAE_ENULL;
+    hipStream_t s = S(stream);
+    const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w;
+
+    MaskParams m; m.noise1 = io->noise1; m.noise2 = io->noise2; m.N = c.N; m.T = g.T; m.L = 9; m.len_t = c.len_t;
+    m.len_l = c.len_l; m.ids_keep = io->ids_keep; m.ids_restore = io->ids_restore; m.mask = io->mask;
+    CK(hs_mask(m, s));
+    PatchParams pp; pp.x = io->x; pp.sn = io->sn; pp.sb = io->sb; pp.sh = io->sh; pp.sw = io->sw; pp.N = c.N; pp.T = g.T;
+    pp.K = c.K; pp.ids_keep = io->ids_keep; pp.out = w.a_pe; pp.pos_ids = nullptr;
+    CK(hs_patch_gather(pp, s));
+    GemmParams p = gp();
+    p.A = w.a_pe; p.lda = 96; p.M = (int)c.Me; p.N = g.D; p.K = 96; p.n_valid = g.D; p.W = io->wpk + c.W.pe; p.bias = P + c.L.peb;
+    p.pos = P + c.L.pos; p.ids = io->ids_keep; p.ldpos = g.D; p.out = w.x0; p.ldo = g.D;
+    CK(hs_gemm(p, A_BF16, E_POS_F32, s));
+
+    const float* x = w.x0;
+    if (g.has_axis) {
+        const float* xa = w.x0;
+        for (int i = 0; i < g.sdepth; ++i) {       // spatial stack: attend within one kept band group (Models.py:553,556)
+            BlkP bp = resolve(c.L.b1[i], c.W.b1[i], P, io->wpk, c.W);
+            CK(block_fwd(bp, xa, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, nullptr, s));
+            xa = w.b1[i].x2;
+        }
+        const float* xb = w.x0;
+        for (int i = 0; i < g.sdepth; ++i) {       // spectral stack: attend within one kept position (Models.py:554,559)
+            BlkP bp = resolve(c.L.b2[i], c.W.b2[i], P, io->wpk, c.W);
+            const float* r2 = (i == g.sdepth - 1) ? xa : nullptr;       // x1 + x2 fused into the last epilogue (Models.py:564)
+            CK(block_fwd(bp, xb, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, r2, s));
+            xb = w.b2[i].x2;
+        }
+        x = xb;
+    }
+    for (int i = 0; i < g.nfus; ++i) {
+        BlkP bp = resolve(c.L.bf[i], c.W.bf[i], P, io->wpk, c.W);
+        CK(block_fwd(bp, x, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, nullptr, s));
+        x = w.bf[i].x2;
+    }
+    // norm + decoder_embed (Models.py:570, 579)
+    p = gp();
+    p.A = x; p.lda = g.D; p.M = (int)c.Me; p.N = g.Dd; p.K = g.D; p.n_valid = g.Dd; p.W = io->wpk + c.W.de; p.bias = P + c.L.deb;
+    p.gamma = P + c.L.nw; p.beta = P + c.L.nb; p.u_out = w.lat; p.ldu = g.D; p.out = w.y; p.ldo = g.Dd;
+    CK(hs_gemm(p, A_F32_LN, E_F32, s));
+    AssembleParams as; std::memset(&as, 0, sizeof(as));
+    as.y = w.y; as.N = c.N; as.K = c.K; as.TL = g.TL; as.Dd = g.Dd; as.ids_restore = io->ids_restore; as.pos = P + c.L.dpos;
+    as.yfull = w.yfull;
+    CK(hs_assemble_fwd(as, s));
+    const float* z = w.yfull;
+    for (int i = 0; i < g.ddepth; ++i) {
+        BlkP bp = resolve(c.L.bd[i], c.W.bd[i], P, io->wpk, c.W);
+        CK(block_fwd(bp, z, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, nullptr, s));
+        z = w.bd[i].x2;
+    }
+    // decoder_norm + decoder_pred (Models.py:597-600)
+    p = gp();
+    p.A = z; p.lda = g.Dd; p.M = (int)c.Md; p.N = 80; p.K = g.Dd; p.n_valid = 72; p.W = io->wpk + c.W.dp; p.bias = P + c.L.dpb;
+    p.gamma = P + c.L.dnw; p.beta = P + c.L.dnb; p.u_out = w.zn; p.ldu = g.Dd; p.out = w.pred; p.ldo = 72;
+    CK(hs_gemm(p, A_F32_LN, E_F32, s));
+    LossParams lp; std::memset(&lp, 0, sizeof(lp));
+    const float sum_mask = (float)((int64_t)c.N * (g.TL - c.K));
+    lp.x = io->x; lp.sn = io->sn; lp.sb = io->sb; lp.sh = io->sh; lp.sw = io->sw; lp.N = c.N; lp.T = g.T; lp.pred = w.pred;
+    lp.mask = io->mask; lp.norm_pix = g.norm_pix; lp.inv_scale = io->grad_scale / (72.f * sum_mask); lp.partial = w.partial;
+    lp.loss = io->loss; lp.sum_mask = sum_mask; lp.dpred = w.dpred;
+    lp.pred_img = io->want_recons ? io->pred_img : nullptr; lp.mask_img = io->want_recons ? io->mask_img : nullptr;
+    CK(hs_loss(lp, s));
+    if (io->pred) CK((int)hipMemcpyAsync(io->pred, w.pred, c.Md * 72 * 4, hipMemcpyDeviceToDevice, s));
+    if (io->latent) CK(hs_ln_fwd(x, P + c.L.nw, P + c.L.nb, io->latent, (int)c.Me, g.D, s));
+    return HSIMAE_OK;
+}
+
+int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads, hsimae_bucket_cb cb, void* user,
+                    void* stream) {
+    Ctx c; CK(make_ctx(cfg, io, c, true));
+    if (!grads || !io->ids_restore) return HSIMAE_ENULL;
+    hipStream_t s = S(stream);
+    const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
+    int stage = 0;
+    auto emit = [&](int64_t off, int64_t end) { if (cb) cb(stage, off, end - off, user); ++stage; };
+
+    // decoder_pred / decoder_norm
+    const float* zlast = w.bd[g.ddepth - 1].x2;
+    GemmParams p = gp();
+    p.A = w.dpred; p.lda = 96; p.M = (int)c.Md; p.N = g.Dd; p.K = 96; p.n_valid = g.Dd; p.W = io->wpk + c.W.dpT; p.out = w.du; p.ldo = g.Dd;
+    CK(hs_gemm(p, A_BF16, E_F32, s));
+    {
+        WgradParams wg; std::memset(&wg, 0, sizeof(wg));
+        WgradTask& t = wg.t[0]; t.dO = w.dpred; t.dO_f32 = 0; t.ldo = 96; t.A = w.zn; t.lda = g.Dd; t.N = 72; t.K = g.Dd;
+        t.dW = grads + L.dpw; t.ldw = g.Dd; t.db = grads + L.dpb;
+        wg.ntasks = 1; wg.M = (int)c.Md; wg.msplit = wgrad_msplit(1, c.Md);
+        CK(hs_wgrad(wg, s));
+    }
+    LnBwdParams l; std::memset(&l, 0, sizeof(l));
+    l.du = w.du; l.x = zlast; l.gamma = P + L.dnw; l.dres = nullptr; l.dx = w.G0; l.dgamma = grads + L.dnw; l.dbeta = grads + L.dnb;
+    l.M = (int)c.Md; l.d = g.Dd;
+    CK(hs_ln_bwd(l, s));
+    emit(L.dnw, L.total);
+
+    for (int i = g.ddepth - 1; i >= 0; --i) {
+        BlkP bp = resolve(L.bd[i], c.W.bd[i], P, io->wpk, c.W);
+        const float* xin = (i == 0) ? w.yfull : w.bd[i - 1].x2;
+        CK(block_bwd(bp, L.bd[i], grads, xin, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, w.G0, w.G1, w, w.G0, 0, s));
+        emit(L.bd[i].n1w, L.bd[i].end);
+    }
+    // sequence assembly + decoder_embed + norm
+    AssembleParams as; std::memset(&as, 0, sizeof(as));
+    as.N = c.N; as.K = c.K; as.TL = g.TL; as.Dd = g.Dd; as.ids_restore = io->ids_restore; as.dyfull = w.G0; as.dy = w.dyb;
+    CK(hs_assemble_bwd(as, s));
+    p = gp();
+    p.A = w.dyb; p.lda = g.Dd; p.M = (int)c.Me; p.N = g.D; p.K = g.Dd; p.n_valid = g.D; p.W = io->wpk + c.W.deT; p.out = w.du; p.ldo = g.D;
+    CK(hs_gemm(p, A_BF16, E_F32, s));
+    {
+        WgradParams wg; std::memset(&wg, 0, sizeof(wg));
+        WgradTask& t = wg.t[0]; t.dO = w.dyb; t.dO_f32 = 0; t.ldo = g.Dd; t.A = w.lat; t.lda = g.D; t.N = g.Dd; t.K = g.D;
+        t.dW = grads + L.dew; t.ldw = g.D; t.db = grads + L.deb;
+        wg.ntasks = 1; wg.M = (int)c.Me; wg.msplit = wgrad_msplit(((g.Dd + 127) / 128) * ((g.D + 127) / 128), c.Me);
+        CK(hs_wgrad(wg, s));
+    }
+    const float* xf = g.nfus ? w.bf[g.nfus - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
+    l.du = w.du; l.x = xf; l.gamma = P + L.nw; l.dres = nullptr; l.dx = w.G0; l.dgamma = grads + L.nw; l.dbeta = grads + L.nb;
+    l.M = (int)c.Me; l.d = g.D;
+    CK(hs_ln_bwd(l, s));
+    emit(L.nw, L.deb + g.Dd);
+
+    for (int i = g.nfus - 1; i >= 0; --i) {
+        BlkP bp = resolve(L.bf[i], c.W.bf[i], P, io->wpk, c.W);
+        const float* xin = (i > 0) ? w.bf[i - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
+        CK(block_bwd(bp, L.bf[i], grads, xin, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, w.G0, w.G1, w, w.G0, 0, s));
+        emit(L.bf[i].n1w, L.bf[i].end);
+    }
+    if (g.has_axis) {
+        // d(x1 + x2) feeds both stacks (Models.py:564)
+        CK((int)hipMemcpyAsync(w.G2, w.G0, c.Me * g.D * 4, hipMemcpyDeviceToDevice, s));
+        for (int i = g.sdepth - 1; i >= 0; --i) {
+            BlkP bp = resolve(L.b2[i], c.W.b2[i], P, io->wpk, c.W);
+            const float* xin = (i > 0) ? w.b2[i - 1].x2 : w.x0;
+            CK(block_bwd(bp, L.b2[i], grads, xin, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, w.G1, w, w.G0, 0, s));
+            emit(L.b2[i].n1w, L.b2[i].end);
+        }
+        for (int i = g.sdepth - 1; i >= 0; --i) {
+            BlkP bp = resolve(L.b1[i], c.W.b1[i], P, io->wpk, c.W);
+            const float* xin = (i > 0) ? w.b1[i - 1].x2 : w.x0;
+            float* out = (i == 0) ? w.G0 : w.G2;          // last one accumulates onto the spectral stack's dX
+            CK(block_bwd(bp, L.b1[i], grads, xin, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.G1, w, out, i == 0, s));
+            emit(L.b1[i].n1w, L.b1[i].end);
+        }
+    }
+    {   // patch_embed.proj: only the kept tokens carry gradient (Models.py:528); no input gradient
+        WgradParams wg; std::memset(&wg, 0, sizeof(wg));
+        WgradTask& t = wg.t[0]; t.dO = w.G0; t.dO_f32 = 1; t.ldo = g.D; t.A = w.a_pe; t.lda = 96; t.N = g.D; t.K = 72;
+        t.dW = grads + L.pew; t.ldw = 72; t.db = grads + L.peb;
+        wg.ntasks = 1; wg.M = (int)c.Me; wg.msplit = wgrad_msplit((g.D + 127) / 128, c.Me);
+        CK(hs_wgrad(wg, s));
+    }
+    emit(0, L.peb + g.D);
+    return HSIMAE_OK;
+}
+
+// ---------------------------------------------------------------------- per-kernel entry points
+int hsimae_mask_from_noise(const hsimae_mask_params* p, void* stream) { return p ? hs_mask(*p, S(stream)) : HSIMAE_ENULL; }
+int hsimae_patch_gather(const hsimae_patch_params* p, void* stream) { return p ? hs_patch_gather(*p, S(stream)) : HSIMAE_ENULL; }
+int hsimae_gemm(const hsimae_gemm_params* p, int32_t a_kind, int32_t epilogue, void* stream) {
+    return p ? hs_gemm(*p, a_kind, epilogue, S(stream)) : HSIMAE_ENULL;
+}
+int hsimae_pack_matrix(const hsimae_pack_desc* d, int32_t n, int32_t max_elems, void* stream) {
+    return d ? hs_pack(d, n, max_elems, S(stream)) : HSIMAE_ENULL;
+}
+int hsimae_attn_fwd(const hsimae_attn_params* p, void* stream) { return p ? hs_attn_fwd(*p, S(stream)) : HSIMAE_ENULL; }
+int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream) { return p ? hs_attn_bwd(*p, S(stream)) : HSIMAE_ENULL; }
+int hsimae_wgrad(const hsimae_wgrad_params* p, void* stream) { return p ? hs_wgrad(*p, S(stream)) : HSIMAE_ENULL; }
+int hsimae_ln_bwd(const hsimae_lnbwd_params* p, void* stream) { return p ? hs_ln_bwd(*p, S(stream)) : HSIMAE_ENULL; }
+int hsimae_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int32_t M, int32_t d, void* stream) {
+    return (x && gamma && beta && out) ? hs_ln_fwd(x, gamma, beta, out, M, d, S(stream)) : HSIMAE_ENULL;
+}
+int hsimae_assemble_fwd(const hsimae_assemble_params* p, void* stream) { return p ? hs_assemble_fwd(*p, S(stream)) : HSIMAE_ENULL; }
+int hsimae_assemble_bwd(const hsimae_assemble_params* p, void* stream) { return p ? hs_assemble_bwd(*p, S(stream)) : HSIMAE_ENULL; }
+int hsimae_loss_partials(int32_t N, int32_t T) { return hs_loss_partials(N, T); }
+int hsimae_loss(const hsimae_loss_params* p, void* stream) { return p ? hs_loss(*p, S(stream)) : HSIMAE_ENULL; }
+
+}  // extern "C"

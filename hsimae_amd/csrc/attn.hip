@@ -1,0 +1,364 @@
+// Small-sequence multi-head attention on MFMA, forward and backward, for the HSIMAE blocks.
+//
+// Every attention on this path is tiny: per sample 14/27/54 kept tokens (encoder, head dim 16) or
+// 54/108/216 tokens (decoder, head dim 8).  The spatial stack attends within one kept band-group, the
+// spectral stack within one kept position, the fusion/decoder blocks over the whole sample.  All three
+// are the same kernel with a per-token class mask (mode 1: class = i / len_l, mode 2: class = i % len_l),
+// so no rearrange / transposed copies of the token grid are ever materialised (Models.py:553-564).
+//
+// One workgroup = one sample x 4 heads, one wave per head.  Scores are computed TRANSPOSED
+// (S^T = K Q^T: key on the accumulator row, query on the lane) so the softmax reductions are in-lane plus
+// two cross-group shuffles, and the bf16-packed probabilities are directly the B operand of the next
+// MFMA (O^T = V^T P^T) with a permuted key order that the V^T LDS image is read in.  The backward
+// recomputes the scores in both orientations instead of transposing dS through LDS.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_row(const bf16_t* base, int row, int g) {
+    // row-major [token][HD] image: A/B fragment element j = feature 8g + j of token `row`
+    if (g * 8 < HD) return *reinterpret_cast<const bf16x8*>(base + row * HD + g * 8);
+    return zero8();
+}
+
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_tr(const bf16_t* base, int vst, int drow, int ta, int tb, int g) {
+    // transposed [feature][token] image: element j<4 = token 16*ta + 4g + j, j>=4 = token 16*tb + 4g + (j-4)
+    if (drow < HD) {
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(base + drow * vst + ta * 16 + g * 4);
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(base + drow * vst + tb * 16 + g * 4);
+        u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+    return zero8();
+}
+
+__device__ __forceinline__ bf16x8 pack_pair(f32x4 a, f32x4 b) {
+    bf16x8 r;
+    r[0] = (bf16_t)a[0]; r[1] = (bf16_t)a[1]; r[2] = (bf16_t)a[2]; r[3] = (bf16_t)a[3];
+    r[4] = (bf16_t)b[0]; r[5] = (bf16_t)b[1]; r[6] = (bf16_t)b[2]; r[7] = (bf16_t)b[3];
+    return r;
+}
+
+__device__ __forceinline__ float group_max(float v) {   // over the 4 lane groups sharing lane&15
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+template <int HD, int NT>
+struct Lay {
+    static constexpr int NTP = (NT + 1) & ~1;            // key tiles rounded to pairs (K = 32 per MFMA)
+    static constexpr int ROWS = NTP * 16;
+    static constexpr int VST = ROWS + 8;                  // transposed-image row stride (elements)
+    static constexpr int RM = ROWS * HD;                  // row-major image elements
+    static constexpr int TR = HD * VST;                   // transposed image elements
+    static constexpr int FWD_WAVE = (2 * RM + TR) * 2;                      // Qr Kr Vt
+    static constexpr int BWD_WAVE = (4 * RM + 3 * TR) * 2 + 2 * ROWS * 4;   // Qr Kr Vr dOr Qt Kt dOt lse delta
+    static constexpr int CLS = ROWS * 4;
+};
+
+template <int HD, int NT>
+__device__ __forceinline__ void fill_cls(int* cls, const AttnParams& p) {
+    using L = Lay<HD, NT>;
+    for (int i = threadIdx.x; i < L::ROWS; i += 256) {
+        int c = -1;
+        if (i < p.Ts) c = (p.mode == 1) ? i / p.len_l : (p.mode == 2) ? i % p.len_l : 0;
+        cls[i] = c;
+    }
+}
+
+// Load one head's [Ts][HD] slice (16-B pieces) into a row-major and/or transposed LDS image.
+template <int HD>
+__device__ __forceinline__ void load_slice(const bf16_t* src, int ld, int Ts, int lane, bf16_t* rowmajor,
+                                           bf16_t* transposed, int vst) {
+    constexpr int PPT = HD / 8;
+    for (int idx = lane; idx < Ts * PPT; idx += 64) {
+        const int tok = idx / PPT, pc = idx % PPT;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)tok * ld + pc * 8);
+        if (rowmajor) *reinterpret_cast<bf16x8*>(rowmajor + tok * HD + pc * 8) = v;
+        if (transposed) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) transposed[(pc * 8 + e) * vst + tok] = v[e];
+        }
+    }
+}
+
+template <int HD, int NT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+    using L = Lay<HD, NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hgroups = (p.heads + 3) / 4;
+    const int sample = blockIdx.x / hgroups, head = (blockIdx.x % hgroups) * 4 + wave;
+    const bool active = head < p.heads;
+    int* cls = reinterpret_cast<int*>(smem);
+    bf16_t* Qr = reinterpret_cast<bf16_t*>(smem + L::CLS + wave * L::FWD_WAVE);
+    bf16_t* Kr = Qr + L::RM;
+    bf16_t* Vt = Kr + L::RM;
+
+    // zero the wave's region (pads must be finite zeros), then fill
+    for (int i = lane; i < L::FWD_WAVE / 16; i += 64)
+        reinterpret_cast<u32x4*>(Qr)[i] = u32x4{0u, 0u, 0u, 0u};
+    fill_cls<HD, NT>(cls, p);
+    __syncthreads();
+    const size_t row_base = (size_t)sample * p.Ts;
+    if (active) {
+        const bf16_t* base = p.qkv + row_base * p.ld + head * HD;
+        load_slice<HD>(base, p.ld, p.Ts, lane, Qr, nullptr, 0);
+        load_slice<HD>(base + p.d, p.ld, p.Ts, lane, Kr, nullptr, 0);
+        load_slice<HD>(base + 2 * p.d, p.ld, p.Ts, lane, nullptr, Vt, L::VST);
+    }
+    __syncthreads();
+    if (!active) return;
+
+    const int c16 = lane & 15, g = lane >> 4;
+    const float sc = rsqrtf((float)HD) * 1.4426950408889634f;   // hd^-0.5 * log2(e)
+
+    for (int qt = 0; qt < NT; ++qt) {
+        const int query = qt * 16 + c16;
+        if (qt * 16 >= p.Ts) break;
+        const int qcls = cls[query];
+        const bf16x8 bq = frag_row<HD>(Qr, query, g);
+        f32x4 s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const bf16x8 ak = frag_row<HD>(Kr, kt * 16 + c16, g);
+            s[kt] = mfma16(ak, bq, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
+            const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
+                s[kt][r] = ok ? s[kt][r] * sc : -INFINITY;
+                m = fmaxf(m, s[kt][r]);
+            }
+        }
+        m = group_max(m);
+        if (m == -INFINITY) m = 0.f;
+        float lsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = exp2f(s[kt][r] - m);
+                s[kt][r] = e;
+                lsum += e;
+            }
+        lsum = group_sum(lsum);
+        const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pp = 0; pp < L::NTP / 2; ++pp) {
+            const int ta = 2 * pp, tb = 2 * pp + 1;
+            const bf16x8 bp = pack_pair(s[ta], tb < NT ? s[tb < NT ? tb : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
+            const bf16x8 av = frag_tr<HD>(Vt, L::VST, c16, ta, tb, g);
+            o = mfma16(av, bp, o);
+        }
+        if (query < p.Ts) {
+            if (g * 4 < HD) {
+                bf16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
+                *reinterpret_cast<bf16x4*>(p.o + (row_base + query) * p.ldo + head * HD + g * 4) = ov;
+            }
+            if (g == 0 && p.lse) p.lse[(row_base + query) * p.heads + head] = m + log2f(fmaxf(lsum, 1e-30f));
+        }
+    }
+}
+
+template <int HD, int NT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
+    using L = Lay<HD, NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hgroups = (p.heads + 3) / 4;
+    const int sample = blockIdx.x / hgroups, head = (blockIdx.x % hgroups) * 4 + wave;
+    const bool active = head < p.heads;
+    int* cls = reinterpret_cast<int*>(smem);
+    bf16_t* Qr = reinterpret_cast<bf16_t*>(smem + L::CLS + wave * L::BWD_WAVE);
+    bf16_t* Kr = Qr + L::RM;
+    bf16_t* Vr = Kr + L::RM;
+    bf16_t* dOr = Vr + L::RM;
+    bf16_t* Qt = dOr + L::RM;
+    bf16_t* Kt = Qt + L::TR;
+    bf16_t* dOt = Kt + L::TR;
+    float* lse = reinterpret_cast<float*>(dOt + L::TR);
+    float* delta = lse + L::ROWS;
+
+    for (int i = lane; i < L::BWD_WAVE / 16; i += 64)
+        reinterpret_cast<u32x4*>(Qr)[i] = u32x4{0u, 0u, 0u, 0u};
+    fill_cls<HD, NT>(cls, p);
+    __syncthreads();
+    const size_t row_base = (size_t)sample * p.Ts;
+    if (active) {
+        const bf16_t* base = p.qkv + row_base * p.ld + head * HD;
+        load_slice<HD>(base, p.ld, p.Ts, lane, Qr, Qt, L::VST);
+        load_slice<HD>(base + p.d, p.ld, p.Ts, lane, Kr, Kt, L::VST);
+        load_slice<HD>(base + 2 * p.d, p.ld, p.Ts, lane, Vr, nullptr, 0);
+        load_slice<HD>(p.dout + row_base * p.lddo + head * HD, p.lddo, p.Ts, lane, dOr, dOt, L::VST);
+        for (int tok = lane; tok < p.Ts; tok += 64) {
+            const bf16_t* orow = p.o + (row_base + tok) * p.ldo + head * HD;
+            const bf16_t* drow = p.dout + (row_base + tok) * p.lddo + head * HD;
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < HD; e += 8) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(orow + e);
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(drow + e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc += bf2f(a[i]) * bf2f(b[i]);
+            }
+            delta[tok] = acc;
+            lse[tok] = p.lse[(row_base + tok) * p.heads + head];
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+
+    const int c16 = lane & 15, g = lane >> 4;
+    const float scale = rsqrtf((float)HD);
+    const float sc = scale * 1.4426950408889634f;
+    bf16_t* dq_base = p.dqkv + row_base * p.ld + head * HD;
+
+    // ---- pass A: S^T orientation (key on rows, query on the lane) -> dQ
+    for (int qt = 0; qt < NT; ++qt) {
+        if (qt * 16 >= p.Ts) break;
+        const int query = qt * 16 + c16;
+        const int qcls = cls[query];
+        const float lq = lse[query], dl = delta[query];
+        const bf16x8 bq = frag_row<HD>(Qr, query, g);
+        const bf16x8 bdo = frag_row<HD>(dOr, query, g);
+        f32x4 ds[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const bf16x8 ak = frag_row<HD>(Kr, kt * 16 + c16, g);
+            const bf16x8 av = frag_row<HD>(Vr, kt * 16 + c16, g);
+            const f32x4 s = mfma16(ak, bq, f32x4{0.f, 0.f, 0.f, 0.f});
+            const f32x4 dp = mfma16(av, bdo, f32x4{0.f, 0.f, 0.f, 0.f});
+            const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
+            const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls) && (qcls >= 0);
+                const float pr = ok ? exp2f(s[r] * sc - lq) : 0.f;
+                ds[kt][r] = pr * (dp[r] - dl) * scale;
+            }
+        }
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pp = 0; pp < L::NTP / 2; ++pp) {
+            const int ta = 2 * pp, tb = 2 * pp + 1;
+            const bf16x8 b = pack_pair(ds[ta], tb < NT ? ds[tb < NT ? tb : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
+            const bf16x8 a = frag_tr<HD>(Kt, L::VST, c16, ta, tb, g);
+            dq = mfma16(a, b, dq);
+        }
+        if (query < p.Ts && g * 4 < HD) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)dq[r];
+            *reinterpret_cast<bf16x4*>(dq_base + (size_t)query * p.ld + g * 4) = v;
+        }
+    }
+
+    // ---- pass B: S orientation (query on rows, key on the lane) -> dK, dV
+    for (int kt = 0; kt < NT; ++kt) {
+        if (kt * 16 >= p.Ts) break;
+        const int key = kt * 16 + c16;
+        const int kcls = cls[key];
+        const bf16x8 bk = frag_row<HD>(Kr, key, g);
+        const bf16x8 bv = frag_row<HD>(Vr, key, g);
+        f32x4 pr[NT], ds[NT];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            const bf16x8 aq = frag_row<HD>(Qr, qt * 16 + c16, g);
+            const bf16x8 ado = frag_row<HD>(dOr, qt * 16 + c16, g);
+            const f32x4 s = mfma16(aq, bk, f32x4{0.f, 0.f, 0.f, 0.f});
+            const f32x4 dp = mfma16(ado, bv, f32x4{0.f, 0.f, 0.f, 0.f});
+            const int4 qc = *reinterpret_cast<const int4*>(cls + qt * 16 + g * 4);
+            const f32x4 lq = *reinterpret_cast<const f32x4*>(lse + qt * 16 + g * 4);
+            const f32x4 dl = *reinterpret_cast<const f32x4*>(delta + qt * 16 + g * 4);
+            const int qcl[4] = {qc.x, qc.y, qc.z, qc.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (qcl[r] >= 0) && (qcl[r] == kcls);
+                const float pv = ok ? exp2f(s[r] * sc - lq[r]) : 0.f;
+                pr[qt][r] = pv;
+                ds[qt][r] = pv * (dp[r] - dl[r]) * scale;
+            }
+        }
+        f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pp = 0; pp < L::NTP / 2; ++pp) {
+            const int ta = 2 * pp, tb = 2 * pp + 1;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const bf16x8 bds = pack_pair(ds[ta], tb < NT ? ds[tb < NT ? tb : 0] : z);
+            const bf16x8 bp = pack_pair(pr[ta], tb < NT ? pr[tb < NT ? tb : 0] : z);
+            const bf16x8 aq = frag_tr<HD>(Qt, L::VST, c16, ta, tb, g);
+            const bf16x8 ado = frag_tr<HD>(dOt, L::VST, c16, ta, tb, g);
+            dk = mfma16(aq, bds, dk);
+            dv = mfma16(ado, bp, dv);
+        }
+        if (key < p.Ts && g * 4 < HD) {
+            bf16x4 vk, vv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vk[r] = (bf16_t)dk[r]; vv[r] = (bf16_t)dv[r]; }
+            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + p.d + g * 4) = vk;
+            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + 2 * p.d + g * 4) = vv;
+        }
+    }
+}
+
+template <int HD, int NT, bool BWD>
+int launch_attn(const AttnParams& p, hipStream_t s) {
+    using L = Lay<HD, NT>;
+    const int hgroups = (p.heads + 3) / 4;
+    const size_t lds = L::CLS + 4 * (size_t)(BWD ? L::BWD_WAVE : L::FWD_WAVE);
+    if (lds > 160 * 1024) return HS_EUNSUPPORTED;
+    static bool attr_set = false;
+    if constexpr (BWD) {
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<HD, NT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+        hipLaunchKernelGGL((attn_bwd_kernel<HD, NT>), dim3(p.nsamples * hgroups), dim3(256), lds, s, p);
+    } else {
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<HD, NT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, NT>), dim3(p.nsamples * hgroups), dim3(256), lds, s, p);
+    }
+    return (int)hipGetLastError();
+}
+
+template <bool BWD>
+int dispatch(const AttnParams& p, hipStream_t s) {
+    if (p.nsamples <= 0) return HS_OK;
+    if (p.d != p.heads * p.hd || p.ld % 8 || p.ldo % 4) return HS_EDIMS;
+    const int nt = (p.Ts + 15) / 16;
+    if (p.hd == 16) {
+        if (nt <= 1) return launch_attn<16, 1, BWD>(p, s);
+        if (nt <= 2) return launch_attn<16, 2, BWD>(p, s);
+        if (nt <= 3) return launch_attn<16, 3, BWD>(p, s);
+        if (nt <= 4) return launch_attn<16, 4, BWD>(p, s);
+        if (nt <= 7) return launch_attn<16, 7, BWD>(p, s);
+    } else if (p.hd == 8) {
+        if (nt <= 1) return launch_attn<8, 1, BWD>(p, s);
+        if (nt <= 2) return launch_attn<8, 2, BWD>(p, s);
+        if (nt <= 3) return launch_attn<8, 3, BWD>(p, s);
+        if (nt <= 4) return launch_attn<8, 4, BWD>(p, s);
+        if (nt <= 7) return launch_attn<8, 7, BWD>(p, s);
+        if (nt <= 14) return launch_attn<8, 14, BWD>(p, s);
+    }
+    return HS_EUNSUPPORTED;
+}
+
+}  // namespace
+
+int hs_attn_fwd(const AttnParams& p, hipStream_t s) { return dispatch<false>(p, s); }
+int hs_attn_bwd(const AttnParams& p, hipStream_t s) { return dispatch<true>(p, s); }

@@ -1,0 +1,62 @@
+// Shared device helpers for the HSIMAE gfx950 kernels (wave = 64, MFMA 16x16x32 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define HS_WAVE 64
+
+// Error codes of the C ABI (include/hsimae_hip.h)
+#define HS_OK 0
+#define HS_EDIMS (-1)
+#define HS_EUNSUPPORTED (-2)
+#define HS_EALIGN (-3)
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    // D[16x16] += A[16x32] * B[32x16].  lane l: A[row l&15][k 8(l>>4)+j], B[k 8(l>>4)+j][col l&15];
+    // D: col = l&15, row = 4*(l>>4)+r.
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 zero8() {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    return __builtin_bit_cast(bf16x8, z);
+}
+
+__device__ __forceinline__ bf16x8 cvt8(const float* v) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (bf16_t)v[i];
+    return r;
+}
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Packed weight image ("wpk"): W[N][K] (row-major, K contiguous) zero-padded to NT=ceil(N/16)
+// n-tiles and KS=ceil(K/32) k-steps, stored in MFMA B-fragment order:
+//   element index ((nt*KS + ks)*64 + lane)*8 + j  holds  W[nt*16 + (lane&15)][ks*32 + 8*(lane>>4) + j]
+// so one wave-instruction of 16 B per lane reads one 1-KiB fragment fully coalesced.
+__host__ __device__ inline int64_t wpk_elems(int N, int K) {
+    return (int64_t)((N + 15) / 16) * ((K + 31) / 32) * 512;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,384 @@
+// HBM-bound glue kernels of the HSIMAE pretraining path: structured masking, patch gather,
+// LayerNorm backward, decoder sequence assembly (fwd/bwd), normalised-pixel MSE loss + recons.
+#include "common.h"
+#include "kernels.h"
+#include <algorithm>
+
+namespace {
+
+// ------------------------------------------------------------------ masking (Models.py:495-535, closed form)
+// One thread per sample: rank-select the len_t smallest of noise_1[n,:T] and the len_l smallest of
+// noise_2[n,:L] (ties: lower index wins), then emit ids_keep (ascending), ids_restore and mask.
+__global__ void mask_kernel(MaskParams p) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= p.N) return;
+    const float* n1 = p.noise1 + (size_t)n * p.T;
+    const float* n2 = p.noise2 + (size_t)n * p.L;
+    unsigned long long kt = 0ull, kl = 0ull;
+    for (int a = 0; a < p.T; ++a) {
+        const float v = n1[a];
+        int rank = 0;
+        for (int b = 0; b < p.T; ++b) {
+            const float w = n1[b];
+            rank += (w < v) || (w == v && b < a);
+        }
+        if (rank < p.len_t) kt |= 1ull << a;
+    }
+    for (int a = 0; a < p.L; ++a) {
+        const float v = n2[a];
+        int rank = 0;
+        for (int b = 0; b < p.L; ++b) {
+            const float w = n2[b];
+            rank += (w < v) || (w == v && b < a);
+        }
+        if (rank < p.len_l) kl |= 1ull << a;
+    }
+    const int TL = p.T * p.L, K = p.len_t * p.len_l;
+    const int c1 = p.len_t * (p.L - p.len_l) + (p.T - p.len_t) * p.len_l;
+    int cnt[3] = {0, K, K + c1};
+    int32_t* keep = p.ids_keep + (size_t)n * K;
+    int32_t* rest = p.ids_restore + (size_t)n * TL;
+    float* mask = p.mask + (size_t)n * TL;
+    for (int a = 0; a < p.T; ++a) {
+        const int ca = ((kt >> a) & 1ull) ? 0 : 1;
+        for (int b = 0; b < p.L; ++b) {
+            const int c = ca + (((kl >> b) & 1ull) ? 0 : 1);
+            const int i = a * p.L + b;
+            const int pos = cnt[c]++;
+            rest[i] = pos;
+            mask[i] = c ? 1.f : 0.f;
+            if (c == 0) keep[pos] = i;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ patch gather (Models.py:151-160 as a GEMM operand)
+// out[n*K + k][f] = x[n, 0, 8*tau + u, 3*i + p, 3*j + q],  f = 9u + 3p + q, token ids_keep[n,k] = 9*tau + 3*i + j
+__global__ __launch_bounds__(256) void patch_gather_kernel(PatchParams p) {
+    const int64_t total = (int64_t)p.N * p.K * 12;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / 12;
+        const int oct = (int)(idx % 12);
+        const int n = (int)(row / p.K);
+        bf16x8 v = zero8();
+        if (oct < 9) {
+            const int tok = p.ids_keep[row];
+            const int tau = tok / 9, sp = tok % 9, gi = sp / 3, gj = sp % 3;
+            const float* base = p.x + (size_t)n * p.sn;
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ft = oct * 8 + e;
+                const int u = ft / 9, pq = ft % 9, pp = pq / 3, q = pq % 3;
+                f[e] = base[(int64_t)(8 * tau + u) * p.sb + (int64_t)(3 * gi + pp) * p.sh + (int64_t)(3 * gj + q) * p.sw];
+            }
+            v = cvt8(f);
+        }
+        *reinterpret_cast<bf16x8*>(p.out + row * 96 + oct * 8) = v;
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+// One wave per row (d <= 512).  dx = dres + rstd * (g*du - mean(g*du) - xhat * mean(g*du*xhat));
+// dgamma += du * xhat, dbeta += du: per-lane partials over the workgroup's rows, one atomic per column per WG.
+constexpr int LN_ROWS_PER_WG = 64;
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
+    __shared__ float red[2][4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nper = (p.d + 63) / 64;
+    float dg[8], db[8], gam[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        dg[i] = 0.f; db[i] = 0.f;
+        const int c = lane + 64 * i;
+        gam[i] = (i < nper && c < p.d) ? p.gamma[c] : 0.f;
+    }
+    const int r0 = blockIdx.x * LN_ROWS_PER_WG;
+    const float invd = 1.f / (float)p.d;
+    for (int r = r0 + wave; r < min(r0 + LN_ROWS_PER_WG, p.M); r += 4) {
+        float x[8], du[8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            const bool ok = (i < nper) && (c < p.d);
+            x[i] = ok ? p.x[(size_t)r * p.d + c] : 0.f;
+            du[i] = ok ? p.du[(size_t)r * p.d + c] : 0.f;
+            s += x[i];
+        }
+        const float mean = wave_sum(s) * invd;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            const float dlt = ((i < nper) && (c < p.d)) ? x[i] - mean : 0.f;
+            x[i] = dlt;
+            q += dlt * dlt;
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invd + 1e-5f);
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x[i] *= rstd;                     // xhat
+            const float t = du[i] * gam[i];
+            a += t;
+            b += t * x[i];
+            dg[i] += du[i] * x[i];
+            db[i] += du[i];
+        }
+        a = wave_sum(a) * invd;
+        b = wave_sum(b) * invd;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            if (i < nper && c < p.d) {
+                float v = rstd * (du[i] * gam[i] - a - x[i] * b);
+                const size_t o = (size_t)r * p.d + c;
+                if (p.dres) v += p.dres[o];
+                if (p.accumulate) v += p.dx[o];
+                p.dx[o] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        red[0][wave][lane + 64 * i] = dg[i];
+        red[1][wave][lane + 64 * i] = db[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.d; c += 256) {
+        const float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        if (p.dgamma) atomicAdd(p.dgamma + c, g);
+        if (p.dbeta) atomicAdd(p.dbeta + c, b);
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float* gamma, const float* beta, float* out,
+                                                      int M, int d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= M) return;
+    float v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < d ? x[(size_t)r * d + c] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        const float dl = c < d ? v[i] - mean : 0.f;
+        q += dl * dl;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < d) out[(size_t)r * d + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+// ------------------------------------------------------------------ decoder sequence assembly (Models.py:579-592)
+// yfull[n,i,:] = (ids_restore[n,i] < K ? y[n, ids_restore[n,i], :] : mean_k y[n,k,:]) + decoder_pos_embed[i,:]
+__global__ __launch_bounds__(256) void assemble_fwd_kernel(AssembleParams p) {
+    __shared__ float meanv[512];
+    const int n = blockIdx.x;
+    const float* y = p.y + (size_t)n * p.K * p.Dd;
+    for (int c = threadIdx.x; c < p.Dd; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < p.K; ++k) s += y[(size_t)k * p.Dd + c];
+        meanv[c] = s / (float)p.K;
+    }
+    __syncthreads();
+    const int total = p.TL * p.Dd;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int i = e / p.Dd, c = e - i * p.Dd;
+        const int r = p.ids_restore[(size_t)n * p.TL + i];
+        const float v = (r < p.K) ? y[(size_t)r * p.Dd + c] : meanv[c];
+        p.yfull[((size_t)n * p.TL + i) * p.Dd + c] = v + p.pos[(size_t)i * p.Dd + c];
+    }
+}
+
+// dy[n,k,:] = dyfull[n, slot(k), :] + (1/K) * sum_{masked i} dyfull[n,i,:]      (bf16 out: GEMM / wgrad operand)
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(AssembleParams p) {
+    __shared__ float msum[512];
+    const int n = blockIdx.x;
+    const float* dyf = p.dyfull + (size_t)n * p.TL * p.Dd;
+    const int32_t* rest = p.ids_restore + (size_t)n * p.TL;
+    for (int c = threadIdx.x; c < p.Dd; c += 256) {
+        float s = 0.f;
+        for (int i = 0; i < p.TL; ++i)
+            if (rest[i] >= p.K) s += dyf[(size_t)i * p.Dd + c];
+        msum[c] = s / (float)p.K;
+    }
+    __syncthreads();
+    const int total = p.TL * p.Dd;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int i = e / p.Dd, c = e - i * p.Dd;
+        const int r = rest[i];
+        if (r < p.K) p.dy[((size_t)n * p.K + r) * p.Dd + c] = (bf16_t)(dyf[(size_t)i * p.Dd + c] + msum[c]);
+    }
+}
+
+// ------------------------------------------------------------------ loss + recons (Models.py:603-625)
+// One wave per token row; lanes own features f = lane and lane + 64 (< 72).
+constexpr int LOSS_ROWS_PER_WG = 32;
+
+__global__ __launch_bounds__(256) void loss_kernel(LossParams p) {
+    __shared__ float wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int TL = p.T * 9;
+    const int64_t M = (int64_t)p.N * TL;
+    const int64_t r0 = (int64_t)blockIdx.x * LOSS_ROWS_PER_WG;
+    float lacc = 0.f;
+    for (int64_t row = r0 + wave; row < min(r0 + (int64_t)LOSS_ROWS_PER_WG, M); row += 4) {
+        const int n = (int)(row / TL), tok = (int)(row % TL);
+        const int tau = tok / 9, sp = tok % 9, gi = sp / 3, gj = sp % 3;
+        const float* base = p.x + (size_t)n * p.sn;
+        float t[2], pr[2];
+        int64_t off[2];
+        float s = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ft = lane + 64 * h;
+            const bool ok = ft < 72;
+            const int u = ft / 9, pq = ft % 9, pp = pq / 3, q = pq % 3;
+            off[h] = (int64_t)(8 * tau + u) * p.sb + (int64_t)(3 * gi + pp) * p.sh + (int64_t)(3 * gj + q) * p.sw;
+            t[h] = ok ? base[off[h]] : 0.f;
+            pr[h] = ok ? p.pred[row * 72 + ft] : 0.f;
+            s += t[h];
+        }
+        float mean = 0.f, std = 1.f;
+        if (p.norm_pix) {
+            mean = wave_sum(s) * (1.f / 72.f);
+            float q2 = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float dlt = (lane + 64 * h < 72) ? t[h] - mean : 0.f;
+                q2 += dlt * dlt;
+            }
+            std = sqrtf(wave_sum(q2) * (1.f / 71.f) + 1.0e-6f);
+        }
+        const float mk = p.mask[row];
+        float e2 = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ft = lane + 64 * h;
+            if (ft < 72) {
+                const float tg = p.norm_pix ? (t[h] - mean) / std : t[h];
+                const float diff = pr[h] - tg;
+                e2 += diff * diff;
+                if (p.dpred) p.dpred[row * 96 + ft] = (bf16_t)(2.f * mk * diff * p.inv_scale);
+                if (p.pred_img) {
+                    // contiguous [N,1,B,9,9] output image
+                    const int u = ft / 9, pq = ft % 9, pp = pq / 3, q = pq % 3;
+                    const size_t o = ((size_t)n * p.T * 8 + (8 * tau + u)) * 81 + (3 * gi + pp) * 9 + (3 * gj + q);
+                    p.pred_img[o] = p.norm_pix ? pr[h] * std + mean : pr[h];
+                    p.mask_img[o] = mk;
+                }
+            } else if (ft < 96 && p.dpred) {
+                p.dpred[row * 96 + ft] = (bf16_t)0.f;
+            }
+        }
+        e2 = wave_sum(e2);
+        lacc += e2 * (1.f / 72.f) * mk;
+    }
+    if (lane == 0) wsum[wave] = lacc;
+    __syncthreads();
+    if (threadIdx.x == 0) p.partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void loss_final_kernel(const float* partial, int n, float sum_mask, float* loss) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(red[0] / (double)sum_mask);
+}
+
+__global__ __launch_bounds__(256) void add2_kernel(const float4* a, const float4* b, float4* o, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 x = a[i], y = b[i];
+        o[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+}
+
+}  // namespace
+
+int hs_mask(const MaskParams& p, hipStream_t s) {
+    if (p.N <= 0) return HS_OK;
+    if (p.T > 64 || p.L > 64 || p.len_t > p.T || p.len_l > p.L || p.len_t < 1 || p.len_l < 1) return HS_EDIMS;
+    hipLaunchKernelGGL(mask_kernel, dim3((p.N + 63) / 64), dim3(64), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+int hs_patch_gather(const PatchParams& p, hipStream_t s) {
+    if (p.N <= 0) return HS_OK;
+    const int64_t total = (int64_t)p.N * p.K * 12;
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(patch_gather_kernel, dim3(grid), dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+int hs_ln_bwd(const LnBwdParams& p, hipStream_t s) {
+    if (p.M <= 0) return HS_OK;
+    if (p.d > 512) return HS_EUNSUPPORTED;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((p.M + LN_ROWS_PER_WG - 1) / LN_ROWS_PER_WG), dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+int hs_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int M, int d, hipStream_t s) {
+    if (M <= 0) return HS_OK;
+    if (d > 512) return HS_EUNSUPPORTED;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, out, M, d);
+    return (int)hipGetLastError();
+}
+
+int hs_assemble_fwd(const AssembleParams& p, hipStream_t s) {
+    if (p.N <= 0) return HS_OK;
+    if (p.Dd > 512) return HS_EUNSUPPORTED;
+    hipLaunchKernelGGL(assemble_fwd_kernel, dim3(p.N), dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+int hs_assemble_bwd(const AssembleParams& p, hipStream_t s) {
+    if (p.N <= 0) return HS_OK;
+    if (p.Dd > 512) return HS_EUNSUPPORTED;
+    hipLaunchKernelGGL(assemble_bwd_kernel, dim3(p.N), dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+int hs_loss(const LossParams& p, hipStream_t s) {
+    const int64_t M = (int64_t)p.N * p.T * 9;
+    if (M <= 0) return HS_OK;
+    const int grid = (int)((M + LOSS_ROWS_PER_WG - 1) / LOSS_ROWS_PER_WG);
+    hipLaunchKernelGGL(loss_kernel, dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, p.partial, grid, p.sum_mask, p.loss);
+    return (int)hipGetLastError();
+}
+
+int hs_loss_partials(int N, int T) {
+    const int64_t M = (int64_t)N * T * 9;
+    return (int)((M + LOSS_ROWS_PER_WG - 1) / LOSS_ROWS_PER_WG);
+}
+
+int hs_add2(const float* a, const float* b, float* out, int64_t n, hipStream_t s) {
+    if (n <= 0) return HS_OK;
+    if (n % 4) return HS_EDIMS;
+    const int64_t n4 = n / 4;
+    const int grid = (int)std::min<int64_t>((n4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(add2_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(a),
+                       reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out), n4);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,126 @@
+// Weight gradients  dW[N][K] += sum_m dO[m][N] * A[m][K]  (contraction over the token rows) on MFMA.
+//
+// Both operands live token-major in HBM, so each 64-row chunk is transposed on its way into LDS
+// ([feature][row] images) and the MFMA fragments become 16-B contiguous LDS reads.  One workgroup owns
+// a 128x128 tile of dW for a slice of the rows (split-M), accumulates it in registers (16 accumulators
+// per wave) and commits it with fp32 atomics; bias gradients (column sums of dO) ride along.
+// Up to 8 linears are batched per launch (one transformer block's q/k/v, proj, w1, w3, w2).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int MC = 64;            // rows per chunk (2 k-steps)
+constexpr int TST = MC + 8;       // transposed LDS row stride (elements)
+
+__device__ __forceinline__ void stage_t(const void* src, bool f32, int ld, int ncols8, int M, int m0, int c0,
+                                        bf16_t* img, int tid) {
+    // img[f][m] = src[m0 + m][c0 + f] for f in [0,128), m in [0,64)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx >> 4, c8 = (idx & 15) * 8;
+        const int row = m0 + r, col = c0 + c8;
+        bf16x8 v = zero8();
+        if (row < M && col < ncols8) {
+            if (f32) {
+                const float* s = reinterpret_cast<const float*>(src) + (size_t)row * ld + col;
+                const float4 x0 = *reinterpret_cast<const float4*>(s);
+                const float4 x1 = *reinterpret_cast<const float4*>(s + 4);
+                const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                v = cvt8(f);
+            } else {
+                v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(src) + (size_t)row * ld + col);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) img[(c8 + e) * TST + r] = v[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t dOt[128 * TST];
+    __shared__ __attribute__((aligned(16))) bf16_t At[128 * TST];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // decode (task, n-slab, k-slab, m-split)
+    int w = blockIdx.x / p.msplit;
+    const int ms = blockIdx.x % p.msplit;
+    int ti = 0, ns = 0, ks = 0;
+    for (; ti < p.ntasks; ++ti) {
+        const int nsl = (p.t[ti].N + 127) / 128, ksl = (p.t[ti].K + 127) / 128;
+        if (w < nsl * ksl) { ns = w / ksl; ks = w % ksl; break; }
+        w -= nsl * ksl;
+    }
+    if (ti >= p.ntasks) return;
+    const WgradTask t = p.t[ti];
+    const int n0 = ns * 128, k0 = ks * 128;
+    const int nchunks = (p.M + MC - 1) / MC;
+    const int cpw = (nchunks + p.msplit - 1) / p.msplit;
+    const int cbeg = ms * cpw, cend = min(nchunks, cbeg + cpw);
+    const int n8 = (t.N + 7) & ~7, k8 = (t.K + 7) & ~7;
+    const bool want_bias = (t.db != nullptr) && (ks == 0);
+
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const int c16 = lane & 15, g = lane >> 4;
+
+    for (int c = cbeg; c < cend; ++c) {
+        const int m0 = c * MC;
+        __syncthreads();
+        stage_t(t.dO, t.dO_f32 != 0, t.ldo, n8, p.M, m0, n0, dOt, tid);
+        stage_t(t.A, false, t.lda, k8, p.M, m0, k0, At, tid);
+        __syncthreads();
+        if (want_bias && tid < 128) {
+#pragma unroll
+            for (int i = 0; i < MC / 8; ++i) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(dOt + tid * TST + i * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum += bf2f(v[e]);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < MC / 32; ++kk) {
+            bf16x8 a[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                a[i] = *reinterpret_cast<const bf16x8*>(dOt + ((wave * 2 + i) * 16 + c16) * TST + kk * 32 + g * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(At + (j * 16 + c16) * TST + kk * 32 + g * 8);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = mfma16(a[i], b, acc[i][j]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + (wave * 2 + i) * 16 + g * 4 + r;
+                const int k = k0 + j * 16 + c16;
+                if (n < t.N && k < t.K) atomicAdd(t.dW + (size_t)n * t.ldw + k, acc[i][j][r]);
+            }
+    if (want_bias && tid < 128 && n0 + tid < t.N) atomicAdd(t.db + n0 + tid, bsum);
+}
+
+}  // namespace
+
+int hs_wgrad(const WgradParams& p, hipStream_t s) {
+    if (p.ntasks <= 0 || p.M <= 0) return HS_OK;
+    if (p.ntasks > 8 || p.msplit < 1) return HS_EDIMS;
+    int tiles = 0;
+    for (int i = 0; i < p.ntasks; ++i) {
+        if (p.t[i].ldo % 8 || p.t[i].lda % 8) return HS_EDIMS;
+        tiles += ((p.t[i].N + 127) / 128) * ((p.t[i].K + 127) / 128);
+    }
+    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * p.msplit), dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,428 @@
+"""`HSIMAE` — the reference's masked-autoencoder module surface on hand-written gfx950 kernels.
+
+Drop-in for `Models.HSIMAE` (reference Models.py:309-634) on the *pretraining* path: same constructor
+signature and defaults, same submodule / parameter tree (so `state_dict()` has the reference's 535 keys,
+shapes and dtypes and a checkpoint loads into the reference's `Model_Finetuning.py` unchanged), same
+`forward(imgs, mask_ratio) -> (loss, pred, mask)` contract, gradients left on the same Parameter objects.
+
+The nn.Conv3d / nn.Linear / nn.LayerNorm children are parameter containers only; all arithmetic runs in
+`libhsimae_hip.so` (see include/hsimae_hip.h).  There is no CPU or eager-PyTorch fallback: tensors that are
+not on a GPU, or a missing library, raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import itertools
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+__all__ = ["HSIMAE", "swiglu_hidden", "sincos_table"]
+
+
+def swiglu_hidden(dim: int, mlp_ratio: float) -> int:
+    """Hidden width of the gated MLP as the reference wires it (Models.py:225 via 300-301)."""
+    hidden = int(dim * mlp_ratio)
+    return int(mlp_ratio * ((2 * hidden // 3 + mlp_ratio - 1) // mlp_ratio))
+
+
+def _sincos_axis(width: int, coords: np.ndarray) -> np.ndarray:
+    freq = np.arange(width // 2, dtype=np.float32)
+    freq /= width / 2.0
+    freq = 1.0 / 10000 ** freq
+    phase = np.einsum("m,d->md", coords.reshape(-1), freq)
+    return np.concatenate([np.sin(phase), np.cos(phase)], axis=1)
+
+
+def sincos_table(dim: int, t_size: int, grid: int) -> torch.Tensor:
+    """Frozen 3-D sin-cos position table [1, t_size*grid^2, dim] (reference Models.py:11-47):
+    first half of the channels encodes the spectral index, second half the (w, h) grid position."""
+    assert dim % 4 == 0
+    half = dim // 2
+    gw, gh = np.meshgrid(np.arange(grid, dtype=np.float32), np.arange(grid, dtype=np.float32))
+    spatial = np.concatenate([_sincos_axis(half // 2, gw), _sincos_axis(half // 2, gh)], axis=1)
+    spectral = _sincos_axis(half, np.arange(t_size, dtype=np.float32))
+    full = np.concatenate([np.repeat(spectral[:, None, :], grid * grid, axis=1),
+                           np.repeat(spatial[None, :, :], t_size, axis=0)], axis=-1)
+    return torch.tensor(full.reshape(-1, dim), dtype=torch.float).unsqueeze(0)
+
+
+# ----------------------------------------------------------------------------- parameter containers
+class PatchEmbed(nn.Module):
+    """Holds `proj` = Conv3d(in_chans, D, k=s=(b_patch, p, p)) (reference Models.py:104-149)."""
+
+    def __init__(self, img_size, patch_size, bands, b_patch_size, in_chans, embed_dim):
+        super().__init__()
+        assert img_size % patch_size == 0
+        assert bands % b_patch_size == 0
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.bands, self.b_patch_size = bands, b_patch_size
+        self.grid_size = img_size // patch_size
+        self.b_grid_size = bands // b_patch_size
+        self.input_size = (self.b_grid_size, self.grid_size, self.grid_size)
+        self.num_patches = self.b_grid_size * self.grid_size ** 2
+        print(f"img_size {self.img_size} patch_size {self.patch_size} bands {bands} b_patch_size {b_patch_size}")
+        ks = [b_patch_size, patch_size, patch_size]
+        self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=ks, stride=ks)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias):
+        super().__init__()
+        assert dim % num_heads == 0, "dim should be divisible by num_heads"
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.k = nn.Linear(dim, dim, bias=qkv_bias)
+        self.v = nn.Linear(dim, dim, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class SwiGLU(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.w1 = nn.Linear(dim, hidden, bias=True)
+        self.w2 = nn.Linear(hidden, dim, bias=True)
+        self.w3 = nn.Linear(dim, hidden, bias=True)
+
+
+class Block(nn.Module):
+    """Pre-LN residual block parameters: norm1, attn, norm2, mlp (reference Models.py:269-301)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias, norm_layer):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads, qkv_bias)
+        self.norm2 = norm_layer(dim)
+        self.mlp = SwiGLU(dim, swiglu_hidden(dim, mlp_ratio))
+
+
+class _Step(torch.autograd.Function):
+    """Whole forward / whole backward as one autograd node; parameter grads are written by the kernels
+    into the model's flat gradient buffer and attached to the Parameters directly."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, imgs, ratio, noise, grid):
+        loss, pred, mask, state = model._run_forward(imgs, ratio, noise, grid, want_latent=False)
+        ctx.model, ctx.state = model, state
+        ctx.mark_non_differentiable(pred, mask)
+        return loss, pred, mask
+
+    @staticmethod
+    def backward(ctx, g_loss, g_pred, g_mask):
+        ctx.model._run_backward(ctx.state, g_loss)
+        return None, None, None, None, None, None
+
+
+class HSIMAE(nn.Module):
+    """Masked autoencoder for 9x9xB hyperspectral cubes, MI355X-native."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16,
+                 decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4.0,
+                 norm_layer=nn.LayerNorm, norm_pix_loss=False, bands=16, b_patch_size=4, no_qkv_bias=False,
+                 trunc_init=False, s_depth=6, **kwargs):
+        super().__init__()
+        self.dim, self.dec_dim = embed_dim, decoder_embed_dim
+        self.s_depth, self.depth = s_depth, depth
+        self.b_pred_patch_size = b_patch_size
+        self.trunc_init, self.norm_pix_loss = trunc_init, norm_pix_loss
+        self.num_heads, self.decoder_num_heads = num_heads, decoder_num_heads
+        self.mlp_ratio, self.in_chans = mlp_ratio, in_chans
+        self._norm_layer, self._no_qkv_bias = norm_layer, no_qkv_bias
+
+        self.patch_embed = PatchEmbed(img_size, patch_size, bands, b_patch_size, in_chans, embed_dim)
+        self.input_size = self.patch_embed.input_size
+        n_tok = self.patch_embed.num_patches
+        self.pos_embed = nn.Parameter(torch.zeros(1, n_tok, embed_dim))
+
+        def stack(n, dim, heads):
+            return nn.ModuleList([Block(dim, heads, mlp_ratio, not no_qkv_bias, norm_layer) for _ in range(n)])
+
+        if s_depth > 0:
+            self.blocks_1 = stack(s_depth, embed_dim, num_heads)
+            self.blocks_2 = stack(s_depth, embed_dim, num_heads)
+        if s_depth < 12:                                   # the reference hard-codes 12 here (Models.py:385)
+            self.blocks = stack(max(0, depth - s_depth), embed_dim, num_heads)
+        self.norm = norm_layer(embed_dim)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, decoder_embed_dim))   # kept for the wire format; unused
+        self.decoder_embed = nn.Linear(embed_dim, decoder_embed_dim, bias=True)
+        self.decoder_pos_embed = nn.Parameter(torch.zeros(1, n_tok, decoder_embed_dim))
+        self.decoder_blocks = stack(decoder_depth, decoder_embed_dim, decoder_num_heads)
+        self.decoder_norm = norm_layer(decoder_embed_dim)
+        self.decoder_pred = nn.Linear(decoder_embed_dim, b_patch_size * patch_size ** 2 * in_chans, bias=True)
+        self.initialize_weights()
+
+        # runtime state (not part of the state_dict)
+        self._flat = self._flat_grad = self._wpk = self._pack_table = self._ws = None
+        self._cfg = None
+        self._packed_version = -1
+        self._anchor = None
+        self._reducer = None
+        self.want_recons = True
+        self.len_t = self.len_l = None
+        print("model initialized")
+
+    # ------------------------------------------------------------------ init (reference Models.py:429-459)
+    def initialize_weights(self):
+        t, g = self.input_size[0], self.input_size[1]
+        self.pos_embed.data.copy_(sincos_table(self.dim, t, g))
+        self.decoder_pos_embed.data.copy_(sincos_table(self.dec_dim, t, g))
+        self.pos_embed.requires_grad = False
+        self.decoder_pos_embed.requires_grad = False
+        w = self.patch_embed.proj.weight.data
+        if self.trunc_init:
+            nn.init.trunc_normal_(w)
+            nn.init.trunc_normal_(self.mask_token, std=0.02)
+        else:
+            nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+            nn.init.normal_(self.mask_token, std=0.02)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            if self.trunc_init:
+                nn.init.trunc_normal_(m.weight, std=0.02)
+            else:
+                nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # ------------------------------------------------------------------ pure index maps (Models.py:461-482)
+    def patchify(self, imgs):
+        N, _, T, H, W = imgs.shape
+        p, u = self.patch_embed.patch_size[0], self.b_pred_patch_size
+        assert H == W and H % p == 0 and T % u == 0
+        h = w = H // p
+        t = T // u
+        x = imgs.reshape(N, t, u, h, p, w, p).permute(0, 1, 3, 5, 2, 4, 6)
+        self.patch_info = (N, T, H, W, p, u, t, h, w)
+        return x.reshape(N, t * h * w, u * p * p)
+
+    def unpatchify(self, x):
+        N, T, H, W, p, u, t, h, w = self.patch_info
+        x = x.reshape(N, t, h, w, u, p, p).permute(0, 1, 4, 2, 5, 3, 6)
+        return x.reshape(N, 1, T, H, W)
+
+    # ------------------------------------------------------------------ host-side grid choice (Models.py:484-493)
+    _cand_cache: dict = {}
+
+    @classmethod
+    def grid_candidates(cls, T, L, mask_ratio):
+        key = (T, L, float(mask_ratio))
+        if key not in cls._cand_cache:
+            pairs = list(itertools.product(range(2, T + 1), range(2, L + 1)))
+            target = (1 - mask_ratio) * T * L
+            dist = abs(target - torch.tensor([a * b for a, b in pairs]))      # fp32, as the reference computes it
+            best = torch.where(dist == torch.min(dist))[0].tolist()
+            cls._cand_cache[key] = [pairs[i] for i in best]
+        return cls._cand_cache[key]
+
+    def get_dim_patches(self, T, L, mask_ratio):
+        """One python-`random` draw per call, even with a single candidate (keeps the RNG stream)."""
+        cands = self.grid_candidates(T, L, mask_ratio)
+        return cands[random.sample(range(len(cands)), 1)[0]]
+
+    # ------------------------------------------------------------------ device-side plumbing
+    def _check_supported(self):
+        pe = self.patch_embed
+        if (pe.img_size[0] != 9 or pe.patch_size[0] != 3 or self.b_pred_patch_size != 8 or self.in_chans != 1):
+            raise NotImplementedError("hsimae_amd kernels are built for img_size=9, patch_size=3, b_patch_size=8, in_chans=1")
+        if self._no_qkv_bias:
+            raise NotImplementedError("no_qkv_bias=True is not supported by the gfx950 kernels")
+        if self._norm_layer is not nn.LayerNorm:
+            raise NotImplementedError("only norm_layer=nn.LayerNorm is supported by the gfx950 kernels")
+
+    def _config(self) -> _lib.Config:
+        if self._cfg is None:
+            self._check_supported()
+            depth = self.depth
+            self._cfg = _lib.Config(
+                bands=self.patch_embed.bands, embed_dim=self.dim, depth=depth, s_depth=self.s_depth,
+                num_heads=self.num_heads, dec_dim=self.dec_dim, dec_depth=len(self.decoder_blocks),
+                dec_heads=self.decoder_num_heads, hidden=swiglu_hidden(self.dim, self.mlp_ratio),
+                dec_hidden=swiglu_hidden(self.dec_dim, self.mlp_ratio), norm_pix_loss=int(bool(self.norm_pix_loss)))
+        return self._cfg
+
+    def _plist(self):
+        return [p for _, p in self.named_parameters()]
+
+    def _ensure_flat(self, device):
+        """Re-home every Parameter as a view of one flat fp32 buffer in registration order (the layout
+        hsimae_param_layout() defines) so kernels address parameters and gradients by offset."""
+        params = self._plist()
+        if (self._flat is not None and self._flat.device == device and
+                params[0].data_ptr() == self._flat.data_ptr() and
+                params[-1].data_ptr() == self._flat.data_ptr() + 4 * (self._flat.numel() - params[-1].numel())):
+            return
+        lib, cfg = _lib.load(), self._config()
+        n = len(params)
+        offs, sizes = (C.c_int64 * n)(), (C.c_int64 * n)()
+        cnt = lib.hsimae_param_layout(C.byref(cfg), offs, sizes, n)
+        if cnt < 0:
+            _lib.check(cnt, "hsimae_param_layout")
+        if cnt != n or any(sizes[i] != params[i].numel() for i in range(n)):
+            raise RuntimeError("parameter tree does not match the kernel library's layout")
+        total = offs[n - 1] + sizes[n - 1]
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+        for i, p in enumerate(params):
+            if p.dtype != torch.float32:
+                raise RuntimeError("hsimae_amd keeps fp32 master parameters; found " + str(p.dtype))
+            view = flat[offs[i]: offs[i] + sizes[i]].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+        self._flat, self._offs, self._sizes = flat, list(offs), list(sizes)
+        self._flat_grad = torch.zeros_like(flat)
+        self._flat_scratch = torch.zeros_like(flat)
+        self._grad_views = [self._flat_grad[o: o + s].view(p.shape) for o, s, p in zip(self._offs, self._sizes, params)]
+        self._trainable = [i for i, p in enumerate(params) if p.requires_grad and i != 1]   # 1 = mask_token (never used)
+        self._params_cache = params
+        wpk_elems = lib.hsimae_wpk_elems(C.byref(cfg))
+        self._wpk = torch.zeros(wpk_elems, dtype=torch.bfloat16, device=device)
+        tb = lib.hsimae_pack_table_bytes(C.byref(cfg))
+        host = torch.empty(tb, dtype=torch.uint8)
+        _lib.check(lib.hsimae_build_pack_table(C.byref(cfg), flat.data_ptr(), self._wpk.data_ptr(), host.data_ptr()),
+                   "hsimae_build_pack_table")
+        self._pack_table = host.to(device)
+        self._packed_version = -1
+        self._anchor = torch.zeros((), device=device, requires_grad=True)
+
+    def _ensure_packed(self, stream):
+        ver = sum(p._version for p in self._params_cache)
+        if ver != self._packed_version:
+            _lib.check(_lib.load().hsimae_pack_params(C.byref(self._config()), self._pack_table.data_ptr(), stream),
+                       "hsimae_pack_params")
+            self._packed_version = ver
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ------------------------------------------------------------------ forward / backward drivers
+    def _run_forward(self, imgs, mask_ratio, noise, grid, want_latent):
+        if not imgs.is_cuda:
+            raise RuntimeError("hsimae_amd.HSIMAE runs on MI355X only (no CPU fallback): move the model and inputs to a GPU")
+        if imgs.dim() != 5 or imgs.shape[1] != 1 or imgs.shape[2] != self.patch_embed.bands or imgs.shape[3:] != (9, 9):
+            raise ValueError(f"expected imgs [N,1,{self.patch_embed.bands},9,9], got {tuple(imgs.shape)}")
+        if imgs.dtype != torch.float32:
+            imgs = imgs.float()
+        dev = imgs.device
+        lib, cfg = _lib.load(), self._config()
+        self._ensure_flat(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        self._ensure_packed(stream)
+        N, T, L = imgs.shape[0], self.input_size[0], self.input_size[1] ** 2
+        # RNG order of the reference: python random (grid), then rand(N,T), then rand(N,L)  (Models.py:501-513)
+        len_t, len_l = grid if grid is not None else self.get_dim_patches(T, L, mask_ratio)
+        if noise is None:
+            n1 = torch.rand(N, T, device=dev)
+            n2 = torch.rand(N, L, device=dev)
+        else:
+            n1 = noise[0].to(device=dev, dtype=torch.float32).contiguous()
+            n2 = noise[1].to(device=dev, dtype=torch.float32).contiguous()
+        self.len_t, self.len_l = int(len_t), int(len_l)
+        K, TL = self.len_t * self.len_l, T * L
+        self.patch_embed.output_size = torch.Size([N, T, L, self.dim])
+        self.patch_info = (N, imgs.shape[2], 9, 9, 3, 8, T, 3, 3)
+
+        nbytes = lib.hsimae_workspace_bytes(C.byref(cfg), N, self.len_t, self.len_l)
+        if nbytes < 0:
+            raise RuntimeError("hsimae_workspace_bytes: unsupported configuration")
+        ws = self._workspace(nbytes + 256, dev)
+        ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        mask = torch.empty(N, TL, dtype=torch.float32, device=dev)
+        ids_keep = torch.empty(N, K, dtype=torch.int32, device=dev)
+        ids_restore = torch.empty(N, TL, dtype=torch.int32, device=dev)
+        pred_img = mask_img = None
+        if self.want_recons:
+            pred_img = torch.empty(N, 1, imgs.shape[2], 9, 9, dtype=torch.float32, device=dev)
+            mask_img = torch.empty_like(pred_img)
+        latent = torch.empty(N, K, self.dim, dtype=torch.float32, device=dev) if want_latent else None
+        world = self._reducer.world_size if self._reducer is not None else 1
+        io = _lib.IO(
+            x=imgs.data_ptr(), sn=imgs.stride(0), sb=imgs.stride(2), sh=imgs.stride(3), sw=imgs.stride(4),
+            N=N, len_t=self.len_t, len_l=self.len_l, noise1=n1.data_ptr(), noise2=n2.data_ptr(),
+            params=self._flat.data_ptr(), wpk=self._wpk.data_ptr(), workspace=ws_ptr, workspace_bytes=nbytes,
+            grad_scale=1.0 / world, want_recons=int(self.want_recons), loss=loss.data_ptr(),
+            pred_img=_lib.ptr(pred_img), mask_img=_lib.ptr(mask_img), mask=mask.data_ptr(),
+            ids_keep=ids_keep.data_ptr(), ids_restore=ids_restore.data_ptr(), latent=_lib.ptr(latent), pred=None)
+        _lib.check(lib.hsimae_forward(C.byref(cfg), C.byref(io), stream), "hsimae_forward")
+        state = {"io": io, "keep": (imgs, n1, n2, mask, ids_keep, ids_restore, ws), "latent": latent,
+                 "ids_keep": ids_keep, "ids_restore": ids_restore, "mask": mask}
+        if pred_img is None:
+            pred_img = torch.empty(0, device=dev)
+            mask_img = torch.empty(0, device=dev)
+        return loss, pred_img, mask_img, state
+
+    def _run_backward(self, state, g_loss):
+        lib, cfg = _lib.load(), self._config()
+        dev = self._flat.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        params = self._params_cache
+        scratch = self._flat_scratch
+        scratch.zero_()                       # weight grads are accumulated with atomics
+        red = self._reducer
+        cb = red.make_callback(scratch) if red is not None else _lib.BUCKET_CB(0)
+        _lib.check(lib.hsimae_backward(C.byref(cfg), C.byref(state["io"]), scratch.data_ptr(), cb, None, stream),
+                   "hsimae_backward")
+        if red is not None:
+            red.finish()
+        # chain rule with d/d(loss) handed in by autograd (1.0 for loss.backward()), then .grad semantics:
+        # assign when the grads were cleared, accumulate otherwise.
+        if params[self._trainable[0]].grad is None:
+            torch.mul(scratch, g_loss, out=self._flat_grad)
+            for i in self._trainable:
+                params[i].grad = self._grad_views[i]
+        else:
+            self._flat_grad.addcmul_(scratch, g_loss)
+
+    # ------------------------------------------------------------------ public API (reference Models.py:537-634)
+    def forward(self, imgs, mask_ratio=0.75, noise=None, grid=None):
+        """-> (loss, pred [N,1,B,9,9], mask [N,1,B,9,9]).  `noise=(noise_1 [N,T], noise_2 [N,9])` and
+        `grid=(len_t, len_l)` optionally replace the RNG draws (parity tests)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if imgs.is_cuda:
+                self._ensure_flat(imgs.device)
+            anchor = self._anchor if self._anchor is not None else torch.zeros((), requires_grad=True)
+            return _Step.apply(anchor, self, imgs, mask_ratio, noise, grid)
+        loss, pred, mask, _ = self._run_forward(imgs, mask_ratio, noise, grid, want_latent=False)
+        return loss, pred, mask
+
+    def forward_encoder(self, x, mask_ratio, noise=None, grid=None):
+        """-> (latent [N,K,D], mask [N,TL], ids_restore [N,TL] int64, ids_keep [N,K] int64); inference only."""
+        with torch.no_grad():
+            _, _, _, st = self._run_forward(x, mask_ratio, noise, grid, want_latent=True)
+        return st["latent"], st["mask"], st["ids_restore"].long(), st["ids_keep"].long()
+
+    def forward_decoder(self, x, ids_restore):
+        raise NotImplementedError("stand-alone forward_decoder is not part of the pretraining hot path; use forward()")
+
+    def forward_loss(self, imgs, pred, mask):
+        raise NotImplementedError("stand-alone forward_loss is not part of the pretraining hot path; use forward()")
+
+    # ------------------------------------------------------------------ data parallel (not in the reference)
+    def enable_data_parallel(self, process_group=None, bucket_bytes=4 << 20, broadcast=True):
+        """One process per GPU: average gradients over the group with bucketed RCCL all-reduce launched from
+        inside the backward schedule (overlapped with the remaining backward kernels)."""
+        from .parallel import GradReducer
+        self._reducer = GradReducer(process_group, bucket_bytes)
+        if broadcast:
+            dev = next(self.parameters()).device
+            if dev.type == "cuda":
+                self._ensure_flat(dev)
+                self._reducer.broadcast(self._flat)
+                self._packed_version = -1
+            else:
+                for p in self.parameters():
+                    self._reducer.broadcast(p.data)
+        return self

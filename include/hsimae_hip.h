@@ -1,0 +1,215 @@
+/* libhsimae_hip.so — C ABI of the MI355X (gfx950) kernels behind the HSIMAE pretraining path.
+ *
+ * The reference (Ryan21wy/HSIMAE) has no native code: its "operator API" for this path is the
+ * `HSIMAE` nn.Module (Models.py:309-634) whose forward dispatches ~700 ATen kernels and whose
+ * backward is autograd.  A reference-side integration binds the entry points below with ctypes
+ *  in place of those ATen calls.  Every entry point names the reference
+ * lines it replaces.
+ *
+ * Contract
+ *  - every pointer is device memory owned by the caller (PyTorch tensors); the library never
+ *    allocates, frees or retains device memory and keeps no global mutable state;
+ *  - all work is enqueued on the caller's `stream` (hipStream_t passed as void*), no implicit sync;
+ *  - return 0 on success; <0 argument errors (HSIMAE_E*); >0 a hipError_t from the launch.
+ *    Nothing throws or exits across the boundary.  hsimae_strerror() names a code.
+ *  - bf16 buffers are raw 16-bit words (`hs_bf16`); activation buffers that feed a GEMM as its
+ *    K operand are zero-padded to a multiple of 32 columns by the kernel that produces them.
+ */
+#ifndef HSIMAE_HIP_H
+#define HSIMAE_HIP_H
+#include <stdint.h>
+
+#ifdef __HIPCC__
+typedef __bf16 hs_bf16;
+#else
+typedef uint16_t hs_bf16;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSIMAE_OK 0
+#define HSIMAE_EDIMS (-1)        /* bad dimensions / strides */
+#define HSIMAE_EUNSUPPORTED (-2) /* configuration outside what the kernels are built for */
+#define HSIMAE_EALIGN (-3)       /* misaligned pointer */
+#define HSIMAE_ENULL (-4)        /* required pointer is NULL */
+
+int hsimae_version(void);
+const char* hsimae_strerror(int code);
+
+/* ------------------------------------------------------------------ model geometry */
+/* Mirrors the HSIMAE constructor arguments that shape the tensors (Models.py:312-332) for the
+ * supported family: img_size 9, patch_size 3, b_patch_size 8, in_chans 1, qkv bias on. */
+typedef struct {
+    int32_t bands;          /* B, multiple of 8; T = B/8 */
+    int32_t embed_dim;      /* D */
+    int32_t depth;          /* total encoder depth */
+    int32_t s_depth;        /* depth of each axis stack (blocks_1 / blocks_2) */
+    int32_t num_heads;
+    int32_t dec_dim;        /* Dd */
+    int32_t dec_depth;
+    int32_t dec_heads;
+    int32_t hidden;         /* SwiGLU hidden of the encoder blocks (Models.py:225) */
+    int32_t dec_hidden;
+    int32_t norm_pix_loss;
+} hsimae_config;
+
+/* Flat fp32 parameter buffer: parameters in `named_parameters()` registration order
+ * (Models.py:342-424), each contiguous, no padding.  Returns the number of parameter tensors;
+ * offsets[i]/sizes[i] (in floats) are filled when non-NULL. Total floats = offsets[n-1]+sizes[n-1]. */
+int hsimae_param_layout(const hsimae_config* cfg, int64_t* offsets, int64_t* sizes, int max_entries);
+
+/* bf16 packed weight images (MFMA B-fragment order; W and W^T of every linear). */
+int64_t hsimae_wpk_elems(const hsimae_config* cfg);
+/* Host-side descriptor table for hsimae_pack_params: fill `table_host` (size from
+ * hsimae_pack_table_bytes) for the given device pointers; the caller uploads it to the device. */
+int64_t hsimae_pack_table_bytes(const hsimae_config* cfg);
+int hsimae_build_pack_table(const hsimae_config* cfg, const float* params_dev, hs_bf16* wpk_dev, void* table_host);
+/* fp32 master weights -> packed bf16 images; run after every optimizer step. */
+int hsimae_pack_params(const hsimae_config* cfg, const void* table_dev, void* stream);
+
+/* ------------------------------------------------------------------ whole-pass entry points */
+/* Replaces HSIMAE.forward (Models.py:627-634): forward_encoder 537-571, forward_decoder 573-601,
+ * forward_loss 603-616, recons 618-625; and, for hsimae_backward, the autograd backward of all
+ * of it (Model_Pretraining.py:101). */
+typedef struct {
+    const float* x;               /* [N,1,B,9,9] fp32 cube, arbitrary strides (elements) */
+    int64_t sn, sb, sh, sw;
+    int32_t N, len_t, len_l;      /* grid drawn on the host (Models.py:484-493) */
+    const float* noise1;          /* [N,T]  (Models.py:506) */
+    const float* noise2;          /* [N,9]  (Models.py:513) */
+    const float* params;          /* flat fp32 parameters */
+    const hs_bf16* wpk;           /* packed images */
+    void* workspace;              /* hsimae_workspace_bytes() bytes, 256-B aligned */
+    int64_t workspace_bytes;
+    float grad_scale;             /* folded into dLoss/dpred (1/world_size for data parallel) */
+    int32_t want_recons;          /* write pred_img / mask_img */
+    /* outputs */
+    float* loss;                  /* [1] */
+    float* pred_img;              /* [N,1,B,9,9] contiguous */
+    float* mask_img;              /* [N,1,B,9,9] contiguous */
+    float* mask;                  /* [N,T*9] 0 keep / 1 remove */
+    int32_t* ids_keep;            /* [N,K] ascending */
+    int32_t* ids_restore;         /* [N,T*9] */
+    float* latent;                /* optional [N*K, D] fp32 copy of the encoder output (may be NULL) */
+    float* pred;                  /* optional [N*T*9, 72] fp32 copy of decoder_pred output (may be NULL) */
+} hsimae_io;
+
+int64_t hsimae_workspace_bytes(const hsimae_config* cfg, int32_t N, int32_t len_t, int32_t len_l);
+int hsimae_forward(const hsimae_config* cfg, const hsimae_io* io, void* stream);
+
+/* Called on the host thread right after the kernels that complete the gradients of
+ * grads[off, off+len) have been enqueued (reverse registration order, so buckets are contiguous
+ * suffixes of the flat buffer).  Used to start the RCCL all-reduce of that bucket on a side stream. */
+typedef void (*hsimae_bucket_cb)(int32_t stage, int64_t off, int64_t len, void* user);
+/* grads: flat fp32 buffer, same layout as params, zeroed by the caller (weight grads are
+ * accumulated with atomics). */
+int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads, hsimae_bucket_cb cb, void* user,
+                    void* stream);
+
+/* ------------------------------------------------------------------ per-kernel entry points */
+/* Structured random masking, closed form of Models.py:495-535 (bit-exact given the noise). */
+typedef struct {
+    const float* noise1; const float* noise2; int32_t N, T, L, len_t, len_l;
+    int32_t* ids_keep; int32_t* ids_restore; float* mask;
+} hsimae_mask_params;
+int hsimae_mask_from_noise(const hsimae_mask_params* p, void* stream);
+
+/* Kept-token patch rows of the cube as a bf16 GEMM operand [N*K, 96] (Conv3d k=s=(8,3,3) == GEMM
+ * with K=72, Models.py:147-158; selection Models.py:527-528 fused in). */
+typedef struct {
+    const float* x; int64_t sn, sb, sh, sw; int32_t N, T, K; const int32_t* ids_keep;
+    hs_bf16* out; int32_t* pos_ids;
+} hsimae_patch_params;
+int hsimae_patch_gather(const hsimae_patch_params* p, void* stream);
+
+/* Row-panel MFMA GEMM out = epi(pro(A) * W^T) — every nn.Linear of Attention/SwiGLU/Block
+ * (Models.py:180-184, 226-228, 402, 420) with LayerNorm (Models.py:288, 299, 399, 419) fused
+ * as prologue and bias / residual / SiLU-gate (Models.py:232, 304-305) as epilogue. */
+enum { HSIMAE_A_BF16 = 0, HSIMAE_A_F32 = 1, HSIMAE_A_F32_LN = 2 };
+enum { HSIMAE_E_BF16 = 0, HSIMAE_E_F32 = 1, HSIMAE_E_RES_F32 = 2, HSIMAE_E_POS_F32 = 3, HSIMAE_E_SWIGLU = 4,
+       HSIMAE_E_SWIGLU_BWD = 5 };
+typedef struct {
+    const void* A; int32_t lda;
+    int32_t M, N, K;
+    int32_t n_valid;
+    const hs_bf16* W; const hs_bf16* W2;
+    const float* bias; const float* bias2;
+    const float* gamma; const float* beta;
+    float* stats;
+    hs_bf16* u_out; int32_t ldu;
+    void* out; int32_t ldo;
+    const float* res; const float* res2; int32_t ldr;
+    const float* pos; const int32_t* ids; int32_t ldpos;
+    hs_bf16* h13; int32_t ldh; int32_t hoff;
+} hsimae_gemm_params;
+int hsimae_gemm(const hsimae_gemm_params* p, int32_t a_kind, int32_t epilogue, void* stream);
+
+/* One fp32 matrix -> packed image (placement n_off/k_off lets q|k|v or w1|w3 share an image). */
+typedef struct {
+    const float* src; int32_t rows, cols;
+    int32_t transpose;
+    int32_t n_off, k_off;
+    int32_t KS;
+    hs_bf16* dst;
+} hsimae_pack_desc;
+int hsimae_pack_matrix(const hsimae_pack_desc* desc_dev, int32_t ndesc, int32_t max_elems, void* stream);
+
+/* Masked multi-head attention over one sample's tokens (Models.py:192-215) and its backward. */
+typedef struct {
+    const hs_bf16* qkv; int32_t ld;
+    int32_t d, heads, hd;
+    int32_t Ts;
+    int32_t nsamples;
+    int32_t mode, len_l;
+    hs_bf16* o; int32_t ldo;
+    float* lse;
+    const hs_bf16* dout; int32_t lddo;
+    hs_bf16* dqkv;
+} hsimae_attn_params;
+int hsimae_attn_fwd(const hsimae_attn_params* p, void* stream);
+int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream);
+
+/* Weight / bias gradients of up to 8 linears in one launch (autograd of F.linear). */
+typedef struct {
+    const void* dO; int32_t dO_f32; int32_t ldo;
+    const hs_bf16* A; int32_t lda;
+    int32_t N, K;
+    float* dW; int32_t ldw;
+    float* db;
+} hsimae_wgrad_task;
+typedef struct { hsimae_wgrad_task t[8]; int32_t ntasks; int32_t M; int32_t msplit; } hsimae_wgrad_params;
+int hsimae_wgrad(const hsimae_wgrad_params* p, void* stream);
+
+/* LayerNorm backward (autograd of Models.py:288/299/399/419), residual grad fused. */
+typedef struct {
+    const float* du; const float* x; const float* stats; const float* gamma; const float* dres;
+    float* dx; int32_t accumulate; float* dgamma; float* dbeta; int32_t M, d;
+} hsimae_lnbwd_params;
+int hsimae_ln_bwd(const hsimae_lnbwd_params* p, void* stream);
+/* Plain LayerNorm forward, fp32 in/out (Models.py:570 when a caller wants the fp32 latent). */
+int hsimae_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int32_t M, int32_t d, void* stream);
+
+/* Decoder sequence assembly: mean-token fill + unshuffle + pos (Models.py:583-592) and backward. */
+typedef struct {
+    const float* y; int32_t N, K, TL, Dd; const int32_t* ids_restore; const float* pos;
+    float* yfull; const float* dyfull; hs_bf16* dy;
+} hsimae_assemble_params;
+int hsimae_assemble_fwd(const hsimae_assemble_params* p, void* stream);
+int hsimae_assemble_bwd(const hsimae_assemble_params* p, void* stream);
+
+/* patchify + norm_pix target + masked MSE + dLoss/dpred + recons images (Models.py:603-625). */
+typedef struct {
+    const float* x; int64_t sn, sb, sh, sw; int32_t N, T; const float* pred; const float* mask;
+    int32_t norm_pix; float inv_scale;
+    float* partial; float* loss; float sum_mask;
+    hs_bf16* dpred; float* pred_img; float* mask_img;
+} hsimae_loss_params;
+int hsimae_loss_partials(int32_t N, int32_t T);   /* floats needed in `partial` */
+int hsimae_loss(const hsimae_loss_params* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

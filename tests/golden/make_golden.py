@@ -183,7 +183,7 @@ def taps_forward(model, x, ratio):
 
 def f3_tiny():
     torch.manual_seed(7); random.seed(7)
-    model = make_mae(32, 32, dec_dim=16, depth=3, s_depth=2, dec_depth=1, heads=2, dec_heads=2)
+    model = make_mae(32, 32, dec_dim=32, depth=3, s_depth=2, dec_depth=2, heads=2, dec_heads=4)
     perturb(model, 11)
     N = 6
     x = torch.rand(N, 1, 32, 9, 9)
@@ -261,7 +261,7 @@ def f5_c1():
 
 def f6_traj():
     torch.manual_seed(3); random.seed(3)
-    model = make_mae(32, 32, dec_dim=16, depth=3, s_depth=2, dec_depth=2, heads=2, dec_heads=2)
+    model = make_mae(32, 32, dec_dim=32, depth=3, s_depth=2, dec_depth=2, heads=2, dec_heads=4)
     perturb(model, 21)
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     N = 8
@@ -284,13 +284,26 @@ def f6_traj():
         arrs[f"n1_{i}"] = a; arrs[f"n2_{i}"] = b
     np.savez_compressed(os.path.join(HERE, "trajectory.npz"), **arrs)
     json.dump({"losses": losses, "grids": grids, "lr": 1e-3, "wd": 5e-2, "betas": [0.9, 0.95], "ratio": 0.5,
-               "cfg": {"bands": 32, "embed_dim": 32, "decoder_embed_dim": 16, "depth": 3, "s_depth": 2,
-                       "decoder_depth": 2, "num_heads": 2, "decoder_num_heads": 2}},
+               "cfg": {"bands": 32, "embed_dim": 32, "decoder_embed_dim": 32, "depth": 3, "s_depth": 2,
+                       "decoder_depth": 2, "num_heads": 2, "decoder_num_heads": 4}},
               open(os.path.join(HERE, "trajectory.json"), "w"))
+
+
+def f7_init():
+    """Parameter values right after construction under a fixed seed (init RNG order, Models.py:429-459)."""
+    out = {}
+    for tag, kw in {"trunc": dict(trunc_init=True), "xavier": dict(trunc_init=False)}.items():
+        torch.manual_seed(0)
+        m = quiet(R.HSIMAE, img_size=9, patch_size=3, in_chans=1, bands=48, b_patch_size=8, embed_dim=128, depth=12,
+                  num_heads=8, s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8,
+                  norm_pix_loss=True, **kw)
+        out[tag] = {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in m.state_dict().items()}
+    json.dump(out, open(os.path.join(HERE, "init_checksums.json"), "w"))
 
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    f7_init(); print("F7 ok")
     f1_manifest(); print("F1 ok")
     f2_masking(); print("F2 ok")
     f3_tiny(); print("F3 ok")

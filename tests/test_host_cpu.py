@@ -1,0 +1,154 @@
+"""Host-side logic of hsimae_amd that runs without a GPU: module surface, state_dict wire format, init RNG order,
+grid choice, C-ABI symbol table / layout helpers, bucket planning, and the no-fallback guarantee."""
+import ctypes as C
+import json
+import os
+import random
+import re
+
+import pytest
+import torch
+
+from hsimae_amd import HSIMAE, _lib, swiglu_hidden
+from hsimae_amd.parallel import plan_buckets
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(__file__))
+
+
+def make(bands=48, dim=128, **kw):
+    args = dict(img_size=9, patch_size=3, in_chans=1, bands=bands, b_patch_size=8, embed_dim=dim, depth=12,
+                num_heads=dim // 16, s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8,
+                norm_pix_loss=True, trunc_init=True)
+    args.update(kw)
+    return HSIMAE(**args)
+
+
+@pytest.mark.parametrize("name,bands,dim", [("C1_base48", 48, 128), ("C2_base96", 96, 128), ("C3_large96", 96, 256)])
+def test_state_dict_manifest_matches_reference(name, bands, dim):
+    man = json.load(open(os.path.join(G, "manifest.json")))
+    sd = make(bands, dim).state_dict()
+    got = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]
+    assert got == man[name]
+    assert len(got) == 535
+
+
+def test_checkpoint_keys_are_subset_of_dualvit_and_cover_hsivit_encoder():
+    man = json.load(open(os.path.join(G, "manifest.json")))
+    mine = {k: (tuple(s), d) for k, s, d in [[k, list(v.shape), str(v.dtype).replace("torch.", "")]
+                                              for k, v in make(32, 128).state_dict().items()]}
+    dual = {k: (tuple(s), d) for k, s, d in man["DualViT_base32"]}
+    vit = {k: (tuple(s), d) for k, s, d in man["HSIViT_base32"]}
+    assert len(dual) == 537 and len(vit) == 385
+    assert all(k in dual and dual[k] == v for k, v in mine.items())          # Model_Finetuning.py:85-96 partial load
+    assert sum(k in mine and mine[k] == v for k, v in vit.items()) == 383
+
+
+def test_named_parameters_order_and_param_groups():
+    man = json.load(open(os.path.join(G, "manifest.json")))
+    m = make(96, 128)
+    names = [n for n, _ in m.named_parameters()]
+    assert names == man["named_parameters_C2"]
+    nd = ["bias", "norm"]
+    assert sum(any(k in n for k in nd) for n in names) == man["no_decay_count_C2"] == 326
+    assert not m.pos_embed.requires_grad and not m.decoder_pos_embed.requires_grad
+    assert sum(p.numel() for p in make(48, 128).parameters() if p.requires_grad) == man["trainable_numel"]["C1_base48"]
+
+
+@pytest.mark.parametrize("tag,trunc", [("trunc", True), ("xavier", False)])
+def test_init_rng_order_matches_reference(tag, trunc):
+    ref = json.load(open(os.path.join(G, "init_checksums.json")))[tag]
+    torch.manual_seed(0)
+    sd = make(48, 128, trunc_init=trunc).state_dict()
+    for k, (s, a) in ref.items():
+        v = sd[k].double()
+        assert abs(float(v.sum()) - s) <= 1e-6 * max(1.0, a), k
+        assert abs(float(v.abs().sum()) - a) <= 1e-6 * max(1.0, a), k
+
+
+def test_constructor_quirks():
+    assert not hasattr(make(48, 128, s_depth=12, depth=12), "blocks")          # Models.py:385
+    m0 = make(48, 128, s_depth=0)
+    assert not hasattr(m0, "blocks_1") and len(m0.blocks) == 12                # Models.py:356
+    with pytest.raises(AssertionError):
+        make(50, 128)
+    with pytest.raises(AssertionError):
+        make(48, 128, num_heads=7)
+    make(48, 128, some_unknown_kwarg=3)                                         # **kwargs swallowed
+    assert swiglu_hidden(128, 4.0) == 344 and swiglu_hidden(256, 4.0) == 684 and swiglu_hidden(64, 4.0) == 172
+
+
+def test_grid_choice_consumes_python_random_like_reference():
+    meta = json.load(open(os.path.join(G, "masking.json")))
+    m = make(48, 128)
+    for c in meta["cases"]:
+        assert [list(x) for x in m.grid_candidates(c["T"], c["L"], c["ratio"])] == c["candidates"]
+        random.seed(c["seed"])
+        assert list(m.get_dim_patches(c["T"], c["L"], c["ratio"])) == [c["len_t"], c["len_l"]]
+    for seed, seq in meta["draws"].items():
+        random.seed(int(seed))
+        assert [list(m.get_dim_patches(12, 9, 0.75)) for _ in seq] == seq
+
+
+def test_patchify_roundtrip_is_reference_index_map():
+    from oracle import hsimae_oracle as O
+    m = make(48, 128)
+    x = torch.rand(3, 1, 48, 9, 9)
+    p = m.patchify(x)
+    assert torch.equal(p, O.patchify(x, O.OracleConfig(bands=48)))
+    assert torch.equal(m.unpatchify(p), x)
+
+
+def test_no_cpu_fallback():
+    m = make(48, 128)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(2, 1, 48, 9, 9))
+    with pytest.raises(NotImplementedError):
+        make(48, 128, no_qkv_bias=True)._config()
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "hsimae_hip.h")).read()
+    declared = set(re.findall(r"\b(hsimae_[a-z0-9_]+)\s*\(", hdr)) - {"hsimae_bucket_cb"}
+    assert declared == set(_lib.SYMBOLS.keys())
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.hsimae_version() >= 100
+    assert b"dimension" in lib.hsimae_strerror(-1)
+
+
+def test_layout_helpers_agree_with_module_tree():
+    lib = _lib.load()
+    for bands, dim in [(48, 128), (96, 256)]:
+        m = make(bands, dim)
+        cfg = m._config()
+        ps = m._plist()
+        n = len(ps)
+        offs, sizes = (C.c_int64 * n)(), (C.c_int64 * n)()
+        assert lib.hsimae_param_layout(C.byref(cfg), offs, sizes, n) == n == 535
+        assert [sizes[i] for i in range(n)] == [p.numel() for p in ps]
+        assert all(offs[i + 1] == offs[i] + sizes[i] for i in range(n - 1)) and offs[0] == 0
+        assert lib.hsimae_wpk_elems(C.byref(cfg)) > 0
+        assert lib.hsimae_workspace_bytes(C.byref(cfg), 64, 2, 7) > 0
+    bad = _lib.Config(bands=50, embed_dim=128, depth=12, s_depth=9, num_heads=8, dec_dim=64, dec_depth=8, dec_heads=8,
+                      hidden=344, dec_hidden=172, norm_pix_loss=1)
+    assert lib.hsimae_wpk_elems(C.byref(bad)) < 0
+    assert lib.hsimae_param_layout(C.byref(bad), None, None, 0) == -1
+    bad2 = _lib.Config(bands=48, embed_dim=96, depth=12, s_depth=9, num_heads=2, dec_dim=64, dec_depth=8, dec_heads=8,
+                       hidden=256, dec_hidden=172, norm_pix_loss=1)
+    assert lib.hsimae_param_layout(C.byref(bad2), None, None, 0) == -2          # head dim 48: unsupported
+
+
+def test_bucket_plan_covers_every_element_once():
+    # ranges arrive back to front, as hsimae_backward reports them
+    sizes = [5, 40, 40, 3, 40, 40, 40, 7]
+    offs = [sum(sizes[:i]) for i in range(len(sizes))]
+    ranges = [(offs[i], sizes[i]) for i in reversed(range(len(sizes)))]
+    plan = plan_buckets(ranges, 64)
+    cover = sorted((lo, lo + ln) for lo, ln, _ in plan)
+    assert cover[0][0] == 0 and cover[-1][1] == sum(sizes)
+    assert all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
+    assert all(ln >= 64 for _, ln, _ in plan[:-1])
+    trig = [t for _, _, t in plan]
+    assert trig == sorted(trig)

@@ -57,8 +57,8 @@ def test_mask_ties_lower_index_wins():
 @pytest.mark.parametrize("tag", ["r50", "r75"])
 def test_tiny_model_all_stages_and_grads(tag):
     z = np.load(os.path.join(G, f"tiny_model_{tag}.npz"))
-    cfg = O.OracleConfig(bands=32, embed_dim=32, depth=3, num_heads=2, s_depth=2, decoder_embed_dim=16,
-                         decoder_depth=1, decoder_num_heads=2)
+    cfg = O.OracleConfig(bands=32, embed_dim=32, depth=3, num_heads=2, s_depth=2, decoder_embed_dim=32,
+                         decoder_depth=2, decoder_num_heads=4)
     P = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_")}
     x = torch.from_numpy(z["x"])
     lt, ll = (int(v) for v in z["len_tl"])
@@ -92,8 +92,8 @@ def test_tiny_model_all_stages_and_grads(tag):
 
 def test_strided_band_fastest_input_is_value_equivalent():
     z = np.load(os.path.join(G, "tiny_model_r50.npz"))
-    cfg = O.OracleConfig(bands=32, embed_dim=32, depth=3, num_heads=2, s_depth=2, decoder_embed_dim=16,
-                         decoder_depth=1, decoder_num_heads=2)
+    cfg = O.OracleConfig(bands=32, embed_dim=32, depth=3, num_heads=2, s_depth=2, decoder_embed_dim=32,
+                         decoder_depth=2, decoder_num_heads=4)
     x = torch.from_numpy(z["x"])
     xs = x[:, 0].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2).unsqueeze(1)
     assert not xs.is_contiguous()
