@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""HSIMAE pretraining fwd+bwd throughput on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one forward + backward of HSIMAE-Base over a per-GPU batch of 4096 synthetic 9x9x96 cubes already
+resident in HBM (mask ratio 0.75), including the RCCL gradient all-reduce when N > 1.  Rank 0 prints ONE JSON
+line; `value` is the whole-job patches/s.  `roofline` prices the dominant kernel against the dense bf16 MFMA
+peak from live HIP-event timings; `cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md chip table
+
+
+def flops_per_sample(bands, D, depth, s_depth, Dd, dec_depth, lt, ll, hidden, dec_hidden):
+    """Algorithmic fwd+bwd FLOPs per cube (SURVEY.md 8a closed form; recompute not credited)."""
+    T = bands // 8
+    TL, K = T * 9, lt * ll
+    nfus = depth - s_depth if s_depth < 12 else 0
+    PE = TL * 72 * D
+    ENCl = K * (4 * D * D + 3 * D * hidden) * (2 * s_depth + nfus)
+    ENCa = K * 2 * D * (s_depth * ll + s_depth * lt + nfus * K)
+    DE = K * D * Dd
+    DECl = TL * (4 * Dd * Dd + 3 * Dd * dec_hidden) * dec_depth
+    DECa = TL * 2 * Dd * TL * dec_depth
+    PRED = TL * Dd * 72
+    fwd = 2 * (PE + ENCl + ENCa + DE + DECl + DECa + PRED)
+    return 3 * fwd - 2 * PE
+
+
+def dominant_kernel_roofline(model, N, K_tok, iters=20):
+    """Live HIP-event timing of the dominant kernel (rocprof: profiles/): the LayerNorm->W1|W3->SiLU-gate
+    row-panel MFMA GEMM of the decoder blocks, at the workload's shape, launched through the C ABI on the
+    current stream.  Algorithmic FLOPs per launch = 2 * M * 2h * d."""
+    from hsimae_amd import _lib, swiglu_hidden
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = model.dec_dim
+    h = swiglu_hidden(d, model.mlp_ratio)
+    hp = (h + 31) // 32 * 32
+    M = N * model.patch_embed.num_patches
+    x = torch.randn(M, d, device=dev)
+    blk = model.decoder_blocks[0]
+    wpk_elems = hp * d
+    w1 = torch.zeros(wpk_elems, dtype=torch.bfloat16, device=dev)
+    w3 = torch.zeros(wpk_elems, dtype=torch.bfloat16, device=dev)
+    descs = (_lib.PackDesc * 2)()
+    srcs = [blk.mlp.w1.weight.detach().float().contiguous(), blk.mlp.w3.weight.detach().float().contiguous()]
+    for i, (src, dst) in enumerate(zip(srcs, (w1, w3))):
+        descs[i] = _lib.PackDesc(src=src.data_ptr(), rows=h, cols=d, transpose=0, n_off=0, k_off=0, KS=d // 32, dst=dst.data_ptr())
+    table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).clone().to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.hsimae_pack_matrix(table.data_ptr(), 2, h * d, s))
+    g = torch.empty(M, hp, dtype=torch.bfloat16, device=dev)
+    h13 = torch.empty(M, 2 * hp, dtype=torch.bfloat16, device=dev)
+    u = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
+    p = _lib.GemmParams(A=x.data_ptr(), lda=d, M=M, N=hp, K=d, n_valid=h, W=w1.data_ptr(), W2=w3.data_ptr(),
+                        bias=blk.mlp.w1.bias.data_ptr(), bias2=blk.mlp.w3.bias.data_ptr(),
+                        gamma=blk.norm2.weight.data_ptr(), beta=blk.norm2.bias.data_ptr(), u_out=u.data_ptr(), ldu=d,
+                        out=g.data_ptr(), ldo=hp, h13=h13.data_ptr(), ldh=2 * hp, hoff=hp)
+    for _ in range(3):
+        _lib.check(lib.hsimae_gemm(C.byref(p), _lib.A_F32_LN, _lib.E_SWIGLU, s))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        _lib.check(lib.hsimae_gemm(C.byref(p), _lib.A_F32_LN, _lib.E_SWIGLU, s))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * M * 2 * h * d
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_kernel<A_F32_LN,E_SWIGLU,128> (decoder LN2->W1|W3->SiLU gate)",
+            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launch_ms": round(ms, 4),
+            "flops_per_launch": flops}
+
+
+def cpu_baseline(bands, n_sample=64, steps=4):
+    """The CPU oracle (a port of the reference's algorithm, validated against it) on the host cores."""
+    from oracle import hsimae_oracle as O
+    # torch's CPU ops on these small shapes stop scaling (and then collapse) past a few dozen threads:
+    # use at most 32 of the host's cores and report that number.
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    cfg = O.OracleConfig(bands=bands)
+    state = O.init_state(cfg, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(n_sample, 1, bands, 9, 9, generator=g)
+    n1, n2 = torch.rand(n_sample, cfg.T, generator=g), torch.rand(n_sample, 9, generator=g)
+    t0 = time.perf_counter()
+    O.forward_backward(state, cfg, x, n1.numpy(), n2.numpy(), 3, 9)            # warm-up (also calibrates the sample)
+    warm = time.perf_counter() - t0
+    steps = max(1, min(steps, int(12.0 / max(warm, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.forward_backward(state, cfg, x, n1.numpy(), n2.numpy(), 3, 9)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_sample * steps / dt, 2), "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+bwd fp32, HSIMAE-Base 9x9x{bands}, batch {n_sample}, {steps} steps after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--model", default="base", choices=["base", "large"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from hsimae_amd import HSIMAE, swiglu_hidden
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    bands, D = 96, (128 if args.model == "base" else 256)
+    torch.manual_seed(0)
+    model = HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=bands, b_patch_size=8, embed_dim=D, depth=12,
+                   num_heads=D // 16, s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8,
+                   norm_pix_loss=True, trunc_init=True).to(dev)
+    if world > 1:
+        model.enable_data_parallel()
+    random.seed(0)                                    # same (len_t, len_l) sequence on every rank
+    torch.manual_seed(1234 + rank)
+    N = args.batch
+    imgs = torch.rand(N, 1, bands, 9, 9, device=dev)  # synthetic cubes, resident in HBM
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        loss, _, _ = model(imgs, mask_ratio=0.75)
+        loss.backward()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    last_loss = float(loss.item())
+
+    if rank == 0:
+        h, hd = swiglu_hidden(D, 4.0), swiglu_hidden(64, 4.0)
+        fl = flops_per_sample(bands, D, 12, 9, 64, 8, 3, 9, h, hd)
+        value = world * N * args.steps / dt
+        step_tflops = value * fl / 1e12 / world
+        out = {
+            "metric": "HSI patches/sec (9x9x96, mask 75%) pretrain fwd+bwd", "value": round(value, 1),
+            "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"HSIMAE-{args.model.capitalize()} pretrain fwd+bwd, 9x9x96 cubes, per-GPU batch {N}, "
+                                   f"mask 0.75, bf16 MFMA operands / fp32 accumulate+residual",
+                       "per_gpu_batch": N, "global_batch": N * world, "parallelism": f"dp{world}"},
+            "per_gpu": round(value / world, 1), "loss": round(last_loss, 6),
+            "step_algorithmic_tflops_per_gpu": round(step_tflops, 2),
+            "step_frac_of_bf16_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
+            "gflop_per_patch": round(fl / 1e9, 4),
+        }
+        out["roofline"] = dominant_kernel_roofline(model, N, 27)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(bands)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

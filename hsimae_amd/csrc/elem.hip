@@ -79,77 +79,93 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(PatchParams p) {
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
-// One wave per row (d <= 512).  dx = dres + rstd * (g*du - mean(g*du) - xhat * mean(g*du*xhat));
-// dgamma += du * xhat, dbeta += du: per-lane partials over the workgroup's rows, one atomic per column per WG.
-constexpr int LN_ROWS_PER_WG = 64;
-
+// dx = dres + rstd * (g*du - mean(g*du) - xhat * mean(g*du*xhat));  dgamma += du * xhat, dbeta += du.
+// A row is owned by TPR adjacent lanes (8 columns each); each thread keeps 4 rows of loads in flight so the
+// kernel streams instead of paying one memory latency per row.  Column sums: per-thread partials over the
+// workgroup's rows, reduced across row groups in LDS, one atomic per column per workgroup.
+template <int TPR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
-    __shared__ float red[2][4][512];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nper = (p.d + 63) / 64;
-    float dg[8], db[8], gam[8];
+    constexpr int G = 256 / TPR, NI = 8, UB = 4, W = 8 * TPR;
+    __shared__ float red[2][G][W];
+    const int tid = threadIdx.x, grp = tid / TPR, c8 = (tid % TPR) * 8;
+    const bool cok = c8 < p.d;
+    float gam[8], dg[8], db[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        dg[i] = 0.f; db[i] = 0.f;
-        const int c = lane + 64 * i;
-        gam[i] = (i < nper && c < p.d) ? p.gamma[c] : 0.f;
-    }
-    const int r0 = blockIdx.x * LN_ROWS_PER_WG;
+    for (int e = 0; e < 8; ++e) { gam[e] = cok ? p.gamma[c8 + e] : 0.f; dg[e] = 0.f; db[e] = 0.f; }
     const float invd = 1.f / (float)p.d;
-    for (int r = r0 + wave; r < min(r0 + LN_ROWS_PER_WG, p.M); r += 4) {
-        float x[8], du[8];
-        float s = 0.f;
+    const int base = blockIdx.x * (G * NI);
+    auto ld8 = [](const float* q, float* o) {
+        const float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    };
+    for (int it = 0; it < NI; it += UB) {
+        float x[UB][8], du[UB][8], rs[UB][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = lane + 64 * i;
-            const bool ok = (i < nper) && (c < p.d);
-            x[i] = ok ? p.x[(size_t)r * p.d + c] : 0.f;
-            du[i] = ok ? p.du[(size_t)r * p.d + c] : 0.f;
-            s += x[i];
+        for (int u = 0; u < UB; ++u) {
+            const int r = base + (it + u) * G + grp;
+            const bool ok = cok && r < p.M;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[u][e] = 0.f; du[u][e] = 0.f; rs[u][e] = 0.f; }
+            if (ok) {
+                const size_t o = (size_t)r * p.d + c8;
+                ld8(p.x + o, x[u]);
+                ld8(p.du + o, du[u]);
+                if (p.dres) ld8(p.dres + o, rs[u]);
+                if (p.accumulate) {
+                    float t[8];
+                    ld8(p.dx + o, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rs[u][e] += t[e];
+                }
+            }
         }
-        const float mean = wave_sum(s) * invd;
-        float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = lane + 64 * i;
-            const float dlt = ((i < nper) && (c < p.d)) ? x[i] - mean : 0.f;
-            x[i] = dlt;
-            q += dlt * dlt;
-        }
-        const float rstd = rsqrtf(wave_sum(q) * invd + 1e-5f);
-        float a = 0.f, b = 0.f;
+        for (int u = 0; u < UB; ++u) {
+            const int r = base + (it + u) * G + grp;
+            float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            x[i] *= rstd;                     // xhat
-            const float t = du[i] * gam[i];
-            a += t;
-            b += t * x[i];
-            dg[i] += du[i] * x[i];
-            db[i] += du[i];
-        }
-        a = wave_sum(a) * invd;
-        b = wave_sum(b) * invd;
+            for (int e = 0; e < 8; ++e) s += x[u][e];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = lane + 64 * i;
-            if (i < nper && c < p.d) {
-                float v = rstd * (du[i] * gam[i] - a - x[i] * b);
-                const size_t o = (size_t)r * p.d + c;
-                if (p.dres) v += p.dres[o];
-                if (p.accumulate) v += p.dx[o];
-                p.dx[o] = v;
+            for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s * invd;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dl = cok ? x[u][e] - mean : 0.f; x[u][e] = dl; q += dl * dl; }
+#pragma unroll
+            for (int o = TPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            const float rstd = rsqrtf(q * invd + 1e-5f);
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                x[u][e] *= rstd;                                   // xhat
+                const float t = du[u][e] * gam[e];
+                a += t;
+                b += t * x[u][e];
+            }
+#pragma unroll
+            for (int o = TPR / 2; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            a *= invd; b *= invd;
+            if (cok && r < p.M) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = rstd * (du[u][e] * gam[e] - a - x[u][e] * b) + rs[u][e];
+                    dg[e] += du[u][e] * x[u][e];
+                    db[e] += du[u][e];
+                }
+                float* op = p.dx + (size_t)r * p.d + c8;
+                *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        red[0][wave][lane + 64 * i] = dg[i];
-        red[1][wave][lane + 64 * i] = db[i];
-    }
+    for (int e = 0; e < 8; ++e) { red[0][grp][c8 + e] = dg[e]; red[1][grp][c8 + e] = db[e]; }
     __syncthreads();
-    for (int c = threadIdx.x; c < p.d; c += 256) {
-        const float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-        const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    for (int c = tid; c < p.d; c += 256) {
+        float g = 0.f, b = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < G; ++k) { g += red[0][k][c]; b += red[1][k][c]; }
         if (p.dgamma) atomicAdd(p.dgamma + c, g);
         if (p.dbeta) atomicAdd(p.dbeta + c, b);
     }
@@ -331,11 +347,20 @@ int hs_patch_gather(const PatchParams& p, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+template <int TPR>
+int launch_ln_bwd(const LnBwdParams& p, hipStream_t s) {
+    const int rows_per_wg = (256 / TPR) * 8;
+    hipLaunchKernelGGL(ln_bwd_kernel<TPR>, dim3((p.M + rows_per_wg - 1) / rows_per_wg), dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
 int hs_ln_bwd(const LnBwdParams& p, hipStream_t s) {
     if (p.M <= 0) return HS_OK;
-    if (p.d > 512) return HS_EUNSUPPORTED;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((p.M + LN_ROWS_PER_WG - 1) / LN_ROWS_PER_WG), dim3(256), 0, s, p);
-    return (int)hipGetLastError();
+    if (p.d > 512 || p.d % 8) return HS_EUNSUPPORTED;
+    if (p.d <= 64) return launch_ln_bwd<8>(p, s);
+    if (p.d <= 128) return launch_ln_bwd<16>(p, s);
+    if (p.d <= 256) return launch_ln_bwd<32>(p, s);
+    return launch_ln_bwd<64>(p, s);
 }
 
 int hs_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int M, int d, hipStream_t s) {

@@ -8,20 +8,28 @@
 //
 // Wave w of the workgroup owns n-tiles {2w, 2w+1} of each 128-column chunk and all 8 m-tiles:
 // 16 accumulators (64 VGPR); the SwiGLU variants carry a second accumulator set for W3.
+//
+// Epilogue: accumulators are passed through an fp32 LDS tile 32 rows at a time so that every global
+// access of the epilogue (output, residual, saved pre-activations) is a 16-B-per-lane row-contiguous
+// access; the first version's per-element 2-byte stores made every GEMM store-issue bound (profiles/).
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
 constexpr int BM = 128;
+constexpr int PR = 32;             // rows per epilogue pass
+constexpr int TS = 132;            // fp32 LDS tile row stride (floats): conflict-free b32 writes
 
 template <int AK, int EPI, int KC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LDA = KC + 8;                       // LDS row stride (elements): 16-B pad => conflict-free b128 reads
+    constexpr bool DUAL = (EPI == E_SWIGLU);
     bf16_t* As = reinterpret_cast<bf16_t*>(smem);     // [128][KC+8]
     float* rstat = reinterpret_cast<float*>(smem + BM * LDA * 2);   // [128][2] mean, rstd
-    constexpr bool DUAL = (EPI == E_SWIGLU);
+    float* T1 = rstat + 2 * BM;                       // [PR][TS]
+    float* T2 = T1 + PR * TS;                         // second tile (SwiGLU pair)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * BM;
@@ -30,39 +38,56 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     const int n_chunks = (NT_total + 7) / 8;
     const int k_chunks = (p.K + KC - 1) / KC;
 
-    if constexpr (AK == A_F32_LN) {
-        // LayerNorm statistics for the panel's rows: one wave per row, two-pass in registers (K <= 512).
+    // LayerNorm prologue: each row is owned by TPR adjacent lanes (8 columns each).  All loads of a batch of
+    // rows are issued before the first reduction, so one memory latency is exposed per batch instead of one per
+    // row (the first version walked rows one wave at a time and was latency bound, profiles/).
+    auto stage_ln = [&]() {
+        constexpr int TPR = KC / 8, RPP = 256 / TPR, NPASS = BM / RPP, NB = NPASS < 8 ? NPASS : 8;
         const float* A = reinterpret_cast<const float*>(p.A);
-        for (int r = wave; r < BM; r += 4) {
-            const int row = min(row0 + r, p.M - 1);
-            float v[8];
-            float s = 0.f;
+        const int c8 = (tid % TPR) * 8;
+        const bool cok = c8 < p.K;
+        float g[8], bt[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = lane + 64 * i;
-                v[i] = (c < p.K) ? A[(size_t)row * p.lda + c] : 0.f;
-                s += v[i];
-            }
-            const float mean = wave_sum(s) / (float)p.K;
-            float q = 0.f;
+        for (int e = 0; e < 8; ++e) { g[e] = cok ? p.gamma[c8 + e] : 0.f; bt[e] = cok ? p.beta[c8 + e] : 0.f; }
+        const float invk = 1.f / (float)p.K;
+        for (int pb = 0; pb < NPASS; pb += NB) {
+            float f[NB][8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = lane + 64 * i;
-                const float d = (c < p.K) ? v[i] - mean : 0.f;
-                q += d * d;
-            }
-            const float rstd = rsqrtf(wave_sum(q) / (float)p.K + 1e-5f);
-            if (lane == 0) {
-                rstat[2 * r] = mean;
-                rstat[2 * r + 1] = rstd;
-                if (p.stats && row0 + r < p.M) {
-                    p.stats[2 * (size_t)(row0 + r)] = mean;
-                    p.stats[2 * (size_t)(row0 + r) + 1] = rstd;
+            for (int i = 0; i < NB; ++i) {
+                const int r = tid / TPR + (pb + i) * RPP;
+                const int row = min(row0 + r, p.M - 1);
+                float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+                if (cok) {
+                    x0 = *reinterpret_cast<const float4*>(A + (size_t)row * p.lda + c8);
+                    x1 = *reinterpret_cast<const float4*>(A + (size_t)row * p.lda + c8 + 4);
                 }
+                f[i][0] = x0.x; f[i][1] = x0.y; f[i][2] = x0.z; f[i][3] = x0.w;
+                f[i][4] = x1.x; f[i][5] = x1.y; f[i][6] = x1.z; f[i][7] = x1.w;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int r = tid / TPR + (pb + i) * RPP;
+                float sm = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm += f[i][e];
+#pragma unroll
+                for (int o = TPR / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+                const float mean = sm * invk;
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float dl = cok ? f[i][e] - mean : 0.f; q += dl * dl; }
+#pragma unroll
+                for (int o = TPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+                const float rstd = rsqrtf(q * invk + 1e-5f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[i][e] = (f[i][e] - mean) * rstd * g[e] + bt[e];
+                const bf16x8 val = cok ? cvt8(f[i]) : zero8();
+                if (cok && p.u_out && row0 + r < p.M)
+                    *reinterpret_cast<bf16x8*>(p.u_out + (size_t)(row0 + r) * p.ldu + c8) = val;
+                *reinterpret_cast<bf16x8*>(As + r * LDA + c8) = val;
             }
         }
-        __syncthreads();
-    }
+    };
 
     auto stage = [&](int kc) {
         constexpr int TPR = KC / 8;                   // threads per row (8 elements each)
@@ -121,7 +146,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         for (int kc = 0; kc < k_chunks; ++kc) {
             if (k_chunks > 1 || nc == 0) {
                 if (!(nc == 0 && kc == 0)) __syncthreads();
-                stage(kc);
+                if constexpr (AK == A_F32_LN) stage_ln(); else stage(kc);
                 __syncthreads();
             }
             const int ks0 = kc * (KC / 32);
@@ -152,58 +177,110 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             }
         }
 
-        // ---------------------------------------------------------------- epilogue for this column chunk
+        // ---------------------------------------------------------------- epilogue for this 128-column chunk
+        const int ccols = min(128, p.N - nc * 128);            // valid columns in this chunk (multiple of 16)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int nt = nt0 + j;
-            if (nt >= NT_total) continue;
-            const int col = nt * 16 + (lane & 15);
-            const bool cvalid = col < p.n_valid;
-            const float bias = (p.bias && cvalid) ? p.bias[col] : 0.f;
-            float bias2 = 0.f;
-            if constexpr (DUAL) bias2 = (p.bias2 && cvalid) ? p.bias2[col] : 0.f;
+        for (int ps = 0; ps < BM / PR; ++ps) {
+            __syncthreads();                                   // previous pass fully consumed
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
+            for (int mi = 0; mi < PR / 16; ++mi)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = row0 + mt * 16 + ag * 4 + r;
-                    if (row >= p.M) continue;
-                    const float v = acc[mt][j][r] + bias;
-                    if constexpr (EPI == E_BF16) {
-                        reinterpret_cast<bf16_t*>(p.out)[(size_t)row * p.ldo + col] = (bf16_t)v;
-                    } else if constexpr (EPI == E_F32) {
-                        if (cvalid) reinterpret_cast<float*>(p.out)[(size_t)row * p.ldo + col] = v;
-                    } else if constexpr (EPI == E_RES_F32) {
-                        if (cvalid) {
-                            float o = v + p.res[(size_t)row * p.ldr + col];
-                            if (p.res2) o += p.res2[(size_t)row * p.ldr + col];
-                            reinterpret_cast<float*>(p.out)[(size_t)row * p.ldo + col] = o;
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = (mi * 16 + ag * 4 + r) * TS + wave * 32 + j * 16 + arow;
+                        T1[o] = acc[ps * (PR / 16) + mi][j][r];
+                        if constexpr (DUAL) T2[o] = acc2[ps * (PR / 16) + mi][j][r];
+                    }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < PR * 16 / 256; ++i) {
+                const int piece = tid + 256 * i;
+                const int rl = piece >> 4, c8 = (piece & 15) * 8;
+                const int row = row0 + ps * PR + rl;
+                const int col = nc * 128 + c8;
+                if (row >= p.M || c8 >= ccols) continue;
+                const float4 t0 = *reinterpret_cast<const float4*>(T1 + rl * TS + c8);
+                const float4 t1 = *reinterpret_cast<const float4*>(T1 + rl * TS + c8 + 4);
+                float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                const int nv = p.n_valid - col;                // valid columns in this octet (>= 8: all)
+                const bool cvalid = nv > 0;
+                if (p.bias && cvalid) {
+                    if (nv >= 8) {
+                        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col);
+                        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) if (e < nv) v[e] += p.bias[col + e];
+                    }
+                }
+                if constexpr (EPI == E_BF16) {
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)row * p.ldo + col) = cvt8(v);
+                } else if constexpr (EPI == E_F32 || EPI == E_RES_F32 || EPI == E_POS_F32) {
+                    if (!cvalid) continue;
+                    if constexpr (EPI == E_RES_F32) {
+                        const float* rp = p.res + (size_t)row * p.ldr + col;
+                        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                        if (p.res2) {
+                            const float* qp = p.res2 + (size_t)row * p.ldr + col;
+                            const float4 q0 = *reinterpret_cast<const float4*>(qp), q1 = *reinterpret_cast<const float4*>(qp + 4);
+                            v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w;
+                            v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
                         }
                     } else if constexpr (EPI == E_POS_F32) {
-                        if (cvalid) {
-                            const float o = v + p.pos[(size_t)p.ids[row] * p.ldpos + col];
-                            reinterpret_cast<float*>(p.out)[(size_t)row * p.ldo + col] = o;
-                        }
-                    } else if constexpr (EPI == E_SWIGLU) {
-                        const float h1 = cvalid ? v : 0.f;
-                        const float h3 = cvalid ? acc2[mt][j][r] + bias2 : 0.f;
-                        const bf16_t h1b = (bf16_t)h1, h3b = (bf16_t)h3;
-                        p.h13[(size_t)row * p.ldh + col] = h1b;
-                        p.h13[(size_t)row * p.ldh + p.hoff + col] = h3b;
-                        const float a1 = bf2f(h1b), a3 = bf2f(h3b);     // same values the backward will see
-                        const float g = a1 / (1.f + __expf(-a1)) * a3;
-                        reinterpret_cast<bf16_t*>(p.out)[(size_t)row * p.ldo + col] = (bf16_t)g;
-                    } else if constexpr (EPI == E_SWIGLU_BWD) {
-                        const float h1 = bf2f(p.h13[(size_t)row * p.ldh + col]);
-                        const float h3 = bf2f(p.h13[(size_t)row * p.ldh + p.hoff + col]);
-                        const float s = 1.f / (1.f + __expf(-h1));
-                        const float dg = acc[mt][j][r];
-                        const float dh1 = dg * h3 * s * (1.f + h1 * (1.f - s));
-                        const float dh3 = dg * h1 * s;
-                        bf16_t* o = reinterpret_cast<bf16_t*>(p.out);
-                        o[(size_t)row * p.ldo + col] = (bf16_t)dh1;
-                        o[(size_t)row * p.ldo + p.hoff + col] = (bf16_t)dh3;
+                        const float* rp = p.pos + (size_t)p.ids[row] * p.ldpos + col;
+                        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
                     }
+                    float* op = reinterpret_cast<float*>(p.out) + (size_t)row * p.ldo + col;
+                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else if constexpr (EPI == E_SWIGLU) {
+                    const float4 s0 = *reinterpret_cast<const float4*>(T2 + rl * TS + c8);
+                    const float4 s1 = *reinterpret_cast<const float4*>(T2 + rl * TS + c8 + 4);
+                    float w[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                    if (p.bias2 && cvalid) {
+                        if (nv >= 8) {
+                            const float4 b0 = *reinterpret_cast<const float4*>(p.bias2 + col);
+                            const float4 b1 = *reinterpret_cast<const float4*>(p.bias2 + col + 4);
+                            w[0] += b0.x; w[1] += b0.y; w[2] += b0.z; w[3] += b0.w;
+                            w[4] += b1.x; w[5] += b1.y; w[6] += b1.z; w[7] += b1.w;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) if (e < nv) w[e] += p.bias2[col + e];
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (e >= nv) { v[e] = 0.f; w[e] = 0.f; }
+                    const bf16x8 h1 = cvt8(v), h3 = cvt8(w);
+                    *reinterpret_cast<bf16x8*>(p.h13 + (size_t)row * p.ldh + col) = h1;
+                    *reinterpret_cast<bf16x8*>(p.h13 + (size_t)row * p.ldh + p.hoff + col) = h3;
+                    float g[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float a1 = bf2f(h1[e]), a3 = bf2f(h3[e]);       // the values the backward will see
+                        g[e] = a1 / (1.f + __expf(-a1)) * a3;
+                    }
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)row * p.ldo + col) = cvt8(g);
+                } else if constexpr (EPI == E_SWIGLU_BWD) {
+                    const bf16x8 h1 = *reinterpret_cast<const bf16x8*>(p.h13 + (size_t)row * p.ldh + col);
+                    const bf16x8 h3 = *reinterpret_cast<const bf16x8*>(p.h13 + (size_t)row * p.ldh + p.hoff + col);
+                    float d1[8], d3[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float a1 = bf2f(h1[e]), a3 = bf2f(h3[e]);
+                        const float s = 1.f / (1.f + __expf(-a1));
+                        d1[e] = v[e] * a3 * s * (1.f + a1 * (1.f - s));
+                        d3[e] = v[e] * a1 * s;
+                    }
+                    bf16_t* o = reinterpret_cast<bf16_t*>(p.out);
+                    *reinterpret_cast<bf16x8*>(o + (size_t)row * p.ldo + col) = cvt8(d1);
+                    *reinterpret_cast<bf16x8*>(o + (size_t)row * p.ldo + p.hoff + col) = cvt8(d3);
                 }
             }
         }
@@ -213,11 +290,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 template <int AK, int EPI, int KC>
 int launch(const GemmParams& p, hipStream_t s) {
     const int grid = (p.M + BM - 1) / BM;
-    const size_t lds = (size_t)BM * (KC + 8) * 2 + BM * 2 * sizeof(float);
+    const size_t lds = (size_t)BM * (KC + 8) * 2 + BM * 2 * sizeof(float) + (EPI == E_SWIGLU ? 2 : 1) * PR * TS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<AK, EPI, KC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_kernel<AK, EPI, KC>), dim3(grid), dim3(256), lds, s, p);
@@ -240,7 +317,8 @@ int launch_kc(const GemmParams& p, hipStream_t s) {
 
 int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s) {
     if (p.M <= 0) return HS_OK;
-    if (p.K % 32 || p.N % 16 || p.lda % 8) return HS_EDIMS;
+    if (p.K % 32 || p.N % 16 || p.lda % 8 || p.ldo % 8) return HS_EDIMS;
+    if ((epi == E_F32 || epi == E_RES_F32 || epi == E_POS_F32) && p.n_valid % 8) return HS_EDIMS;
 #define CASE(AK, EP) \
     if (akind == AK && epi == EP) return launch_kc<AK, EP>(p, s);
     CASE(A_F32_LN, E_BF16)
