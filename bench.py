@@ -42,10 +42,14 @@ def flops_per_sample(bands, D, depth, s_depth, Dd, dec_depth, lt, ll, hidden, de
     return 3 * fwd - 2 * PE
 
 
+PEAK_HBM_GBS = 8000.0              # HBM3E spec, same guide
+
+
 def dominant_kernel_roofline(model, N, K_tok, iters=20):
-    """Live HIP-event timing of the dominant kernel (rocprof: profiles/): the LayerNorm->W1|W3->SiLU-gate
-    row-panel MFMA GEMM of the decoder blocks, at the workload's shape, launched through the C ABI on the
-    current stream.  Algorithmic FLOPs per launch = 2 * M * 2h * d."""
+    """Live HIP-event timing of the dominant kernel of the step (profiles/r01_v3: `wgrad_kernel`, 18.7 % of
+    kernel time): the batched weight-gradient launch of one decoder block (q, k, v, proj, w1, w3, w2) at the
+    workload's shape, through the C ABI on the current stream.  HBM-bound: algorithmic bytes per launch =
+    every operand read once = M * (dqkv 3d*2 + u d*2 + dx1 d*4 + o d*2 + dh13 2hp*2 + u2 d*2 + dY d*4 + g hp*2)."""
     from hsimae_amd import _lib, swiglu_hidden
     lib = _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -53,40 +57,39 @@ def dominant_kernel_roofline(model, N, K_tok, iters=20):
     h = swiglu_hidden(d, model.mlp_ratio)
     hp = (h + 31) // 32 * 32
     M = N * model.patch_embed.num_patches
-    x = torch.randn(M, d, device=dev)
-    blk = model.decoder_blocks[0]
-    wpk_elems = hp * d
-    w1 = torch.zeros(wpk_elems, dtype=torch.bfloat16, device=dev)
-    w3 = torch.zeros(wpk_elems, dtype=torch.bfloat16, device=dev)
-    descs = (_lib.PackDesc * 2)()
-    srcs = [blk.mlp.w1.weight.detach().float().contiguous(), blk.mlp.w3.weight.detach().float().contiguous()]
-    for i, (src, dst) in enumerate(zip(srcs, (w1, w3))):
-        descs[i] = _lib.PackDesc(src=src.data_ptr(), rows=h, cols=d, transpose=0, n_off=0, k_off=0, KS=d // 32, dst=dst.data_ptr())
-    table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).clone().to(dev)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    dqkv, u, o, u2 = (torch.randn(M, w, **bf) for w in (3 * d, d, d, d))
+    dh13, g = torch.randn(M, 2 * hp, **bf), torch.randn(M, hp, **bf)
+    G0, G1 = torch.randn(M, d, device=dev), torch.randn(M, d, device=dev)
+    dW = [torch.zeros(n, k, device=dev) for n, k in ((d, d),) * 4 + ((h, d),) * 2 + ((d, h),)]
+    db = [torch.zeros(w.shape[0], device=dev) for w in dW]
+    wp = _lib.WgradParams()
+    spec = [(dqkv.data_ptr(), 0, 3 * d, u, d, d, d), (dqkv.data_ptr() + 2 * d, 0, 3 * d, u, d, d, d),
+            (dqkv.data_ptr() + 4 * d, 0, 3 * d, u, d, d, d), (G1.data_ptr(), 1, d, o, d, d, d),
+            (dh13.data_ptr(), 0, 2 * hp, u2, d, h, d), (dh13.data_ptr() + 2 * hp, 0, 2 * hp, u2, d, h, d),
+            (G0.data_ptr(), 1, d, g, hp, d, h)]
+    tiles = 0
+    for i, (dO, f32, ldo, A, lda, n, k) in enumerate(spec):
+        wp.t[i] = _lib.WgradTask(dO=dO, dO_f32=f32, ldo=ldo, A=A.data_ptr(), lda=lda, N=n, K=k, dW=dW[i].data_ptr(),
+                                 ldw=k, db=db[i].data_ptr())
+        tiles += ((n + 127) // 128) * ((k + 127) // 128)
+    wp.ntasks, wp.M, wp.msplit = len(spec), M, max(1, 640 // tiles)
     s = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.hsimae_pack_matrix(table.data_ptr(), 2, h * d, s))
-    g = torch.empty(M, hp, dtype=torch.bfloat16, device=dev)
-    h13 = torch.empty(M, 2 * hp, dtype=torch.bfloat16, device=dev)
-    u = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
-    p = _lib.GemmParams(A=x.data_ptr(), lda=d, M=M, N=hp, K=d, n_valid=h, W=w1.data_ptr(), W2=w3.data_ptr(),
-                        bias=blk.mlp.w1.bias.data_ptr(), bias2=blk.mlp.w3.bias.data_ptr(),
-                        gamma=blk.norm2.weight.data_ptr(), beta=blk.norm2.bias.data_ptr(), u_out=u.data_ptr(), ldu=d,
-                        out=g.data_ptr(), ldo=hp, h13=h13.data_ptr(), ldh=2 * hp, hoff=hp)
     for _ in range(3):
-        _lib.check(lib.hsimae_gemm(C.byref(p), _lib.A_F32_LN, _lib.E_SWIGLU, s))
+        _lib.check(lib.hsimae_wgrad(C.byref(wp), s))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        _lib.check(lib.hsimae_gemm(C.byref(p), _lib.A_F32_LN, _lib.E_SWIGLU, s))
+        _lib.check(lib.hsimae_wgrad(C.byref(wp), s))
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * M * 2 * h * d
-    achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_kernel<A_F32_LN,E_SWIGLU,128> (decoder LN2->W1|W3->SiLU gate)",
-            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launch_ms": round(ms, 4),
-            "flops_per_launch": flops}
+    nbytes = float(M) * (3 * d * 2 + d * 2 + d * 4 + d * 2 + 2 * hp * 2 + d * 2 + d * 4 + hp * 2)
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "wgrad_kernel (decoder block: dW/db of q,k,v,proj,w1,w3,w2 in one launch)",
+            "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None, "launch_ms": round(ms, 4),
+            "bytes_per_launch": nbytes}
 
 
 def cpu_baseline(bands, n_sample=64, steps=4):
