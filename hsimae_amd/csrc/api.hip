@@ -5,6 +5,7 @@
 #include <vector>
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 
 namespace {
 
@@ -208,6 +209,22 @@ BlkP resolve(const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk,
 }
 
 #define CK(expr) do { int _e = (expr); if (_e) return _e; } while (0)
+
+// HSIMAE_FUSED_DEC=0 forces the layer-at-a-time decoder (A/B testing of the fused decoder kernels)
+bool fused_dec_enabled(const Geo& g) {
+    const char* e = getenv("HSIMAE_FUSED_DEC");
+    if (e && e[0] == '0') return false;
+    return hs_dec_fused_supported(g.Dd, g.Hd, g.hdec, g.TL);
+}
+
+DecBlockPtrs dec_ptrs(const BlkP& b, int h) {
+    DecBlockPtrs d;
+    d.n1w = b.n1w; d.n1b = b.n1b; d.bqkv = b.bqkv; d.pb = b.pb; d.n2w = b.n2w; d.n2b = b.n2b;
+    d.w1b = b.w1b; d.w3b = b.w3b; d.w2b = b.w2b;
+    d.qkv = b.qkv; d.p = b.p; d.w1 = b.w1; d.w3 = b.w3; d.w2 = b.w2;
+    d.qkvT = b.qkvT; d.pT = b.pT; d.w13T = b.w13T; d.w2T = b.w2T; d.h = h;
+    return d;
+}
 
 GemmParams gp() { GemmParams p; std::memset(&p, 0, sizeof(p)); return p; }
 
@@ -436,9 +453,11 @@ int hsimae_forward(const hsimae_config* cfg, const hsimae_io* io, void* stream) 
     as.yfull = w.yfull;
     CK(hs_assemble_fwd(as, s));
     const float* z = w.yfull;
+    const bool fdec = fused_dec_enabled(g);
     for (int i = 0; i < g.ddepth; ++i) {
         BlkP bp = resolve(c.L.bd[i], c.W.bd[i], P, io->wpk, c.W);
-        CK(block_fwd(bp, z, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, nullptr, s));
+        if (fdec) CK(hs_dec_block_fwd(z, w.bd[i].x1, w.bd[i].x2, c.N, g.TL, dec_ptrs(bp, g.hdec), s));
+        else CK(block_fwd(bp, z, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, nullptr, s));
         z = w.bd[i].x2;
     }
     // decoder_norm + decoder_pred (Models.py:597-600)
@@ -485,10 +504,22 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
     CK(hs_ln_bwd(l, s));
     emit(L.dnw, L.total);
 
+    const bool fdec = fused_dec_enabled(g);
     for (int i = g.ddepth - 1; i >= 0; --i) {
         BlkP bp = resolve(L.bd[i], c.W.bd[i], P, io->wpk, c.W);
         const float* xin = (i == 0) ? w.yfull : w.bd[i - 1].x2;
-        CK(block_bwd(bp, L.bd[i], grads, xin, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, w.G0, w.G1, w, w.G0, 0, s));
+        if (fdec) {
+            const BlkOff& o = L.bd[i];
+            DecBlockGrads dg;
+            dg.n1w = grads + o.n1w; dg.n1b = grads + o.n1b; dg.qw = grads + o.qw; dg.qb = grads + o.qb;
+            dg.kw = grads + o.kw; dg.kb = grads + o.kb; dg.vw = grads + o.vw; dg.vb = grads + o.vb;
+            dg.pw = grads + o.pw; dg.pb = grads + o.pb; dg.n2w = grads + o.n2w; dg.n2b = grads + o.n2b;
+            dg.w1w = grads + o.w1w; dg.w1b = grads + o.w1b; dg.w2w = grads + o.w2w; dg.w2b = grads + o.w2b;
+            dg.w3w = grads + o.w3w; dg.w3b = grads + o.w3b;
+            CK(hs_dec_block_bwd(xin, w.bd[i].x1, w.G0, w.G1, w.G0, c.N, g.TL, dec_ptrs(bp, g.hdec), dg, s));
+        } else {
+            CK(block_bwd(bp, L.bd[i], grads, xin, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, w.G0, w.G1, w, w.G0, 0, s));
+        }
         emit(L.bd[i].n1w, L.bd[i].end);
     }
     // sequence assembly + decoder_embed + norm

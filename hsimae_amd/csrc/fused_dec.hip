@@ -1,0 +1,1161 @@
+// Fused decoder Block (Models.py:303-306 at d=64, 8 heads of 8, SwiGLU hidden 172) — one workgroup per sample.
+//
+// The decoder is [8 blocks, width 64] for every HSIMAE size (Model_Pretraining.py:131) and runs on all T*9
+// tokens, so it is half of the step.  Layer-at-a-time kernels are HBM-bound here (32 FLOP/B at d=64); this
+// kernel keeps one sample's 54/108/216 tokens (4/7/14 MFMA m-tiles) resident in LDS/registers through the
+// whole block: LN1 -> q|k|v -> 8-head attention -> proj(+x) -> LN2 -> W1|W3 -> SiLU gate -> W2(+x1).
+// HBM traffic per token: read x (256 B), write x1 and x2 (512 B) instead of ~3.2 KB.
+//
+// Workgroup = 8 waves as 4(M) x 2(N): wave (wm, wn) owns m-tiles [wm*MH, ...) and n-tiles {2wn, 2wn+1} of every
+// 64-column chunk.  The residual stream lives in registers in MFMA accumulator layout (proj / W2 accumulate
+// straight onto it); LayerNorm is done in a row-contiguous "wide" layout (8 lanes per row) through an fp32
+// LDS staging tile, which is also how x / x1 / x2 move to and from HBM with 16-B accesses.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int D = 64, HD = 8, HPD = 192;
+constexpr int LU = D + 8;        // bf16 image row stride (elements)
+constexpr int LG = HPD + 8;
+constexpr int LX = D + 4;        // fp32 staging row stride (floats)
+constexpr int NT_ = 512;         // threads per workgroup (8 waves: one attention head per wave)
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int MT>
+struct DL {
+    static constexpr int R = MT * 16;
+    static constexpr int MH = (MT + 3) / 4;
+    static constexpr int VST = R + 8;                      // transposed-V row stride (elements)
+    static constexpr int U_BYTES = R * LU * 2;
+    static constexpr int QKV_BYTES = 2 * U_BYTES + D * VST * 2;
+    static constexpr int REG2 = cmax(cmax(QKV_BYTES, R * LG * 2), R * LX * 4);
+    static constexpr int FWD_TOTAL = U_BYTES + REG2;
+};
+
+struct Geo4 { int lane, c16, g, wave, wm, wn; };
+
+__device__ __forceinline__ Geo4 geo() {
+    Geo4 q;
+    q.lane = threadIdx.x & 63; q.c16 = q.lane & 15; q.g = q.lane >> 4;
+    q.wave = threadIdx.x >> 6; q.wm = q.wave >> 1; q.wn = q.wave & 1;
+    return q;
+}
+
+// acc[mi][j] += A[rows of m-tile mt0+mi][k] * W[n-tile nt0+j][k]  over KS k-steps starting at A column `kofs`
+// and packed k-step ks0.  All B fragments are fetched up front (one exposed L2 latency per call).
+template <int MH, int KS>
+__device__ __forceinline__ void mm(const bf16_t* A, int lda, int kofs, const bf16_t* W, int KS_total, int nt0,
+                                   int ks0, int mt0, int MT, const Geo4& q, f32x4 (&acc)[MH][2]) {
+    bf16x8 b[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            b[ks][j] = *reinterpret_cast<const bf16x8*>(W + (((size_t)(nt0 + j) * KS_total + ks0 + ks) * 64 + q.lane) * 8);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi) {
+            const int mt = mt0 + mi;
+            if (mt < MT) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + q.c16) * lda + kofs + ks * 32 + q.g * 8);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[mi][j] = mfma16(a, b[ks][j], acc[mi][j]);
+            }
+        }
+}
+
+// Weight fragments of one product, fetched ahead of use (global/L2 latency is 1-2 us under load: every
+// exposed fetch costs more than the MFMAs it feeds, so callers issue `load` one stage early).
+template <int KS>
+struct Fr {
+    bf16x8 b[KS][2];
+    __device__ __forceinline__ void load(const bf16_t* W, int KS_total, int nt0, int ks0, const Geo4& q) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                b[ks][j] = *reinterpret_cast<const bf16x8*>(W + (((size_t)(nt0 + j) * KS_total + ks0 + ks) * 64 + q.lane) * 8);
+    }
+};
+
+template <int MH, int KS>
+__device__ __forceinline__ void mm_f(const bf16_t* A, int lda, int kofs, const Fr<KS>& f, int mt0, int MT, const Geo4& q,
+                                     f32x4 (&acc)[MH][2]) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi) {
+            const int mt = mt0 + mi;
+            if (mt < MT) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + q.c16) * lda + kofs + ks * 32 + q.g * 8);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[mi][j] = mfma16(a, f.b[ks][j], acc[mi][j]);
+            }
+        }
+}
+
+// Wide layout: piece p -> (row p>>3, columns 8*(p&7)..+7); the 8 lanes of a row are adjacent.
+// Loads rows of `src` (global fp32 [Ts,64]; rows >= Ts read as zero), optionally mirrors them into the fp32
+// staging tile, and writes LayerNorm(row) as bf16 into the LDS image `U`.
+template <int MT, bool FROM_LDS>
+__device__ __forceinline__ void ln_rows(const float* src, int Ts, const float* gamma, const float* beta, bf16_t* U,
+                                        float* XS, float* copy_out) {
+    constexpr int R = MT * 16;
+    const int c8 = (threadIdx.x & 7) * 8;
+    float gm[8], bt[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gm[e] = gamma[c8 + e]; bt[e] = beta[c8 + e]; }
+#pragma unroll
+    for (int i = 0; i < (R * 8 + NT_ - 1) / NT_; ++i) {
+        const int p = threadIdx.x + NT_ * i;
+        if (p < R * 8) {
+            const int row = p >> 3;
+            float f[8];
+            if constexpr (FROM_LDS) {
+                const float4 a = *reinterpret_cast<const float4*>(XS + row * LX + c8);
+                const float4 b = *reinterpret_cast<const float4*>(XS + row * LX + c8 + 4);
+                f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+                if (copy_out && row < Ts) {
+                    *reinterpret_cast<float4*>(copy_out + (size_t)row * D + c8) = a;
+                    *reinterpret_cast<float4*>(copy_out + (size_t)row * D + c8 + 4) = b;
+                }
+            } else {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+                if (row < Ts) {
+                    a = *reinterpret_cast<const float4*>(src + (size_t)row * D + c8);
+                    b = *reinterpret_cast<const float4*>(src + (size_t)row * D + c8 + 4);
+                }
+                f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+                if (XS) {
+                    *reinterpret_cast<float4*>(XS + row * LX + c8) = a;
+                    *reinterpret_cast<float4*>(XS + row * LX + c8 + 4) = b;
+                }
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[e];
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            const float mean = s * (1.f / D);
+            float v = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dl = f[e] - mean; v += dl * dl; }
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+            const float rstd = rsqrtf(v * (1.f / D) + 1e-5f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd * gm[e] + bt[e];
+            *reinterpret_cast<bf16x8*>(U + row * LU + c8) = cvt8(f);
+        }
+    }
+}
+
+template <int MH>
+__device__ __forceinline__ void acc_from_xs(const float* XS, int mt0, int MT, const Geo4& q, f32x4 (&x)[MH][2]) {
+#pragma unroll
+    for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mt = mt0 + mi;
+                x[mi][j][r] = (mt < MT) ? XS[(mt * 16 + q.g * 4 + r) * LX + (q.wn * 2 + j) * 16 + q.c16] : 0.f;
+            }
+}
+
+template <int MH>
+__device__ __forceinline__ void acc_to_xs(float* XS, int mt0, int MT, const Geo4& q, const f32x4 (&x)[MH][2]) {
+#pragma unroll
+    for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mt = mt0 + mi;
+                if (mt < MT) XS[(mt * 16 + q.g * 4 + r) * LX + (q.wn * 2 + j) * 16 + q.c16] = x[mi][j][r];
+            }
+}
+
+__device__ __forceinline__ void store_rows(const float* XS, int R, int Ts, float* dst) {
+    const int c8 = (threadIdx.x & 7) * 8;
+    for (int p = threadIdx.x; p < R * 8; p += NT_) {
+        const int row = p >> 3;
+        if (row < Ts) {
+            *reinterpret_cast<float4*>(dst + (size_t)row * D + c8) = *reinterpret_cast<const float4*>(XS + row * LX + c8);
+            *reinterpret_cast<float4*>(dst + (size_t)row * D + c8 + 4) = *reinterpret_cast<const float4*>(XS + row * LX + c8 + 4);
+        }
+    }
+}
+
+__device__ __forceinline__ bf16x8 pack2(f32x4 a, f32x4 b) {
+    bf16x8 r;
+    r[0] = (bf16_t)a[0]; r[1] = (bf16_t)a[1]; r[2] = (bf16_t)a[2]; r[3] = (bf16_t)a[3];
+    r[4] = (bf16_t)b[0]; r[5] = (bf16_t)b[1]; r[6] = (bf16_t)b[2]; r[7] = (bf16_t)b[3];
+    return r;
+}
+
+__device__ __forceinline__ bf16x8 rowfrag8(const bf16_t* img, int ld, int row, int coloff, int g) {
+    // head dim 8: only k-group 0 carries data
+    if (g == 0) return *reinterpret_cast<const bf16x8*>(img + row * ld + coloff);
+    return zero8();
+}
+
+__device__ __forceinline__ bf16x8 trfrag8(const bf16_t* vt, int vst, int drow, int ta, int tb, bool tb_ok, int g) {
+    if (drow < HD) {
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(vt + drow * vst + ta * 16 + g * 4);
+        u32x2 hi = {0u, 0u};
+        if (tb_ok) hi = *reinterpret_cast<const u32x2*>(vt + drow * vst + tb * 16 + g * 4);
+        u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+    return zero8();
+}
+
+// One head of full (unmasked) attention over the sample's Ts tokens; writes O (bf16) into `O` columns head*8..
+template <int MT>
+__device__ __forceinline__ void attn_head_fwd(const bf16_t* Qb, const bf16_t* Kb, const bf16_t* Vt, bf16_t* O, int head,
+                                              int Ts, const Geo4& q, float* lse_out) {
+    using L = DL<MT>;
+    const float sc = 0.35355339059327373f * 1.4426950408889634f;     // 8^-0.5 * log2(e)
+    const bf16_t* vth = Vt + head * HD * L::VST;
+    for (int qt = 0; qt * 16 < Ts; ++qt) {
+        const int query = qt * 16 + q.c16;
+        const bf16x8 bq = rowfrag8(Qb, LU, query, head * HD, q.g);
+        f32x4 s[MT];
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt)
+            s[kt] = mfma16(rowfrag8(Kb, LU, kt * 16 + q.c16, head * HD, q.g), bq, f32x4{0.f, 0.f, 0.f, 0.f});
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+            if ((kt + 1) * 16 > Ts) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + q.g * 4 + r >= Ts) s[kt][r] = -INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float nm = -m * sc;
+        float lsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc, nm));
+                s[kt][r] = e;
+                lsum += e;
+            }
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        const float inv = 1.f / lsum;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pp = 0; pp < (MT + 1) / 2; ++pp) {
+            const int ta = 2 * pp, tb = 2 * pp + 1;
+            const bool tb_ok = tb < MT;
+            const bf16x8 bp = pack2(s[ta], tb_ok ? s[tb_ok ? tb : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
+            o = mfma16(trfrag8(vth, L::VST, q.c16, ta, tb, tb_ok, q.g), bp, o);
+        }
+        if (q.g < 2) {
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
+            *reinterpret_cast<bf16x4*>(O + query * LU + head * HD + q.g * 4) = ov;
+        }
+        if (lse_out && q.g == 0) lse_out[query] = m * sc + __builtin_amdgcn_logf(lsum);   // log2-domain lse
+    }
+}
+
+struct DecW {               // one decoder block's parameters
+    const float *n1w, *n1b, *bqkv, *pb, *n2w, *n2b, *w1b, *w3b, *w2b;
+    const bf16_t *qkv, *p, *w1, *w3, *w2;
+    int h;
+};
+
+// The weight images are invariant across the samples a workgroup walks; left alone, the compiler hoists every
+// fragment load out of the sample loop and then spills them.  Laundering the pointers once per iteration keeps
+// the loads where they are used.
+template <class T>
+__device__ __forceinline__ const T* launder(const T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+__device__ __forceinline__ DecW launder_w(const DecW& a) {
+    DecW w = a;
+    w.qkv = launder(a.qkv); w.p = launder(a.p); w.w1 = launder(a.w1); w.w3 = launder(a.w3); w.w2 = launder(a.w2);
+    return w;
+}
+
+struct DecFwdArgs { const float* x; float* x1; float* x2; int nsamples, Ts; DecW w; };
+
+// q|k|v for the whole sample from the LN image U:  Qb, Kb row-major bf16; V transposed into Vt.
+template <int MT>
+__device__ __forceinline__ void qkv_stage(const bf16_t* U, const DecW& w, const Fr<2> (&fq)[3], bf16_t* Qb, bf16_t* Kb,
+                                          bf16_t* Vt, int mt0, const Geo4& q) {
+    using L = DL<MT>;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        f32x4 acc[L::MH][2];
+#pragma unroll
+        for (int mi = 0; mi < L::MH; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float b = w.bqkv[c * D + (q.wn * 2 + j) * 16 + q.c16];
+                acc[mi][j] = f32x4{b, b, b, b};
+            }
+        mm_f<L::MH, 2>(U, LU, 0, fq[c], mt0, MT, q, acc);
+#pragma unroll
+        for (int mi = 0; mi < L::MH; ++mi) {
+            const int mt = mt0 + mi;
+            if (mt >= MT) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = (q.wn * 2 + j) * 16 + q.c16;
+                const int row = mt * 16 + q.g * 4;
+                if (c < 2) {
+                    bf16_t* dst = (c == 0 ? Qb : Kb);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[(row + r) * LU + col] = (bf16_t)acc[mi][j][r];
+                } else {
+                    bf16x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[mi][j][r];
+                    *reinterpret_cast<bf16x4*>(Vt + col * L::VST + row) = v;
+                }
+            }
+        }
+    }
+}
+
+// g = silu(u2 W1^T + b1) * (u2 W3^T + b3) for hidden chunk c (64 columns) -> bf16 image columns [c*64, +64)
+template <int MT>
+__device__ __forceinline__ void gate_chunk(const bf16_t* U, const DecW& w, int c, int mt0, const Geo4& q,
+                                           f32x4 (&h1)[DL<MT>::MH][2], f32x4 (&h3)[DL<MT>::MH][2]) {
+    using L = DL<MT>;
+#pragma unroll
+    for (int mi = 0; mi < L::MH; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
+            const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
+            h1[mi][j] = f32x4{b1, b1, b1, b1};
+            h3[mi][j] = f32x4{b3, b3, b3, b3};
+        }
+    mm<L::MH, 2>(U, LU, 0, w.w1, 2, c * 4 + q.wn * 2, 0, mt0, MT, q, h1);
+    mm<L::MH, 2>(U, LU, 0, w.w3, 2, c * 4 + q.wn * 2, 0, mt0, MT, q, h3);
+}
+
+__device__ __forceinline__ float silu_f(float a) { return a / (1.f + __expf(-a)); }
+
+template <int MT>
+__global__ __launch_bounds__(512, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
+    using L = DL<MT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* U = reinterpret_cast<bf16_t*>(smem);
+    char* reg2 = smem + L::U_BYTES;
+    bf16_t* Qb = reinterpret_cast<bf16_t*>(reg2);
+    bf16_t* Kb = Qb + L::R * LU;
+    bf16_t* Vt = Kb + L::R * LU;
+    float* XS = reinterpret_cast<float*>(reg2);
+    bf16_t* Gb = reinterpret_cast<bf16_t*>(reg2);
+    const Geo4 q = geo();
+    const int mt0 = q.wm * L::MH;
+
+    for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
+        const size_t rb = (size_t)sample * p.Ts;
+        const DecW w = launder_w(p.w);
+        // LN1 (wide layout) + residual into accumulator layout; q|k|v weight fragments are already in flight
+        Fr<2> fq[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fq[c].load(w.qkv, 2, c * 4 + q.wn * 2, 0, q);
+        ln_rows<MT, false>(p.x + rb * D, p.Ts, w.n1w, w.n1b, U, XS, nullptr);
+        __syncthreads();
+        f32x4 xr[L::MH][2];
+        acc_from_xs<L::MH>(XS, mt0, MT, q, xr);
+        __syncthreads();
+        qkv_stage<MT>(U, w, fq, Qb, Kb, Vt, mt0, q);
+        Fr<2> fp;
+        fp.load(w.p, 2, q.wn * 2, 0, q);
+        __syncthreads();
+        attn_head_fwd<MT>(Qb, Kb, Vt, U, q.wave, p.Ts, q, nullptr);
+        __syncthreads();
+        // proj accumulates onto the residual
+#pragma unroll
+        for (int mi = 0; mi < L::MH; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float b = w.pb[(q.wn * 2 + j) * 16 + q.c16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xr[mi][j][r] += b;
+            }
+        mm_f<L::MH, 2>(U, LU, 0, fp, mt0, MT, q, xr);
+        Fr<2> f1, f3;
+        f1.load(w.w1, 2, q.wn * 2, 0, q);
+        f3.load(w.w3, 2, q.wn * 2, 0, q);
+        acc_to_xs<L::MH>(XS, mt0, MT, q, xr);
+        __syncthreads();
+        ln_rows<MT, true>(nullptr, p.Ts, w.n2w, w.n2b, U, XS, p.x1 + rb * D);      // LN2; x1 saved for the backward
+        __syncthreads();
+        Fr<6> f2;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f32x4 h1[L::MH][2], h3[L::MH][2];
+#pragma unroll
+            for (int mi = 0; mi < L::MH; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
+                    const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
+                    h1[mi][j] = f32x4{b1, b1, b1, b1};
+                    h3[mi][j] = f32x4{b3, b3, b3, b3};
+                }
+            mm_f<L::MH, 2>(U, LU, 0, f1, mt0, MT, q, h1);
+            mm_f<L::MH, 2>(U, LU, 0, f3, mt0, MT, q, h3);
+            if (c < 2) {
+                f1.load(w.w1, 2, (c + 1) * 4 + q.wn * 2, 0, q);
+                f3.load(w.w3, 2, (c + 1) * 4 + q.wn * 2, 0, q);
+            } else {
+                f2.load(w.w2, 6, q.wn * 2, 0, q);
+            }
+#pragma unroll
+            for (int mi = 0; mi < L::MH; ++mi) {
+                const int mt = mt0 + mi;
+                if (mt >= MT) continue;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float gv = col < w.h ? silu_f(h1[mi][j][r]) * h3[mi][j][r] : 0.f;
+                        Gb[(mt * 16 + q.g * 4 + r) * LG + col] = (bf16_t)gv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < L::MH; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float b = w.w2b[(q.wn * 2 + j) * 16 + q.c16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xr[mi][j][r] += b;
+            }
+        mm_f<L::MH, 6>(Gb, LG, 0, f2, mt0, MT, q, xr);
+        __syncthreads();
+        acc_to_xs<L::MH>(XS, mt0, MT, q, xr);
+        __syncthreads();
+        store_rows(XS, L::R, p.Ts, p.x2 + rb * D);
+        __syncthreads();
+    }
+}
+
+// ====================================================================== backward
+// The decoder block's backward is two persistent kernels per block (weight gradients stay in registers across
+// all the samples a workgroup walks and are committed once with atomics — 198 KB of dW per block fit on chip):
+//   dec_bwd_mlp_kernel : reads x1, dY          -> dx1 = dY + LN2/SwiGLU branch grads ; dW1 dW3 dW2 db* dLN2
+//   dec_bwd_attn_kernel: reads x, dx1          -> dx  = dx1 + LN1/attention branch grads ; dWq dWk dWv dWp db* dLN1
+// Everything else (u, q, k, v, P, o, h1, h3, g) is recomputed from x / x1 inside the tile.
+typedef __attribute__((address_space(3))) bf16x4* lds_b64;
+
+// MFMA operand whose k index runs over image ROWS (tokens): element j<4 = img[rowa + 4g + j][col0 + c16],
+// j>=4 = img[rowb + 4g + (j-4)][col0 + c16], via two transpose reads (EXEC must be full).
+__device__ __forceinline__ bf16x8 trfrag(const bf16_t* img, int ld, int rowa, int rowb, bool b_ok, int col0, bool lane_ok,
+                                         const Geo4& q) {
+    const int q4 = q.c16 >> 2, p4 = q.c16 & 3;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + (rowa + 4 * q.g + q4) * ld + col0 + 4 * p4));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + ((b_ok ? rowb : rowa) + 4 * q.g + q4) * ld + col0 + 4 * p4));
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        r[e] = lane_ok ? lo[e] : (bf16_t)0.f;
+        r[4 + e] = (lane_ok && b_ok) ? hi[e] : (bf16_t)0.f;
+    }
+    return r;
+}
+
+// 16x16 tile of  dO[:, n0..n0+15]^T * A[:, k0..k0+15]  summed over the R image rows (32 per MFMA).
+template <int MT>
+__device__ __forceinline__ void wg_tile(const bf16_t* dO, int n0, const bf16_t* A, int k0, const Geo4& q, f32x4& acc) {
+    constexpr int R = MT * 16;
+#pragma unroll
+    for (int kk = 0; kk < (R + 31) / 32; ++kk) {
+        const bool b_ok = kk * 32 + 16 < R;              // second 16-row half exists
+        // element j of lane group g is row kk*32 + 8g + j: as two 4-row reads at rows kk*32+8g and kk*32+8g+4
+        const int q4 = q.c16 >> 2, p4 = q.c16 & 3;
+        const bool ok = kk * 32 + 8 * q.g < R;
+        const int rb = ok ? kk * 32 + 8 * q.g : kk * 32;
+        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(dO + (rb + q4) * LU + n0 + 4 * p4));
+        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(dO + (rb + 4 + q4) * LU + n0 + 4 * p4));
+        const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(A + (rb + q4) * LU + k0 + 4 * p4));
+        const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(A + (rb + 4 + q4) * LU + k0 + 4 * p4));
+        (void)b_ok;
+        bf16x8 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = ok ? a0[e] : (bf16_t)0.f; a[4 + e] = ok ? a1[e] : (bf16_t)0.f;
+            b[e] = ok ? b0[e] : (bf16_t)0.f; b[4 + e] = ok ? b1[e] : (bf16_t)0.f;
+        }
+        acc = mfma16(a, b, acc);
+    }
+}
+
+// Row (token) fragment pair for one k-step of a weight-gradient product (see wg_tile), zeroed past row R.
+template <int MT>
+__device__ __forceinline__ bf16x8 wg_frag(const bf16_t* img, int col0, int kk, const Geo4& q) {
+    constexpr int R = MT * 16;
+    const int q4 = q.c16 >> 2, p4 = q.c16 & 3;
+    const bool ok = kk * 32 + 8 * q.g < R;
+    const int rb = ok ? kk * 32 + 8 * q.g : kk * 32;
+    const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + (rb + q4) * LU + col0 + 4 * p4));
+    const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + (rb + 4 + q4) * LU + col0 + 4 * p4));
+    bf16x8 a;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = ok ? a0[e] : (bf16_t)0.f; a[4 + e] = ok ? a1[e] : (bf16_t)0.f; }
+    return a;
+}
+
+__device__ __forceinline__ void ld8(const float* p, float* o) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void st8(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ float red8(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+// Commit per-thread column partials (wide layout: thread owns columns 8*(tid&7)..+7) with one atomic per column.
+__device__ __forceinline__ void flush_wide(float* red /* [NT_][8] LDS */, const float* part, float* dst) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = part[e];
+    __syncthreads();
+    if (threadIdx.x < D) {
+        const int c = threadIdx.x, c8 = c >> 3, e = c & 7;
+        float s = 0.f;
+        for (int t = c8; t < NT_; t += 8) s += red[t * 8 + e];
+        atomicAdd(dst + c, s);
+    }
+}
+
+struct DecBwdMlpArgs {
+    const float* x1; const float* dy; float* dx1; int nsamples, Ts; DecW w; const bf16_t *w2T, *w13T;
+    float *g_n2w, *g_n2b, *g_w1w, *g_w1b, *g_w3w, *g_w3b, *g_w2w, *g_w2b;
+};
+
+template <int MT>
+__global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
+    using L = DL<MT>;
+    constexpr int R = L::R, IMG = R * LU, NPW = (R * 8 + NT_ - 1) / NT_;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* DYb = U2 + IMG;
+    bf16_t* Gc = DYb + IMG;
+    bf16_t* DH1 = Gc + IMG;
+    bf16_t* DH3 = DH1 + IMG;
+    float* XS = reinterpret_cast<float*>(DH3 + IMG);
+    const Geo4 q = geo();
+    const int mt0 = q.wm * L::MH;
+    const int c8 = (threadIdx.x & 7) * 8;
+
+    f32x4 accW[3][3][2];                 // [hidden chunk][this wave's n-tile][this wave's k-tile]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) accW[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dgam[8], dbet[8], db2[8], db1[3][2], db3[3][2];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; db2[e] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { db1[c][0] = db1[c][1] = db3[c][0] = db3[c][1] = 0.f; }
+
+    for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
+        const size_t rb = (size_t)sample * p.Ts;
+        const DecW w = launder_w(p.w);
+        const bf16_t* w2T = launder(p.w2T);
+        const bf16_t* w13T = launder(p.w13T);
+        const float* n2w = launder(p.w.n2w);
+        const float* n2b = launder(p.w.n2b);
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int pc = threadIdx.x + NT_ * i;
+            if (pc < R * 8) {
+                const int row = pc >> 3;
+                float f[8], dyv[8], gm[8], bt[8];
+                ld8(n2w + c8, gm); ld8(n2b + c8, bt);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f[e] = 0.f; dyv[e] = 0.f; }
+                if (row < p.Ts) { ld8(p.x1 + (rb + row) * D + c8, f); ld8(p.dy + (rb + row) * D + c8, dyv); }
+                const float mean = red8(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
+                float v = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f[e] -= mean; v += f[e] * f[e]; }
+                const float rstd = rsqrtf(red8(v) * (1.f / D) + 1e-5f);
+                float u[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { u[e] = f[e] * rstd * gm[e] + bt[e]; db2[e] += dyv[e]; }
+                *reinterpret_cast<bf16x8*>(U2 + row * LU + c8) = cvt8(u);
+                *reinterpret_cast<bf16x8*>(DYb + row * LU + c8) = cvt8(dyv);
+            }
+        }
+        __syncthreads();
+        f32x4 du2[L::MH][2];
+#pragma unroll
+        for (int mi = 0; mi < L::MH; ++mi) { du2[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; du2[mi][1] = du2[mi][0]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            {
+                f32x4 h1[L::MH][2], h3[L::MH][2], dg[L::MH][2];
+                gate_chunk<MT>(U2, w, c, mt0, q, h1, h3);
+#pragma unroll
+                for (int mi = 0; mi < L::MH; ++mi) { dg[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dg[mi][1] = dg[mi][0]; }
+                mm<L::MH, 2>(DYb, LU, 0, w2T, 2, c * 4 + q.wn * 2, 0, mt0, MT, q, dg);
+#pragma unroll
+                for (int mi = 0; mi < L::MH; ++mi) {
+                    const int mt = mt0 + mi;
+                    if (mt >= MT) continue;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int lc = (q.wn * 2 + j) * 16 + q.c16;
+                        const bool ok = c * 64 + lc < w.h;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float a1 = h1[mi][j][r], a3 = h3[mi][j][r], dv = dg[mi][j][r];
+                            const float sg = 1.f / (1.f + __expf(-a1));
+                            const float sl = a1 * sg;
+                            const float gv = ok ? sl * a3 : 0.f;
+                            const float d1 = ok ? dv * a3 * sg * (1.f + a1 * (1.f - sg)) : 0.f;
+                            const float d3 = ok ? dv * sl : 0.f;
+                            const int o = (mt * 16 + q.g * 4 + r) * LU + lc;
+                            Gc[o] = (bf16_t)gv; DH1[o] = (bf16_t)d1; DH3[o] = (bf16_t)d3;
+                            db1[c][j] += d1; db3[c][j] += d3;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // weight gradients of this hidden chunk: 12 (n-tile) x 4 (k-tile) output tiles, 3 x 2 per wave
+#pragma unroll 1
+            for (int kk = 0; kk < (R + 31) / 32; ++kk) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;   // mat 0: dW2, 1: dW1, 2: dW3
+                    const bf16_t* dOi = mat == 0 ? DYb : (mat == 1 ? DH1 : DH3);
+                    const bf16_t* Ai = mat == 0 ? Gc : U2;
+                    const bf16x8 a = wg_frag<MT>(dOi, nt * 16, kk, q);
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2)
+                        accW[c][t][k2] = mfma16(a, wg_frag<MT>(Ai, ((q.wave & 1) * 2 + k2) * 16, kk, q), accW[c][t][k2]);
+                }
+            }
+            // data gradient through W1 / W3
+            mm<L::MH, 2>(DH1, LU, 0, w13T, 12, q.wn * 2, 2 * c, mt0, MT, q, du2);
+            mm<L::MH, 2>(DH3, LU, 0, w13T, 12, q.wn * 2, 6 + 2 * c, mt0, MT, q, du2);
+            __syncthreads();
+        }
+        acc_to_xs<L::MH>(XS, mt0, MT, q, du2);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int pc = threadIdx.x + NT_ * i;
+            if (pc < R * 8) {
+                const int row = pc >> 3;
+                float du[8], t[8], xh[8], dyv[8], gm[8];
+                ld8(XS + row * LX + c8, du);
+                ld8(n2w + c8, gm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xh[e] = 0.f; dyv[e] = 0.f; }
+                if (row < p.Ts) { ld8(p.x1 + (rb + row) * D + c8, xh); ld8(p.dy + (rb + row) * D + c8, dyv); }   // L2-hot re-read
+                const float mean = red8(xh[0] + xh[1] + xh[2] + xh[3] + xh[4] + xh[5] + xh[6] + xh[7]) * (1.f / D);
+                float v = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xh[e] -= mean; v += xh[e] * xh[e]; }
+                const float rstd = rsqrtf(red8(v) * (1.f / D) + 1e-5f);
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xh[e] *= rstd; t[e] = du[e] * gm[e]; a += t[e]; b += t[e] * xh[e]; }
+                a = red8(a) * (1.f / D); b = red8(b) * (1.f / D);
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = dyv[e] + rstd * (t[e] - a - xh[e] * b);
+                    dgam[e] += du[e] * xh[e];
+                    dbet[e] += du[e];
+                }
+                if (row < p.Ts) st8(p.dx1 + (rb + row) * D + c8, o);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- commit
+    float* red = XS;
+    flush_wide(red, dgam, p.g_n2w);
+    flush_wide(red, dbet, p.g_n2b);
+    flush_wide(red, db2, p.g_w2b);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float a = db1[c][j], b = db3[c][j];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
+            if (q.g == 0 && col < p.w.h) { atomicAdd(p.g_w1b + col, a); atomicAdd(p.g_w3b + col, b); }
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nt * 16 + q.g * 4 + r, k = ((q.wave & 1) * 2 + k2) * 16 + q.c16;
+                    const float v = accW[c][t][k2][r];
+                    if (mat == 0) {                       // dW2[d][h]: row n (model dim), column c*64 + k (hidden)
+                        if (c * 64 + k < p.w.h) atomicAdd(p.g_w2w + (size_t)n * p.w.h + c * 64 + k, v);
+                    } else {                              // dW1 / dW3 [h][d]: row c*64 + n (hidden), column k
+                        float* dst = mat == 1 ? p.g_w1w : p.g_w3w;
+                        if (c * 64 + n < p.w.h) atomicAdd(dst + (size_t)(c * 64 + n) * D + k, v);
+                    }
+                }
+        }
+}
+
+struct DecBwdAttnArgs {
+    const float* x; const float* dx1; float* dx; int nsamples, Ts; DecW w; const bf16_t *qkvT, *pT;
+    float *g_n1w, *g_n1b, *g_qw, *g_qb, *g_kw, *g_kb, *g_vw, *g_vb, *g_pw, *g_pb;
+};
+
+template <int MT>
+__global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) {
+    using L = DL<MT>;
+    constexpr int R = L::R, IMG = R * LU, NPW = (R * 8 + NT_ - 1) / NT_;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* U = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Qb = U + IMG;
+    bf16_t* Kb = Qb + IMG;
+    bf16_t* Vb = Kb + IMG;
+    bf16_t* Ob = Vb + IMG;            // attention output, later the image of dO
+    bf16_t* DXb = Ob + IMG;           // bf16 image of dx1
+    bf16_t* DQb = DXb + IMG;          // dq (q itself is still needed by the dK pass)
+    float* XS = reinterpret_cast<float*>(DQb + IMG);
+    float* lse = XS + R * LX;         // [8][R]
+    float* dlt = lse + 8 * R;         // [8][R]
+    const Geo4 q = geo();
+    const int mt0 = q.wm * L::MH;
+    const int c8 = (threadIdx.x & 7) * 8;
+    const float sc = 0.35355339059327373f * 1.4426950408889634f, scale = 0.35355339059327373f;
+
+    f32x4 accP[2], accQ[3][2];         // dWp: n-tile = wave>>1; dWq|dWk|dWv: 12 n-tiles x 4 k-tiles, 3 x 2 per wave
+#pragma unroll
+    for (int a = 0; a < 2; ++a) accP[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) accQ[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dgam[8], dbet[8], dbp[8];
+    float dbq[1][4], dbk[1][4], dbv[1][4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; dbp[e] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dbq[0][r] = 0.f; dbk[0][r] = 0.f; dbv[0][r] = 0.f; }
+
+    for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
+        const size_t rb = (size_t)sample * p.Ts;
+        const DecW w = launder_w(p.w);
+        const bf16_t* qkvT = launder(p.qkvT);
+        const bf16_t* pT = launder(p.pT);
+        const float* n1w = launder(p.w.n1w);
+        const float* n1b = launder(p.w.n1b);
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int pc = threadIdx.x + NT_ * i;
+            if (pc < R * 8) {
+                const int row = pc >> 3;
+                float f[8], d1[8], gm[8], bt[8];
+                ld8(n1w + c8, gm); ld8(n1b + c8, bt);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f[e] = 0.f; d1[e] = 0.f; }
+                if (row < p.Ts) { ld8(p.x + (rb + row) * D + c8, f); ld8(p.dx1 + (rb + row) * D + c8, d1); }
+                const float mean = red8(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
+                float v = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f[e] -= mean; v += f[e] * f[e]; }
+                const float rstd = rsqrtf(red8(v) * (1.f / D) + 1e-5f);
+                float u[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { u[e] = f[e] * rstd * gm[e] + bt[e]; dbp[e] += d1[e]; }
+                *reinterpret_cast<bf16x8*>(U + row * LU + c8) = cvt8(u);
+                *reinterpret_cast<bf16x8*>(DXb + row * LU + c8) = cvt8(d1);
+            }
+        }
+        __syncthreads();
+        // q | k | v, all row-major
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f32x4 acc[L::MH][2];
+#pragma unroll
+            for (int mi = 0; mi < L::MH; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float b = w.bqkv[c * D + (q.wn * 2 + j) * 16 + q.c16];
+                    acc[mi][j] = f32x4{b, b, b, b};
+                }
+            mm<L::MH, 2>(U, LU, 0, w.qkv, 2, c * 4 + q.wn * 2, 0, mt0, MT, q, acc);
+            bf16_t* dst = c == 0 ? Qb : (c == 1 ? Kb : Vb);
+#pragma unroll
+            for (int mi = 0; mi < L::MH; ++mi) {
+                const int mt = mt0 + mi;
+                if (mt >= MT) continue;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dst[(mt * 16 + q.g * 4 + r) * LU + (q.wn * 2 + j) * 16 + q.c16] = (bf16_t)acc[mi][j][r];
+            }
+        }
+        __syncthreads();
+        // attention forward (recompute): O image + log2-domain logsumexp per (head, query)
+        {
+            const int head = q.wave;
+            for (int qt = 0; qt * 16 < p.Ts; ++qt) {
+                const int query = qt * 16 + q.c16;
+                const bf16x8 bq = rowfrag8(Qb, LU, query, head * HD, q.g);
+                f32x4 s[MT];
+#pragma unroll
+                for (int kt = 0; kt < MT; ++kt)
+                    s[kt] = mfma16(rowfrag8(Kb, LU, kt * 16 + q.c16, head * HD, q.g), bq, f32x4{0.f, 0.f, 0.f, 0.f});
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < MT; ++kt) {
+                    if ((kt + 1) * 16 > p.Ts) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kt * 16 + q.g * 4 + r >= p.Ts) s[kt][r] = -INFINITY;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
+                }
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                const float nm = -m * sc;
+                float lsum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc, nm));
+                        s[kt][r] = e;
+                        lsum += e;
+                    }
+                lsum += __shfl_xor(lsum, 16, 64);
+                lsum += __shfl_xor(lsum, 32, 64);
+                const float inv = 1.f / lsum;
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pp = 0; pp < (MT + 1) / 2; ++pp) {
+                    const int ta = 2 * pp, tb = 2 * pp + 1;
+                    const bool tb_ok = tb < MT;
+                    const bf16x8 bp = pack2(s[ta], tb_ok ? s[tb_ok ? tb : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
+                    o = mfma16(trfrag(Vb, LU, ta * 16, tb * 16, tb_ok, head * HD, q.c16 < HD, q), bp, o);
+                }
+                if (q.g < 2) {
+                    bf16x4 ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
+                    *reinterpret_cast<bf16x4*>(Ob + query * LU + head * HD + q.g * 4) = ov;
+                }
+                if (q.g == 0) lse[head * R + query] = m * sc + __builtin_amdgcn_logf(lsum);
+            }
+        }
+        __syncthreads();
+        // dO = dx1 * Wp ; dWp += dx1^T * O
+        f32x4 dO[L::MH][2];
+#pragma unroll
+        for (int mi = 0; mi < L::MH; ++mi) { dO[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dO[mi][1] = dO[mi][0]; }
+        mm<L::MH, 2>(DXb, LU, 0, pT, 2, q.wn * 2, 0, mt0, MT, q, dO);
+#pragma unroll 1
+        for (int kk = 0; kk < (R + 31) / 32; ++kk) {
+            const bf16x8 a = wg_frag<MT>(DXb, (q.wave >> 1) * 16, kk, q);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+                accP[k2] = mfma16(a, wg_frag<MT>(Ob, ((q.wave & 1) * 2 + k2) * 16, kk, q), accP[k2]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < L::MH; ++mi) {
+            const int mt = mt0 + mi;
+            if (mt >= MT) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Ob[(mt * 16 + q.g * 4 + r) * LU + (q.wn * 2 + j) * 16 + q.c16] = (bf16_t)dO[mi][j][r];
+        }
+        __syncthreads();
+        // attention backward, two heads per wave, dq/dk/dv written in place over q/k/v
+        {
+            constexpr int hh = 0;
+            const int head = q.wave, hc = head * HD;
+            // pass A: S^T orientation (key on accumulator rows, query on the lane) -> delta, dQ
+#pragma unroll 1
+            for (int qt = 0; qt < MT; ++qt) {
+                const int query = qt * 16 + q.c16;
+                const float lq = lse[head * R + query];
+                const bf16x8 bq = rowfrag8(Qb, LU, query, hc, q.g);
+                const bf16x8 bdo = rowfrag8(Ob, LU, query, hc, q.g);
+                f32x4 pr[MT], dp[MT];
+                float dsum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < MT; ++kt) {
+                    const f32x4 s = mfma16(rowfrag8(Kb, LU, kt * 16 + q.c16, hc, q.g), bq, f32x4{0.f, 0.f, 0.f, 0.f});
+                    dp[kt] = mfma16(rowfrag8(Vb, LU, kt * 16 + q.c16, hc, q.g), bdo, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = kt * 16 + q.g * 4 + r < p.Ts;
+                        pr[kt][r] = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, -lq)) : 0.f;
+                        dsum += pr[kt][r] * dp[kt][r];
+                    }
+                }
+                dsum += __shfl_xor(dsum, 16, 64);
+                dsum += __shfl_xor(dsum, 32, 64);
+                if (q.g == 0) dlt[head * R + query] = dsum;
+#pragma unroll
+                for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr[kt][r] = pr[kt][r] * (dp[kt][r] - dsum) * scale;     // dS
+                f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pp = 0; pp < (MT + 1) / 2; ++pp) {
+                    const int ta = 2 * pp, tb = 2 * pp + 1;
+                    const bool tb_ok = tb < MT;
+                    const bf16x8 b = pack2(pr[ta], tb_ok ? pr[tb_ok ? tb : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
+                    dq = mfma16(trfrag(Kb, LU, ta * 16, tb * 16, tb_ok, hc, q.c16 < HD, q), b, dq);
+                }
+                if (q.g < 2) {
+                    bf16x4 vq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { vq[r] = (bf16_t)dq[r]; dbq[hh][r] += query < p.Ts ? dq[r] : 0.f; }
+                    *reinterpret_cast<bf16x4*>(DQb + query * LU + hc + q.g * 4) = vq;
+                }
+            }
+            __syncthreads();           // delta of this head visible (uniform: every wave runs 2 heads)
+            // pass B: S orientation (query on accumulator rows, key on the lane) -> dK, dV
+#pragma unroll 1
+            for (int kt = 0; kt < MT; ++kt) {
+                const int key = kt * 16 + q.c16;
+                const bool kok = key < p.Ts;
+                const bf16x8 bk = rowfrag8(Kb, LU, key, hc, q.g);
+                const bf16x8 bv = rowfrag8(Vb, LU, key, hc, q.g);
+                f32x4 pr[MT], ds[MT];
+#pragma unroll
+                for (int qt = 0; qt < MT; ++qt) {
+                    const f32x4 s = mfma16(rowfrag8(Qb, LU, qt * 16 + q.c16, hc, q.g), bk, f32x4{0.f, 0.f, 0.f, 0.f});
+                    const f32x4 dp = mfma16(rowfrag8(Ob, LU, qt * 16 + q.c16, hc, q.g), bv, f32x4{0.f, 0.f, 0.f, 0.f});
+                    const f32x4 lq = *reinterpret_cast<const f32x4*>(lse + head * R + qt * 16 + q.g * 4);
+                    const f32x4 dl = *reinterpret_cast<const f32x4*>(dlt + head * R + qt * 16 + q.g * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = kok && (qt * 16 + q.g * 4 + r < p.Ts);
+                        const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, -lq[r])) : 0.f;
+                        pr[qt][r] = pv;
+                        ds[qt][r] = pv * (dp[r] - dl[r]) * scale;
+                    }
+                }
+                f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pp = 0; pp < (MT + 1) / 2; ++pp) {
+                    const int ta = 2 * pp, tb = 2 * pp + 1;
+                    const bool tb_ok = tb < MT;
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const bf16x8 bds = pack2(ds[ta], tb_ok ? ds[tb_ok ? tb : 0] : z);
+                    const bf16x8 bp = pack2(pr[ta], tb_ok ? pr[tb_ok ? tb : 0] : z);
+                    dk = mfma16(trfrag(Qb, LU, ta * 16, tb * 16, tb_ok, hc, q.c16 < HD, q), bds, dk);
+                    dv = mfma16(trfrag(Ob, LU, ta * 16, tb * 16, tb_ok, hc, q.c16 < HD, q), bp, dv);
+                }
+                // in place: only this wave reads this head's k / v columns, and never tile kt again
+                if (q.g < 2) {
+                    bf16x4 vk, vv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        vk[r] = (bf16_t)dk[r]; vv[r] = (bf16_t)dv[r];
+                        dbk[hh][r] += kok ? dk[r] : 0.f; dbv[hh][r] += kok ? dv[r] : 0.f;
+                    }
+                    *reinterpret_cast<bf16x4*>(Kb + key * LU + hc + q.g * 4) = vk;
+                    *reinterpret_cast<bf16x4*>(Vb + key * LU + hc + q.g * 4) = vv;
+                }
+            }
+        }
+        __syncthreads();
+        // du = dq Wq + dk Wk + dv Wv ; dWq|dWk|dWv += d{q,k,v}^T u
+        f32x4 du[L::MH][2];
+#pragma unroll
+        for (int mi = 0; mi < L::MH; ++mi) { du[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; du[mi][1] = du[mi][0]; }
+        mm<L::MH, 2>(DQb, LU, 0, qkvT, 6, q.wn * 2, 0, mt0, MT, q, du);
+        mm<L::MH, 2>(Kb, LU, 0, qkvT, 6, q.wn * 2, 2, mt0, MT, q, du);
+        mm<L::MH, 2>(Vb, LU, 0, qkvT, 6, q.wn * 2, 4, mt0, MT, q, du);
+#pragma unroll 1
+        for (int kk = 0; kk < (R + 31) / 32; ++kk) {
+            bf16x8 b[2];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) b[k2] = wg_frag<MT>(U, ((q.wave & 1) * 2 + k2) * 16, kk, q);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
+                const bf16_t* dOi = mat == 0 ? DQb : (mat == 1 ? Kb : Vb);
+                const bf16x8 a = wg_frag<MT>(dOi, nt * 16, kk, q);
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) accQ[t][k2] = mfma16(a, b[k2], accQ[t][k2]);
+            }
+        }
+        acc_to_xs<L::MH>(XS, mt0, MT, q, du);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int pc = threadIdx.x + NT_ * i;
+            if (pc < R * 8) {
+                const int row = pc >> 3;
+                float dv[8], t[8], xh[8], d1[8], gm[8];
+                ld8(XS + row * LX + c8, dv);
+                ld8(n1w + c8, gm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xh[e] = 0.f; d1[e] = 0.f; }
+                if (row < p.Ts) { ld8(p.x + (rb + row) * D + c8, xh); ld8(p.dx1 + (rb + row) * D + c8, d1); }     // L2-hot re-read
+                const float mean = red8(xh[0] + xh[1] + xh[2] + xh[3] + xh[4] + xh[5] + xh[6] + xh[7]) * (1.f / D);
+                float v = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xh[e] -= mean; v += xh[e] * xh[e]; }
+                const float rstd = rsqrtf(red8(v) * (1.f / D) + 1e-5f);
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xh[e] *= rstd; t[e] = dv[e] * gm[e]; a += t[e]; b += t[e] * xh[e]; }
+                a = red8(a) * (1.f / D); b = red8(b) * (1.f / D);
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = d1[e] + rstd * (t[e] - a - xh[e] * b);
+                    dgam[e] += dv[e] * xh[e];
+                    dbet[e] += dv[e];
+                }
+                if (row < p.Ts) st8(p.dx + (rb + row) * D + c8, o);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- commit
+    float* red = XS;
+    flush_wide(red, dgam, p.g_n1w);
+    flush_wide(red, dbet, p.g_n1b);
+    flush_wide(red, dbp, p.g_pb);
+#pragma unroll
+    for (int hh = 0; hh < 1; ++hh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = dbq[hh][r], b = dbk[hh][r], c = dbv[hh][r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
+            const int col = q.wave * HD + q.g * 4 + r;
+            if (q.c16 == 0 && q.g < 2) { atomicAdd(p.g_qb + col, a); atomicAdd(p.g_kb + col, b); atomicAdd(p.g_vb + col, c); }
+        }
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            atomicAdd(p.g_pw + (size_t)((q.wave >> 1) * 16 + q.g * 4 + r) * D + ((q.wave & 1) * 2 + k2) * 16 + q.c16, accP[k2][r]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
+        float* dst = mat == 0 ? p.g_qw : (mat == 1 ? p.g_kw : p.g_vw);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                atomicAdd(dst + (size_t)(nt * 16 + q.g * 4 + r) * D + ((q.wave & 1) * 2 + k2) * 16 + q.c16, accQ[t][k2][r]);
+    }
+}
+
+template <int MT>
+int launch_fwd(const DecFwdArgs& a, hipStream_t s) {
+    using L = DL<MT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_block_fwd_kernel<MT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, L::FWD_TOTAL);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dec_block_fwd_kernel<MT>), dim3(a.nsamples), dim3(NT_), L::FWD_TOTAL, s, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+template <int MT>
+int launch_bwd(const DecBwdMlpArgs& a, const DecBwdAttnArgs& b, hipStream_t s) {
+    using L = DL<MT>;
+    constexpr int IMG = L::R * LU * 2;
+    constexpr int LDS_A = 5 * IMG + L::R * LX * 4;
+    constexpr int LDS_B = 7 * IMG + L::R * LX * 4 + 2 * 8 * L::R * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_mlp_kernel<MT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_A);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_attn_kernel<MT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+        attr_set = true;
+    }
+    const int grid = a.nsamples < 256 ? a.nsamples : 256;      // persistent: one workgroup per CU
+    hipLaunchKernelGGL((dec_bwd_mlp_kernel<MT>), dim3(grid), dim3(NT_), LDS_A, s, a);
+    hipLaunchKernelGGL((dec_bwd_attn_kernel<MT>), dim3(grid), dim3(NT_), LDS_B, s, b);
+    return (int)hipGetLastError();
+}
+
+bool hs_dec_fused_supported(int d, int heads, int hidden, int Ts) {
+    // the backward kernels keep 5-6 bf16 images + an fp32 tile of the sample in LDS: up to 7 m-tiles (112 tokens)
+    return d == D && heads == 8 && hidden <= HPD && hidden % 4 == 0 && Ts <= 112 && Ts >= 16;
+}
+
+int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx1_tmp, float* dx, int nsamples, int Ts,
+                     const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s) {
+    DecW w;
+    w.n1w = bp.n1w; w.n1b = bp.n1b; w.bqkv = bp.bqkv; w.pb = bp.pb; w.n2w = bp.n2w; w.n2b = bp.n2b;
+    w.w1b = bp.w1b; w.w3b = bp.w3b; w.w2b = bp.w2b;
+    w.qkv = bp.qkv; w.p = bp.p; w.w1 = bp.w1; w.w3 = bp.w3; w.w2 = bp.w2; w.h = bp.h;
+    DecBwdMlpArgs a;
+    a.x1 = x1; a.dy = dy; a.dx1 = dx1_tmp; a.nsamples = nsamples; a.Ts = Ts; a.w = w; a.w2T = bp.w2T; a.w13T = bp.w13T;
+    a.g_n2w = g.n2w; a.g_n2b = g.n2b; a.g_w1w = g.w1w; a.g_w1b = g.w1b; a.g_w3w = g.w3w; a.g_w3b = g.w3b;
+    a.g_w2w = g.w2w; a.g_w2b = g.w2b;
+    DecBwdAttnArgs b;
+    b.x = x; b.dx1 = dx1_tmp; b.dx = dx; b.nsamples = nsamples; b.Ts = Ts; b.w = w; b.qkvT = bp.qkvT; b.pT = bp.pT;
+    b.g_n1w = g.n1w; b.g_n1b = g.n1b; b.g_qw = g.qw; b.g_qb = g.qb; b.g_kw = g.kw; b.g_kb = g.kb; b.g_vw = g.vw;
+    b.g_vb = g.vb; b.g_pw = g.pw; b.g_pb = g.pb;
+    const int mt = (Ts + 15) / 16;
+    if (mt <= 4) return launch_bwd<4>(a, b, s);
+    if (mt <= 7) return launch_bwd<7>(a, b, s);
+    return HS_EUNSUPPORTED;
+}
+
+int hs_dec_block_fwd(const float* x, float* x1, float* x2, int nsamples, int Ts, const DecBlockPtrs& bp, hipStream_t s) {
+    DecFwdArgs a;
+    a.x = x; a.x1 = x1; a.x2 = x2; a.nsamples = nsamples; a.Ts = Ts;
+    a.w.n1w = bp.n1w; a.w.n1b = bp.n1b; a.w.bqkv = bp.bqkv; a.w.pb = bp.pb; a.w.n2w = bp.n2w; a.w.n2b = bp.n2b;
+    a.w.w1b = bp.w1b; a.w.w3b = bp.w3b; a.w.w2b = bp.w2b;
+    a.w.qkv = bp.qkv; a.w.p = bp.p; a.w.w1 = bp.w1; a.w.w3 = bp.w3; a.w.w2 = bp.w2; a.w.h = bp.h;
+    const int mt = (Ts + 15) / 16;
+    if (mt <= 4) return launch_fwd<4>(a, s);
+    if (mt <= 7) return launch_fwd<7>(a, s);
+    return HS_EUNSUPPORTED;
+}

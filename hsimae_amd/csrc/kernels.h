@@ -33,3 +33,15 @@ int hs_assemble_bwd(const AssembleParams& p, hipStream_t s);
 int hs_loss(const LossParams& p, hipStream_t s);
 int hs_loss_partials(int N, int T);
 int hs_add2(const float* a, const float* b, float* out, int64_t n, hipStream_t s);
+
+// ------------------------------------------------------------------ fused_dec.hip (decoder Block, one workgroup per sample)
+struct DecBlockPtrs {
+    const float *n1w, *n1b, *bqkv, *pb, *n2w, *n2b, *w1b, *w3b, *w2b;
+    const bf16_t *qkv, *p, *w1, *w3, *w2, *qkvT, *pT, *w13T, *w2T;
+    int h;
+};
+struct DecBlockGrads { float *n1w, *n1b, *qw, *qb, *kw, *kb, *vw, *vb, *pw, *pb, *n2w, *n2b, *w1w, *w1b, *w2w, *w2b, *w3w, *w3b; };
+bool hs_dec_fused_supported(int d, int heads, int hidden, int Ts);
+int hs_dec_block_fwd(const float* x, float* x1, float* x2, int nsamples, int Ts, const DecBlockPtrs& bp, hipStream_t s);
+int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx1_tmp, float* dx, int nsamples, int Ts,
+                     const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s);
