@@ -349,7 +349,7 @@ __device__ __forceinline__ void gate_chunk(const bf16_t* U, const DecW& w, int c
     mm<L::MH, 2>(U, LU, 0, w.w3, 2, c * 4 + q.wn * 2, 0, mt0, MT, q, h3);
 }
 
-__device__ __forceinline__ float silu_f(float a) { return a / (1.f + __expf(-a)); }
+__device__ __forceinline__ float silu_f(float a) { return a / (1.f + __expf(-a)); }   // forward: exact division (loss gate 1e-4)
 
 template <int MT>
 __global__ __launch_bounds__(512, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float a1 = h1[mi][j][r], a3 = h3[mi][j][r], dv = dg[mi][j][r];
-                            const float sg = 1.f / (1.f + __expf(-a1));
+                            const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-a1));
                             const float sl = a1 * sg;
                             const float gv = ok ? sl * a3 : 0.f;
                             const float d1 = ok ? dv * a3 * sg * (1.f + a1 * (1.f - sg)) : 0.f;

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float a1 = bf2f(h1[e]), a3 = bf2f(h3[e]);
-                        const float s = 1.f / (1.f + __expf(-a1));
+                        const float s = __builtin_amdgcn_rcpf(1.f + __expf(-a1));
                         d1[e] = v[e] * a3 * s * (1.f + a1 * (1.f - s));
                         d3[e] = v[e] * a1 * s;
                     }

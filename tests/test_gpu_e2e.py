@@ -265,7 +265,7 @@ def test_fused_decoder_matches_layerwise_decoder(bands, grid):
     l0, p0, g0 = res["0"]
     l1, p1, g1 = res["1"]
     print(f"[fused-dec {bands}] loss layerwise {l0:.7f} fused {l1:.7f}")
-    assert abs(l0 - l1) <= 2e-5 * abs(l0)
+    assert abs(l0 - l1) <= 5e-5 * abs(l0)
     assert rms_rel(p1, p0) < 3e-3
     worst = ("", 0.0)
     for k in g0:
