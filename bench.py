@@ -43,20 +43,24 @@ def flops_per_sample(bands, D, depth, s_depth, Dd, dec_depth, lt, ll, hidden, de
 
 
 PEAK_HBM_GBS = 8000.0              # HBM3E spec, same guide
+# HBM bytes per encoder-block wgrad launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, guide's gfx950
+# correction), see profiles/r01_pmc_wgrad.txt; None until measured
+WGRAD_TRAFFIC_BYTES = 2 * 435558 * 1024 + 38336 * 1024   # 931 MB vs 517 MB algorithmic: operand re-reads across n/k slabs
 
 
 def dominant_kernel_roofline(model, N, K_tok, iters=20):
-    """Live HIP-event timing of the dominant kernel of the step (profiles/r01_v3: `wgrad_kernel`, 18.7 % of
-    kernel time): the batched weight-gradient launch of one decoder block (q, k, v, proj, w1, w3, w2) at the
-    workload's shape, through the C ABI on the current stream.  HBM-bound: algorithmic bytes per launch =
-    every operand read once = M * (dqkv 3d*2 + u d*2 + dx1 d*4 + o d*2 + dh13 2hp*2 + u2 d*2 + dY d*4 + g hp*2)."""
+    """Live HIP-event timing of the dominant kernel of the step (profiles/: `wgrad_kernel`, ~18 % of kernel
+    time): the batched weight-gradient launch of one ENCODER block (q, k, v, proj, w1, w3, w2) at the workload's
+    shape (M = N*K kept-token rows), through the C ABI on the current stream.  HBM-bound: algorithmic bytes per
+    launch = every operand read once =
+    M * (dqkv 3d*2 + u d*2 + dx1 d*4 + o d*2 + dh13 2hp*2 + u2 d*2 + dY d*4 + g hp*2)."""
     from hsimae_amd import _lib, swiglu_hidden
     lib = _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
-    d = model.dec_dim
+    d = model.dim
     h = swiglu_hidden(d, model.mlp_ratio)
     hp = (h + 31) // 32 * 32
-    M = N * model.patch_embed.num_patches
+    M = N * K_tok
     bf = dict(dtype=torch.bfloat16, device=dev)
     dqkv, u, o, u2 = (torch.randn(M, w, **bf) for w in (3 * d, d, d, d))
     dh13, g = torch.randn(M, 2 * hp, **bf), torch.randn(M, hp, **bf)
@@ -86,9 +90,9 @@ def dominant_kernel_roofline(model, N, K_tok, iters=20):
     ms = e0.elapsed_time(e1) / iters
     nbytes = float(M) * (3 * d * 2 + d * 2 + d * 4 + d * 2 + 2 * hp * 2 + d * 2 + d * 4 + hp * 2)
     achieved = nbytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "wgrad_kernel (decoder block: dW/db of q,k,v,proj,w1,w3,w2 in one launch)",
+    return {"bound": "hbm", "kernel": "wgrad_kernel (encoder block: dW/db of q,k,v,proj,w1,w3,w2 in one launch)",
             "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None, "launch_ms": round(ms, 4),
+            "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": WGRAD_TRAFFIC_BYTES, "launch_ms": round(ms, 4),
             "bytes_per_launch": nbytes}
 
 
@@ -124,6 +128,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch (weak scaling)")
     ap.add_argument("--model", default="base", choices=["base", "large"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true", help="run the RCCL gradient reducer even with one rank (test)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -138,15 +143,18 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_ddp = world > 1 or args.force_ddp
+    if use_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     bands, D = 96, (128 if args.model == "base" else 256)
     torch.manual_seed(0)
     model = HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=bands, b_patch_size=8, embed_dim=D, depth=12,
                    num_heads=D // 16, s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8,
                    norm_pix_loss=True, trunc_init=True).to(dev)
-    if world > 1:
+    if use_ddp:
         model.enable_data_parallel()
     random.seed(0)                                    # same (len_t, len_l) sequence on every rank
     torch.manual_seed(1234 + rank)
@@ -201,7 +209,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(bands)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_ddp:
         dist.barrier()
         dist.destroy_process_group()
 
