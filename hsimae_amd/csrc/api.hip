@@ -149,7 +149,10 @@ void pack_descs(const Geo& g, const PLayout& L, const WLayout& W, const float* P
 // ------------------------------------------------------------------ workspace
 struct BlkBuf { hs_bf16* u; hs_bf16* qkv; float* lse; hs_bf16* o; float* x1; hs_bf16* u2; hs_bf16* h13; hs_bf16* g; float* x2; };
 
+struct Scr { float* G1; float* du; hs_bf16* dh13; hs_bf16* dob; hs_bf16* dqkv; };   // per-stream backward scratch
+
 struct Ws {
+    Scr sc, sc2;                      // sc2: encoder-sized second set for the side stream (spectral stack)
     hs_bf16* a_pe; float* x0;
     std::vector<BlkBuf> b1, b2, bf, bd;
     hs_bf16* lat; float* y; float* yfull; hs_bf16* zn; float* pred; hs_bf16* dpred; float* partial;
@@ -190,6 +193,10 @@ void carve(const Geo& g, int N, int K, char* base, Ws& w) {
     w.dob = (hs_bf16*)take(gmax * 2);
     w.dqkv = (hs_bf16*)take(gmax * 3 * 2);
     w.dyb = (hs_bf16*)take(Me * g.Dd * 2);
+    w.sc.G1 = w.G1; w.sc.du = w.du; w.sc.dh13 = w.dh13; w.sc.dob = w.dob; w.sc.dqkv = w.dqkv;
+    w.sc2.G1 = (float*)take(Me * g.D * 4); w.sc2.du = (float*)take(Me * g.D * 4);
+    w.sc2.dh13 = (hs_bf16*)take(Me * 2 * g.hp * 2); w.sc2.dob = (hs_bf16*)take(Me * g.D * 2);
+    w.sc2.dqkv = (hs_bf16*)take(Me * g.D * 3 * 2);
     w.bytes = cur;
 }
 
@@ -209,6 +216,24 @@ BlkP resolve(const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk,
 }
 
 #define CK(expr) do { int _e = (expr); if (_e) return _e; } while (0)
+
+// The two axis stacks (blocks_1 / blocks_2, Models.py:556-560) are independent until x1 + x2: the spectral
+// stack runs on a side stream so two kernels are resident at once (a single 864-workgroup launch leaves a
+// ~45 % tail on 256 CUs).  The stream and its two events are created once per process; HSIMAE_TWO_STREAMS=0
+// keeps everything on the caller's stream.
+struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
+Side& side() {
+    static Side sd = [] {
+        Side x;
+        const char* e = getenv("HSIMAE_TWO_STREAMS");
+        if (e && e[0] == '0') return x;
+        x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+        return x;
+    }();
+    return sd;
+}
 
 // HSIMAE_FUSED_DEC=0 forces the layer-at-a-time decoder (A/B testing of the fused decoder kernels)
 bool fused_dec_enabled(const Geo& g) {
@@ -263,8 +288,9 @@ int wgrad_msplit(int tiles, int64_t M) {
 
 // One Block backward: data grads (7 launches) + all weight/bias grads of the block (1 launch).
 int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, const BlkBuf& b, int64_t M, int d,
-              int heads, int h, int hp, int Ts, int nsamples, int mode, int len_l, float* G0, float* G1, const Ws& w,
+              int heads, int h, int hp, int Ts, int nsamples, int mode, int len_l, float* G0, const Scr& w,
               float* dx_out, int accumulate, hipStream_t s) {
+    float* G1 = w.G1;
     GemmParams p = gp();
     p.A = G0; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = hp; p.W = P.w2T; p.out = w.dh13; p.ldo = 2 * hp;
     p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp;
@@ -423,17 +449,28 @@ int hsimae_forward(const hsimae_config* cfg, const hsimae_io* io, void* stream) 
 
     const float* x = w.x0;
     if (g.has_axis) {
-        const float* xa = w.x0;
-        for (int i = 0; i < g.sdepth; ++i) {       // spatial stack: attend within one kept band group (Models.py:553,556)
-            BlkP bp = resolve(c.L.b1[i], c.W.b1[i], P, io->wpk, c.W);
-            CK(block_fwd(bp, xa, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, nullptr, s));
-            xa = w.b1[i].x2;
+        Side& sd = side();
+        const bool forked = sd.ok && g.sdepth > 1;
+        if (forked) {
+            CK((int)hipEventRecord(sd.fork, s));
+            CK((int)hipStreamWaitEvent(sd.s, sd.fork, 0));
         }
+        const float* xa = w.x0;
         const float* xb = w.x0;
-        for (int i = 0; i < g.sdepth; ++i) {       // spectral stack: attend within one kept position (Models.py:554,559)
-            BlkP bp = resolve(c.L.b2[i], c.W.b2[i], P, io->wpk, c.W);
-            const float* r2 = (i == g.sdepth - 1) ? xa : nullptr;       // x1 + x2 fused into the last epilogue (Models.py:564)
-            CK(block_fwd(bp, xb, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, r2, s));
+        for (int i = 0; i < g.sdepth; ++i) {
+            // spatial stack: attend within one kept band group (Models.py:553,556)
+            BlkP b1 = resolve(c.L.b1[i], c.W.b1[i], P, io->wpk, c.W);
+            CK(block_fwd(b1, xa, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, nullptr, s));
+            xa = w.b1[i].x2;
+            // spectral stack: attend within one kept position (Models.py:554,559)
+            BlkP b2 = resolve(c.L.b2[i], c.W.b2[i], P, io->wpk, c.W);
+            const bool last = (i == g.sdepth - 1);
+            const float* r2 = last ? xa : nullptr;                      // x1 + x2 fused into the last epilogue (Models.py:564)
+            if (last && forked) {                                       // needs the spatial stack's result: rejoin first
+                CK((int)hipEventRecord(sd.join, sd.s));
+                CK((int)hipStreamWaitEvent(s, sd.join, 0));
+            }
+            CK(block_fwd(b2, xb, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, r2, (forked && !last) ? sd.s : s));
             xb = w.b2[i].x2;
         }
         x = xb;
@@ -518,7 +555,7 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
             dg.w3w = grads + o.w3w; dg.w3b = grads + o.w3b;
             CK(hs_dec_block_bwd(xin, w.bd[i].x1, w.G0, w.G1, w.G0, c.N, g.TL, dec_ptrs(bp, g.hdec), dg, s));
         } else {
-            CK(block_bwd(bp, L.bd[i], grads, xin, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, w.G0, w.G1, w, w.G0, 0, s));
+            CK(block_bwd(bp, L.bd[i], grads, xin, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, w.G0, w.sc, w.G0, 0, s));
         }
         emit(L.bd[i].n1w, L.bd[i].end);
     }
@@ -545,25 +582,36 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
     for (int i = g.nfus - 1; i >= 0; --i) {
         BlkP bp = resolve(L.bf[i], c.W.bf[i], P, io->wpk, c.W);
         const float* xin = (i > 0) ? w.bf[i - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
-        CK(block_bwd(bp, L.bf[i], grads, xin, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, w.G0, w.G1, w, w.G0, 0, s));
+        CK(block_bwd(bp, L.bf[i], grads, xin, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, w.G0, w.sc, w.G0, 0, s));
         emit(L.bf[i].n1w, L.bf[i].end);
     }
     if (g.has_axis) {
-        // d(x1 + x2) feeds both stacks (Models.py:564)
+        // d(x1 + x2) feeds both stacks (Models.py:564); the spectral stack's backward runs on the side stream
+        Side& sd = side();
+        const bool forked = sd.ok && g.sdepth > 1;
         CK((int)hipMemcpyAsync(w.G2, w.G0, c.Me * g.D * 4, hipMemcpyDeviceToDevice, s));
-        for (int i = g.sdepth - 1; i >= 0; --i) {
-            BlkP bp = resolve(L.b2[i], c.W.b2[i], P, io->wpk, c.W);
-            const float* xin = (i > 0) ? w.b2[i - 1].x2 : w.x0;
-            CK(block_bwd(bp, L.b2[i], grads, xin, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, w.G1, w, w.G0, 0, s));
-            emit(L.b2[i].n1w, L.b2[i].end);
+        if (forked) {
+            CK((int)hipEventRecord(sd.fork, s));
+            CK((int)hipStreamWaitEvent(sd.s, sd.fork, 0));
         }
+        hipStream_t s2 = forked ? sd.s : s;
+        const Scr& scr2 = forked ? w.sc2 : w.sc;
         for (int i = g.sdepth - 1; i >= 0; --i) {
-            BlkP bp = resolve(L.b1[i], c.W.b1[i], P, io->wpk, c.W);
-            const float* xin = (i > 0) ? w.b1[i - 1].x2 : w.x0;
-            float* out = (i == 0) ? w.G0 : w.G2;          // last one accumulates onto the spectral stack's dX
-            CK(block_bwd(bp, L.b1[i], grads, xin, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.G1, w, out, i == 0, s));
-            emit(L.b1[i].n1w, L.b1[i].end);
+            BlkP b2 = resolve(L.b2[i], c.W.b2[i], P, io->wpk, c.W);
+            const float* xin2 = (i > 0) ? w.b2[i - 1].x2 : w.x0;
+            CK(block_bwd(b2, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, scr2, w.G0, 0, s2));
+            if (i == 0 && forked) {                 // the spatial stack's last step accumulates onto the spectral dX
+                CK((int)hipEventRecord(sd.join, sd.s));
+                CK((int)hipStreamWaitEvent(s, sd.join, 0));
+            }
+            BlkP b1 = resolve(L.b1[i], c.W.b1[i], P, io->wpk, c.W);
+            const float* xin1 = (i > 0) ? w.b1[i - 1].x2 : w.x0;
+            float* out = (i == 0) ? w.G0 : w.G2;
+            CK(block_bwd(b1, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, out, i == 0, s));
         }
+        // gradient ranges in back-to-front order, all complete on the caller's stream by now
+        for (int i = g.sdepth - 1; i >= 0; --i) emit(L.b2[i].n1w, L.b2[i].end);
+        for (int i = g.sdepth - 1; i >= 0; --i) emit(L.b1[i].n1w, L.b1[i].end);
     }
     {   // patch_embed.proj: only the kept tokens carry gradient (Models.py:528); no input gradient
         WgradParams wg; std::memset(&wg, 0, sizeof(wg));
