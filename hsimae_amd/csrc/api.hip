@@ -242,6 +242,20 @@ bool fused_dec_enabled(const Geo& g) {
     return hs_dec_fused_supported(g.Dd, g.Hd, g.hdec, g.TL);
 }
 
+// HSIMAE_FUSED_MLP=0 forces the layer-at-a-time MLP half of the encoder blocks
+bool fused_mlp_enabled(int d, int h) {
+    const char* e = getenv("HSIMAE_FUSED_MLP");
+    if (e && e[0] == '0') return false;
+    return hs_enc_mlp_fused_supported(d, h);
+}
+
+EncMlpPtrs mlp_ptrs(const BlkP& b, int h) {
+    EncMlpPtrs m;
+    m.n2w = b.n2w; m.n2b = b.n2b; m.w1b = b.w1b; m.w3b = b.w3b; m.w2b = b.w2b;
+    m.w1 = b.w1; m.w3 = b.w3; m.w2 = b.w2; m.w2T = b.w2T; m.w13T = b.w13T; m.h = h;
+    return m;
+}
+
 DecBlockPtrs dec_ptrs(const BlkP& b, int h) {
     DecBlockPtrs d;
     d.n1w = b.n1w; d.n1b = b.n1b; d.bqkv = b.bqkv; d.pb = b.pb; d.n2w = b.n2w; d.n2b = b.n2b;
@@ -268,6 +282,7 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
     p.A = b.o; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d; p.W = P.p; p.bias = P.pb;
     p.res = x_in; p.ldr = d; p.out = b.x1; p.ldo = d;
     CK(hs_gemm(p, A_BF16, E_RES_F32, s));
+    if (fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, mlp_ptrs(P, h), s);
     p = gp();
     p.A = b.x1; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = h; p.W = P.w1; p.W2 = P.w3; p.bias = P.w1b;
     p.bias2 = P.w3b; p.gamma = P.n2w; p.beta = P.n2b; p.u_out = b.u2; p.ldu = d; p.out = b.g; p.ldo = hp;
@@ -292,16 +307,22 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
               float* dx_out, int accumulate, hipStream_t s) {
     float* G1 = w.G1;
     GemmParams p = gp();
-    p.A = G0; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = hp; p.W = P.w2T; p.out = w.dh13; p.ldo = 2 * hp;
-    p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp;
-    CK(hs_gemm(p, A_F32, E_SWIGLU_BWD, s));
-    p = gp();
-    p.A = w.dh13; p.lda = 2 * hp; p.M = (int)M; p.N = d; p.K = 2 * hp; p.n_valid = d; p.W = P.w13T; p.out = w.du; p.ldo = d;
-    CK(hs_gemm(p, A_BF16, E_F32, s));
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
-    l.du = w.du; l.x = b.x1; l.gamma = P.n2w; l.dres = G0; l.dx = G1; l.accumulate = 0;
-    l.dgamma = grads + o.n2w; l.dbeta = grads + o.n2b; l.M = (int)M; l.d = d;
-    CK(hs_ln_bwd(l, s));
+    l.M = (int)M; l.d = d;
+    if (fused_mlp_enabled(d, h)) {
+        // recompute u2 / h1 / h3 / g inside the tile; emits dx1 and the wgrad operands u2, dh1|dh3, g
+        CK(hs_enc_mlp_bwd(b.x1, G0, G1, b.u2, w.dh13, b.g, (int)M, mlp_ptrs(P, h), grads + o.n2w, grads + o.n2b, s));
+    } else {
+        p.A = G0; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = hp; p.W = P.w2T; p.out = w.dh13; p.ldo = 2 * hp;
+        p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp;
+        CK(hs_gemm(p, A_F32, E_SWIGLU_BWD, s));
+        p = gp();
+        p.A = w.dh13; p.lda = 2 * hp; p.M = (int)M; p.N = d; p.K = 2 * hp; p.n_valid = d; p.W = P.w13T; p.out = w.du; p.ldo = d;
+        CK(hs_gemm(p, A_BF16, E_F32, s));
+        l.du = w.du; l.x = b.x1; l.gamma = P.n2w; l.dres = G0; l.dx = G1; l.accumulate = 0;
+        l.dgamma = grads + o.n2w; l.dbeta = grads + o.n2b;
+        CK(hs_ln_bwd(l, s));
+    }
     p = gp();
     p.A = G1; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d; p.W = P.pT; p.out = w.dob; p.ldo = d;
     CK(hs_gemm(p, A_F32, E_BF16, s));

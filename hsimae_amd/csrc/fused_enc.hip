@@ -1,0 +1,435 @@
+// Fused MLP half of an encoder Block at D = 128 (HSIMAE-Base):  x2 = x1 + W2( silu(W1 LN2(x1)) * (W3 LN2(x1)) )
+// (Models.py:231-232, 299, 305) and its backward.  Layer-at-a-time, this half moves ~1.1 KB of bf16
+// intermediates per token per direction (u2, h1|h3, g) and is HBM-bound at 64 FLOP/B; here a workgroup keeps a
+// 128-row panel in LDS/registers from LayerNorm to the residual add.
+//   forward : reads x1 (512 B/row), writes x2 (512 B/row)                — nothing else touches HBM
+//   backward: reads x1, dY, recomputes u2/h1/h3/g, writes dx1 and the three weight-gradient operands
+//             (u2, dh1|dh3, g) that `wgrad_kernel` consumes; LayerNorm-2 parameter grads via atomics.
+// Workgroup = 8 waves as 4(M) x 2(N): wave (wm, wn) owns m-tiles {2wm, 2wm+1} and n-tiles {2wn, 2wn+1} of every
+// 64-column chunk.  Weight fragments are prefetched one chunk ahead.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int D = 128, HPE = 352, R = 128, MH = 2, NTH = 512;
+constexpr int LU = D + 8;          // bf16 panel row stride (elements)
+constexpr int LX = D + 4;          // fp32 staging row stride (floats)
+constexpr int LG = HPE + 8;        // gate image row stride
+constexpr int LC = 64 + 8;         // 64-column chunk image row stride
+constexpr int NCH = (HPE + 63) / 64;   // hidden chunks (6, the last one half full)
+
+struct G8 { int lane, c16, g, wave, wm, wn; };
+__device__ __forceinline__ G8 geo8() {
+    G8 q;
+    q.lane = threadIdx.x & 63; q.c16 = q.lane & 15; q.g = q.lane >> 4;
+    q.wave = threadIdx.x >> 6; q.wm = q.wave >> 1; q.wn = q.wave & 1;
+    return q;
+}
+
+template <int KS>
+struct Fr {
+    bf16x8 b[KS][2];
+    __device__ __forceinline__ void load(const bf16_t* W, int KS_total, int nt0, int ks0, int nt_total, const G8& q) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                b[ks][j] = (nt0 + j < nt_total)
+                               ? *reinterpret_cast<const bf16x8*>(W + (((size_t)(nt0 + j) * KS_total + ks0 + ks) * 64 + q.lane) * 8)
+                               : zero8();
+    }
+};
+
+template <int KS>
+__device__ __forceinline__ void mm_f(const bf16_t* A, int lda, int kofs, const Fr<KS>& f, const G8& q, f32x4 (&acc)[MH][2]) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + ((q.wm * MH + mi) * 16 + q.c16) * lda + kofs + ks * 32 + q.g * 8);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[mi][j] = mfma16(a, f.b[ks][j], acc[mi][j]);
+        }
+}
+
+template <class T>
+__device__ __forceinline__ const T* launder(const T* p) { asm volatile("" : "+s"(p)); return p; }
+
+__device__ __forceinline__ void ld8(const float* p, float* o) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void st8(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ float red16(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+struct EncMlpW {
+    const float *n2w, *n2b, *w1b, *w3b, *w2b;
+    const bf16_t *w1, *w3, *w2, *w2T, *w13T;
+    int h;
+};
+
+struct EncMlpFwdArgs { const float* x1; const float* res2; float* x2; int M; EncMlpW w; };
+
+__global__ __launch_bounds__(512, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
+    float* XS = reinterpret_cast<float*>(smem + R * LU * 2);
+    bf16_t* Gb = reinterpret_cast<bf16_t*>(smem + R * LU * 2);
+    const G8 q = geo8();
+    const int row0 = blockIdx.x * R;
+    const EncMlpW& w = p.w;
+    const int nt_h = HPE / 16;
+    const int c8 = (threadIdx.x & 15) * 8;
+
+    Fr<4> f1, f3;
+    f1.load(w.w1, 4, q.wn * 2, 0, nt_h, q);
+    f3.load(w.w3, 4, q.wn * 2, 0, nt_h, q);
+    {   // LayerNorm-2 in the wide layout (16 lanes per row) + fp32 copy for the residual
+        float gm[8], bt[8];
+        ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
+#pragma unroll
+        for (int i = 0; i < R * 16 / NTH; ++i) {
+            const int pc = threadIdx.x + NTH * i, row = pc >> 4;
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = 0.f;
+            if (row0 + row < p.M) ld8(p.x1 + (size_t)(row0 + row) * D + c8, f);
+            st8(XS + row * LX + c8, f);
+            const float mean = red16(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
+            float v = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[e] -= mean; v += f[e] * f[e]; }
+            const float rstd = rsqrtf(red16(v) * (1.f / D) + 1e-5f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
+            *reinterpret_cast<bf16x8*>(U2 + row * LU + c8) = cvt8(f);
+        }
+    }
+    __syncthreads();
+    f32x4 xr[2][MH][2];                          // residual, [output chunk][m-tile][n-tile] in accumulator layout
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = cc * 64 + (q.wn * 2 + j) * 16 + q.c16;
+                const float b = w.w2b[col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xr[cc][mi][j][r] = XS[((q.wm * MH + mi) * 16 + q.g * 4 + r) * LX + col] + b;
+            }
+    __syncthreads();                             // XS consumed: the gate image may overwrite it
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bool live = c * 4 + q.wn * 2 < nt_h;                      // last chunk: only wn == 0 has columns
+        f32x4 h1[MH][2], h3[MH][2];
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
+                const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
+                h1[mi][j] = f32x4{b1, b1, b1, b1};
+                h3[mi][j] = f32x4{b3, b3, b3, b3};
+            }
+        if (live) { mm_f<4>(U2, LU, 0, f1, q, h1); mm_f<4>(U2, LU, 0, f3, q, h3); }
+        if (c + 1 < NCH) {
+            f1.load(w.w1, 4, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
+            f3.load(w.w3, 4, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
+        }
+        if (live) {
+#pragma unroll
+            for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
+                    if (col < HPE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float a1 = h1[mi][j][r];
+                            const float gv = col < w.h ? a1 / (1.f + __expf(-a1)) * h3[mi][j][r] : 0.f;
+                            Gb[((q.wm * MH + mi) * 16 + q.g * 4 + r) * LG + col] = (bf16_t)gv;
+                        }
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    // x2 = x1 + b2 + g W2^T : K = 352 = 11 k-steps, two 64-column output chunks
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        Fr<6> fa;
+        Fr<5> fb;
+        fa.load(w.w2, 11, cc * 4 + q.wn * 2, 0, D / 16, q);
+        fb.load(w.w2, 11, cc * 4 + q.wn * 2, 6, D / 16, q);
+        mm_f<6>(Gb, LG, 0, fa, q, xr[cc]);
+        mm_f<5>(Gb, LG, 192, fb, q, xr[cc]);
+    }
+    __syncthreads();                             // gate image consumed: reuse the region as the fp32 store tile
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    XS[((q.wm * MH + mi) * 16 + q.g * 4 + r) * LX + cc * 64 + (q.wn * 2 + j) * 16 + q.c16] = xr[cc][mi][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < R * 16 / NTH; ++i) {
+        const int pc = threadIdx.x + NTH * i, row = pc >> 4;
+        if (row0 + row < p.M) {
+            float f[8];
+            ld8(XS + row * LX + c8, f);
+            if (p.res2) {
+                float t[8];
+                ld8(p.res2 + (size_t)(row0 + row) * D + c8, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += t[e];
+            }
+            st8(p.x2 + (size_t)(row0 + row) * D + c8, f);
+        }
+    }
+}
+
+struct EncMlpBwdArgs {
+    const float* x1; const float* dy; float* dx1; bf16_t* u2; bf16_t* dh13; bf16_t* g; int M; EncMlpW w;
+    float* g_n2w; float* g_n2b;
+};
+
+__global__ __launch_bounds__(512, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* DYb = U2 + R * LU;
+    bf16_t* DH1 = DYb + R * LU;
+    bf16_t* DH3 = DH1 + R * LC;
+    bf16_t* Gc = DH3 + R * LC;
+    float* XS = reinterpret_cast<float*>(DYb);           // after the chunk loop: fp32 tile of du2
+    const G8 q = geo8();
+    const int row0 = blockIdx.x * R;
+    const EncMlpW& w = p.w;
+    const int nt_h = HPE / 16;
+    const int c8 = (threadIdx.x & 15) * 8;
+
+    Fr<4> f1, f3, f2;
+    f1.load(w.w1, 4, q.wn * 2, 0, nt_h, q);
+    f3.load(w.w3, 4, q.wn * 2, 0, nt_h, q);
+    f2.load(w.w2T, 4, q.wn * 2, 0, nt_h, q);
+    {
+        float gm[8], bt[8];
+        ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
+#pragma unroll
+        for (int i = 0; i < R * 16 / NTH; ++i) {
+            const int pc = threadIdx.x + NTH * i, row = pc >> 4;
+            const bool ok = row0 + row < p.M;
+            float f[8], dyv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[e] = 0.f; dyv[e] = 0.f; }
+            if (ok) { ld8(p.x1 + (size_t)(row0 + row) * D + c8, f); ld8(p.dy + (size_t)(row0 + row) * D + c8, dyv); }
+            const float mean = red16(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
+            float v = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[e] -= mean; v += f[e] * f[e]; }
+            const float rstd = rsqrtf(red16(v) * (1.f / D) + 1e-5f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
+            const bf16x8 ub = cvt8(f);
+            *reinterpret_cast<bf16x8*>(U2 + row * LU + c8) = ub;
+            *reinterpret_cast<bf16x8*>(DYb + row * LU + c8) = cvt8(dyv);
+            if (ok) *reinterpret_cast<bf16x8*>(p.u2 + (size_t)(row0 + row) * D + c8) = ub;     // wgrad operand
+        }
+    }
+    __syncthreads();
+    f32x4 du2[2][MH][2];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi) { du2[cc][mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; du2[cc][mi][1] = du2[cc][mi][0]; }
+
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bool live = c * 4 + q.wn * 2 < nt_h;
+        {
+            f32x4 h1[MH][2], h3[MH][2], dg[MH][2];
+#pragma unroll
+            for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
+                    const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
+                    h1[mi][j] = f32x4{b1, b1, b1, b1};
+                    h3[mi][j] = f32x4{b3, b3, b3, b3};
+                    dg[mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            if (live) { mm_f<4>(U2, LU, 0, f1, q, h1); mm_f<4>(U2, LU, 0, f3, q, h3); mm_f<4>(DYb, LU, 0, f2, q, dg); }
+            if (c + 1 < NCH) {
+                f1.load(w.w1, 4, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
+                f3.load(w.w3, 4, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
+                f2.load(w.w2T, 4, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int lc = (q.wn * 2 + j) * 16 + q.c16;
+                    const bool ok = live && (c * 64 + lc < w.h);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a1 = h1[mi][j][r], a3 = h3[mi][j][r], dv = dg[mi][j][r];
+                        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-a1));
+                        const float sl = a1 * sg;
+                        const int o = ((q.wm * MH + mi) * 16 + q.g * 4 + r) * LC + lc;
+                        Gc[o] = (bf16_t)(ok ? sl * a3 : 0.f);
+                        DH1[o] = (bf16_t)(ok ? dv * a3 * sg * (1.f + a1 * (1.f - sg)) : 0.f);
+                        DH3[o] = (bf16_t)(ok ? dv * sl : 0.f);
+                    }
+                }
+        }
+        __syncthreads();
+        // weight-gradient operands of this chunk to HBM (row-contiguous 16-B stores), columns < 352 only
+        {
+            const int ncol = (c * 64 + 64 <= HPE) ? 64 : HPE - c * 64;       // 64 or 32
+            for (int pc = threadIdx.x; pc < R * 8; pc += NTH) {
+                const int row = pc >> 3, k8 = (pc & 7) * 8;
+                if (row0 + row < p.M && k8 < ncol) {
+                    const size_t gr = (size_t)(row0 + row);
+                    *reinterpret_cast<bf16x8*>(p.g + gr * HPE + c * 64 + k8) = *reinterpret_cast<const bf16x8*>(Gc + row * LC + k8);
+                    *reinterpret_cast<bf16x8*>(p.dh13 + gr * 2 * HPE + c * 64 + k8) = *reinterpret_cast<const bf16x8*>(DH1 + row * LC + k8);
+                    *reinterpret_cast<bf16x8*>(p.dh13 + gr * 2 * HPE + HPE + c * 64 + k8) = *reinterpret_cast<const bf16x8*>(DH3 + row * LC + k8);
+                }
+            }
+        }
+        // data gradient through W1 / W3:  du2 += dh1_c W1[c] + dh3_c W3[c]   (packed [N=128][K=704], W3 at k-step 11)
+        if (c < NCH - 1) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                Fr<2> a, b;
+                a.load(w.w13T, 22, cc * 4 + q.wn * 2, 2 * c, D / 16, q);
+                b.load(w.w13T, 22, cc * 4 + q.wn * 2, 11 + 2 * c, D / 16, q);
+                mm_f<2>(DH1, LC, 0, a, q, du2[cc]);
+                mm_f<2>(DH3, LC, 0, b, q, du2[cc]);
+            }
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                Fr<1> a, b;
+                a.load(w.w13T, 22, cc * 4 + q.wn * 2, 2 * c, D / 16, q);
+                b.load(w.w13T, 22, cc * 4 + q.wn * 2, 11 + 2 * c, D / 16, q);
+                mm_f<1>(DH1, LC, 0, a, q, du2[cc]);
+                mm_f<1>(DH3, LC, 0, b, q, du2[cc]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    XS[((q.wm * MH + mi) * 16 + q.g * 4 + r) * LX + cc * 64 + (q.wn * 2 + j) * 16 + q.c16] = du2[cc][mi][j][r];
+    __syncthreads();
+    float dgam[8], dbet[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; }
+    {
+        float gm[8];
+        ld8(w.n2w + c8, gm);
+#pragma unroll
+        for (int i = 0; i < R * 16 / NTH; ++i) {
+            const int pc = threadIdx.x + NTH * i, row = pc >> 4;
+            const bool ok = row0 + row < p.M;
+            float du[8], xh[8], dyv[8], t[8];
+            ld8(XS + row * LX + c8, du);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xh[e] = 0.f; dyv[e] = 0.f; }
+            if (ok) { ld8(p.x1 + (size_t)(row0 + row) * D + c8, xh); ld8(p.dy + (size_t)(row0 + row) * D + c8, dyv); }
+            const float mean = red16(xh[0] + xh[1] + xh[2] + xh[3] + xh[4] + xh[5] + xh[6] + xh[7]) * (1.f / D);
+            float v = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xh[e] -= mean; v += xh[e] * xh[e]; }
+            const float rstd = rsqrtf(red16(v) * (1.f / D) + 1e-5f);
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xh[e] *= rstd; t[e] = du[e] * gm[e]; a += t[e]; b += t[e] * xh[e]; }
+            a = red16(a) * (1.f / D); b = red16(b) * (1.f / D);
+            if (ok) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = dyv[e] + rstd * (t[e] - a - xh[e] * b);
+                    dgam[e] += du[e] * xh[e];
+                    dbet[e] += du[e];
+                }
+                st8(p.dx1 + (size_t)(row0 + row) * D + c8, o);
+            }
+        }
+    }
+    // LayerNorm-2 parameter grads: reduce the 32 threads that share a column octet, one atomic per column
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [512][8] x 2 fits in the U2 + DYb panels
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[threadIdx.x * 8 + e] = dgam[e]; red[NTH * 8 + threadIdx.x * 8 + e] = dbet[e]; }
+    __syncthreads();
+    if (threadIdx.x < 2 * D) {
+        const int which = threadIdx.x >> 7, c = threadIdx.x & (D - 1), o8 = c >> 3, e = c & 7;
+        float s = 0.f;
+        for (int t = o8; t < NTH; t += 16) s += red[which * NTH * 8 + t * 8 + e];
+        atomicAdd((which ? p.g_n2b : p.g_n2w) + c, s);
+    }
+}
+
+constexpr int LDS_FWD = R * LU * 2 + R * LG * 2;
+constexpr int LDS_BWD = 2 * R * LU * 2 + 3 * R * LC * 2;
+static_assert(R * LG * 2 >= R * LX * 4, "gate image region must hold the fp32 staging tile");
+static_assert(R * LU * 2 + 3 * R * LC * 2 >= R * LX * 4, "dY panel + chunk images must hold the fp32 staging tile");
+static_assert(2 * R * LU * 2 >= 2 * NTH * 8 * 4, "reduction scratch must fit in the two panels");
+
+}  // namespace
+
+bool hs_enc_mlp_fused_supported(int d, int hidden) { return d == D && hidden <= HPE && ((hidden + 31) / 32 * 32) == HPE; }
+
+static EncMlpW mkw(const EncMlpPtrs& b) {
+    EncMlpW w;
+    w.n2w = b.n2w; w.n2b = b.n2b; w.w1b = b.w1b; w.w3b = b.w3b; w.w2b = b.w2b;
+    w.w1 = b.w1; w.w3 = b.w3; w.w2 = b.w2; w.w2T = b.w2T; w.w13T = b.w13T; w.h = b.h;
+    return w;
+}
+
+int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, const EncMlpPtrs& b, hipStream_t s) {
+    if (M <= 0) return HS_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FWD);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BWD);
+        attr_set = true;
+    }
+    EncMlpFwdArgs a; a.x1 = x1; a.res2 = res2; a.x2 = x2; a.M = M; a.w = mkw(b);
+    hipLaunchKernelGGL(enc_mlp_fwd_kernel, dim3((M + R - 1) / R), dim3(NTH), LDS_FWD, s, a);
+    return (int)hipGetLastError();
+}
+
+int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, int M,
+                   const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s) {
+    if (M <= 0) return HS_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FWD);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BWD);
+        attr_set = true;
+    }
+    EncMlpBwdArgs a; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.u2 = u2; a.dh13 = dh13; a.g = g; a.M = M; a.w = mkw(b);
+    a.g_n2w = g_n2w; a.g_n2b = g_n2b;
+    hipLaunchKernelGGL(enc_mlp_bwd_kernel, dim3((M + R - 1) / R), dim3(NTH), LDS_BWD, s, a);
+    return (int)hipGetLastError();
+}

@@ -45,3 +45,14 @@ bool hs_dec_fused_supported(int d, int heads, int hidden, int Ts);
 int hs_dec_block_fwd(const float* x, float* x1, float* x2, int nsamples, int Ts, const DecBlockPtrs& bp, hipStream_t s);
 int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx1_tmp, float* dx, int nsamples, int Ts,
                      const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s);
+
+// ------------------------------------------------------------------ fused_enc.hip (MLP half of an encoder Block, D = 128)
+struct EncMlpPtrs {
+    const float *n2w, *n2b, *w1b, *w3b, *w2b;
+    const bf16_t *w1, *w3, *w2, *w2T, *w13T;
+    int h;
+};
+bool hs_enc_mlp_fused_supported(int d, int hidden);
+int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, const EncMlpPtrs& b, hipStream_t s);
+int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, int M,
+                   const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s);
