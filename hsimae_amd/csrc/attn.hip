@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     for (int i = lane; i < L::FWD_WAVE / 16; i += 64)
         reinterpret_cast<u32x4*>(Qr)[i] = u32x4{0u, 0u, 0u, 0u};
     fill_cls<HD, NT>(cls, p);
-    __syncthreads();
+    lds_barrier();
     const size_t row_base = (size_t)sample * p.Ts;
     if (active) {
         const bf16_t* base = p.qkv + row_base * p.ld + head * HD;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         load_slice<HD>(base + p.d, p.ld, p.Ts, lane, Kr, nullptr, 0);
         load_slice<HD>(base + 2 * p.d, p.ld, p.Ts, lane, nullptr, Vt, L::VST);
     }
-    __syncthreads();
+    lds_barrier();
     if (!active) return;
 
     const int c16 = lane & 15, g = lane >> 4;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     for (int i = lane; i < L::BWD_WAVE / 16; i += 64)
         reinterpret_cast<u32x4*>(Qr)[i] = u32x4{0u, 0u, 0u, 0u};
     fill_cls<HD, NT>(cls, p);
-    __syncthreads();
+    lds_barrier();
     const size_t row_base = (size_t)sample * p.Ts;
     if (active) {
         const bf16_t* base = p.qkv + row_base * p.ld + head * HD;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
             lse[tok] = p.lse[(row_base + tok) * p.heads + head];
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (!active) return;
 
     const int c16 = lane & 15, g = lane >> 4;

@@ -25,6 +25,14 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// Workgroup barrier that orders LDS traffic only.  `__syncthreads()` also emits `s_waitcnt vmcnt(0)`, which on
+// gfx950 counts stores as well as loads: every barrier then drains the prefetched weight fragments and the
+// epilogue's HBM stores (measured: the fused kernels spent 50-70 % of their wave-cycles parked, profiles/).
+// Use this wherever the barrier only publishes LDS data to the other waves of the workgroup.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ bf16x8 zero8() {
     u32x4 z = {0u, 0u, 0u, 0u};
     return __builtin_bit_cast(bf16x8, z);

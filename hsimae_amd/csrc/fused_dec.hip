@@ -373,16 +373,16 @@ __global__ __launch_bounds__(512, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) fq[c].load(w.qkv, 2, c * 4 + q.wn * 2, 0, q);
         ln_rows<MT, false>(p.x + rb * D, p.Ts, w.n1w, w.n1b, U, XS, nullptr);
-        __syncthreads();
+        lds_barrier();
         f32x4 xr[L::MH][2];
         acc_from_xs<L::MH>(XS, mt0, MT, q, xr);
-        __syncthreads();
+        lds_barrier();
         qkv_stage<MT>(U, w, fq, Qb, Kb, Vt, mt0, q);
         Fr<2> fp;
         fp.load(w.p, 2, q.wn * 2, 0, q);
-        __syncthreads();
+        lds_barrier();
         attn_head_fwd<MT>(Qb, Kb, Vt, U, q.wave, p.Ts, q, nullptr);
-        __syncthreads();
+        lds_barrier();
         // proj accumulates onto the residual
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi)
@@ -397,9 +397,9 @@ __global__ __launch_bounds__(512, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
         f1.load(w.w1, 2, q.wn * 2, 0, q);
         f3.load(w.w3, 2, q.wn * 2, 0, q);
         acc_to_xs<L::MH>(XS, mt0, MT, q, xr);
-        __syncthreads();
+        lds_barrier();
         ln_rows<MT, true>(nullptr, p.Ts, w.n2w, w.n2b, U, XS, p.x1 + rb * D);      // LN2; x1 saved for the backward
-        __syncthreads();
+        lds_barrier();
         Fr<6> f2;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi)
 #pragma unroll
@@ -446,11 +446,11 @@ __global__ __launch_bounds__(512, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
                 for (int r = 0; r < 4; ++r) xr[mi][j][r] += b;
             }
         mm_f<L::MH, 6>(Gb, LG, 0, f2, mt0, MT, q, xr);
-        __syncthreads();
+        lds_barrier();
         acc_to_xs<L::MH>(XS, mt0, MT, q, xr);
-        __syncthreads();
+        lds_barrier();
         store_rows(XS, L::R, p.Ts, p.x2 + rb * D);
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -534,10 +534,10 @@ __device__ __forceinline__ float red8(float v) {
 
 // Commit per-thread column partials (wide layout: thread owns columns 8*(tid&7)..+7) with one atomic per column.
 __device__ __forceinline__ void flush_wide(float* red /* [NT_][8] LDS */, const float* part, float* dst) {
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = part[e];
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < D) {
         const int c = threadIdx.x, c8 = c >> 3, e = c & 7;
         float s = 0.f;
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                 *reinterpret_cast<bf16x8*>(DYb + row * LU + c8) = cvt8(dyv);
             }
         }
-        __syncthreads();
+        lds_barrier();
         f32x4 du2[L::MH][2];
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) { du2[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; du2[mi][1] = du2[mi][0]; }
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // weight gradients of this hidden chunk: 12 (n-tile) x 4 (k-tile) output tiles, 3 x 2 per wave
 #pragma unroll 1
             for (int kk = 0; kk < (R + 31) / 32; ++kk) {
@@ -661,10 +661,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             // data gradient through W1 / W3
             mm<L::MH, 2>(DH1, LU, 0, w13T, 12, q.wn * 2, 2 * c, mt0, MT, q, du2);
             mm<L::MH, 2>(DH3, LU, 0, w13T, 12, q.wn * 2, 6 + 2 * c, mt0, MT, q, du2);
-            __syncthreads();
+            lds_barrier();
         }
         acc_to_xs<L::MH>(XS, mt0, MT, q, du2);
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pc = threadIdx.x + NT_ * i;
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                 if (row < p.Ts) st8(p.dx1 + (rb + row) * D + c8, o);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---- commit
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 *reinterpret_cast<bf16x8*>(DXb + row * LU + c8) = cvt8(d1);
             }
         }
-        __syncthreads();
+        lds_barrier();
         // q | k | v, all row-major
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                         dst[(mt * 16 + q.g * 4 + r) * LU + (q.wn * 2 + j) * 16 + q.c16] = (bf16_t)acc[mi][j][r];
             }
         }
-        __syncthreads();
+        lds_barrier();
         // attention forward (recompute): O image + log2-domain logsumexp per (head, query)
         {
             const int head = q.wave;
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 if (q.g == 0) lse[head * R + query] = m * sc + __builtin_amdgcn_logf(lsum);
             }
         }
-        __syncthreads();
+        lds_barrier();
         // dO = dx1 * Wp ; dWp += dx1^T * O
         f32x4 dO[L::MH][2];
 #pragma unroll
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             for (int k2 = 0; k2 < 2; ++k2)
                 accP[k2] = mfma16(a, wg_frag<MT>(Ob, ((q.wave & 1) * 2 + k2) * 16, kk, q), accP[k2]);
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) {
             const int mt = mt0 + mi;
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 for (int r = 0; r < 4; ++r)
                     Ob[(mt * 16 + q.g * 4 + r) * LU + (q.wn * 2 + j) * 16 + q.c16] = (bf16_t)dO[mi][j][r];
         }
-        __syncthreads();
+        lds_barrier();
         // attention backward, two heads per wave, dq/dk/dv written in place over q/k/v
         {
             constexpr int hh = 0;
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                     *reinterpret_cast<bf16x4*>(DQb + query * LU + hc + q.g * 4) = vq;
                 }
             }
-            __syncthreads();           // delta of this head visible (uniform: every wave runs 2 heads)
+            lds_barrier();           // delta of this head visible (uniform: every wave runs 2 heads)
             // pass B: S orientation (query on accumulator rows, key on the lane) -> dK, dV
 #pragma unroll 1
             for (int kt = 0; kt < MT; ++kt) {
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         // du = dq Wq + dk Wk + dv Wv ; dWq|dWk|dWv += d{q,k,v}^T u
         f32x4 du[L::MH][2];
 #pragma unroll
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             }
         }
         acc_to_xs<L::MH>(XS, mt0, MT, q, du);
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pc = threadIdx.x + NT_ * i;
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 if (row < p.Ts) st8(p.dx + (rb + row) * D + c8, o);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---- commit

@@ -35,7 +35,7 @@ struct Fr {
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                b[ks][j] = (nt0 + j < nt_total)
+                b[ks][j] = (nt0 + j < nt_total && ks0 + ks < KS_total)
                                ? *reinterpret_cast<const bf16x8*>(W + (((size_t)(nt0 + j) * KS_total + ks0 + ks) * 64 + q.lane) * 8)
                                : zero8();
     }
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(512, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     Fr<4> f1, f3;
     f1.load(w.w1, 4, q.wn * 2, 0, nt_h, q);
     f3.load(w.w3, 4, q.wn * 2, 0, nt_h, q);
+    __builtin_amdgcn_sched_barrier(0);           // keep the fetches here: hipcc otherwise sinks them next to the MFMAs
     {   // LayerNorm-2 in the wide layout (16 lanes per row) + fp32 copy for the residual
         float gm[8], bt[8];
         ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
             *reinterpret_cast<bf16x8*>(U2 + row * LU + c8) = cvt8(f);
         }
     }
-    __syncthreads();
+    lds_barrier();
     f32x4 xr[2][MH][2];                          // residual, [output chunk][m-tile][n-tile] in accumulator layout
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc)
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xr[cc][mi][j][r] = XS[((q.wm * MH + mi) * 16 + q.g * 4 + r) * LX + col] + b;
             }
-    __syncthreads();                             // XS consumed: the gate image may overwrite it
+    lds_barrier();                             // XS consumed: the gate image may overwrite it
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const bool live = c * 4 + q.wn * 2 < nt_h;                      // last chunk: only wn == 0 has columns
@@ -140,10 +141,12 @@ __global__ __launch_bounds__(512, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
                 h3[mi][j] = f32x4{b3, b3, b3, b3};
             }
         if (live) { mm_f<4>(U2, LU, 0, f1, q, h1); mm_f<4>(U2, LU, 0, f3, q, h3); }
+        __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < NCH) {
             f1.load(w.w1, 4, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
             f3.load(w.w3, 4, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (live) {
 #pragma unroll
             for (int mi = 0; mi < MH; ++mi)
@@ -161,18 +164,22 @@ __global__ __launch_bounds__(512, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
                 }
         }
     }
-    __syncthreads();
     // x2 = x1 + b2 + g W2^T : K = 352 = 11 k-steps, two 64-column output chunks
+    Fr<6> fa[2];
+    Fr<5> fb[2];
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
-        Fr<6> fa;
-        Fr<5> fb;
-        fa.load(w.w2, 11, cc * 4 + q.wn * 2, 0, D / 16, q);
-        fb.load(w.w2, 11, cc * 4 + q.wn * 2, 6, D / 16, q);
-        mm_f<6>(Gb, LG, 0, fa, q, xr[cc]);
-        mm_f<5>(Gb, LG, 192, fb, q, xr[cc]);
+        fa[cc].load(w.w2, 11, cc * 4 + q.wn * 2, 0, D / 16, q);
+        fb[cc].load(w.w2, 11, cc * 4 + q.wn * 2, 6, D / 16, q);
     }
-    __syncthreads();                             // gate image consumed: reuse the region as the fp32 store tile
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        mm_f<6>(Gb, LG, 0, fa[cc], q, xr[cc]);
+        mm_f<5>(Gb, LG, 192, fb[cc], q, xr[cc]);
+    }
+    lds_barrier();                             // gate image consumed: reuse the region as the fp32 store tile
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     XS[((q.wm * MH + mi) * 16 + q.g * 4 + r) * LX + cc * 64 + (q.wn * 2 + j) * 16 + q.c16] = xr[cc][mi][j][r];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < R * 16 / NTH; ++i) {
         const int pc = threadIdx.x + NTH * i, row = pc >> 4;
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
             if (ok) *reinterpret_cast<bf16x8*>(p.u2 + (size_t)(row0 + row) * D + c8) = ub;     // wgrad operand
         }
     }
-    __syncthreads();
+    lds_barrier();
     f32x4 du2[2][MH][2];
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc)
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
                     }
                 }
         }
-        __syncthreads();
+        lds_barrier();
         // weight-gradient operands of this chunk to HBM (row-contiguous 16-B stores), columns < 352 only
         {
             const int ncol = (c * 64 + 64 <= HPE) ? 64 : HPE - c * 64;       // 64 or 32
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
                 mm_f<1>(DH3, LC, 0, b, q, du2[cc]);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc)
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     XS[((q.wm * MH + mi) * 16 + q.g * 4 + r) * LX + cc * 64 + (q.wn * 2 + j) * 16 + q.c16] = du2[cc][mi][j][r];
-    __syncthreads();
+    lds_barrier();
     float dgam[8], dbet[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; }
@@ -376,11 +383,11 @@ __global__ __launch_bounds__(512, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
         }
     }
     // LayerNorm-2 parameter grads: reduce the 32 threads that share a column octet, one atomic per column
-    __syncthreads();
+    lds_barrier();
     float* red = reinterpret_cast<float*>(smem);            // [512][8] x 2 fits in the U2 + DYb panels
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[threadIdx.x * 8 + e] = dgam[e]; red[NTH * 8 + threadIdx.x * 8 + e] = dbet[e]; }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < 2 * D) {
         const int which = threadIdx.x >> 7, c = threadIdx.x & (D - 1), o8 = c >> 3, e = c & 7;
         float s = 0.f;

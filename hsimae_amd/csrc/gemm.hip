@@ -145,9 +145,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
         for (int kc = 0; kc < k_chunks; ++kc) {
             if (k_chunks > 1 || nc == 0) {
-                if (!(nc == 0 && kc == 0)) __syncthreads();
+                if (!(nc == 0 && kc == 0)) lds_barrier();
                 if constexpr (AK == A_F32_LN) stage_ln(); else stage(kc);
-                __syncthreads();
+                lds_barrier();
             }
             const int ks0 = kc * (KC / 32);
             const int nks = min(KC / 32, KS_total - ks0);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         const int ccols = min(128, p.N - nc * 128);            // valid columns in this chunk (multiple of 16)
 #pragma unroll
         for (int ps = 0; ps < BM / PR; ++ps) {
-            __syncthreads();                                   // previous pass fully consumed
+            lds_barrier();                                   // previous pass fully consumed
 #pragma unroll
             for (int mi = 0; mi < PR / 16; ++mi)
 #pragma unroll
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                         T1[o] = acc[ps * (PR / 16) + mi][j][r];
                         if constexpr (DUAL) T2[o] = acc2[ps * (PR / 16) + mi][j][r];
                     }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int i = 0; i < PR * 16 / 256; ++i) {
                 const int piece = tid + 256 * i;

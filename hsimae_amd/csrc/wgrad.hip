@@ -86,10 +86,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 
     for (int c = cbeg; c < cend; ++c) {
         const int m0 = c * MC;
-        __syncthreads();
+        lds_barrier();
         stage_rows(t.dO, t.dO_f32 != 0, t.ldo, n8, p.M, m0, n0, dOt, tid);
         stage_rows(t.A, false, t.lda, k8, p.M, m0, k0, At, tid);
-        __syncthreads();
+        lds_barrier();
         if (want_bias) {
 #pragma unroll 8
             for (int i = 0; i < MC / 2; ++i) bsum += bf2f(dOt[(bhalf * (MC / 2) + i) * TST + bcol]);
