@@ -26,7 +26,8 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 template <int MT>
 struct DL {
     static constexpr int R = MT * 16;
-    static constexpr int MH = (MT + 3) / 4;
+    static constexpr int MH = (MT + 3) / 4;                // m-tiles per wave, 8-wave kernels (4 x 2 wave grid)
+    static constexpr int MHF = (MT + 1) / 2;               // forward kernel: 4 waves (2 x 2), two workgroups per CU
     static constexpr int VST = R + 8;                      // transposed-V row stride (elements)
     static constexpr int U_BYTES = R * LU * 2;
     static constexpr int QKV_BYTES = 2 * U_BYTES + D * VST * 2;
@@ -100,7 +101,7 @@ __device__ __forceinline__ void mm_f(const bf16_t* A, int lda, int kofs, const F
 // Wide layout: piece p -> (row p>>3, columns 8*(p&7)..+7); the 8 lanes of a row are adjacent.
 // Loads rows of `src` (global fp32 [Ts,64]; rows >= Ts read as zero), optionally mirrors them into the fp32
 // staging tile, and writes LayerNorm(row) as bf16 into the LDS image `U`.
-template <int MT, bool FROM_LDS>
+template <int MT, bool FROM_LDS, int NTHR = NT_>
 __device__ __forceinline__ void ln_rows(const float* src, int Ts, const float* gamma, const float* beta, bf16_t* U,
                                         float* XS, float* copy_out) {
     constexpr int R = MT * 16;
@@ -109,8 +110,8 @@ __device__ __forceinline__ void ln_rows(const float* src, int Ts, const float* g
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gm[e] = gamma[c8 + e]; bt[e] = beta[c8 + e]; }
 #pragma unroll
-    for (int i = 0; i < (R * 8 + NT_ - 1) / NT_; ++i) {
-        const int p = threadIdx.x + NT_ * i;
+    for (int i = 0; i < (R * 8 + NTHR - 1) / NTHR; ++i) {
+        const int p = threadIdx.x + NTHR * i;
         if (p < R * 8) {
             const int row = p >> 3;
             float f[8];
@@ -177,9 +178,10 @@ __device__ __forceinline__ void acc_to_xs(float* XS, int mt0, int MT, const Geo4
             }
 }
 
+template <int NTHR = NT_>
 __device__ __forceinline__ void store_rows(const float* XS, int R, int Ts, float* dst) {
     const int c8 = (threadIdx.x & 7) * 8;
-    for (int p = threadIdx.x; p < R * 8; p += NT_) {
+    for (int p = threadIdx.x; p < R * 8; p += NTHR) {
         const int row = p >> 3;
         if (row < Ts) {
             *reinterpret_cast<float4*>(dst + (size_t)row * D + c8) = *reinterpret_cast<const float4*>(XS + row * LX + c8);
@@ -293,23 +295,23 @@ __device__ __forceinline__ DecW launder_w(const DecW& a) {
 struct DecFwdArgs { const float* x; float* x1; float* x2; int nsamples, Ts; DecW w; };
 
 // q|k|v for the whole sample from the LN image U:  Qb, Kb row-major bf16; V transposed into Vt.
-template <int MT>
+template <int MT, int MHX>
 __device__ __forceinline__ void qkv_stage(const bf16_t* U, const DecW& w, const Fr<2> (&fq)[3], bf16_t* Qb, bf16_t* Kb,
                                           bf16_t* Vt, int mt0, const Geo4& q) {
     using L = DL<MT>;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        f32x4 acc[L::MH][2];
+        f32x4 acc[MHX][2];
 #pragma unroll
-        for (int mi = 0; mi < L::MH; ++mi)
+        for (int mi = 0; mi < MHX; ++mi)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float b = w.bqkv[c * D + (q.wn * 2 + j) * 16 + q.c16];
                 acc[mi][j] = f32x4{b, b, b, b};
             }
-        mm_f<L::MH, 2>(U, LU, 0, fq[c], mt0, MT, q, acc);
+        mm_f<MHX, 2>(U, LU, 0, fq[c], mt0, MT, q, acc);
 #pragma unroll
-        for (int mi = 0; mi < L::MH; ++mi) {
+        for (int mi = 0; mi < MHX; ++mi) {
             const int mt = mt0 + mi;
             if (mt >= MT) continue;
 #pragma unroll
@@ -352,7 +354,7 @@ __device__ __forceinline__ void gate_chunk(const bf16_t* U, const DecW& w, int c
 __device__ __forceinline__ float silu_f(float a) { return a / (1.f + __expf(-a)); }   // forward: exact division (loss gate 1e-4)
 
 template <int MT>
-__global__ __launch_bounds__(512, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
+__global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
     using L = DL<MT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* U = reinterpret_cast<bf16_t*>(smem);
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
     float* XS = reinterpret_cast<float*>(reg2);
     bf16_t* Gb = reinterpret_cast<bf16_t*>(reg2);
     const Geo4 q = geo();
-    const int mt0 = q.wm * L::MH;
+    const int mt0 = q.wm * L::MHF;
 
     for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
         const size_t rb = (size_t)sample * p.Ts;
@@ -372,40 +374,41 @@ __global__ __launch_bounds__(512, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
         Fr<2> fq[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) fq[c].load(w.qkv, 2, c * 4 + q.wn * 2, 0, q);
-        ln_rows<MT, false>(p.x + rb * D, p.Ts, w.n1w, w.n1b, U, XS, nullptr);
+        ln_rows<MT, false, 256>(p.x + rb * D, p.Ts, w.n1w, w.n1b, U, XS, nullptr);
         lds_barrier();
-        f32x4 xr[L::MH][2];
-        acc_from_xs<L::MH>(XS, mt0, MT, q, xr);
+        f32x4 xr[L::MHF][2];
+        acc_from_xs<L::MHF>(XS, mt0, MT, q, xr);
         lds_barrier();
-        qkv_stage<MT>(U, w, fq, Qb, Kb, Vt, mt0, q);
+        qkv_stage<MT, L::MHF>(U, w, fq, Qb, Kb, Vt, mt0, q);
         Fr<2> fp;
         fp.load(w.p, 2, q.wn * 2, 0, q);
         lds_barrier();
-        attn_head_fwd<MT>(Qb, Kb, Vt, U, q.wave, p.Ts, q, nullptr);
+#pragma unroll 1
+        for (int hh = 0; hh < 2; ++hh) attn_head_fwd<MT>(Qb, Kb, Vt, U, q.wave * 2 + hh, p.Ts, q, nullptr);
         lds_barrier();
         // proj accumulates onto the residual
 #pragma unroll
-        for (int mi = 0; mi < L::MH; ++mi)
+        for (int mi = 0; mi < L::MHF; ++mi)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float b = w.pb[(q.wn * 2 + j) * 16 + q.c16];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xr[mi][j][r] += b;
             }
-        mm_f<L::MH, 2>(U, LU, 0, fp, mt0, MT, q, xr);
+        mm_f<L::MHF, 2>(U, LU, 0, fp, mt0, MT, q, xr);
         Fr<2> f1, f3;
         f1.load(w.w1, 2, q.wn * 2, 0, q);
         f3.load(w.w3, 2, q.wn * 2, 0, q);
-        acc_to_xs<L::MH>(XS, mt0, MT, q, xr);
+        acc_to_xs<L::MHF>(XS, mt0, MT, q, xr);
         lds_barrier();
-        ln_rows<MT, true>(nullptr, p.Ts, w.n2w, w.n2b, U, XS, p.x1 + rb * D);      // LN2; x1 saved for the backward
+        ln_rows<MT, true, 256>(nullptr, p.Ts, w.n2w, w.n2b, U, XS, p.x1 + rb * D);      // LN2; x1 saved for the backward
         lds_barrier();
         Fr<6> f2;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            f32x4 h1[L::MH][2], h3[L::MH][2];
+            f32x4 h1[L::MHF][2], h3[L::MHF][2];
 #pragma unroll
-            for (int mi = 0; mi < L::MH; ++mi)
+            for (int mi = 0; mi < L::MHF; ++mi)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
@@ -413,8 +416,8 @@ __global__ __launch_bounds__(512, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
                     h1[mi][j] = f32x4{b1, b1, b1, b1};
                     h3[mi][j] = f32x4{b3, b3, b3, b3};
                 }
-            mm_f<L::MH, 2>(U, LU, 0, f1, mt0, MT, q, h1);
-            mm_f<L::MH, 2>(U, LU, 0, f3, mt0, MT, q, h3);
+            mm_f<L::MHF, 2>(U, LU, 0, f1, mt0, MT, q, h1);
+            mm_f<L::MHF, 2>(U, LU, 0, f3, mt0, MT, q, h3);
             if (c < 2) {
                 f1.load(w.w1, 2, (c + 1) * 4 + q.wn * 2, 0, q);
                 f3.load(w.w3, 2, (c + 1) * 4 + q.wn * 2, 0, q);
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
                 f2.load(w.w2, 6, q.wn * 2, 0, q);
             }
 #pragma unroll
-            for (int mi = 0; mi < L::MH; ++mi) {
+            for (int mi = 0; mi < L::MHF; ++mi) {
                 const int mt = mt0 + mi;
                 if (mt >= MT) continue;
 #pragma unroll
@@ -438,18 +441,18 @@ __global__ __launch_bounds__(512, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
         }
         lds_barrier();
 #pragma unroll
-        for (int mi = 0; mi < L::MH; ++mi)
+        for (int mi = 0; mi < L::MHF; ++mi)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float b = w.w2b[(q.wn * 2 + j) * 16 + q.c16];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xr[mi][j][r] += b;
             }
-        mm_f<L::MH, 6>(Gb, LG, 0, f2, mt0, MT, q, xr);
+        mm_f<L::MHF, 6>(Gb, LG, 0, f2, mt0, MT, q, xr);
         lds_barrier();
-        acc_to_xs<L::MH>(XS, mt0, MT, q, xr);
+        acc_to_xs<L::MHF>(XS, mt0, MT, q, xr);
         lds_barrier();
-        store_rows(XS, L::R, p.Ts, p.x2 + rb * D);
+        store_rows<256>(XS, L::R, p.Ts, p.x2 + rb * D);
         lds_barrier();
     }
 }
@@ -1097,7 +1100,7 @@ int launch_fwd(const DecFwdArgs& a, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, L::FWD_TOTAL);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dec_block_fwd_kernel<MT>), dim3(a.nsamples), dim3(NT_), L::FWD_TOTAL, s, a);
+    hipLaunchKernelGGL((dec_block_fwd_kernel<MT>), dim3(a.nsamples), dim3(256), L::FWD_TOTAL, s, a);
     return (int)hipGetLastError();
 }
 

@@ -5,14 +5,14 @@
 //   forward : reads x1 (512 B/row), writes x2 (512 B/row)                — nothing else touches HBM
 //   backward: reads x1, dY, recomputes u2/h1/h3/g, writes dx1 and the three weight-gradient operands
 //             (u2, dh1|dh3, g) that `wgrad_kernel` consumes; LayerNorm-2 parameter grads via atomics.
-// Workgroup = 8 waves as 4(M) x 2(N): wave (wm, wn) owns m-tiles {2wm, 2wm+1} and n-tiles {2wn, 2wn+1} of every
+// Workgroup = 4 waves as 2(M) x 2(N) on a 64-row panel: wave (wm, wn) owns m-tiles {2wm, 2wm+1} and n-tiles {2wn, 2wn+1} of every
 // 64-column chunk.  Weight fragments are prefetched one chunk ahead.
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-constexpr int D = 128, HPE = 352, R = 128, MH = 2, NTH = 512;
+constexpr int D = 128, HPE = 352, R = 64, MH = 2, NTH = 256;   // two independent 4-wave workgroups per CU   // two independent 4-wave workgroups per CU
 constexpr int LU = D + 8;          // bf16 panel row stride (elements)
 constexpr int LX = D + 4;          // fp32 staging row stride (floats)
 constexpr int LG = HPE + 8;        // gate image row stride
@@ -77,7 +77,7 @@ struct EncMlpW {
 
 struct EncMlpFwdArgs { const float* x1; const float* res2; float* x2; int M; EncMlpW w; };
 
-__global__ __launch_bounds__(512, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
+__global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
     float* XS = reinterpret_cast<float*>(smem + R * LU * 2);
@@ -212,7 +212,7 @@ struct EncMlpBwdArgs {
     float* g_n2w; float* g_n2b;
 };
 
-__global__ __launch_bounds__(512, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
+__global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
     bf16_t* DYb = U2 + R * LU;
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(512, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[threadIdx.x * 8 + e] = dgam[e]; red[NTH * 8 + threadIdx.x * 8 + e] = dbet[e]; }
     lds_barrier();
-    if (threadIdx.x < 2 * D) {
-        const int which = threadIdx.x >> 7, c = threadIdx.x & (D - 1), o8 = c >> 3, e = c & 7;
+    for (int t2 = threadIdx.x; t2 < 2 * D; t2 += NTH) {
+        const int which = t2 >> 7, c = t2 & (D - 1), o8 = c >> 3, e = c & 7;
         float s = 0.f;
         for (int t = o8; t < NTH; t += 16) s += red[which * NTH * 8 + t * 8 + e];
         atomicAdd((which ? p.g_n2b : p.g_n2w) + c, s);
