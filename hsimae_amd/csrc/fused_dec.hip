@@ -1126,9 +1126,41 @@ int launch_bwd(const DecBwdMlpArgs& a, const DecBwdAttnArgs& b, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+template <int MT>
+int launch_bwd_attn(const DecBwdAttnArgs& b, hipStream_t s) {
+    using L = DL<MT>;
+    constexpr int IMG = L::R * LU * 2;
+    constexpr int LDS_B = 7 * IMG + L::R * LX * 4 + 2 * 8 * L::R * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_attn_kernel<MT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+        attr_set = true;
+    }
+    const int grid = b.nsamples < 256 ? b.nsamples : 256;
+    hipLaunchKernelGGL((dec_bwd_attn_kernel<MT>), dim3(grid), dim3(NT_), LDS_B, s, b);
+    return (int)hipGetLastError();
+}
+
 bool hs_dec_fused_supported(int d, int heads, int hidden, int Ts) {
     // the backward kernels keep 5-6 bf16 images + an fp32 tile of the sample in LDS: up to 7 m-tiles (112 tokens)
     return d == D && heads == 8 && hidden <= HPD && hidden % 4 == 0 && Ts <= 112 && Ts >= 16;
+}
+
+int hs_dec_bwd_attn(const float* x, const float* dx1, float* dx, int nsamples, int Ts, const DecBlockPtrs& bp,
+                    const DecBlockGrads& g, hipStream_t s) {
+    DecW w;
+    w.n1w = bp.n1w; w.n1b = bp.n1b; w.bqkv = bp.bqkv; w.pb = bp.pb; w.n2w = bp.n2w; w.n2b = bp.n2b;
+    w.w1b = bp.w1b; w.w3b = bp.w3b; w.w2b = bp.w2b;
+    w.qkv = bp.qkv; w.p = bp.p; w.w1 = bp.w1; w.w3 = bp.w3; w.w2 = bp.w2; w.h = bp.h;
+    DecBwdAttnArgs b;
+    b.x = x; b.dx1 = dx1; b.dx = dx; b.nsamples = nsamples; b.Ts = Ts; b.w = w; b.qkvT = bp.qkvT; b.pT = bp.pT;
+    b.g_n1w = g.n1w; b.g_n1b = g.n1b; b.g_qw = g.qw; b.g_qb = g.qb; b.g_kw = g.kw; b.g_kb = g.kb; b.g_vw = g.vw;
+    b.g_vb = g.vb; b.g_pw = g.pw; b.g_pb = g.pb;
+    const int mt = (Ts + 15) / 16;
+    if (mt <= 4) return launch_bwd_attn<4>(b, s);
+    if (mt <= 7) return launch_bwd_attn<7>(b, s);
+    return HS_EUNSUPPORTED;
 }
 
 int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx1_tmp, float* dx, int nsamples, int Ts,

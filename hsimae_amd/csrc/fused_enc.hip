@@ -12,12 +12,27 @@
 
 namespace {
 
-constexpr int D = 128, HPE = 352, R = 64, MH = 2, NTH = 256;   // two independent 4-wave workgroups per CU   // two independent 4-wave workgroups per CU
-constexpr int LU = D + 8;          // bf16 panel row stride (elements)
-constexpr int LX = D + 4;          // fp32 staging row stride (floats)
-constexpr int LG = HPE + 8;        // gate image row stride
+constexpr int R = 64, MH = 2, NTH = 256;   // 64-row panels: several independent 4-wave workgroups per CU
 constexpr int LC = 64 + 8;         // 64-column chunk image row stride
-constexpr int NCH = (HPE + 63) / 64;   // hidden chunks (6, the last one half full)
+
+// Geometry for model width D and padded hidden width HP (multiples of 64 / 32).
+template <int D, int HP>
+struct MG {
+    static constexpr int LU = D + 8;            // bf16 panel row stride (elements)
+    static constexpr int LX = D + 4;            // fp32 staging row stride (floats)
+    static constexpr int LG = HP + 8;           // gate image row stride
+    static constexpr int NCH = (HP + 63) / 64;  // hidden chunks (the last one may be half full)
+    static constexpr int NCC = D / 64;          // 64-column chunks of the model width
+    static constexpr int KSD = D / 32;          // k-steps over the model width
+    static constexpr int KSH = HP / 32;         // k-steps over the hidden width
+    static constexpr int LPR = D / 8;           // lanes per row in the wide layout
+    static constexpr int KA = KSH > 6 ? 6 : KSH, KB = KSH - KA;
+    static constexpr int LDS_FWD = R * LU * 2 + R * LG * 2;
+    static constexpr int LDS_BWD = 2 * R * LU * 2 + 3 * R * LC * 2;
+    static_assert(R * LG * 2 >= R * LX * 4, "gate image region must hold the fp32 staging tile");
+    static_assert(R * LU * 2 + 3 * R * LC * 2 >= R * LX * 4, "dY panel + chunk images must hold the fp32 staging tile");
+    static_assert(2 * R * LU * 2 >= 2 * NTH * 8 * 4, "reduction scratch must fit in the two panels");
+};
 
 struct G8 { int lane, c16, g, wave, wm, wn; };
 __device__ __forceinline__ G8 geo8() {
@@ -64,8 +79,10 @@ __device__ __forceinline__ void st8(float* p, const float* v) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
-__device__ __forceinline__ float red16(float v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+template <int LPR>
+__device__ __forceinline__ float redrow(float v) {          // sum over the LPR adjacent lanes that own one row
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
@@ -77,7 +94,10 @@ struct EncMlpW {
 
 struct EncMlpFwdArgs { const float* x1; const float* res2; float* x2; int M; EncMlpW w; };
 
+template <int D, int HPE>
 __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
+    using G = MG<D, HPE>;
+    constexpr int LU = G::LU, LX = G::LX, LG = G::LG, NCH = G::NCH, NCC = G::NCC, KSD = G::KSD, LPR = G::LPR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
     float* XS = reinterpret_cast<float*>(smem + R * LU * 2);
@@ -86,37 +106,37 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     const int row0 = blockIdx.x * R;
     const EncMlpW& w = p.w;
     const int nt_h = HPE / 16;
-    const int c8 = (threadIdx.x & 15) * 8;
+    const int c8 = (threadIdx.x % LPR) * 8;
 
-    Fr<4> f1, f3;
-    f1.load(w.w1, 4, q.wn * 2, 0, nt_h, q);
-    f3.load(w.w3, 4, q.wn * 2, 0, nt_h, q);
+    Fr<KSD> f1, f3;
+    f1.load(w.w1, KSD, q.wn * 2, 0, nt_h, q);
+    f3.load(w.w3, KSD, q.wn * 2, 0, nt_h, q);
     __builtin_amdgcn_sched_barrier(0);           // keep the fetches here: hipcc otherwise sinks them next to the MFMAs
     {   // LayerNorm-2 in the wide layout (16 lanes per row) + fp32 copy for the residual
         float gm[8], bt[8];
         ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
 #pragma unroll
-        for (int i = 0; i < R * 16 / NTH; ++i) {
-            const int pc = threadIdx.x + NTH * i, row = pc >> 4;
+        for (int i = 0; i < R * LPR / NTH; ++i) {
+            const int pc = threadIdx.x + NTH * i, row = pc / LPR;
             float f[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = 0.f;
             if (row0 + row < p.M) ld8(p.x1 + (size_t)(row0 + row) * D + c8, f);
             st8(XS + row * LX + c8, f);
-            const float mean = red16(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
+            const float mean = redrow<LPR>(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
             float v = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { f[e] -= mean; v += f[e] * f[e]; }
-            const float rstd = rsqrtf(red16(v) * (1.f / D) + 1e-5f);
+            const float rstd = rsqrtf(redrow<LPR>(v) * (1.f / D) + 1e-5f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
             *reinterpret_cast<bf16x8*>(U2 + row * LU + c8) = cvt8(f);
         }
     }
     lds_barrier();
-    f32x4 xr[2][MH][2];                          // residual, [output chunk][m-tile][n-tile] in accumulator layout
+    f32x4 xr[NCC][MH][2];                          // residual, [output chunk][m-tile][n-tile] in accumulator layout
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
+    for (int cc = 0; cc < NCC; ++cc)
 #pragma unroll
         for (int mi = 0; mi < MH; ++mi)
 #pragma unroll
@@ -140,11 +160,11 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
                 h1[mi][j] = f32x4{b1, b1, b1, b1};
                 h3[mi][j] = f32x4{b3, b3, b3, b3};
             }
-        if (live) { mm_f<4>(U2, LU, 0, f1, q, h1); mm_f<4>(U2, LU, 0, f3, q, h3); }
+        if (live) { mm_f<KSD>(U2, LU, 0, f1, q, h1); mm_f<KSD>(U2, LU, 0, f3, q, h3); }
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < NCH) {
-            f1.load(w.w1, 4, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
-            f3.load(w.w3, 4, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
+            f1.load(w.w1, KSD, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
+            f3.load(w.w3, KSD, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (live) {
@@ -165,23 +185,23 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
         }
     }
     // x2 = x1 + b2 + g W2^T : K = 352 = 11 k-steps, two 64-column output chunks
-    Fr<6> fa[2];
-    Fr<5> fb[2];
+    Fr<G::KA> fa[NCC];
+    Fr<(G::KB > 0 ? G::KB : 1)> fb[NCC];
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-        fa[cc].load(w.w2, 11, cc * 4 + q.wn * 2, 0, D / 16, q);
-        fb[cc].load(w.w2, 11, cc * 4 + q.wn * 2, 6, D / 16, q);
+    for (int cc = 0; cc < NCC; ++cc) {
+        fa[cc].load(w.w2, G::KSH, cc * 4 + q.wn * 2, 0, D / 16, q);
+        if constexpr (G::KB > 0) fb[cc].load(w.w2, G::KSH, cc * 4 + q.wn * 2, G::KA, D / 16, q);
     }
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-        mm_f<6>(Gb, LG, 0, fa[cc], q, xr[cc]);
-        mm_f<5>(Gb, LG, 192, fb[cc], q, xr[cc]);
+    for (int cc = 0; cc < NCC; ++cc) {
+        mm_f<G::KA>(Gb, LG, 0, fa[cc], q, xr[cc]);
+        if constexpr (G::KB > 0) mm_f<G::KB>(Gb, LG, G::KA * 32, fb[cc], q, xr[cc]);
     }
     lds_barrier();                             // gate image consumed: reuse the region as the fp32 store tile
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
+    for (int cc = 0; cc < NCC; ++cc)
 #pragma unroll
         for (int mi = 0; mi < MH; ++mi)
 #pragma unroll
@@ -191,8 +211,8 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
                     XS[((q.wm * MH + mi) * 16 + q.g * 4 + r) * LX + cc * 64 + (q.wn * 2 + j) * 16 + q.c16] = xr[cc][mi][j][r];
     lds_barrier();
 #pragma unroll
-    for (int i = 0; i < R * 16 / NTH; ++i) {
-        const int pc = threadIdx.x + NTH * i, row = pc >> 4;
+    for (int i = 0; i < R * LPR / NTH; ++i) {
+        const int pc = threadIdx.x + NTH * i, row = pc / LPR;
         if (row0 + row < p.M) {
             float f[8];
             ld8(XS + row * LX + c8, f);
@@ -212,7 +232,10 @@ struct EncMlpBwdArgs {
     float* g_n2w; float* g_n2b;
 };
 
+template <int D, int HPE>
 __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
+    using G = MG<D, HPE>;
+    constexpr int LU = G::LU, LX = G::LX, NCH = G::NCH, NCC = G::NCC, KSD = G::KSD, KSH = G::KSH, LPR = G::LPR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
     bf16_t* DYb = U2 + R * LU;
@@ -224,28 +247,28 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     const int row0 = blockIdx.x * R;
     const EncMlpW& w = p.w;
     const int nt_h = HPE / 16;
-    const int c8 = (threadIdx.x & 15) * 8;
+    const int c8 = (threadIdx.x % LPR) * 8;
 
-    Fr<4> f1, f3, f2;
-    f1.load(w.w1, 4, q.wn * 2, 0, nt_h, q);
-    f3.load(w.w3, 4, q.wn * 2, 0, nt_h, q);
-    f2.load(w.w2T, 4, q.wn * 2, 0, nt_h, q);
+    Fr<KSD> f1, f3, f2;
+    f1.load(w.w1, KSD, q.wn * 2, 0, nt_h, q);
+    f3.load(w.w3, KSD, q.wn * 2, 0, nt_h, q);
+    f2.load(w.w2T, KSD, q.wn * 2, 0, nt_h, q);
     {
         float gm[8], bt[8];
         ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
 #pragma unroll
-        for (int i = 0; i < R * 16 / NTH; ++i) {
-            const int pc = threadIdx.x + NTH * i, row = pc >> 4;
+        for (int i = 0; i < R * LPR / NTH; ++i) {
+            const int pc = threadIdx.x + NTH * i, row = pc / LPR;
             const bool ok = row0 + row < p.M;
             float f[8], dyv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { f[e] = 0.f; dyv[e] = 0.f; }
             if (ok) { ld8(p.x1 + (size_t)(row0 + row) * D + c8, f); ld8(p.dy + (size_t)(row0 + row) * D + c8, dyv); }
-            const float mean = red16(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
+            const float mean = redrow<LPR>(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
             float v = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { f[e] -= mean; v += f[e] * f[e]; }
-            const float rstd = rsqrtf(red16(v) * (1.f / D) + 1e-5f);
+            const float rstd = rsqrtf(redrow<LPR>(v) * (1.f / D) + 1e-5f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
             const bf16x8 ub = cvt8(f);
@@ -255,9 +278,9 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
         }
     }
     lds_barrier();
-    f32x4 du2[2][MH][2];
+    f32x4 du2[NCC][MH][2];
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
+    for (int cc = 0; cc < NCC; ++cc)
 #pragma unroll
         for (int mi = 0; mi < MH; ++mi) { du2[cc][mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; du2[cc][mi][1] = du2[cc][mi][0]; }
 
@@ -276,11 +299,11 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
                     h3[mi][j] = f32x4{b3, b3, b3, b3};
                     dg[mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-            if (live) { mm_f<4>(U2, LU, 0, f1, q, h1); mm_f<4>(U2, LU, 0, f3, q, h3); mm_f<4>(DYb, LU, 0, f2, q, dg); }
+            if (live) { mm_f<KSD>(U2, LU, 0, f1, q, h1); mm_f<KSD>(U2, LU, 0, f3, q, h3); mm_f<KSD>(DYb, LU, 0, f2, q, dg); }
             if (c + 1 < NCH) {
-                f1.load(w.w1, 4, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
-                f3.load(w.w3, 4, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
-                f2.load(w.w2T, 4, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
+                f1.load(w.w1, KSD, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
+                f3.load(w.w3, KSD, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
+                f2.load(w.w2T, KSD, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
             }
 #pragma unroll
             for (int mi = 0; mi < MH; ++mi)
@@ -315,21 +338,21 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
             }
         }
         // data gradient through W1 / W3:  du2 += dh1_c W1[c] + dh3_c W3[c]   (packed [N=128][K=704], W3 at k-step 11)
-        if (c < NCH - 1) {
+        if (c < NCH - 1 || HPE % 64 == 0) {
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
+            for (int cc = 0; cc < NCC; ++cc) {
                 Fr<2> a, b;
-                a.load(w.w13T, 22, cc * 4 + q.wn * 2, 2 * c, D / 16, q);
-                b.load(w.w13T, 22, cc * 4 + q.wn * 2, 11 + 2 * c, D / 16, q);
+                a.load(w.w13T, 2 * KSH, cc * 4 + q.wn * 2, 2 * c, D / 16, q);
+                b.load(w.w13T, 2 * KSH, cc * 4 + q.wn * 2, KSH + 2 * c, D / 16, q);
                 mm_f<2>(DH1, LC, 0, a, q, du2[cc]);
                 mm_f<2>(DH3, LC, 0, b, q, du2[cc]);
             }
         } else {
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
+            for (int cc = 0; cc < NCC; ++cc) {
                 Fr<1> a, b;
-                a.load(w.w13T, 22, cc * 4 + q.wn * 2, 2 * c, D / 16, q);
-                b.load(w.w13T, 22, cc * 4 + q.wn * 2, 11 + 2 * c, D / 16, q);
+                a.load(w.w13T, 2 * KSH, cc * 4 + q.wn * 2, 2 * c, D / 16, q);
+                b.load(w.w13T, 2 * KSH, cc * 4 + q.wn * 2, KSH + 2 * c, D / 16, q);
                 mm_f<1>(DH1, LC, 0, a, q, du2[cc]);
                 mm_f<1>(DH3, LC, 0, b, q, du2[cc]);
             }
@@ -337,7 +360,7 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
         lds_barrier();
     }
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
+    for (int cc = 0; cc < NCC; ++cc)
 #pragma unroll
         for (int mi = 0; mi < MH; ++mi)
 #pragma unroll
@@ -353,23 +376,23 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
         float gm[8];
         ld8(w.n2w + c8, gm);
 #pragma unroll
-        for (int i = 0; i < R * 16 / NTH; ++i) {
-            const int pc = threadIdx.x + NTH * i, row = pc >> 4;
+        for (int i = 0; i < R * LPR / NTH; ++i) {
+            const int pc = threadIdx.x + NTH * i, row = pc / LPR;
             const bool ok = row0 + row < p.M;
             float du[8], xh[8], dyv[8], t[8];
             ld8(XS + row * LX + c8, du);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { xh[e] = 0.f; dyv[e] = 0.f; }
             if (ok) { ld8(p.x1 + (size_t)(row0 + row) * D + c8, xh); ld8(p.dy + (size_t)(row0 + row) * D + c8, dyv); }
-            const float mean = red16(xh[0] + xh[1] + xh[2] + xh[3] + xh[4] + xh[5] + xh[6] + xh[7]) * (1.f / D);
+            const float mean = redrow<LPR>(xh[0] + xh[1] + xh[2] + xh[3] + xh[4] + xh[5] + xh[6] + xh[7]) * (1.f / D);
             float v = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { xh[e] -= mean; v += xh[e] * xh[e]; }
-            const float rstd = rsqrtf(red16(v) * (1.f / D) + 1e-5f);
+            const float rstd = rsqrtf(redrow<LPR>(v) * (1.f / D) + 1e-5f);
             float a = 0.f, b = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { xh[e] *= rstd; t[e] = du[e] * gm[e]; a += t[e]; b += t[e] * xh[e]; }
-            a = red16(a) * (1.f / D); b = red16(b) * (1.f / D);
+            a = redrow<LPR>(a) * (1.f / D); b = redrow<LPR>(b) * (1.f / D);
             if (ok) {
                 float o[8];
 #pragma unroll
@@ -389,22 +412,20 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     for (int e = 0; e < 8; ++e) { red[threadIdx.x * 8 + e] = dgam[e]; red[NTH * 8 + threadIdx.x * 8 + e] = dbet[e]; }
     lds_barrier();
     for (int t2 = threadIdx.x; t2 < 2 * D; t2 += NTH) {
-        const int which = t2 >> 7, c = t2 & (D - 1), o8 = c >> 3, e = c & 7;
+        const int which = t2 / D, c = t2 % D, o8 = c >> 3, e = c & 7;
         float s = 0.f;
-        for (int t = o8; t < NTH; t += 16) s += red[which * NTH * 8 + t * 8 + e];
+        for (int t = o8; t < NTH; t += LPR) s += red[which * NTH * 8 + t * 8 + e];
         atomicAdd((which ? p.g_n2b : p.g_n2w) + c, s);
     }
 }
 
-constexpr int LDS_FWD = R * LU * 2 + R * LG * 2;
-constexpr int LDS_BWD = 2 * R * LU * 2 + 3 * R * LC * 2;
-static_assert(R * LG * 2 >= R * LX * 4, "gate image region must hold the fp32 staging tile");
-static_assert(R * LU * 2 + 3 * R * LC * 2 >= R * LX * 4, "dY panel + chunk images must hold the fp32 staging tile");
-static_assert(2 * R * LU * 2 >= 2 * NTH * 8 * 4, "reduction scratch must fit in the two panels");
-
 }  // namespace
 
-bool hs_enc_mlp_fused_supported(int d, int hidden) { return d == D && hidden <= HPE && ((hidden + 31) / 32 * 32) == HPE; }
+static int hp_of(int hidden) { return (hidden + 31) / 32 * 32; }
+
+bool hs_enc_mlp_fused_supported(int d, int hidden) {
+    return d == 128 && hp_of(hidden) == 352;      // the kernels are templates on <D, HP>; only Base is instantiated
+}
 
 static EncMlpW mkw(const EncMlpPtrs& b) {
     EncMlpW w;
@@ -413,30 +434,37 @@ static EncMlpW mkw(const EncMlpPtrs& b) {
     return w;
 }
 
-int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, const EncMlpPtrs& b, hipStream_t s) {
+template <int D, int HP>
+static void set_attrs() {
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_fwd_kernel<D, HP>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_FWD);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel<D, HP>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_BWD);
+    done = true;
+}
+
+int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, const EncMlpPtrs& b, hipStream_t s) {
     if (M <= 0) return HS_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FWD);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BWD);
-        attr_set = true;
-    }
     EncMlpFwdArgs a; a.x1 = x1; a.res2 = res2; a.x2 = x2; a.M = M; a.w = mkw(b);
-    hipLaunchKernelGGL(enc_mlp_fwd_kernel, dim3((M + R - 1) / R), dim3(NTH), LDS_FWD, s, a);
+    if (d == 128) {
+        set_attrs<128, 352>();
+        hipLaunchKernelGGL((enc_mlp_fwd_kernel<128, 352>), dim3((M + R - 1) / R), dim3(NTH), (MG<128, 352>::LDS_FWD), s, a);
+    } else {
+        return HS_EUNSUPPORTED;
+    }
     return (int)hipGetLastError();
 }
 
-int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, int M,
+int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, int M, int d,
                    const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s) {
     if (M <= 0) return HS_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FWD);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BWD);
-        attr_set = true;
-    }
     EncMlpBwdArgs a; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.u2 = u2; a.dh13 = dh13; a.g = g; a.M = M; a.w = mkw(b);
     a.g_n2w = g_n2w; a.g_n2b = g_n2b;
-    hipLaunchKernelGGL(enc_mlp_bwd_kernel, dim3((M + R - 1) / R), dim3(NTH), LDS_BWD, s, a);
+    if (d == 128) {
+        set_attrs<128, 352>();
+        hipLaunchKernelGGL((enc_mlp_bwd_kernel<128, 352>), dim3((M + R - 1) / R), dim3(NTH), (MG<128, 352>::LDS_BWD), s, a);
+    } else {
+        return HS_EUNSUPPORTED;
+    }
     return (int)hipGetLastError();
 }

@@ -43,6 +43,8 @@ struct DecBlockPtrs {
 struct DecBlockGrads { float *n1w, *n1b, *qw, *qb, *kw, *kb, *vw, *vb, *pw, *pb, *n2w, *n2b, *w1w, *w1b, *w2w, *w2b, *w3w, *w3b; };
 bool hs_dec_fused_supported(int d, int heads, int hidden, int Ts);
 int hs_dec_block_fwd(const float* x, float* x1, float* x2, int nsamples, int Ts, const DecBlockPtrs& bp, hipStream_t s);
+int hs_dec_bwd_attn(const float* x, const float* dx1, float* dx, int nsamples, int Ts, const DecBlockPtrs& bp,
+                    const DecBlockGrads& g, hipStream_t s);
 int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx1_tmp, float* dx, int nsamples, int Ts,
                      const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s);
 
@@ -53,6 +55,6 @@ struct EncMlpPtrs {
     int h;
 };
 bool hs_enc_mlp_fused_supported(int d, int hidden);
-int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, const EncMlpPtrs& b, hipStream_t s);
-int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, int M,
+int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, const EncMlpPtrs& b, hipStream_t s);
+int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, int M, int d,
                    const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s);
