@@ -12,6 +12,7 @@
 // LDS staging tile, which is also how x / x1 / x2 move to and from HBM with 16-B accesses.
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -508,18 +509,25 @@ __device__ __forceinline__ void wg_tile(const bf16_t* dO, int n0, const bf16_t* 
 }
 
 // Row (token) fragment pair for one k-step of a weight-gradient product (see wg_tile), zeroed past row R.
-template <int MT>
+// TAIL = the k-step that runs past row R (R % 32 == 16): lane groups 2,3 would read rows >= R and supply zeros
+// instead.  Full k-steps skip the per-element selects (they were ~40 % of the backward kernels' VALU work).
+template <int MT, bool TAIL>
 __device__ __forceinline__ bf16x8 wg_frag(const bf16_t* img, int col0, int kk, const Geo4& q) {
     constexpr int R = MT * 16;
     const int q4 = q.c16 >> 2, p4 = q.c16 & 3;
-    const bool ok = kk * 32 + 8 * q.g < R;
-    const int rb = ok ? kk * 32 + 8 * q.g : kk * 32;
-    const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + (rb + q4) * LU + col0 + 4 * p4));
-    const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + (rb + 4 + q4) * LU + col0 + 4 * p4));
-    bf16x8 a;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { a[e] = ok ? a0[e] : (bf16_t)0.f; a[4 + e] = ok ? a1[e] : (bf16_t)0.f; }
-    return a;
+    if constexpr (!TAIL) {
+        const bf16_t* a = img + (kk * 32 + 8 * q.g + q4) * LU + col0 + 4 * p4;
+        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(a));
+        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(a + 4 * LU));
+        return __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+    } else {
+        const bool ok = kk * 32 + 8 * q.g < R;
+        const int rb = ok ? kk * 32 + 8 * q.g : kk * 32;
+        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + (rb + q4) * LU + col0 + 4 * p4));
+        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + (rb + 4 + q4) * LU + col0 + 4 * p4));
+        const bf16x8 v = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        return ok ? v : zero8();
+    }
 }
 
 __device__ __forceinline__ void ld8(const float* p, float* o) {
@@ -649,16 +657,28 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             lds_barrier();
             // weight gradients of this hidden chunk: 12 (n-tile) x 4 (k-tile) output tiles, 3 x 2 per wave
 #pragma unroll 1
-            for (int kk = 0; kk < (R + 31) / 32; ++kk) {
+            for (int kk = 0; kk < R / 32; ++kk) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;   // mat 0: dW2, 1: dW1, 2: dW3
                     const bf16_t* dOi = mat == 0 ? DYb : (mat == 1 ? DH1 : DH3);
                     const bf16_t* Ai = mat == 0 ? Gc : U2;
-                    const bf16x8 a = wg_frag<MT>(dOi, nt * 16, kk, q);
+                    const bf16x8 a = wg_frag<MT, false>(dOi, nt * 16, kk, q);
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2)
-                        accW[c][t][k2] = mfma16(a, wg_frag<MT>(Ai, ((q.wave & 1) * 2 + k2) * 16, kk, q), accW[c][t][k2]);
+                        accW[c][t][k2] = mfma16(a, wg_frag<MT, false>(Ai, ((q.wave & 1) * 2 + k2) * 16, kk, q), accW[c][t][k2]);
+                }
+            }
+            if constexpr (R % 32 != 0) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;   // mat 0: dW2, 1: dW1, 2: dW3
+                    const bf16_t* dOi = mat == 0 ? DYb : (mat == 1 ? DH1 : DH3);
+                    const bf16_t* Ai = mat == 0 ? Gc : U2;
+                    const bf16x8 a = wg_frag<MT, true>(dOi, nt * 16, R / 32, q);
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2)
+                        accW[c][t][k2] = mfma16(a, wg_frag<MT, true>(Ai, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accW[c][t][k2]);
                 }
             }
             // data gradient through W1 / W3
@@ -891,11 +911,17 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         for (int mi = 0; mi < L::MH; ++mi) { dO[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dO[mi][1] = dO[mi][0]; }
         mm<L::MH, 2>(DXb, LU, 0, pT, 2, q.wn * 2, 0, mt0, MT, q, dO);
 #pragma unroll 1
-        for (int kk = 0; kk < (R + 31) / 32; ++kk) {
-            const bf16x8 a = wg_frag<MT>(DXb, (q.wave >> 1) * 16, kk, q);
+        for (int kk = 0; kk < R / 32; ++kk) {
+            const bf16x8 a = wg_frag<MT, false>(DXb, (q.wave >> 1) * 16, kk, q);
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
-                accP[k2] = mfma16(a, wg_frag<MT>(Ob, ((q.wave & 1) * 2 + k2) * 16, kk, q), accP[k2]);
+                accP[k2] = mfma16(a, wg_frag<MT, false>(Ob, ((q.wave & 1) * 2 + k2) * 16, kk, q), accP[k2]);
+        }
+        if constexpr (R % 32 != 0) {
+            const bf16x8 a = wg_frag<MT, true>(DXb, (q.wave >> 1) * 16, R / 32, q);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+                accP[k2] = mfma16(a, wg_frag<MT, true>(Ob, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accP[k2]);
         }
         lds_barrier();
 #pragma unroll
@@ -1011,15 +1037,28 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         mm<L::MH, 2>(Kb, LU, 0, qkvT, 6, q.wn * 2, 2, mt0, MT, q, du);
         mm<L::MH, 2>(Vb, LU, 0, qkvT, 6, q.wn * 2, 4, mt0, MT, q, du);
 #pragma unroll 1
-        for (int kk = 0; kk < (R + 31) / 32; ++kk) {
+        for (int kk = 0; kk < R / 32; ++kk) {
             bf16x8 b[2];
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) b[k2] = wg_frag<MT>(U, ((q.wave & 1) * 2 + k2) * 16, kk, q);
+            for (int k2 = 0; k2 < 2; ++k2) b[k2] = wg_frag<MT, false>(U, ((q.wave & 1) * 2 + k2) * 16, kk, q);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
                 const bf16_t* dOi = mat == 0 ? DQb : (mat == 1 ? Kb : Vb);
-                const bf16x8 a = wg_frag<MT>(dOi, nt * 16, kk, q);
+                const bf16x8 a = wg_frag<MT, false>(dOi, nt * 16, kk, q);
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) accQ[t][k2] = mfma16(a, b[k2], accQ[t][k2]);
+            }
+        }
+        if constexpr (R % 32 != 0) {
+            bf16x8 b[2];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) b[k2] = wg_frag<MT, true>(U, ((q.wave & 1) * 2 + k2) * 16, R / 32, q);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
+                const bf16_t* dOi = mat == 0 ? DQb : (mat == 1 ? Kb : Vb);
+                const bf16x8 a = wg_frag<MT, true>(dOi, nt * 16, R / 32, q);
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) accQ[t][k2] = mfma16(a, b[k2], accQ[t][k2]);
             }

@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int BM = 128;
-constexpr int PR = 32;             // rows per epilogue pass
+template <int KC> struct EpiRows { static constexpr int v = KC >= 512 ? 16 : 32; };   // rows per epilogue pass (LDS budget at K = 512)
 constexpr int TS = 132;            // fp32 LDS tile row stride (floats): conflict-free b32 writes
 
 template <int AK, int EPI, int KC>
@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LDA = KC + 8;                       // LDS row stride (elements): 16-B pad => conflict-free b128 reads
     constexpr bool DUAL = (EPI == E_SWIGLU);
+    constexpr int PR = EpiRows<KC>::v;
     bf16_t* As = reinterpret_cast<bf16_t*>(smem);     // [128][KC+8]
     float* rstat = reinterpret_cast<float*>(smem + BM * LDA * 2);   // [128][2] mean, rstd
     float* T1 = rstat + 2 * BM;                       // [PR][TS]
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 template <int AK, int EPI, int KC>
 int launch(const GemmParams& p, hipStream_t s) {
     const int grid = (p.M + BM - 1) / BM;
-    const size_t lds = (size_t)BM * (KC + 8) * 2 + BM * 2 * sizeof(float) + (EPI == E_SWIGLU ? 2 : 1) * PR * TS * sizeof(float);
+    const size_t lds = (size_t)BM * (KC + 8) * 2 + BM * 2 * sizeof(float) + (EPI == E_SWIGLU ? 2 : 1) * EpiRows<KC>::v * TS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<AK, EPI, KC>),

@@ -320,3 +320,34 @@ def test_fused_encoder_mlp_matches_layerwise(bands, grid, N):
             worst = (k, r)
         assert r < 3e-2, (k, r)
     print(f"[fused-mlp {bands}] worst grad rms-rel vs layerwise {worst}")
+
+
+@pytest.mark.parametrize("name,bands,dim,grid,N", [("C3-Large", 96, 256, (3, 9), 12), ("C5-Huge@512", 192, 512, (6, 9), 6),
+                                                   ("C5-Huge@512", 192, 512, (18, 3), 6)])
+def test_large_and_huge_widths_against_oracle(name, bands, dim, grid, N):
+    """Configs C3 (Large, D = 256, 16 heads) and C5 ("Huge" is not defined by the reference: D = 512, 32 heads,
+    192 bands) at a small batch against the fp32 oracle: layer-at-a-time encoder kernels at
+    K = 256 / 512, 216-token decoder attention (14 key tiles), reference weight scale."""
+    cfg = O.OracleConfig(bands=bands, embed_dim=dim, num_heads=dim // 16)
+    state = O.init_state(cfg, seed=3, std=0.02)
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(N, 1, bands, 9, 9, generator=g)
+    n1, n2 = torch.rand(N, bands // 8, generator=g), torch.rand(N, 9, generator=g)
+    ref_loss, ref_pred, ref_mask, ref_grads = O.forward_backward(state, cfg, x, n1.numpy(), n2.numpy(), *grid)
+    m = build(cfg, state)
+    loss, pred, mask = m(x.to(DEV), 0.75, noise=(n1, n2), grid=grid)
+    loss.backward()
+    torch.cuda.synchronize()
+    rel = abs(loss.item() - ref_loss.item()) / ref_loss.item()
+    print(f"[{name} {grid}] loss {loss.item():.7f} oracle {ref_loss.item():.7f} rel {rel:.2e}")
+    assert torch.equal(mask.cpu(), ref_mask)
+    assert rel <= 1e-4
+    assert rms_rel(pred, ref_pred) < 1e-2
+    named = dict(m.named_parameters())
+    worst = ("", 0.0)
+    for k in ref_grads:
+        r = grad_err(named, ref_grads, k)
+        if r > worst[1]:
+            worst = (k, r)
+        assert r < 3e-2, (k, r)
+    print(f"[{name}] worst grad rms-rel {worst}")
