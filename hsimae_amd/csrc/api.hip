@@ -514,7 +514,7 @@ int hsimae_forward(const hsimae_config* cfg, const hsimae_io* io, void* stream) 
     const bool fdec = fused_dec_enabled(g);
     for (int i = 0; i < g.ddepth; ++i) {
         BlkP bp = resolve(c.L.bd[i], c.W.bd[i], P, io->wpk, c.W);
-        if (fdec) CK(hs_dec_block_fwd(z, w.bd[i].x1, w.bd[i].x2, c.N, g.TL, dec_ptrs(bp, g.hdec), s));
+        if (fdec) CK(hs_dec_block_fwd(z, w.bd[i].x1, w.bd[i].x2, w.bd[i].o, w.bd[i].lse, c.N, g.TL, dec_ptrs(bp, g.hdec), s));
         else CK(block_fwd(bp, z, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, nullptr, s));
         z = w.bd[i].x2;
     }
@@ -576,7 +576,7 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
             dg.w3w = grads + o.w3w; dg.w3b = grads + o.w3b;
             // MLP half then attention half, both persistent with the block's weight gradients held in registers
             // (measured equal to "row-tile kernel + wgrad operands through HBM" at d = 64, with 0.7 GB less traffic)
-            CK(hs_dec_block_bwd(xin, w.bd[i].x1, w.G0, w.G1, w.G0, c.N, g.TL, dec_ptrs(bp, g.hdec), dg, s));
+            CK(hs_dec_block_bwd(xin, w.bd[i].x1, w.G0, w.G1, w.G0, w.bd[i].o, w.bd[i].lse, c.N, g.TL, dec_ptrs(bp, g.hdec), dg, s));
         } else {
             CK(block_bwd(bp, L.bd[i], grads, xin, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, w.G0, w.sc, w.G0, 0, s));
         }

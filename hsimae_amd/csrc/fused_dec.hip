@@ -269,7 +269,7 @@ __device__ __forceinline__ void attn_head_fwd(const bf16_t* Qb, const bf16_t* Kb
             for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
             *reinterpret_cast<bf16x4*>(O + query * LU + head * HD + q.g * 4) = ov;
         }
-        if (lse_out && q.g == 0) lse_out[query] = m * sc + __builtin_amdgcn_logf(lsum);   // log2-domain lse
+        if (lse_out && q.g == 0 && query < Ts) lse_out[(size_t)query * 8 + head] = m * sc + __builtin_amdgcn_logf(lsum);   // log2-domain lse, [row][head]
     }
 }
 
@@ -293,7 +293,7 @@ __device__ __forceinline__ DecW launder_w(const DecW& a) {
     return w;
 }
 
-struct DecFwdArgs { const float* x; float* x1; float* x2; int nsamples, Ts; DecW w; };
+struct DecFwdArgs { const float* x; float* x1; float* x2; bf16_t* o; float* lse; int nsamples, Ts; DecW w; };
 
 // q|k|v for the whole sample from the LN image U:  Qb, Kb row-major bf16; V transposed into Vt.
 template <int MT, int MHX>
@@ -385,8 +385,13 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
         fp.load(w.p, 2, q.wn * 2, 0, q);
         lds_barrier();
 #pragma unroll 1
-        for (int hh = 0; hh < 2; ++hh) attn_head_fwd<MT>(Qb, Kb, Vt, U, q.wave * 2 + hh, p.Ts, q, nullptr);
+        for (int hh = 0; hh < 2; ++hh) attn_head_fwd<MT>(Qb, Kb, Vt, U, q.wave * 2 + hh, p.Ts, q, p.lse + rb * 8);
         lds_barrier();
+        // attention output kept for the backward (dWp operand; saves it the softmax recompute), 16-B row pieces
+        for (int pc = threadIdx.x; pc < L::R * 8; pc += 256) {
+            const int row = pc >> 3, k8 = (pc & 7) * 8;
+            if (row < p.Ts) *reinterpret_cast<bf16x8*>(p.o + (rb + row) * D + k8) = *reinterpret_cast<const bf16x8*>(U + row * LU + k8);
+        }
         // proj accumulates onto the residual
 #pragma unroll
         for (int mi = 0; mi < L::MHF; ++mi)
@@ -758,7 +763,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
 }
 
 struct DecBwdAttnArgs {
-    const float* x; const float* dx1; float* dx; int nsamples, Ts; DecW w; const bf16_t *qkvT, *pT;
+    const float* x; const float* dx1; float* dx; const bf16_t* o; const float* lse_g; int nsamples, Ts; DecW w; const bf16_t *qkvT, *pT;
     float *g_n1w, *g_n1b, *g_qw, *g_qb, *g_kw, *g_kb, *g_vw, *g_vb, *g_pw, *g_pb;
 };
 
@@ -851,57 +856,19 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             }
         }
         lds_barrier();
-        // attention forward (recompute): O image + log2-domain logsumexp per (head, query)
-        {
-            const int head = q.wave;
-            for (int qt = 0; qt * 16 < p.Ts; ++qt) {
-                const int query = qt * 16 + q.c16;
-                const bf16x8 bq = rowfrag8(Qb, LU, query, head * HD, q.g);
-                f32x4 s[MT];
+        // attention output and log2-domain logsumexp come from the forward kernel (no softmax recompute)
+        for (int pc = threadIdx.x; pc < R * 8; pc += NT_) {
+            const int row = pc >> 3, k8 = (pc & 7) * 8;
+            bf16x8 v = zero8();
+            if (row < p.Ts) v = *reinterpret_cast<const bf16x8*>(p.o + (rb + row) * D + k8);
+            *reinterpret_cast<bf16x8*>(Ob + row * LU + k8) = v;
+            float l8[8];
 #pragma unroll
-                for (int kt = 0; kt < MT; ++kt)
-                    s[kt] = mfma16(rowfrag8(Kb, LU, kt * 16 + q.c16, head * HD, q.g), bq, f32x4{0.f, 0.f, 0.f, 0.f});
-                float m = -INFINITY;
+            for (int e = 0; e < 8; ++e) l8[e] = 0.f;
+            if (k8 == 0 && row < p.Ts) ld8(p.lse_g + (rb + row) * 8, l8);
+            if (k8 == 0) {
 #pragma unroll
-                for (int kt = 0; kt < MT; ++kt) {
-                    if ((kt + 1) * 16 > p.Ts) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (kt * 16 + q.g * 4 + r >= p.Ts) s[kt][r] = -INFINITY;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
-                }
-                m = fmaxf(m, __shfl_xor(m, 16, 64));
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
-                const float nm = -m * sc;
-                float lsum = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < MT; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc, nm));
-                        s[kt][r] = e;
-                        lsum += e;
-                    }
-                lsum += __shfl_xor(lsum, 16, 64);
-                lsum += __shfl_xor(lsum, 32, 64);
-                const float inv = 1.f / lsum;
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int pp = 0; pp < (MT + 1) / 2; ++pp) {
-                    const int ta = 2 * pp, tb = 2 * pp + 1;
-                    const bool tb_ok = tb < MT;
-                    const bf16x8 bp = pack2(s[ta], tb_ok ? s[tb_ok ? tb : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
-                    o = mfma16(trfrag(Vb, LU, ta * 16, tb * 16, tb_ok, head * HD, q.c16 < HD, q), bp, o);
-                }
-                if (q.g < 2) {
-                    bf16x4 ov;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
-                    *reinterpret_cast<bf16x4*>(Ob + query * LU + head * HD + q.g * 4) = ov;
-                }
-                if (q.g == 0) lse[head * R + query] = m * sc + __builtin_amdgcn_logf(lsum);
+                for (int e = 0; e < 8; ++e) lse[e * R + row] = l8[e];
             }
         }
         lds_barrier();
@@ -1186,14 +1153,14 @@ bool hs_dec_fused_supported(int d, int heads, int hidden, int Ts) {
     return d == D && heads == 8 && hidden <= HPD && hidden % 4 == 0 && Ts <= 112 && Ts >= 16;
 }
 
-int hs_dec_bwd_attn(const float* x, const float* dx1, float* dx, int nsamples, int Ts, const DecBlockPtrs& bp,
-                    const DecBlockGrads& g, hipStream_t s) {
+int hs_dec_bwd_attn(const float* x, const float* dx1, float* dx, const hs_bf16* o, const float* lse, int nsamples, int Ts,
+                    const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s) {
     DecW w;
     w.n1w = bp.n1w; w.n1b = bp.n1b; w.bqkv = bp.bqkv; w.pb = bp.pb; w.n2w = bp.n2w; w.n2b = bp.n2b;
     w.w1b = bp.w1b; w.w3b = bp.w3b; w.w2b = bp.w2b;
     w.qkv = bp.qkv; w.p = bp.p; w.w1 = bp.w1; w.w3 = bp.w3; w.w2 = bp.w2; w.h = bp.h;
     DecBwdAttnArgs b;
-    b.x = x; b.dx1 = dx1; b.dx = dx; b.nsamples = nsamples; b.Ts = Ts; b.w = w; b.qkvT = bp.qkvT; b.pT = bp.pT;
+    b.x = x; b.dx1 = dx1; b.dx = dx; b.o = o; b.lse_g = lse; b.nsamples = nsamples; b.Ts = Ts; b.w = w; b.qkvT = bp.qkvT; b.pT = bp.pT;
     b.g_n1w = g.n1w; b.g_n1b = g.n1b; b.g_qw = g.qw; b.g_qb = g.qb; b.g_kw = g.kw; b.g_kb = g.kb; b.g_vw = g.vw;
     b.g_vb = g.vb; b.g_pw = g.pw; b.g_pb = g.pb;
     const int mt = (Ts + 15) / 16;
@@ -1202,8 +1169,8 @@ int hs_dec_bwd_attn(const float* x, const float* dx1, float* dx, int nsamples, i
     return HS_EUNSUPPORTED;
 }
 
-int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx1_tmp, float* dx, int nsamples, int Ts,
-                     const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s) {
+int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o,
+                     const float* lse, int nsamples, int Ts, const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s) {
     DecW w;
     w.n1w = bp.n1w; w.n1b = bp.n1b; w.bqkv = bp.bqkv; w.pb = bp.pb; w.n2w = bp.n2w; w.n2b = bp.n2b;
     w.w1b = bp.w1b; w.w3b = bp.w3b; w.w2b = bp.w2b;
@@ -1213,7 +1180,7 @@ int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx
     a.g_n2w = g.n2w; a.g_n2b = g.n2b; a.g_w1w = g.w1w; a.g_w1b = g.w1b; a.g_w3w = g.w3w; a.g_w3b = g.w3b;
     a.g_w2w = g.w2w; a.g_w2b = g.w2b;
     DecBwdAttnArgs b;
-    b.x = x; b.dx1 = dx1_tmp; b.dx = dx; b.nsamples = nsamples; b.Ts = Ts; b.w = w; b.qkvT = bp.qkvT; b.pT = bp.pT;
+    b.x = x; b.dx1 = dx1_tmp; b.dx = dx; b.o = o; b.lse_g = lse; b.nsamples = nsamples; b.Ts = Ts; b.w = w; b.qkvT = bp.qkvT; b.pT = bp.pT;
     b.g_n1w = g.n1w; b.g_n1b = g.n1b; b.g_qw = g.qw; b.g_qb = g.qb; b.g_kw = g.kw; b.g_kb = g.kb; b.g_vw = g.vw;
     b.g_vb = g.vb; b.g_pw = g.pw; b.g_pb = g.pb;
     const int mt = (Ts + 15) / 16;
@@ -1222,9 +1189,10 @@ int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx
     return HS_EUNSUPPORTED;
 }
 
-int hs_dec_block_fwd(const float* x, float* x1, float* x2, int nsamples, int Ts, const DecBlockPtrs& bp, hipStream_t s) {
+int hs_dec_block_fwd(const float* x, float* x1, float* x2, hs_bf16* o, float* lse, int nsamples, int Ts,
+                     const DecBlockPtrs& bp, hipStream_t s) {
     DecFwdArgs a;
-    a.x = x; a.x1 = x1; a.x2 = x2; a.nsamples = nsamples; a.Ts = Ts;
+    a.x = x; a.x1 = x1; a.x2 = x2; a.o = o; a.lse = lse; a.nsamples = nsamples; a.Ts = Ts;
     a.w.n1w = bp.n1w; a.w.n1b = bp.n1b; a.w.bqkv = bp.bqkv; a.w.pb = bp.pb; a.w.n2w = bp.n2w; a.w.n2b = bp.n2b;
     a.w.w1b = bp.w1b; a.w.w3b = bp.w3b; a.w.w2b = bp.w2b;
     a.w.qkv = bp.qkv; a.w.p = bp.p; a.w.w1 = bp.w1; a.w.w3 = bp.w3; a.w.w2 = bp.w2; a.w.h = bp.h;
