@@ -96,6 +96,31 @@ def dominant_kernel_roofline(model, N, K_tok, iters=20):
             "bytes_per_launch": nbytes}
 
 
+def optimizer_step_ms(model, iters=10):
+    """Not part of the metric (fwd+bwd only): the reference loop's optimizer.step() (Model_Pretraining.py:102) as
+    stock torch AdamW over 535 tensors vs the one-launch FusedAdamW + packed-weight refresh."""
+    from hsimae_amd import FusedAdamW
+    nd = ["bias", "norm"]
+    groups = [{"params": [p for n, p in model.named_parameters() if not any(k in n for k in nd)], "weight_decay": 5e-2},
+              {"params": [p for n, p in model.named_parameters() if any(k in n for k in nd)], "weight_decay": 0.0}]
+    ref = torch.optim.AdamW(groups, lr=1e-9, weight_decay=5e-2, betas=(0.9, 0.95))
+    fused = FusedAdamW(model, lr=1e-9, weight_decay=5e-2, betas=(0.9, 0.95))
+    stream = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for name, opt in (("torch_adamw", ref), ("fused_adamw_plus_repack", fused)):
+        for _ in range(2):
+            opt.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            opt.step()
+            if opt is fused:
+                model._ensure_packed(stream)
+        torch.cuda.synchronize()
+        res[name] = round((time.perf_counter() - t0) / iters * 1e3, 3)
+    return res
+
+
 def cpu_baseline(bands, n_sample=64, steps=4):
     """The CPU oracle (a port of the reference's algorithm, validated against it) on the host cores."""
     from oracle import hsimae_oracle as O
@@ -206,6 +231,7 @@ def main():
             "gflop_per_patch": round(fl / 1e9, 4),
         }
         out["roofline"] = dominant_kernel_roofline(model, N, 27)
+        out["optimizer_step_ms"] = optimizer_step_ms(model)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(bands)
         print(json.dumps(out), flush=True)

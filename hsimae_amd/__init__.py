@@ -4,5 +4,6 @@
 `libhsimae_hip.so` (hand-written HIP kernels, C ABI in include/hsimae_hip.h).
 """
 from .model import HSIMAE, swiglu_hidden, sincos_table  # noqa: F401
+from .optim import FusedAdamW  # noqa: F401
 
 __version__ = "0.1.0"

@@ -112,6 +112,7 @@ SYMBOLS = {
     "hsimae_assemble_bwd": (C.c_int, [C.POINTER(AssembleParams), vp]),
     "hsimae_loss_partials": (C.c_int, [i32, i32]),
     "hsimae_loss": (C.c_int, [C.POINTER(LossParams), vp]),
+    "hsimae_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
 }
 
 A_BF16, A_F32, A_F32_LN = 0, 1, 2

@@ -665,6 +665,11 @@ int hsimae_ln_fwd(const float* x, const float* gamma, const float* beta, float* 
 }
 int hsimae_assemble_fwd(const hsimae_assemble_params* p, void* stream) { return p ? hs_assemble_fwd(*p, S(stream)) : HSIMAE_ENULL; }
 int hsimae_assemble_bwd(const hsimae_assemble_params* p, void* stream) { return p ? hs_assemble_bwd(*p, S(stream)) : HSIMAE_ENULL; }
+int hsimae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* group, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !group) return HSIMAE_ENULL;
+    return hs_adamw(params, grads, exp_avg, exp_avg_sq, group, n, lr, beta1, beta2, eps, weight_decay, step, S(stream));
+}
 int hsimae_loss_partials(int32_t N, int32_t T) { return hs_loss_partials(N, T); }
 int hsimae_loss(const hsimae_loss_params* p, void* stream) { return p ? hs_loss(*p, S(stream)) : HSIMAE_ENULL; }
 

@@ -3,6 +3,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <algorithm>
+#include <cmath>
 
 namespace {
 
@@ -323,6 +324,35 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const float* partial, i
     if (threadIdx.x == 0) loss[0] = (float)(red[0] / (double)sum_mask);
 }
 
+// ------------------------------------------------------------------ fused AdamW over the flat parameter buffer
+// torch.optim.AdamW semantics (decoupled decay, bias correction), one launch for all 535 tensors
+// (Model_Pretraining.py:80-86,102).  group[i]: 0 = weight decay, 1 = no decay ('bias' / 'norm' names), 2 = frozen.
+__global__ __launch_bounds__(256) void adamw_kernel(float4* p, const float4* g, float4* m, float4* v, const uchar4* group,
+                                                    int64_t n4, float lr, float b1, float b2, float eps, float wd,
+                                                    float inv_bc1, float inv_sqrt_bc2) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const uchar4 gr = group[i];
+        if (gr.x == 2 && gr.y == 2 && gr.z == 2 && gr.w == 2) continue;
+        float4 P = p[i], M = m[i], V = v[i];
+        const float4 G = g[i];
+        float* pp = &P.x; float* mm = &M.x; float* vv = &V.x;
+        const float* gg = &G.x;
+        const unsigned char grp[4] = {gr.x, gr.y, gr.z, gr.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (grp[e] == 2) continue;
+            float x = pp[e];
+            if (grp[e] == 0) x *= 1.f - lr * wd;
+            const float mn = mm[e] + (gg[e] - mm[e]) * (1.f - b1);          // lerp, as torch does it
+            const float vn = vv[e] * b2 + gg[e] * gg[e] * (1.f - b2);
+            const float denom = sqrtf(vn) * inv_sqrt_bc2 + eps;
+            pp[e] = x - lr * inv_bc1 * (mn / denom);
+            mm[e] = mn; vv[e] = vn;
+        }
+        p[i] = P; m[i] = M; v[i] = V;
+    }
+}
+
 __global__ __launch_bounds__(256) void add2_kernel(const float4* a, const float4* b, float4* o, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 x = a[i], y = b[i];
@@ -405,5 +435,18 @@ int hs_add2(const float* a, const float* b, float* out, int64_t n, hipStream_t s
     const int grid = (int)std::min<int64_t>((n4 + 255) / 256, 4096);
     hipLaunchKernelGGL(add2_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float4*>(a),
                        reinterpret_cast<const float4*>(b), reinterpret_cast<float4*>(out), n4);
+    return (int)hipGetLastError();
+}
+
+int hs_adamw(float* p, const float* g, float* m, float* v, const unsigned char* group, int64_t n, float lr, float b1, float b2,
+             float eps, float wd, int step, hipStream_t s) {
+    if (n <= 0) return HS_OK;
+    if (n % 4 || step < 1) return HS_EDIMS;
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    const int64_t n4 = n / 4;
+    const int grid = (int)std::min<int64_t>((n4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<float4*>(p), reinterpret_cast<const float4*>(g),
+                       reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v), reinterpret_cast<const uchar4*>(group), n4, lr, b1,
+                       b2, eps, wd, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
     return (int)hipGetLastError();
 }

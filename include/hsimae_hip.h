@@ -209,6 +209,13 @@ typedef struct {
 int hsimae_loss_partials(int32_t N, int32_t T);   /* floats needed in `partial` */
 int hsimae_loss(const hsimae_loss_params* p, void* stream);
 
+/* ------------------------------------------------------------------ next row N1: optimizer step */
+/* AdamW over the flat parameter / gradient buffers in ONE launch, torch.optim.AdamW semantics
+ * (Model_Pretraining.py:80-86,102: betas (.9,.95), decay only on names without 'bias'/'norm').
+ * group[i] per element: 0 = decayed, 1 = not decayed, 2 = frozen / unused (left untouched). `step` is 1-based. */
+int hsimae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* group, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -351,3 +351,51 @@ def test_large_and_huge_widths_against_oracle(name, bands, dim, grid, N):
             worst = (k, r)
         assert r < 3e-2, (k, r)
     print(f"[{name}] worst grad rms-rel {worst}")
+
+
+def test_fused_adamw_matches_torch_adamw_and_training_step():
+    """hsimae_adamw_step (one launch over the flat buffer) against torch.optim.AdamW with the reference's two
+    name-filtered groups (Model_Pretraining.py:80-86), 6 steps on the same gradients; then a real training loop."""
+    from hsimae_amd import FusedAdamW
+    cfg = O.OracleConfig(bands=48)
+    state = O.init_state(cfg, seed=9, std=0.02)
+    ma, mb = build(cfg, state), build(cfg, state)
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(16, 1, 48, 9, 9, generator=g).to(DEV)
+    nd = ["bias", "norm"]
+    groups = [{"params": [p for n, p in ma.named_parameters() if not any(k in n for k in nd)], "weight_decay": 5e-2},
+              {"params": [p for n, p in ma.named_parameters() if any(k in n for k in nd)], "weight_decay": 0.0}]
+    ref = torch.optim.AdamW(groups, lr=5e-3, weight_decay=5e-2, betas=(0.9, 0.95))
+    fused = FusedAdamW(mb, lr=5e-3, weight_decay=5e-2, betas=(0.9, 0.95))
+    la, lb = [], []
+    for step in range(6):
+        n = (torch.rand(16, 6, generator=g), torch.rand(16, 9, generator=g))
+        for m_, opt, acc in ((ma, ref, la), (mb, fused, lb)):
+            loss, _, _ = m_(x, 0.75, noise=n, grid=(2, 7))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            acc.append(loss.item())
+    print("[adamw] torch", [f"{v:.5f}" for v in la])
+    print("[adamw] fused", [f"{v:.5f}" for v in lb])
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 2e-3 * abs(a)          # two independent bf16 runs drift apart through the atomics' order
+    worst = 0.0
+    for (pname, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        if pname in ("pos_embed", "decoder_pos_embed", "mask_token"):
+            assert torch.equal(pa, pb)                # frozen / unused: untouched
+            continue
+        worst = max(worst, rms_rel(pb, pa))
+    print(f"[adamw] worst parameter rms-rel after 6 steps {worst:.2e}")
+    assert worst < 2e-2
+    # exactness of the arithmetic itself: identical gradients in, one step
+    mc, md = build(cfg, state), build(cfg, state)
+    for m_ in (mc, md):
+        m_(x, 0.75, noise=n, grid=(2, 7))[0].backward()
+    md._flat_grad.copy_(mc._flat_grad)
+    groups = [{"params": [p for n_, p in mc.named_parameters() if not any(k in n_ for k in nd)], "weight_decay": 5e-2},
+              {"params": [p for n_, p in mc.named_parameters() if any(k in n_ for k in nd)], "weight_decay": 0.0}]
+    torch.optim.AdamW(groups, lr=5e-3, weight_decay=5e-2, betas=(0.9, 0.95)).step()
+    FusedAdamW(md, lr=5e-3, weight_decay=5e-2, betas=(0.9, 0.95)).step()
+    torch.cuda.synchronize()
+    assert float((mc._flat - md._flat).abs().max()) <= 1e-6
