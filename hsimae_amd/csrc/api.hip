@@ -203,6 +203,7 @@ void carve(const Geo& g, int N, int K, char* base, Ws& w) {
 struct BlkP {            // resolved pointers of one block
     const float *n1w, *n1b, *bqkv, *pb, *n2w, *n2b, *w1b, *w3b, *w2b;
     const hs_bf16 *qkv, *p, *w1, *w3, *w2, *qkvT, *pT, *w13T, *w2T;
+    const float *qf, *kf, *vf, *pf, *w1f, *w3f;     // fp32 master weights (row-major), staged as bf16 by the fused decoder backward
 };
 
 BlkP resolve(const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk, const WLayout& WL) {
@@ -212,6 +213,7 @@ BlkP resolve(const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk,
     b.w1b = P + o.w1b; b.w3b = P + o.w3b; b.w2b = P + o.w2b;
     b.qkv = wpk + w.qkv; b.p = wpk + w.p; b.w1 = wpk + w.w1; b.w3 = wpk + w.w3; b.w2 = wpk + w.w2;
     b.qkvT = wpk + w.qkvT; b.pT = wpk + w.pT; b.w13T = wpk + w.w13T; b.w2T = wpk + w.w2T;
+    b.qf = P + o.qw; b.kf = P + o.kw; b.vf = P + o.vw; b.pf = P + o.pw; b.w1f = P + o.w1w; b.w3f = P + o.w3w;
     return b;
 }
 
@@ -262,6 +264,7 @@ DecBlockPtrs dec_ptrs(const BlkP& b, int h) {
     d.w1b = b.w1b; d.w3b = b.w3b; d.w2b = b.w2b;
     d.qkv = b.qkv; d.p = b.p; d.w1 = b.w1; d.w3 = b.w3; d.w2 = b.w2;
     d.qkvT = b.qkvT; d.pT = b.pT; d.w13T = b.w13T; d.w2T = b.w2T; d.h = h;
+    d.qf = b.qf; d.kf = b.kf; d.vf = b.vf; d.pf = b.pf; d.w1f = b.w1f; d.w3f = b.w3f;
     return d;
 }
 

@@ -14,12 +14,30 @@
 #include "kernels.h"
 #include <type_traits>
 
+// Per-phase cycle accounting for scripts/phase_timing.py (compiled only with -DHS_PHASE_TIMING; never in the shipped library)
+#ifdef HS_PHASE_TIMING
+__device__ unsigned long long hs_phase_cycles[32];
+extern "C" int hsimae_debug_phases(unsigned long long* out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hs_phase_cycles), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(hs_phase_cycles), z, sizeof(z)); }
+    return rc;
+}
+#define PH_DECL unsigned long long ph_t0 = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PH(i) { const unsigned long long ph_t = __builtin_readcyclecounter(); ph_acc[i] += ph_t - ph_t0; ph_t0 = ph_t; }
+#define PH_FLUSH(base) if (threadIdx.x == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&hs_phase_cycles[(base) + i], ph_acc[i]); }
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_FLUSH(base)
+#endif
+
 namespace {
 
 constexpr int D = 64, HD = 8, HPD = 192;
 constexpr int LU = D + 8;        // bf16 image row stride (elements)
 constexpr int LG = HPD + 8;
 constexpr int LX = D + 4;        // fp32 staging row stride (floats)
+constexpr int WRM = HPD * LU;    // one row-major [192][LU] bf16 weight image staged in LDS (elements)
 constexpr int NT_ = 512;         // threads per workgroup (8 waves: one attention head per wave)
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
@@ -34,7 +52,12 @@ struct DL {
     static constexpr int QKV_BYTES = 2 * U_BYTES + D * VST * 2;
     static constexpr int REG2 = cmax(cmax(QKV_BYTES, R * LG * 2), R * LX * 4);
     static constexpr int FWD_TOTAL = U_BYTES + REG2;
+    // backward attention kernel: fp32 staging tile, aliased by the per-wave transposition tiles of the attention core
+    static constexpr int XT_BYTES = cmax(R * LX * 4, 8 * 2 * 2 * 16 * 24 * 2);
+    static constexpr int BWD_ATTN_LDS = 6 * U_BYTES + XT_BYTES + 2 * 8 * R * 4;
 };
+constexpr int TTS = 24;                    // transposition tile row stride (elements)
+constexpr int TT_WAVE = 2 * 2 * 16 * TTS;  // per wave: [ring of 2][P | dS][16 queries][TTS]
 
 struct Geo4 { int lane, c16, g, wave, wm, wn; };
 
@@ -47,15 +70,21 @@ __device__ __forceinline__ Geo4 geo() {
 
 // acc[mi][j] += A[rows of m-tile mt0+mi][k] * W[n-tile nt0+j][k]  over KS k-steps starting at A column `kofs`
 // and packed k-step ks0.  All B fragments are fetched up front (one exposed L2 latency per call).
-template <int MH, int KS>
+typedef __attribute__((address_space(3))) const bf16x8* lds_cb128;
+typedef __attribute__((address_space(3))) const float* lds_cf32;
+
+// WLDS: the packed weight image is resident in LDS (explicit address space: a generic pointer would become flat loads)
+template <int MH, int KS, bool WLDS = false>
 __device__ __forceinline__ void mm(const bf16_t* A, int lda, int kofs, const bf16_t* W, int KS_total, int nt0,
                                    int ks0, int mt0, int MT, const Geo4& q, f32x4 (&acc)[MH][2]) {
     bf16x8 b[KS][2];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            b[ks][j] = *reinterpret_cast<const bf16x8*>(W + (((size_t)(nt0 + j) * KS_total + ks0 + ks) * 64 + q.lane) * 8);
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (WLDS) b[ks][j] = *(lds_cb128)(W + (((nt0 + j) * KS_total + ks0 + ks) * 64 + q.lane) * 8);
+            else b[ks][j] = *reinterpret_cast<const bf16x8*>(W + (((size_t)(nt0 + j) * KS_total + ks0 + ks) * 64 + q.lane) * 8);
+        }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -95,6 +124,28 @@ __device__ __forceinline__ void mm_f(const bf16_t* A, int lda, int kofs, const F
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + q.c16) * lda + kofs + ks * 32 + q.g * 8);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[mi][j] = mfma16(a, f.b[ks][j], acc[mi][j]);
+            }
+        }
+}
+
+// acc += A * W^T with W row-major bf16 [n][LU] resident in LDS (k contiguous): B fragment = 16-byte row pieces
+template <int MH, int KS>
+__device__ __forceinline__ void mm_rm(const bf16_t* A, int lda, const bf16_t* Wr, int nt0, int mt0, int MT, const Geo4& q,
+                                      f32x4 (&acc)[MH][2]) {
+    bf16x8 b[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[ks][j] = *(lds_cb128)(Wr + ((nt0 + j) * 16 + q.c16) * LU + ks * 32 + q.g * 8);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi) {
+            const int mt = mt0 + mi;
+            if (mt < MT) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + q.c16) * lda + ks * 32 + q.g * 8);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[mi][j] = mfma16(a, b[ks][j], acc[mi][j]);
             }
         }
 }
@@ -282,10 +333,17 @@ struct DecW {               // one decoder block's parameters
 // The weight images are invariant across the samples a workgroup walks; left alone, the compiler hoists every
 // fragment load out of the sample loop and then spills them.  Laundering the pointers once per iteration keeps
 // the loads where they are used.
+__device__ __forceinline__ int launder_i(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
 template <class T>
 __device__ __forceinline__ const T* launder(const T* p) {
-    asm volatile("" : "+s"(p));
-    return p;
+    // launder it as a global-memory pointer: through a generic one every load becomes a flat_load, which ties the
+    // LDS counter (lgkmcnt) to L2 latency
+    const __attribute__((address_space(1))) T* g = (const __attribute__((address_space(1))) T*)p;
+    asm volatile("" : "+s"(g));
+    return (const T*)g;
 }
 __device__ __forceinline__ DecW launder_w(const DecW& a) {
     DecW w = a;
@@ -334,24 +392,6 @@ __device__ __forceinline__ void qkv_stage(const bf16_t* U, const DecW& w, const 
     }
 }
 
-// g = silu(u2 W1^T + b1) * (u2 W3^T + b3) for hidden chunk c (64 columns) -> bf16 image columns [c*64, +64)
-template <int MT>
-__device__ __forceinline__ void gate_chunk(const bf16_t* U, const DecW& w, int c, int mt0, const Geo4& q,
-                                           f32x4 (&h1)[DL<MT>::MH][2], f32x4 (&h3)[DL<MT>::MH][2]) {
-    using L = DL<MT>;
-#pragma unroll
-    for (int mi = 0; mi < L::MH; ++mi)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
-            const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
-            h1[mi][j] = f32x4{b1, b1, b1, b1};
-            h3[mi][j] = f32x4{b3, b3, b3, b3};
-        }
-    mm<L::MH, 2>(U, LU, 0, w.w1, 2, c * 4 + q.wn * 2, 0, mt0, MT, q, h1);
-    mm<L::MH, 2>(U, LU, 0, w.w3, 2, c * 4 + q.wn * 2, 0, mt0, MT, q, h3);
-}
-
 __device__ __forceinline__ float silu_f(float a) { return a / (1.f + __expf(-a)); }   // forward: exact division (loss gate 1e-4)
 
 template <int MT>
@@ -368,6 +408,7 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
     const Geo4 q = geo();
     const int mt0 = q.wm * L::MHF;
 
+    PH_DECL
     for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
         const size_t rb = (size_t)sample * p.Ts;
         const DecW w = launder_w(p.w);
@@ -377,16 +418,20 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
         for (int c = 0; c < 3; ++c) fq[c].load(w.qkv, 2, c * 4 + q.wn * 2, 0, q);
         ln_rows<MT, false, 256>(p.x + rb * D, p.Ts, w.n1w, w.n1b, U, XS, nullptr);
         lds_barrier();
+        PH(0)
         f32x4 xr[L::MHF][2];
         acc_from_xs<L::MHF>(XS, mt0, MT, q, xr);
         lds_barrier();
+        PH(0)
         qkv_stage<MT, L::MHF>(U, w, fq, Qb, Kb, Vt, mt0, q);
         Fr<2> fp;
         fp.load(w.p, 2, q.wn * 2, 0, q);
         lds_barrier();
+        PH(1)
 #pragma unroll 1
         for (int hh = 0; hh < 2; ++hh) attn_head_fwd<MT>(Qb, Kb, Vt, U, q.wave * 2 + hh, p.Ts, q, p.lse + rb * 8);
         lds_barrier();
+        PH(2)
         // attention output kept for the backward (dWp operand; saves it the softmax recompute), 16-B row pieces
         for (int pc = threadIdx.x; pc < L::R * 8; pc += 256) {
             const int row = pc >> 3, k8 = (pc & 7) * 8;
@@ -407,8 +452,10 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
         f3.load(w.w3, 2, q.wn * 2, 0, q);
         acc_to_xs<L::MHF>(XS, mt0, MT, q, xr);
         lds_barrier();
+        PH(3)
         ln_rows<MT, true, 256>(nullptr, p.Ts, w.n2w, w.n2b, U, XS, p.x1 + rb * D);      // LN2; x1 saved for the backward
         lds_barrier();
+        PH(4)
         Fr<6> f2;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -446,6 +493,7 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
             }
         }
         lds_barrier();
+        PH(5)
 #pragma unroll
         for (int mi = 0; mi < L::MHF; ++mi)
 #pragma unroll
@@ -456,11 +504,14 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
             }
         mm_f<L::MHF, 6>(Gb, LG, 0, f2, mt0, MT, q, xr);
         lds_barrier();
+        PH(6)
         acc_to_xs<L::MHF>(XS, mt0, MT, q, xr);
         lds_barrier();
         store_rows<256>(XS, L::R, p.Ts, p.x2 + rb * D);
         lds_barrier();
+        PH(7)
     }
+    PH_FLUSH(16)
 }
 
 // ====================================================================== backward
@@ -563,7 +614,7 @@ __device__ __forceinline__ void flush_wide(float* red /* [NT_][8] LDS */, const 
 }
 
 struct DecBwdMlpArgs {
-    const float* x1; const float* dy; float* dx1; int nsamples, Ts; DecW w; const bf16_t *w2T, *w13T;
+    const float* x1; const float* dy; float* dx1; int nsamples, Ts; DecW w; const bf16_t *w2T, *w13T; const float *w1f, *w3f;
     float *g_n2w, *g_n2b, *g_w1w, *g_w1b, *g_w3w, *g_w3b, *g_w2w, *g_w2b;
 };
 
@@ -577,10 +628,29 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
     bf16_t* Gc = DYb + IMG;
     bf16_t* DH1 = Gc + IMG;
     bf16_t* DH3 = DH1 + IMG;
-    float* XS = reinterpret_cast<float*>(DH3 + IMG);
+    float* XS = reinterpret_cast<float*>(Gc);            // fp32 staging aliases Gc|DH1 (dead once the chunk loop is done)
+    bf16_t* WL = DH3 + IMG;                              // W1 | W3 as row-major bf16 [192][LU] (rows past h zero), resident
+    float* BL = reinterpret_cast<float*>(WL + 2 * WRM);  // b1 | b3, zero-padded to 192
     const Geo4 q = geo();
     const int mt0 = q.wm * L::MH;
     const int c8 = (threadIdx.x & 7) * 8;
+    // The weights are the same for every sample this workgroup walks: stage W1 and W3 once, row-major.  The gate
+    // products read them as 16-byte row pieces and the data gradient (which needs the transposed operand) reads the
+    // same image with transpose reads, so the per-sample body fetches only the W2^T fragments from L2.
+    for (int i = threadIdx.x; i < 2 * HPD * 8; i += NT_) {
+        const int m = i / (HPD * 8), row = (i % (HPD * 8)) >> 3, k8 = (i & 7) * 8;
+        bf16x8 v = zero8();
+        if (row < p.w.h) {
+            float f[8];
+            ld8((m == 0 ? p.w1f : p.w3f) + (size_t)row * D + k8, f);
+            v = cvt8(f);
+        }
+        *reinterpret_cast<bf16x8*>(WL + m * WRM + row * LU + k8) = v;
+    }
+    for (int i = threadIdx.x; i < 2 * HPD; i += NT_) {
+        const int m = i / HPD, o = i % HPD;
+        BL[i] = o < p.w.h ? (m == 0 ? p.w.w1b[o] : p.w.w3b[o]) : 0.f;
+    }
 
     f32x4 accW[3][3][2];                 // [hidden chunk][this wave's n-tile][this wave's k-tile]
 #pragma unroll
@@ -595,11 +665,15 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) { db1[c][0] = db1[c][1] = db3[c][0] = db3[c][1] = 0.f; }
 
+    PH_DECL
     for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
         const size_t rb = (size_t)sample * p.Ts;
-        const DecW w = launder_w(p.w);
+        const int wl = launder_i(0);                   // keeps the LDS weight reads inside the sample loop (no LICM + spill)
+        const bf16_t* w1L = WL + wl;
+        const bf16_t* w3L = WL + WRM + wl;
         const bf16_t* w2T = launder(p.w2T);
-        const bf16_t* w13T = launder(p.w13T);
+        Fr<2> f2;                                      // W2^T fragments of the next hidden chunk (the only global weights)
+        f2.load(w2T, 2, q.wn * 2, 0, q);
         const float* n2w = launder(p.w.n2w);
         const float* n2b = launder(p.w.n2b);
 #pragma unroll
@@ -625,41 +699,56 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             }
         }
         lds_barrier();
+        PH(0)
         f32x4 du2[L::MH][2];
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) { du2[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; du2[mi][1] = du2[mi][0]; }
+        // warm L2 / TLB with the next sample's rows (one dword per 64 B); nothing else is fetched until the epilogue
+        float touch0 = 0.f, touch1 = 0.f;
+        {
+            const int nxt = sample + gridDim.x;
+            const size_t o = (size_t)nxt * p.Ts * D + threadIdx.x * 16;
+            if (nxt < p.nsamples && threadIdx.x * 16 < p.Ts * D) { touch0 = p.x1[o]; touch1 = p.dy[o]; }
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            {
-                f32x4 h1[L::MH][2], h3[L::MH][2], dg[L::MH][2];
-                gate_chunk<MT>(U2, w, c, mt0, q, h1, h3);
+            // one m-tile at a time (h1, h3, dg of two tiles at once pushed the kernel into scratch)
 #pragma unroll
-                for (int mi = 0; mi < L::MH; ++mi) { dg[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dg[mi][1] = dg[mi][0]; }
-                mm<L::MH, 2>(DYb, LU, 0, w2T, 2, c * 4 + q.wn * 2, 0, mt0, MT, q, dg);
+            for (int mi = 0; mi < L::MH; ++mi) {
+                const int mt = mt0 + mi;
+                if (mt >= MT) continue;
+                f32x4 h1[1][2], h3[1][2], dg[1][2];
 #pragma unroll
-                for (int mi = 0; mi < L::MH; ++mi) {
-                    const int mt = mt0 + mi;
-                    if (mt >= MT) continue;
+                for (int j = 0; j < 2; ++j) {
+                    const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
+                    const float b1 = *(lds_cf32)(BL + wl + col), b3 = *(lds_cf32)(BL + HPD + wl + col);
+                    h1[0][j] = f32x4{b1, b1, b1, b1};
+                    h3[0][j] = f32x4{b3, b3, b3, b3};
+                    dg[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                mm_rm<1, 2>(U2, LU, w1L, c * 4 + q.wn * 2, mt, MT, q, h1);
+                mm_rm<1, 2>(U2, LU, w3L, c * 4 + q.wn * 2, mt, MT, q, h3);
+                mm_f<1, 2>(DYb, LU, 0, f2, mt, MT, q, dg);
+                // columns past the hidden width: W1/W3 rows and biases are zero-padded, so g = d1 = d3 = 0 there
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int lc = (q.wn * 2 + j) * 16 + q.c16;
-                        const bool ok = c * 64 + lc < w.h;
+                for (int j = 0; j < 2; ++j) {
+                    const int lc = (q.wn * 2 + j) * 16 + q.c16;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float a1 = h1[mi][j][r], a3 = h3[mi][j][r], dv = dg[mi][j][r];
-                            const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-a1));
-                            const float sl = a1 * sg;
-                            const float gv = ok ? sl * a3 : 0.f;
-                            const float d1 = ok ? dv * a3 * sg * (1.f + a1 * (1.f - sg)) : 0.f;
-                            const float d3 = ok ? dv * sl : 0.f;
-                            const int o = (mt * 16 + q.g * 4 + r) * LU + lc;
-                            Gc[o] = (bf16_t)gv; DH1[o] = (bf16_t)d1; DH3[o] = (bf16_t)d3;
-                            db1[c][j] += d1; db3[c][j] += d3;
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const float a1 = h1[0][j][r], a3 = h3[0][j][r], dv = dg[0][j][r];
+                        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-a1));
+                        const float sl = a1 * sg;
+                        const float d1 = dv * a3 * sg * (1.f + a1 * (1.f - sg));
+                        const float d3 = dv * sl;
+                        const int o = (mt * 16 + q.g * 4 + r) * LU + lc;
+                        Gc[o] = (bf16_t)(sl * a3); DH1[o] = (bf16_t)d1; DH3[o] = (bf16_t)d3;
+                        db1[c][j] += d1; db3[c][j] += d3;
                     }
                 }
             }
+            if (c < 2) f2.load(w2T, 2, (c + 1) * 4 + q.wn * 2, 0, q);
             lds_barrier();
+        PH(1)
             // weight gradients of this hidden chunk: 12 (n-tile) x 4 (k-tile) output tiles, 3 x 2 per wave
 #pragma unroll 1
             for (int kk = 0; kk < R / 32; ++kk) {
@@ -686,13 +775,34 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                         accW[c][t][k2] = mfma16(a, wg_frag<MT, true>(Ai, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accW[c][t][k2]);
                 }
             }
+            PH(2)
             // data gradient through W1 / W3
-            mm<L::MH, 2>(DH1, LU, 0, w13T, 12, q.wn * 2, 2 * c, mt0, MT, q, du2);
-            mm<L::MH, 2>(DH3, LU, 0, w13T, 12, q.wn * 2, 6 + 2 * c, mt0, MT, q, du2);
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                const bf16_t* Ai = m2 == 0 ? DH1 : DH3;
+                const bf16_t* Wc = (m2 == 0 ? w1L : w3L) + c * 64 * LU;      // this chunk's 64 hidden rows
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 b[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) b[j] = wg_frag<4, false>(Wc, (q.wn * 2 + j) * 16, ks, q);
+#pragma unroll
+                    for (int mi = 0; mi < L::MH; ++mi) {
+                        const int mt = mt0 + mi;
+                        if (mt >= MT) continue;
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ai + (mt * 16 + q.c16) * LU + ks * 32 + q.g * 8);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) du2[mi][j] = mfma16(a, b[j], du2[mi][j]);
+                    }
+                }
+            }
             lds_barrier();
+        PH(5)
         }
         acc_to_xs<L::MH>(XS, mt0, MT, q, du2);
+        asm volatile("" :: "v"(touch0), "v"(touch1));
         lds_barrier();
+        PH(3)
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pc = threadIdx.x + NT_ * i;
@@ -724,8 +834,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             }
         }
         lds_barrier();
+        PH(4)
     }
 
+    PH_FLUSH(8)
     // ---- commit
     float* red = XS;
     flush_wide(red, dgam, p.g_n2w);
@@ -762,6 +874,111 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
         }
 }
 
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ f32x4 mfma16k16(bf16x4 a, bf16x4 b, f32x4 c) {
+    // D[16x16] += A[16x16] * B[16x16].  lane l: A[row l&15][k 4(l>>4)+j], B[k 4(l>>4)+j][col l&15]; D as mfma16.
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4 zero4() {
+    u32x2 z = {0u, 0u};
+    return __builtin_bit_cast(bf16x4, z);
+}
+__device__ __forceinline__ bf16x4 cvt4(f32x4 v) {
+    bf16x4 r;
+    r[0] = (bf16_t)v[0]; r[1] = (bf16_t)v[1]; r[2] = (bf16_t)v[2]; r[3] = (bf16_t)v[3];
+    return r;
+}
+// 4 consecutive image rows of one column per lane: element j of lane (c16, g) = img[row0(g) + j][col0 + c16];
+// `a` is the lane's own 8-byte piece img[row0(g) + (c16 >> 2)][col0 + 4 (c16 & 3) ..].
+__device__ __forceinline__ bf16x4 tr4(const bf16_t* a) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(a));
+}
+
+// One head of the decoder attention backward, single pass over the (query tile, key tile) grid.
+// Scores are formed key-major (S^T[key 4g+r][query c16], K = 16 MFMAs over the 8 head dims): that accumulator layout
+// is directly the B operand of dq^T += K^T dS^T.  dk^T / dv^T contract over queries and need the tile transposed:
+// P and dS go through a per-wave LDS tile (8-byte writes, one transpose read each) instead of a second
+// score/exp pass.  delta and logsumexp come precomputed, so nothing waits on a full row.
+// Masking: lse = 1e30 for rows past Ts (P = 0 for dead queries); only the last key tile masks its dead rows.
+template <int MT>
+__device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb, const bf16_t* dOb, const float* lse_h,
+                                              const float* dlt_h, bf16_t* T, int head, int Ts, const Geo4& q,
+                                              float (&dbq)[4], float (&dbk)[4], float (&dbv)[4]) {
+    const float sc = 0.35355339059327373f * 1.4426950408889634f, scale = 0.35355339059327373f;
+    const int hc = head * HD;
+    const int q4 = q.c16 >> 2, p4 = q.c16 & 3;
+    const int colw = (hc + 4 * q.g) & 63;       // head-dim fragment column; lane groups 2,3 read finite filler (x 0)
+    const int troff = (4 * q.g + q4) * LU + hc + 4 * p4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dkT[MT], dvT[MT];
+    bf16x4 KT[MT];
+#pragma unroll
+    for (int kt = 0; kt < MT; ++kt) {
+        dkT[kt] = z4; dvT[kt] = z4;
+        KT[kt] = tr4(Kb + kt * 16 * LU + troff);
+    }
+#pragma unroll 1
+    for (int qt = 0; qt < MT; ++qt) {
+        const int query = qt * 16 + q.c16;
+        bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qb + query * LU + colw);
+        bf16x4 bdo = *reinterpret_cast<const bf16x4*>(dOb + query * LU + colw);
+        if (q.g >= 2) { bq = zero4(); bdo = zero4(); }
+        const float lqn = -lse_h[query], dl = dlt_h[query];
+        const bf16x4 QT = tr4(Qb + qt * 16 * LU + troff);
+        const bf16x4 dOT = tr4(dOb + qt * 16 * LU + troff);
+        f32x4 dqT = z4;
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+            const bf16x4 Kf = *reinterpret_cast<const bf16x4*>(Kb + (kt * 16 + q.c16) * LU + colw);
+            const bf16x4 Vf = *reinterpret_cast<const bf16x4*>(Vb + (kt * 16 + q.c16) * LU + colw);
+            const f32x4 s = mfma16k16(Kf, bq, z4);
+            const f32x4 dp = mfma16k16(Vf, bdo, z4);
+            f32x4 pv, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn));
+            if ((kt + 1) * 16 > Ts) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + q.g * 4 + r >= Ts) pv[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[r] = pv[r] * (dp[r] - dl);
+            const bf16x4 pb = cvt4(pv), dsb = cvt4(ds);
+            dqT = mfma16k16(KT[kt], dsb, dqT);
+            bf16_t* tp = T + (kt & 1) * (2 * 16 * TTS);
+            bf16_t* td = tp + 16 * TTS;
+            *reinterpret_cast<bf16x4*>(tp + q.c16 * TTS + 4 * q.g) = pb;
+            *reinterpret_cast<bf16x4*>(td + q.c16 * TTS + 4 * q.g) = dsb;
+            asm volatile("" ::: "memory");
+            const bf16x4 Bp = tr4(tp + (4 * q.g + q4) * TTS + 4 * p4);
+            const bf16x4 Bds = tr4(td + (4 * q.g + q4) * TTS + 4 * p4);
+            dkT[kt] = mfma16k16(QT, Bds, dkT[kt]);
+            dvT[kt] = mfma16k16(dOT, Bp, dvT[kt]);
+        }
+        if (q.g < 2) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float x = dqT[r] * scale; v[r] = (bf16_t)x; dbq[r] += x; }
+            *reinterpret_cast<bf16x4*>(Qb + query * LU + hc + 4 * q.g) = v;
+        }
+    }
+    if (q.g < 2) {
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+            bf16x4 vk, vv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float xk = dkT[kt][r] * scale, xv = dvT[kt][r];
+                vk[r] = (bf16_t)xk; vv[r] = (bf16_t)xv;
+                dbk[r] += xk; dbv[r] += xv;
+            }
+            *reinterpret_cast<bf16x4*>(Kb + (kt * 16 + q.c16) * LU + hc + 4 * q.g) = vk;
+            *reinterpret_cast<bf16x4*>(Vb + (kt * 16 + q.c16) * LU + hc + 4 * q.g) = vv;
+        }
+    }
+}
+
 struct DecBwdAttnArgs {
     const float* x; const float* dx1; float* dx; const bf16_t* o; const float* lse_g; int nsamples, Ts; DecW w; const bf16_t *qkvT, *pT;
     float *g_n1w, *g_n1b, *g_qw, *g_qb, *g_kw, *g_kb, *g_vw, *g_vb, *g_pw, *g_pb;
@@ -778,9 +995,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     bf16_t* Vb = Kb + IMG;
     bf16_t* Ob = Vb + IMG;            // attention output, later the image of dO
     bf16_t* DXb = Ob + IMG;           // bf16 image of dx1
-    bf16_t* DQb = DXb + IMG;          // dq (q itself is still needed by the dK pass)
-    float* XS = reinterpret_cast<float*>(DQb + IMG);
-    float* lse = XS + R * LX;         // [8][R]
+    float* XS = reinterpret_cast<float*>(DXb + IMG);
+    bf16_t* TT = reinterpret_cast<bf16_t*>(XS);                   // attention transposition tiles alias the staging tile
+    float* lse = reinterpret_cast<float*>(reinterpret_cast<char*>(XS) + L::XT_BYTES);    // [8][R]
     float* dlt = lse + 8 * R;         // [8][R]
     const Geo4 q = geo();
     const int mt0 = q.wm * L::MH;
@@ -795,12 +1012,13 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
         for (int b = 0; b < 2; ++b) accQ[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dgam[8], dbet[8], dbp[8];
-    float dbq[1][4], dbk[1][4], dbv[1][4];
+    float dbq[4], dbk[4], dbv[4];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; dbp[e] = 0.f; }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { dbq[0][r] = 0.f; dbk[0][r] = 0.f; dbv[0][r] = 0.f; }
+    for (int r = 0; r < 4; ++r) { dbq[r] = 0.f; dbk[r] = 0.f; dbv[r] = 0.f; }
 
+    PH_DECL
     for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
         const size_t rb = (size_t)sample * p.Ts;
         const DecW w = launder_w(p.w);
@@ -831,6 +1049,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             }
         }
         lds_barrier();
+        PH(0)
         // q | k | v, all row-major
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -856,6 +1075,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             }
         }
         lds_barrier();
+        PH(1)
         // attention output and log2-domain logsumexp come from the forward kernel (no softmax recompute)
         for (int pc = threadIdx.x; pc < R * 8; pc += NT_) {
             const int row = pc >> 3, k8 = (pc & 7) * 8;
@@ -864,7 +1084,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             *reinterpret_cast<bf16x8*>(Ob + row * LU + k8) = v;
             float l8[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) l8[e] = 0.f;
+            for (int e = 0; e < 8; ++e) l8[e] = 1e30f;            // rows past Ts: exp2(s - 1e30) = 0, no per-element mask
             if (k8 == 0 && row < p.Ts) ld8(p.lse_g + (rb + row) * 8, l8);
             if (k8 == 0) {
 #pragma unroll
@@ -872,6 +1092,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             }
         }
         lds_barrier();
+        PH(2)
         // dO = dx1 * Wp ; dWp += dx1^T * O
         f32x4 dO[L::MH][2];
 #pragma unroll
@@ -890,7 +1111,24 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             for (int k2 = 0; k2 < 2; ++k2)
                 accP[k2] = mfma16(a, wg_frag<MT, true>(Ob, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accP[k2]);
         }
+        // delta[head][row] = sum_keys P dP = sum_d dO[row][d] O[row][d] over the head's 8 columns (8 adjacent lanes)
+        bf16_t dOb16[L::MH][2][4];
+#pragma unroll
+        for (int mi = 0; mi < L::MH; ++mi) {
+            const int mt = mt0 + mi;
+            if (mt >= MT) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = mt * 16 + q.g * 4 + r, col = (q.wn * 2 + j) * 16 + q.c16;
+                    dOb16[mi][j][r] = (bf16_t)dO[mi][j][r];
+                    const float v = red8(bf2f(dOb16[mi][j][r]) * bf2f(Ob[row * LU + col]));
+                    if ((q.c16 & 7) == 0) dlt[(col >> 3) * R + row] = v;
+                }
+        }
         lds_barrier();
+        PH(3)
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) {
             const int mt = mt0 + mi;
@@ -899,108 +1137,20 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    Ob[(mt * 16 + q.g * 4 + r) * LU + (q.wn * 2 + j) * 16 + q.c16] = (bf16_t)dO[mi][j][r];
+                    Ob[(mt * 16 + q.g * 4 + r) * LU + (q.wn * 2 + j) * 16 + q.c16] = dOb16[mi][j][r];
         }
         lds_barrier();
-        // attention backward, two heads per wave, dq/dk/dv written in place over q/k/v
-        {
-            constexpr int hh = 0;
-            const int head = q.wave, hc = head * HD;
-            // pass A: S^T orientation (key on accumulator rows, query on the lane) -> delta, dQ
-#pragma unroll 1
-            for (int qt = 0; qt < MT; ++qt) {
-                const int query = qt * 16 + q.c16;
-                const float lq = lse[head * R + query];
-                const bf16x8 bq = rowfrag8(Qb, LU, query, hc, q.g);
-                const bf16x8 bdo = rowfrag8(Ob, LU, query, hc, q.g);
-                f32x4 pr[MT], dp[MT];
-                float dsum = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < MT; ++kt) {
-                    const f32x4 s = mfma16(rowfrag8(Kb, LU, kt * 16 + q.c16, hc, q.g), bq, f32x4{0.f, 0.f, 0.f, 0.f});
-                    dp[kt] = mfma16(rowfrag8(Vb, LU, kt * 16 + q.c16, hc, q.g), bdo, f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool ok = kt * 16 + q.g * 4 + r < p.Ts;
-                        pr[kt][r] = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, -lq)) : 0.f;
-                        dsum += pr[kt][r] * dp[kt][r];
-                    }
-                }
-                dsum += __shfl_xor(dsum, 16, 64);
-                dsum += __shfl_xor(dsum, 32, 64);
-                if (q.g == 0) dlt[head * R + query] = dsum;
-#pragma unroll
-                for (int kt = 0; kt < MT; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pr[kt][r] = pr[kt][r] * (dp[kt][r] - dsum) * scale;     // dS
-                f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int pp = 0; pp < (MT + 1) / 2; ++pp) {
-                    const int ta = 2 * pp, tb = 2 * pp + 1;
-                    const bool tb_ok = tb < MT;
-                    const bf16x8 b = pack2(pr[ta], tb_ok ? pr[tb_ok ? tb : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
-                    dq = mfma16(trfrag(Kb, LU, ta * 16, tb * 16, tb_ok, hc, q.c16 < HD, q), b, dq);
-                }
-                if (q.g < 2) {
-                    bf16x4 vq;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { vq[r] = (bf16_t)dq[r]; dbq[hh][r] += query < p.Ts ? dq[r] : 0.f; }
-                    *reinterpret_cast<bf16x4*>(DQb + query * LU + hc + q.g * 4) = vq;
-                }
-            }
-            lds_barrier();           // delta of this head visible (uniform: every wave runs 2 heads)
-            // pass B: S orientation (query on accumulator rows, key on the lane) -> dK, dV
-#pragma unroll 1
-            for (int kt = 0; kt < MT; ++kt) {
-                const int key = kt * 16 + q.c16;
-                const bool kok = key < p.Ts;
-                const bf16x8 bk = rowfrag8(Kb, LU, key, hc, q.g);
-                const bf16x8 bv = rowfrag8(Vb, LU, key, hc, q.g);
-                f32x4 pr[MT], ds[MT];
-#pragma unroll
-                for (int qt = 0; qt < MT; ++qt) {
-                    const f32x4 s = mfma16(rowfrag8(Qb, LU, qt * 16 + q.c16, hc, q.g), bk, f32x4{0.f, 0.f, 0.f, 0.f});
-                    const f32x4 dp = mfma16(rowfrag8(Ob, LU, qt * 16 + q.c16, hc, q.g), bv, f32x4{0.f, 0.f, 0.f, 0.f});
-                    const f32x4 lq = *reinterpret_cast<const f32x4*>(lse + head * R + qt * 16 + q.g * 4);
-                    const f32x4 dl = *reinterpret_cast<const f32x4*>(dlt + head * R + qt * 16 + q.g * 4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool ok = kok && (qt * 16 + q.g * 4 + r < p.Ts);
-                        const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, -lq[r])) : 0.f;
-                        pr[qt][r] = pv;
-                        ds[qt][r] = pv * (dp[r] - dl[r]) * scale;
-                    }
-                }
-                f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int pp = 0; pp < (MT + 1) / 2; ++pp) {
-                    const int ta = 2 * pp, tb = 2 * pp + 1;
-                    const bool tb_ok = tb < MT;
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    const bf16x8 bds = pack2(ds[ta], tb_ok ? ds[tb_ok ? tb : 0] : z);
-                    const bf16x8 bp = pack2(pr[ta], tb_ok ? pr[tb_ok ? tb : 0] : z);
-                    dk = mfma16(trfrag(Qb, LU, ta * 16, tb * 16, tb_ok, hc, q.c16 < HD, q), bds, dk);
-                    dv = mfma16(trfrag(Ob, LU, ta * 16, tb * 16, tb_ok, hc, q.c16 < HD, q), bp, dv);
-                }
-                // in place: only this wave reads this head's k / v columns, and never tile kt again
-                if (q.g < 2) {
-                    bf16x4 vk, vv;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        vk[r] = (bf16_t)dk[r]; vv[r] = (bf16_t)dv[r];
-                        dbk[hh][r] += kok ? dk[r] : 0.f; dbv[hh][r] += kok ? dv[r] : 0.f;
-                    }
-                    *reinterpret_cast<bf16x4*>(Kb + key * LU + hc + q.g * 4) = vk;
-                    *reinterpret_cast<bf16x4*>(Vb + key * LU + hc + q.g * 4) = vv;
-                }
-            }
-        }
+        PH(4)
+        // attention backward, one head per wave, dq/dk/dv written in place over q/k/v
+        attn_head_bwd<MT>(Qb, Kb, Vb, Ob, lse + q.wave * R, dlt + q.wave * R, TT + q.wave * TT_WAVE, q.wave, p.Ts, q,
+                          dbq, dbk, dbv);
         lds_barrier();
+        PH(5)
         // du = dq Wq + dk Wk + dv Wv ; dWq|dWk|dWv += d{q,k,v}^T u
         f32x4 du[L::MH][2];
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) { du[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; du[mi][1] = du[mi][0]; }
-        mm<L::MH, 2>(DQb, LU, 0, qkvT, 6, q.wn * 2, 0, mt0, MT, q, du);
+        mm<L::MH, 2>(Qb, LU, 0, qkvT, 6, q.wn * 2, 0, mt0, MT, q, du);
         mm<L::MH, 2>(Kb, LU, 0, qkvT, 6, q.wn * 2, 2, mt0, MT, q, du);
         mm<L::MH, 2>(Vb, LU, 0, qkvT, 6, q.wn * 2, 4, mt0, MT, q, du);
 #pragma unroll 1
@@ -1011,7 +1161,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
-                const bf16_t* dOi = mat == 0 ? DQb : (mat == 1 ? Kb : Vb);
+                const bf16_t* dOi = mat == 0 ? Qb : (mat == 1 ? Kb : Vb);
                 const bf16x8 a = wg_frag<MT, false>(dOi, nt * 16, kk, q);
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) accQ[t][k2] = mfma16(a, b[k2], accQ[t][k2]);
@@ -1024,7 +1174,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
-                const bf16_t* dOi = mat == 0 ? DQb : (mat == 1 ? Kb : Vb);
+                const bf16_t* dOi = mat == 0 ? Qb : (mat == 1 ? Kb : Vb);
                 const bf16x8 a = wg_frag<MT, true>(dOi, nt * 16, R / 32, q);
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) accQ[t][k2] = mfma16(a, b[k2], accQ[t][k2]);
@@ -1032,6 +1182,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         }
         acc_to_xs<L::MH>(XS, mt0, MT, q, du);
         lds_barrier();
+        PH(6)
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pc = threadIdx.x + NT_ * i;
@@ -1063,23 +1214,25 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             }
         }
         lds_barrier();
+        PH(7)
     }
 
+    PH_FLUSH(0)
     // ---- commit
     float* red = XS;
     flush_wide(red, dgam, p.g_n1w);
     flush_wide(red, dbet, p.g_n1b);
     flush_wide(red, dbp, p.g_pb);
-#pragma unroll
-    for (int hh = 0; hh < 1; ++hh)
+    {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float a = dbq[hh][r], b = dbk[hh][r], c = dbv[hh][r];
+            float a = dbq[r], b = dbk[r], c = dbv[r];
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
             const int col = q.wave * HD + q.g * 4 + r;
             if (q.c16 == 0 && q.g < 2) { atomicAdd(p.g_qb + col, a); atomicAdd(p.g_kb + col, b); atomicAdd(p.g_vb + col, c); }
         }
+    }
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
@@ -1116,8 +1269,9 @@ template <int MT>
 int launch_bwd(const DecBwdMlpArgs& a, const DecBwdAttnArgs& b, hipStream_t s) {
     using L = DL<MT>;
     constexpr int IMG = L::R * LU * 2;
-    constexpr int LDS_A = 5 * IMG + L::R * LX * 4;
-    constexpr int LDS_B = 7 * IMG + L::R * LX * 4 + 2 * 8 * L::R * 4;
+    constexpr int LDS_A = 5 * IMG + 2 * WRM * 2 + 2 * HPD * 4;
+    static_assert(2 * IMG >= L::R * LX * 4, "fp32 staging tile must fit over Gc|DH1");
+    constexpr int LDS_B = L::BWD_ATTN_LDS;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_mlp_kernel<MT>),
@@ -1136,7 +1290,7 @@ template <int MT>
 int launch_bwd_attn(const DecBwdAttnArgs& b, hipStream_t s) {
     using L = DL<MT>;
     constexpr int IMG = L::R * LU * 2;
-    constexpr int LDS_B = 7 * IMG + L::R * LX * 4 + 2 * 8 * L::R * 4;
+    constexpr int LDS_B = L::BWD_ATTN_LDS;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_attn_kernel<MT>),
@@ -1177,6 +1331,7 @@ int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx
     w.qkv = bp.qkv; w.p = bp.p; w.w1 = bp.w1; w.w3 = bp.w3; w.w2 = bp.w2; w.h = bp.h;
     DecBwdMlpArgs a;
     a.x1 = x1; a.dy = dy; a.dx1 = dx1_tmp; a.nsamples = nsamples; a.Ts = Ts; a.w = w; a.w2T = bp.w2T; a.w13T = bp.w13T;
+    a.w1f = bp.w1f; a.w3f = bp.w3f;
     a.g_n2w = g.n2w; a.g_n2b = g.n2b; a.g_w1w = g.w1w; a.g_w1b = g.w1b; a.g_w3w = g.w3w; a.g_w3b = g.w3b;
     a.g_w2w = g.w2w; a.g_w2b = g.w2b;
     DecBwdAttnArgs b;

@@ -38,6 +38,7 @@ int hs_add2(const float* a, const float* b, float* out, int64_t n, hipStream_t s
 struct DecBlockPtrs {
     const float *n1w, *n1b, *bqkv, *pb, *n2w, *n2b, *w1b, *w3b, *w2b;
     const bf16_t *qkv, *p, *w1, *w3, *w2, *qkvT, *pT, *w13T, *w2T;
+    const float *qf, *kf, *vf, *pf, *w1f, *w3f;    // fp32 row-major weights [out][in] (the backward stages them in LDS as bf16)
     int h;
 };
 struct DecBlockGrads { float *n1w, *n1b, *qw, *qb, *kw, *kb, *vw, *vb, *pw, *pb, *n2w, *n2b, *w1w, *w1b, *w2w, *w2b, *w3w, *w3b; };

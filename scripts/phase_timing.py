@@ -1,0 +1,73 @@
+"""Per-phase cycle shares of the fused decoder kernels (run on the GPU box: python3 scripts/phase_timing.py).
+
+Builds a second copy of the library with -DHS_PHASE_TIMING (wave 0 of every workgroup accumulates s_memtime deltas
+between the kernels' barriers), runs one C2-sized forward+backward and prints where each kernel's time goes.
+The shipped libhsimae_hip.so is not touched and never contains the instrumentation.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build_variant() -> str:
+    from hsimae_amd import build as B
+    tmp = tempfile.mkdtemp(prefix="hs_phase_")
+    objs = []
+    for u in B.UNITS:
+        obj = os.path.join(tmp, u + ".o")
+        flags = B.FLAGS + (["-DHS_PHASE_TIMING"] if u == "fused_dec" else [])
+        src_obj = os.path.join(B.HERE, "build", u + ".o")
+        if u != "fused_dec" and os.path.exists(src_obj):
+            shutil.copy(src_obj, obj)
+        else:
+            subprocess.run([B.HIPCC] + flags + ["-c", os.path.join(B.CSRC, u + ".hip"), "-o", obj], check=True)
+        objs.append(obj)
+    lib = os.path.join(tmp, "libhsimae_hip.so")
+    subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, check=True)
+    return lib
+
+
+def main():
+    lib_path = build_variant()
+    import hsimae_amd._lib as L
+    L.LIB_PATH = lib_path
+    import torch
+    from hsimae_amd import HSIMAE
+    batch = int(os.environ.get("BATCH", "4096"))
+    torch.manual_seed(0)
+    m = HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=96, b_patch_size=8, embed_dim=128, depth=12, num_heads=8,
+               s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8, norm_pix_loss=True,
+               trunc_init=True).cuda()
+    x = torch.rand(batch, 1, 96, 9, 9, device="cuda")
+    lib = L.load()
+    lib.hsimae_debug_phases.restype = ctypes.c_int
+    lib.hsimae_debug_phases.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+    buf = (ctypes.c_uint64 * 32)()
+    for it in range(3):
+        loss, _, _ = m(x, 0.75)
+        loss.backward()
+        torch.cuda.synchronize()
+        lib.hsimae_debug_phases(buf, 1)
+    v = list(buf)
+    names = {
+        "dec_bwd_attn": (0, ["prologue LN", "qkv mm", "O/lse load", "dO mm + dWp + delta", "dO store", "attention",
+                             "du mm + dWqkv", "epilogue LN bwd"]),
+        "dec_bwd_mlp": (8, ["prologue LN", "gate mm + silu", "wgrad", "du2 stage", "epilogue LN bwd", "du2 mm", "-", "-"]),
+        "dec_fwd": (16, ["LN1 + residual", "qkv", "attention", "o store + proj", "LN2", "gate chunks", "w2 mm", "store"]),
+    }
+    for k, (base, ph) in names.items():
+        tot = sum(v[base:base + 8]) or 1
+        print(f"{k}: total wave-0 cycles {tot}")
+        for i, n in enumerate(ph):
+            if v[base + i]:
+                print(f"    {n:24s} {100.0 * v[base + i] / tot:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
