@@ -53,11 +53,11 @@ struct DL {
     static constexpr int REG2 = cmax(cmax(QKV_BYTES, R * LG * 2), R * LX * 4);
     static constexpr int FWD_TOTAL = U_BYTES + REG2;
     // backward attention kernel: fp32 staging tile, aliased by the per-wave transposition tiles of the attention core
-    static constexpr int XT_BYTES = cmax(R * LX * 4, 8 * 2 * 2 * 16 * 24 * 2);
-    static constexpr int BWD_ATTN_LDS = 6 * U_BYTES + XT_BYTES + 2 * 8 * R * 4;
+    static constexpr int BWD_ATTN_LDS = 6 * U_BYTES + 2 * 8 * R * 4 + 8 * 2 * 16 * 24 * 2 + 4 * D * LU * 2 + 5 * D * 4;
+    static_assert(2 * U_BYTES >= R * LX * 4, "fp32 staging tile must fit over Ob|DXb");
 };
 constexpr int TTS = 24;                    // transposition tile row stride (elements)
-constexpr int TT_WAVE = 2 * 2 * 16 * TTS;  // per wave: [ring of 2][P | dS][16 queries][TTS]
+constexpr int TT_WAVE = 2 * 16 * TTS;      // per wave: [P | dS][16 queries][TTS]
 
 struct Geo4 { int lane, c16, g, wave, wm, wn; };
 
@@ -151,6 +151,32 @@ __device__ __forceinline__ void mm_rm(const bf16_t* A, int lda, const bf16_t* Wr
 }
 
 // Wide layout: piece p -> (row p>>3, columns 8*(p&7)..+7); the 8 lanes of a row are adjacent.
+// (mm_wt below needs wg_frag, declared further down)
+template <int MT, bool TAIL>
+__device__ __forceinline__ bf16x8 wg_frag(const bf16_t* img, int col0, int kk, const Geo4& q);
+
+// acc += A[:, 0:64] * W with W row-major bf16 [64 k-rows][LU] resident in LDS (n contiguous): the B fragment needs
+// 8 consecutive k of one column, i.e. a transpose read of the same image the forward-orientation product reads by rows
+template <int MH>
+__device__ __forceinline__ void mm_wt(const bf16_t* A, int lda, const bf16_t* Wr, int mt0, int MT, const Geo4& q,
+                                      f32x4 (&acc)[MH][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = wg_frag<4, false>(Wr, (q.wn * 2 + j) * 16, ks, q);
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi) {
+            const int mt = mt0 + mi;
+            if (mt < MT) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + q.c16) * lda + ks * 32 + q.g * 8);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[mi][j] = mfma16(a, b[j], acc[mi][j]);
+            }
+        }
+    }
+}
+
 // Loads rows of `src` (global fp32 [Ts,64]; rows >= Ts read as zero), optionally mirrors them into the fp32
 // staging tile, and writes LayerNorm(row) as bf16 into the LDS image `U`.
 template <int MT, bool FROM_LDS, int NTHR = NT_>
@@ -778,7 +804,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             PH(2)
             // data gradient through W1 / W3
 #pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2) {
+            for (int m2 = 0; m2 < 2; ++m2) {          // (spelled out: two mm_wt calls here cost 170 B/lane of scratch)
                 const bf16_t* Ai = m2 == 0 ? DH1 : DH3;
                 const bf16_t* Wc = (m2 == 0 ? w1L : w3L) + c * 64 * LU;      // this chunk's 64 hidden rows
 #pragma unroll
@@ -946,7 +972,7 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
             for (int r = 0; r < 4; ++r) ds[r] = pv[r] * (dp[r] - dl);
             const bf16x4 pb = cvt4(pv), dsb = cvt4(ds);
             dqT = mfma16k16(KT[kt], dsb, dqT);
-            bf16_t* tp = T + (kt & 1) * (2 * 16 * TTS);
+            bf16_t* tp = T;                     // one tile pair per wave: LDS executes a wave's accesses in order
             bf16_t* td = tp + 16 * TTS;
             *reinterpret_cast<bf16x4*>(tp + q.c16 * TTS + 4 * q.g) = pb;
             *reinterpret_cast<bf16x4*>(td + q.c16 * TTS + 4 * q.g) = dsb;
@@ -981,6 +1007,7 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
 
 struct DecBwdAttnArgs {
     const float* x; const float* dx1; float* dx; const bf16_t* o; const float* lse_g; int nsamples, Ts; DecW w; const bf16_t *qkvT, *pT;
+    const float *qf, *kf, *vf, *pf;
     float *g_n1w, *g_n1b, *g_qw, *g_qb, *g_kw, *g_kb, *g_vw, *g_vb, *g_pw, *g_pb;
 };
 
@@ -995,14 +1022,25 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     bf16_t* Vb = Kb + IMG;
     bf16_t* Ob = Vb + IMG;            // attention output, later the image of dO
     bf16_t* DXb = Ob + IMG;           // bf16 image of dx1
-    float* XS = reinterpret_cast<float*>(DXb + IMG);
-    bf16_t* TT = reinterpret_cast<bf16_t*>(XS);                   // attention transposition tiles alias the staging tile
-    float* lse = reinterpret_cast<float*>(reinterpret_cast<char*>(XS) + L::XT_BYTES);    // [8][R]
+    float* XS = reinterpret_cast<float*>(Ob);                     // fp32 staging tile aliases Ob|DXb (both dead by then)
+    float* lse = reinterpret_cast<float*>(DXb + IMG);             // [8][R]
     float* dlt = lse + 8 * R;         // [8][R]
+    bf16_t* TT = reinterpret_cast<bf16_t*>(dlt + 8 * R);          // per-wave transposition tiles of the attention core
+    bf16_t* WQ = TT + 8 * TT_WAVE;                                // Wq|Wk|Wv row-major bf16 [192][LU], resident
+    bf16_t* WP = WQ + 3 * D * LU;                                 // Wp row-major bf16 [64][LU], resident
+    float* CB = reinterpret_cast<float*>(WP + D * LU);            // bq|bk|bv (192), LN1 gamma (64), beta (64)
     const Geo4 q = geo();
     const int mt0 = q.wm * L::MH;
     const int c8 = (threadIdx.x & 7) * 8;
-    const float sc = 0.35355339059327373f * 1.4426950408889634f, scale = 0.35355339059327373f;
+    // Weights staged once per workgroup (see dec_bwd_mlp_kernel): q|k|v read them as row pieces, the data gradients
+    // (dO = dx1 Wp, du = dq Wq + dk Wk + dv Wv) read the same images with transpose reads.
+    for (int i = threadIdx.x; i < 4 * D * 8; i += NT_) {
+        const int m = i / (D * 8), row = (i % (D * 8)) >> 3, k8 = (i & 7) * 8;
+        float f[8];
+        ld8((m == 0 ? p.qf : (m == 1 ? p.kf : (m == 2 ? p.vf : p.pf))) + (size_t)row * D + k8, f);
+        *reinterpret_cast<bf16x8*>(WQ + (m * D + row) * LU + k8) = cvt8(f);
+    }
+    for (int i = threadIdx.x; i < 5 * D; i += NT_) CB[i] = i < 3 * D ? p.w.bqkv[i] : (i < 4 * D ? p.w.n1w[i - 3 * D] : p.w.n1b[i - 4 * D]);
 
     f32x4 accP[2], accQ[3][2];         // dWp: n-tile = wave>>1; dWq|dWk|dWv: 12 n-tiles x 4 k-tiles, 3 x 2 per wave
 #pragma unroll
@@ -1021,21 +1059,31 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     PH_DECL
     for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
         const size_t rb = (size_t)sample * p.Ts;
-        const DecW w = launder_w(p.w);
-        const bf16_t* qkvT = launder(p.qkvT);
-        const bf16_t* pT = launder(p.pT);
-        const float* n1w = launder(p.w.n1w);
-        const float* n1b = launder(p.w.n1b);
+        const int wl = launder_i(0);                  // keeps the LDS weight reads inside the sample loop
+        const bf16_t* WQl = WQ + wl;
+        const bf16_t* WPl = WP + wl;
+        const float* CBl = CB + wl;
+        // x, dx1, O and logsumexp of this sample: the only exposed HBM round trip of the iteration
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pc = threadIdx.x + NT_ * i;
             if (pc < R * 8) {
                 const int row = pc >> 3;
-                float f[8], d1[8], gm[8], bt[8];
-                ld8(n1w + c8, gm); ld8(n1b + c8, bt);
+                float f[8], d1[8], gm[8], bt[8], l8[8];
+                bf16x8 ov = zero8();
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { f[e] = 0.f; d1[e] = 0.f; }
-                if (row < p.Ts) { ld8(p.x + (rb + row) * D + c8, f); ld8(p.dx1 + (rb + row) * D + c8, d1); }
+                for (int e = 0; e < 8; ++e) { f[e] = 0.f; d1[e] = 0.f; l8[e] = 1e30f; }   // rows past Ts: exp2(s - 1e30) = 0
+                if (row < p.Ts) {
+                    ld8(p.x + (rb + row) * D + c8, f); ld8(p.dx1 + (rb + row) * D + c8, d1);
+                    ov = *reinterpret_cast<const bf16x8*>(p.o + (rb + row) * D + c8);
+                    if (c8 == 0) ld8(p.lse_g + (rb + row) * 8, l8);
+                }
+                ld8(CBl + 3 * D + c8, gm); ld8(CBl + 4 * D + c8, bt);
+                *reinterpret_cast<bf16x8*>(Ob + row * LU + c8) = ov;
+                if (c8 == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) lse[e * R + row] = l8[e];
+                }
                 const float mean = red8(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
                 float v = 0.f;
 #pragma unroll
@@ -1058,10 +1106,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             for (int mi = 0; mi < L::MH; ++mi)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const float b = w.bqkv[c * D + (q.wn * 2 + j) * 16 + q.c16];
+                    const float b = *(lds_cf32)(CBl + c * D + (q.wn * 2 + j) * 16 + q.c16);
                     acc[mi][j] = f32x4{b, b, b, b};
                 }
-            mm<L::MH, 2>(U, LU, 0, w.qkv, 2, c * 4 + q.wn * 2, 0, mt0, MT, q, acc);
+            mm_rm<L::MH, 2>(U, LU, WQl, c * 4 + q.wn * 2, mt0, MT, q, acc);
             bf16_t* dst = c == 0 ? Qb : (c == 1 ? Kb : Vb);
 #pragma unroll
             for (int mi = 0; mi < L::MH; ++mi) {
@@ -1074,30 +1122,12 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                         dst[(mt * 16 + q.g * 4 + r) * LU + (q.wn * 2 + j) * 16 + q.c16] = (bf16_t)acc[mi][j][r];
             }
         }
-        lds_barrier();
         PH(1)
-        // attention output and log2-domain logsumexp come from the forward kernel (no softmax recompute)
-        for (int pc = threadIdx.x; pc < R * 8; pc += NT_) {
-            const int row = pc >> 3, k8 = (pc & 7) * 8;
-            bf16x8 v = zero8();
-            if (row < p.Ts) v = *reinterpret_cast<const bf16x8*>(p.o + (rb + row) * D + k8);
-            *reinterpret_cast<bf16x8*>(Ob + row * LU + k8) = v;
-            float l8[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) l8[e] = 1e30f;            // rows past Ts: exp2(s - 1e30) = 0, no per-element mask
-            if (k8 == 0 && row < p.Ts) ld8(p.lse_g + (rb + row) * 8, l8);
-            if (k8 == 0) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) lse[e * R + row] = l8[e];
-            }
-        }
-        lds_barrier();
-        PH(2)
         // dO = dx1 * Wp ; dWp += dx1^T * O
         f32x4 dO[L::MH][2];
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) { dO[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dO[mi][1] = dO[mi][0]; }
-        mm<L::MH, 2>(DXb, LU, 0, pT, 2, q.wn * 2, 0, mt0, MT, q, dO);
+        mm_wt<L::MH>(DXb, LU, WPl, mt0, MT, q, dO);
 #pragma unroll 1
         for (int kk = 0; kk < R / 32; ++kk) {
             const bf16x8 a = wg_frag<MT, false>(DXb, (q.wave >> 1) * 16, kk, q);
@@ -1141,6 +1171,18 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         }
         lds_barrier();
         PH(4)
+        // warm L2 / TLB with the next sample's rows while the attention core runs (no global loads in there)
+        float touch[4] = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int nxt = sample + gridDim.x;
+            const size_t nb = (size_t)nxt * p.Ts;
+            const int t16 = threadIdx.x * 16;
+            if (nxt < p.nsamples) {
+                if (t16 < p.Ts * D) { touch[0] = p.x[nb * D + t16]; touch[1] = p.dx1[nb * D + t16]; }
+                if (2 * t16 < p.Ts * D) touch[2] = bf2f(p.o[nb * D + 2 * t16]);
+                if (t16 < p.Ts * 8) touch[3] = p.lse_g[nb * 8 + t16];
+            }
+        }
         // attention backward, one head per wave, dq/dk/dv written in place over q/k/v
         attn_head_bwd<MT>(Qb, Kb, Vb, Ob, lse + q.wave * R, dlt + q.wave * R, TT + q.wave * TT_WAVE, q.wave, p.Ts, q,
                           dbq, dbk, dbv);
@@ -1150,9 +1192,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         f32x4 du[L::MH][2];
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) { du[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; du[mi][1] = du[mi][0]; }
-        mm<L::MH, 2>(Qb, LU, 0, qkvT, 6, q.wn * 2, 0, mt0, MT, q, du);
-        mm<L::MH, 2>(Kb, LU, 0, qkvT, 6, q.wn * 2, 2, mt0, MT, q, du);
-        mm<L::MH, 2>(Vb, LU, 0, qkvT, 6, q.wn * 2, 4, mt0, MT, q, du);
+        asm volatile("" :: "v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]));
+        mm_wt<L::MH>(Qb, LU, WQl, mt0, MT, q, du);
+        mm_wt<L::MH>(Kb, LU, WQl + D * LU, mt0, MT, q, du);
+        mm_wt<L::MH>(Vb, LU, WQl + 2 * D * LU, mt0, MT, q, du);
 #pragma unroll 1
         for (int kk = 0; kk < R / 32; ++kk) {
             bf16x8 b[2];
@@ -1190,7 +1233,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 const int row = pc >> 3;
                 float dv[8], t[8], xh[8], d1[8], gm[8];
                 ld8(XS + row * LX + c8, dv);
-                ld8(n1w + c8, gm);
+                ld8(CBl + 3 * D + c8, gm);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { xh[e] = 0.f; d1[e] = 0.f; }
                 if (row < p.Ts) { ld8(p.x + (rb + row) * D + c8, xh); ld8(p.dx1 + (rb + row) * D + c8, d1); }     // L2-hot re-read
@@ -1315,6 +1358,7 @@ int hs_dec_bwd_attn(const float* x, const float* dx1, float* dx, const hs_bf16* 
     w.qkv = bp.qkv; w.p = bp.p; w.w1 = bp.w1; w.w3 = bp.w3; w.w2 = bp.w2; w.h = bp.h;
     DecBwdAttnArgs b;
     b.x = x; b.dx1 = dx1; b.dx = dx; b.o = o; b.lse_g = lse; b.nsamples = nsamples; b.Ts = Ts; b.w = w; b.qkvT = bp.qkvT; b.pT = bp.pT;
+    b.qf = bp.qf; b.kf = bp.kf; b.vf = bp.vf; b.pf = bp.pf;
     b.g_n1w = g.n1w; b.g_n1b = g.n1b; b.g_qw = g.qw; b.g_qb = g.qb; b.g_kw = g.kw; b.g_kb = g.kb; b.g_vw = g.vw;
     b.g_vb = g.vb; b.g_pw = g.pw; b.g_pb = g.pb;
     const int mt = (Ts + 15) / 16;
@@ -1336,6 +1380,7 @@ int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx
     a.g_w2w = g.w2w; a.g_w2b = g.w2b;
     DecBwdAttnArgs b;
     b.x = x; b.dx1 = dx1_tmp; b.dx = dx; b.o = o; b.lse_g = lse; b.nsamples = nsamples; b.Ts = Ts; b.w = w; b.qkvT = bp.qkvT; b.pT = bp.pT;
+    b.qf = bp.qf; b.kf = bp.kf; b.vf = bp.vf; b.pf = bp.pf;
     b.g_n1w = g.n1w; b.g_n1b = g.n1b; b.g_qw = g.qw; b.g_qb = g.qb; b.g_kw = g.kw; b.g_kb = g.kb; b.g_vw = g.vw;
     b.g_vb = g.vb; b.g_pw = g.pw; b.g_pb = g.pb;
     const int mt = (Ts + 15) / 16;

@@ -56,7 +56,7 @@ def main():
         lib.hsimae_debug_phases(buf, 1)
     v = list(buf)
     names = {
-        "dec_bwd_attn": (0, ["prologue LN", "qkv mm", "O/lse load", "dO mm + dWp + delta", "dO store", "attention",
+        "dec_bwd_attn": (0, ["prologue (x dx1 O lse) + LN", "qkv mm", "-", "dO mm + dWp + delta", "dO store", "attention",
                              "du mm + dWqkv", "epilogue LN bwd"]),
         "dec_bwd_mlp": (8, ["prologue LN", "gate mm + silu", "wgrad", "du2 stage", "epilogue LN bwd", "du2 mm", "-", "-"]),
         "dec_fwd": (16, ["LN1 + residual", "qkv", "attention", "o store + proj", "LN2", "gate chunks", "w2 mm", "store"]),
