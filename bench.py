@@ -77,7 +77,7 @@ def dominant_kernel_roofline(model, N, K_tok, iters=20):
         wp.t[i] = _lib.WgradTask(dO=dO, dO_f32=f32, ldo=ldo, A=A.data_ptr(), lda=lda, N=n, K=k, dW=dW[i].data_ptr(),
                                  ldw=k, db=db[i].data_ptr())
         tiles += ((n + 127) // 128) * ((k + 127) // 128)
-    wp.ntasks, wp.M, wp.msplit = len(spec), M, max(1, 640 // tiles)
+    wp.ntasks, wp.M, wp.msplit = len(spec), M, max(1, (640 // tiles) & ~7)    # as api.hip wgrad_msplit
     s = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
         _lib.check(lib.hsimae_wgrad(C.byref(wp), s))

@@ -301,6 +301,7 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
 int wgrad_msplit(int tiles, int64_t M) {
     const int chunks = (int)((M + 63) / 64);
     int ms = std::max(1, 640 / std::max(1, tiles));
+    if (ms >= 8) ms &= ~7;              // whole XCD groups (wgrad.hip places row slice ms on XCD ms % 8)
     return std::min(ms, chunks);
 }
 

@@ -954,16 +954,24 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
         const bf16x4 QT = tr4(Qb + qt * 16 * LU + troff);
         const bf16x4 dOT = tr4(dOb + qt * 16 * LU + troff);
         f32x4 dqT = z4;
+        // Software pipeline over the key tiles: the transposed operands of tile kt-1 (LDS write -> transpose read, ~200
+        // cycles of latency) are consumed after the score MFMAs of tile kt have been issued, and those MFMAs' own
+        // latency is covered by the dk/dv MFMAs of tile kt-1.
+        bf16x4 Bp = zero4(), Bds = zero4();
 #pragma unroll
         for (int kt = 0; kt < MT; ++kt) {
             const bf16x4 Kf = *reinterpret_cast<const bf16x4*>(Kb + (kt * 16 + q.c16) * LU + colw);
             const bf16x4 Vf = *reinterpret_cast<const bf16x4*>(Vb + (kt * 16 + q.c16) * LU + colw);
             const f32x4 s = mfma16k16(Kf, bq, z4);
             const f32x4 dp = mfma16k16(Vf, bdo, z4);
+            if (kt > 0) {
+                dkT[kt - 1] = mfma16k16(QT, Bds, dkT[kt - 1]);
+                dvT[kt - 1] = mfma16k16(dOT, Bp, dvT[kt - 1]);
+            }
             f32x4 pv, ds;
 #pragma unroll
             for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn));
-            if ((kt + 1) * 16 > Ts) {
+            if (kt == MT - 1) {                 // only the last key tile can hold rows past Ts
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (kt * 16 + q.g * 4 + r >= Ts) pv[r] = 0.f;
@@ -977,11 +985,11 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
             *reinterpret_cast<bf16x4*>(tp + q.c16 * TTS + 4 * q.g) = pb;
             *reinterpret_cast<bf16x4*>(td + q.c16 * TTS + 4 * q.g) = dsb;
             asm volatile("" ::: "memory");
-            const bf16x4 Bp = tr4(tp + (4 * q.g + q4) * TTS + 4 * p4);
-            const bf16x4 Bds = tr4(td + (4 * q.g + q4) * TTS + 4 * p4);
-            dkT[kt] = mfma16k16(QT, Bds, dkT[kt]);
-            dvT[kt] = mfma16k16(dOT, Bp, dvT[kt]);
+            Bp = tr4(tp + (4 * q.g + q4) * TTS + 4 * p4);
+            Bds = tr4(td + (4 * q.g + q4) * TTS + 4 * p4);
         }
+        dkT[MT - 1] = mfma16k16(QT, Bds, dkT[MT - 1]);
+        dvT[MT - 1] = mfma16k16(dOT, Bp, dvT[MT - 1]);
         if (q.g < 2) {
             bf16x4 v;
 #pragma unroll

@@ -57,9 +57,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t At[MC * TST];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // decode (task, n-slab, k-slab, m-split)
-    int w = blockIdx.x / p.msplit;
-    const int ms = blockIdx.x % p.msplit;
+    // decode (task, n-slab, k-slab, m-split).  Workgroups go round-robin over the 8 XCDs (blockIdx % 8) and each XCD
+    // has its own L2: all tiles of one row slice are placed on the same XCD, next to each other in launch order, so
+    // the operand slabs they share (x-hat under q|k|v, u2 under w1|w3, dy under w2's k-slabs) are fetched from HBM
+    // once and hit in L2 for the rest (measured before: 1.8x the algorithmic bytes).
+    int tiles = 0;
+    for (int i = 0; i < p.ntasks; ++i) tiles += ((p.t[i].N + 127) / 128) * ((p.t[i].K + 127) / 128);
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    int w = li % tiles;
+    const int ms = xcd + 8 * (li / tiles);
+    if (ms >= p.msplit) return;
     int ti = 0, ns = 0, ks = 0;
     for (; ti < p.ntasks; ++ti) {
         const int nsl = (p.t[ti].N + 127) / 128, ksl = (p.t[ti].K + 127) / 128;
@@ -131,6 +138,6 @@ int hs_wgrad(const WgradParams& p, hipStream_t s) {
         if (p.t[i].ldo % 8 || p.t[i].lda % 8) return HS_EDIMS;
         tiles += ((p.t[i].N + 127) / 128) * ((p.t[i].K + 127) / 128);
     }
-    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * p.msplit), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(8 * tiles * ((p.msplit + 7) / 8)), dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
