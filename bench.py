@@ -53,7 +53,7 @@ def dominant_kernel_roofline(model, N, K_tok, iters=20):
     time): the batched weight-gradient launch of one ENCODER block (q, k, v, proj, w1, w3, w2) at the workload's
     shape (M = N*K kept-token rows), through the C ABI on the current stream.  HBM-bound: algorithmic bytes per
     launch = every operand read once =
-    M * (dqkv 3d*2 + u d*2 + dx1 d*4 + o d*2 + dh13 2hp*2 + u2 d*2 + dY d*4 + g hp*2)."""
+    M * (dqkv 3d*2 + u d*2 + dx1 d*2 + o d*2 + dh13 2hp*2 + u2 d*2 + dY d*2 + g hp*2)  (all operands bf16)."""
     from hsimae_amd import _lib, swiglu_hidden
     lib = _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -64,20 +64,20 @@ def dominant_kernel_roofline(model, N, K_tok, iters=20):
     bf = dict(dtype=torch.bfloat16, device=dev)
     dqkv, u, o, u2 = (torch.randn(M, w, **bf) for w in (3 * d, d, d, d))
     dh13, g = torch.randn(M, 2 * hp, **bf), torch.randn(M, hp, **bf)
-    G0, G1 = torch.randn(M, d, device=dev), torch.randn(M, d, device=dev)
+    G0, G1 = torch.randn(M, d, **bf), torch.randn(M, d, **bf)      # bf16 copies of dY / dx1 (emitted by enc_mlp_bwd)
     dW = [torch.zeros(n, k, device=dev) for n, k in ((d, d),) * 4 + ((h, d),) * 2 + ((d, h),)]
     db = [torch.zeros(w.shape[0], device=dev) for w in dW]
     wp = _lib.WgradParams()
     spec = [(dqkv.data_ptr(), 0, 3 * d, u, d, d, d), (dqkv.data_ptr() + 2 * d, 0, 3 * d, u, d, d, d),
-            (dqkv.data_ptr() + 4 * d, 0, 3 * d, u, d, d, d), (G1.data_ptr(), 1, d, o, d, d, d),
+            (dqkv.data_ptr() + 4 * d, 0, 3 * d, u, d, d, d), (G1.data_ptr(), 0, d, o, d, d, d),
             (dh13.data_ptr(), 0, 2 * hp, u2, d, h, d), (dh13.data_ptr() + 2 * hp, 0, 2 * hp, u2, d, h, d),
-            (G0.data_ptr(), 1, d, g, hp, d, h)]
+            (G0.data_ptr(), 0, d, g, hp, d, h)]
     tiles = 0
     for i, (dO, f32, ldo, A, lda, n, k) in enumerate(spec):
         wp.t[i] = _lib.WgradTask(dO=dO, dO_f32=f32, ldo=ldo, A=A.data_ptr(), lda=lda, N=n, K=k, dW=dW[i].data_ptr(),
                                  ldw=k, db=db[i].data_ptr())
         tiles += ((n + 127) // 128) * ((k + 127) // 128)
-    wp.ntasks, wp.M, wp.msplit = len(spec), M, max(1, (640 // tiles) & ~7)    # as api.hip wgrad_msplit
+    wp.ntasks, wp.M, wp.msplit = len(spec), M, lib.hsimae_wgrad_msplit(tiles, M)    # what hsimae_backward launches
     s = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
         _lib.check(lib.hsimae_wgrad(C.byref(wp), s))
@@ -88,7 +88,7 @@ def dominant_kernel_roofline(model, N, K_tok, iters=20):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    nbytes = float(M) * (3 * d * 2 + d * 2 + d * 4 + d * 2 + 2 * hp * 2 + d * 2 + d * 4 + hp * 2)
+    nbytes = float(M) * (3 * d * 2 + d * 2 + d * 2 + d * 2 + 2 * hp * 2 + d * 2 + d * 2 + hp * 2)
     achieved = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "wgrad_kernel (encoder block: dW/db of q,k,v,proj,w1,w3,w2 in one launch)",
             "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -106,6 +106,7 @@ SYMBOLS = {
     "hsimae_attn_fwd": (C.c_int, [C.POINTER(AttnParams), vp]),
     "hsimae_attn_bwd": (C.c_int, [C.POINTER(AttnParams), vp]),
     "hsimae_wgrad": (C.c_int, [C.POINTER(WgradParams), vp]),
+    "hsimae_wgrad_msplit": (i32, [i32, i64]),
     "hsimae_ln_bwd": (C.c_int, [C.POINTER(LnBwdParams), vp]),
     "hsimae_ln_fwd": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
     "hsimae_assemble_fwd": (C.c_int, [C.POINTER(AssembleParams), vp]),

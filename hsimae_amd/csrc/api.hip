@@ -149,7 +149,7 @@ void pack_descs(const Geo& g, const PLayout& L, const WLayout& W, const float* P
 // ------------------------------------------------------------------ workspace
 struct BlkBuf { hs_bf16* u; hs_bf16* qkv; float* lse; hs_bf16* o; float* x1; hs_bf16* u2; hs_bf16* h13; hs_bf16* g; float* x2; };
 
-struct Scr { float* G1; float* du; hs_bf16* dh13; hs_bf16* dob; hs_bf16* dqkv; };   // per-stream backward scratch
+struct Scr { float* G1; float* du; hs_bf16* dh13; hs_bf16* dob; hs_bf16* dqkv; hs_bf16* g0b; hs_bf16* g1b; };   // per-stream backward scratch (g0b/g1b: bf16 dY / dx1)
 
 struct Ws {
     Scr sc, sc2;                      // sc2: encoder-sized second set for the side stream (spectral stack)
@@ -197,6 +197,8 @@ void carve(const Geo& g, int N, int K, char* base, Ws& w) {
     w.sc2.G1 = (float*)take(Me * g.D * 4); w.sc2.du = (float*)take(Me * g.D * 4);
     w.sc2.dh13 = (hs_bf16*)take(Me * 2 * g.hp * 2); w.sc2.dob = (hs_bf16*)take(Me * g.D * 2);
     w.sc2.dqkv = (hs_bf16*)take(Me * g.D * 3 * 2);
+    w.sc.g0b = (hs_bf16*)take(Me * g.D * 2); w.sc.g1b = (hs_bf16*)take(Me * g.D * 2);
+    w.sc2.g0b = (hs_bf16*)take(Me * g.D * 2); w.sc2.g1b = (hs_bf16*)take(Me * g.D * 2);
     w.bytes = cur;
 }
 
@@ -300,7 +302,11 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
 
 int wgrad_msplit(int tiles, int64_t M) {
     const int chunks = (int)((M + 63) / 64);
-    int ms = std::max(1, 640 / std::max(1, tiles));
+    // the kernel holds 2 workgroups per CU (196 registers: 64 accumulators + the prefetched next chunk): keep the
+    // launch to one resident wave of workgroups (HSIMAE_WGRAD_WGS overrides the 512 for experiments)
+    static int budget = 0;
+    if (!budget) { const char* e = getenv("HSIMAE_WGRAD_WGS"); budget = e ? std::max(8, atoi(e)) : 512; }
+    int ms = std::max(1, budget / std::max(1, tiles));
     if (ms >= 8) ms &= ~7;              // whole XCD groups (wgrad.hip places row slice ms on XCD ms % 8)
     return std::min(ms, chunks);
 }
@@ -313,9 +319,11 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     GemmParams p = gp();
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
     l.M = (int)M; l.d = d;
-    if (fused_mlp_enabled(d, h)) {
-        // recompute u2 / h1 / h3 / g inside the tile; emits dx1 and the wgrad operands u2, dh1|dh3, g
-        CK(hs_enc_mlp_bwd(b.x1, G0, G1, b.u2, w.dh13, b.g, (int)M, d, mlp_ptrs(P, h), grads + o.n2w, grads + o.n2b, s));
+    const bool fmlp = fused_mlp_enabled(d, h);
+    if (fmlp) {
+        // recompute u2 / h1 / h3 / g inside the tile; emits dx1 and the wgrad operands u2, dh1|dh3, g, bf16 dY and dx1
+        CK(hs_enc_mlp_bwd(b.x1, G0, G1, b.u2, w.dh13, b.g, w.g0b, w.g1b, (int)M, d, mlp_ptrs(P, h), grads + o.n2w,
+                          grads + o.n2b, s));
     } else {
         p.A = G0; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = hp; p.W = P.w2T; p.out = w.dh13; p.ldo = 2 * hp;
         p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp;
@@ -328,8 +336,9 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         CK(hs_ln_bwd(l, s));
     }
     p = gp();
-    p.A = G1; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d; p.W = P.pT; p.out = w.dob; p.ldo = d;
-    CK(hs_gemm(p, A_F32, E_BF16, s));
+    p.A = fmlp ? (const void*)w.g1b : (const void*)G1; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d;
+    p.W = P.pT; p.out = w.dob; p.ldo = d;
+    CK(hs_gemm(p, fmlp ? A_BF16 : A_F32, E_BF16, s));
     AttnParams a; std::memset(&a, 0, sizeof(a));
     a.qkv = b.qkv; a.ld = 3 * d; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
     a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = d; a.lse = b.lse; a.dout = w.dob; a.lddo = d; a.dqkv = w.dqkv;
@@ -347,10 +356,12 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     task(w.dqkv, 0, 3 * d, b.u, d, d, d, o.qw, o.qb);
     task(w.dqkv + d, 0, 3 * d, b.u, d, d, d, o.kw, o.kb);
     task(w.dqkv + 2 * d, 0, 3 * d, b.u, d, d, d, o.vw, o.vb);
-    task(G1, 1, d, b.o, d, d, d, o.pw, o.pb);
+    if (fmlp) task(w.g1b, 0, d, b.o, d, d, d, o.pw, o.pb);      // all-bf16 operands: wgrad takes its LDS-DMA path
+    else task(G1, 1, d, b.o, d, d, d, o.pw, o.pb);
     task(w.dh13, 0, 2 * hp, b.u2, d, h, d, o.w1w, o.w1b);
     task(w.dh13 + hp, 0, 2 * hp, b.u2, d, h, d, o.w3w, o.w3b);
-    task(G0, 1, d, b.g, hp, d, h, o.w2w, o.w2b);
+    if (fmlp) task(w.g0b, 0, d, b.g, hp, d, h, o.w2w, o.w2b);
+    else task(G0, 1, d, b.g, hp, d, h, o.w2w, o.w2b);
     g.M = (int)M;
     int tiles = 0;
     for (int i = 0; i < g.ntasks; ++i) tiles += ((g.t[i].N + 127) / 128) * ((g.t[i].K + 127) / 128);
@@ -663,6 +674,7 @@ int hsimae_pack_matrix(const hsimae_pack_desc* d, int32_t n, int32_t max_elems, 
 int hsimae_attn_fwd(const hsimae_attn_params* p, void* stream) { return p ? hs_attn_fwd(*p, S(stream)) : HSIMAE_ENULL; }
 int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream) { return p ? hs_attn_bwd(*p, S(stream)) : HSIMAE_ENULL; }
 int hsimae_wgrad(const hsimae_wgrad_params* p, void* stream) { return p ? hs_wgrad(*p, S(stream)) : HSIMAE_ENULL; }
+int32_t hsimae_wgrad_msplit(int32_t tiles, int64_t M) { return wgrad_msplit(tiles, M); }
 int hsimae_ln_bwd(const hsimae_lnbwd_params* p, void* stream) { return p ? hs_ln_bwd(*p, S(stream)) : HSIMAE_ENULL; }
 int hsimae_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int32_t M, int32_t d, void* stream) {
     return (x && gamma && beta && out) ? hs_ln_fwd(x, gamma, beta, out, M, d, S(stream)) : HSIMAE_ENULL;

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
 struct EncMlpBwdArgs {
     const float* x1; const float* dy; float* dx1; bf16_t* u2; bf16_t* dh13; bf16_t* g; int M; EncMlpW w;
     float* g_n2w; float* g_n2b;
+    bf16_t* dyb; bf16_t* dx1b;       // bf16 copies of dY and dx1: the dO operands of dW2 / dWproj (and proj's data gradient)
 };
 
 template <int D, int HPE>
@@ -273,8 +274,12 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
             for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
             const bf16x8 ub = cvt8(f);
             *reinterpret_cast<bf16x8*>(U2 + row * LU + c8) = ub;
-            *reinterpret_cast<bf16x8*>(DYb + row * LU + c8) = cvt8(dyv);
-            if (ok) *reinterpret_cast<bf16x8*>(p.u2 + (size_t)(row0 + row) * D + c8) = ub;     // wgrad operand
+            const bf16x8 dyb8 = cvt8(dyv);
+            *reinterpret_cast<bf16x8*>(DYb + row * LU + c8) = dyb8;
+            if (ok) {
+                *reinterpret_cast<bf16x8*>(p.u2 + (size_t)(row0 + row) * D + c8) = ub;     // wgrad operands
+                *reinterpret_cast<bf16x8*>(p.dyb + (size_t)(row0 + row) * D + c8) = dyb8;
+            }
         }
     }
     lds_barrier();
@@ -402,6 +407,7 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
                     dbet[e] += du[e];
                 }
                 st8(p.dx1 + (size_t)(row0 + row) * D + c8, o);
+                *reinterpret_cast<bf16x8*>(p.dx1b + (size_t)(row0 + row) * D + c8) = cvt8(o);
             }
         }
     }
@@ -455,11 +461,11 @@ int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, 
     return (int)hipGetLastError();
 }
 
-int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, int M, int d,
-                   const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s) {
+int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
+                   hs_bf16* dx1b, int M, int d, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s) {
     if (M <= 0) return HS_OK;
     EncMlpBwdArgs a; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.u2 = u2; a.dh13 = dh13; a.g = g; a.M = M; a.w = mkw(b);
-    a.g_n2w = g_n2w; a.g_n2b = g_n2b;
+    a.g_n2w = g_n2w; a.g_n2b = g_n2b; a.dyb = dyb; a.dx1b = dx1b;
     if (d == 128) {
         set_attrs<128, 352>();
         hipLaunchKernelGGL((enc_mlp_bwd_kernel<128, 352>), dim3((M + R - 1) / R), dim3(NTH), (MG<128, 352>::LDS_BWD), s, a);

@@ -8,6 +8,7 @@
 // along.  Up to 8 linears are batched per launch (one transformer block's q, k, v, proj, w1, w3, w2).
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -28,25 +29,48 @@ __device__ __forceinline__ bf16x8 frag_tr_rows(const bf16_t* tile, int mbase, in
     return r;
 }
 
-__device__ __forceinline__ void stage_rows(const void* src, bool f32, int ld, int ncols8, int M, int m0, int c0,
-                                           bf16_t* img, int tid) {
-    // img[m][f] = src[m0 + m][c0 + f] for m in [0,64), f in [0,128); zero outside the matrix
+// One 64-row chunk of an operand slab, held in registers between its global load and its LDS store so that the
+// loads of chunk c+1 are in flight while chunk c is being multiplied (the kernel was bound by one exposed HBM
+// round trip per chunk).  fp32 operands (dx1, dy) stay raw and are rounded to bf16 on the way into LDS.
+struct RowRegs {
+    bf16x8 h[4];
+    float4 f0[4], f1[4];
+};
+
+__device__ __forceinline__ void load_rows(const void* src, bool f32, int ld, int ncols8, int M, int m0, int c0, int tid,
+                                          RowRegs& rr) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + 256 * i;
         const int r = idx >> 4, c8 = (idx & 15) * 8;
         const int row = m0 + r, col = c0 + c8;
-        bf16x8 v = zero8();
-        if (row < M && col < ncols8) {
-            if (f32) {
+        const bool ok = row < M && col < ncols8;
+        if (f32) {
+            rr.f0[i] = make_float4(0.f, 0.f, 0.f, 0.f); rr.f1[i] = rr.f0[i];
+            if (ok) {
                 const float* s = reinterpret_cast<const float*>(src) + (size_t)row * ld + col;
-                const float4 x0 = *reinterpret_cast<const float4*>(s);
-                const float4 x1 = *reinterpret_cast<const float4*>(s + 4);
-                const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                v = cvt8(f);
-            } else {
-                v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(src) + (size_t)row * ld + col);
+                rr.f0[i] = *reinterpret_cast<const float4*>(s);
+                rr.f1[i] = *reinterpret_cast<const float4*>(s + 4);
             }
+        } else {
+            rr.h[i] = zero8();
+            if (ok) rr.h[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(src) + (size_t)row * ld + col);
+        }
+    }
+}
+
+__device__ __forceinline__ void store_rows(const RowRegs& rr, bool f32, bf16_t* img, int tid) {
+    // img[m][f] = slab[m0 + m][c0 + f] for m in [0,64), f in [0,128); zero outside the matrix
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx >> 4, c8 = (idx & 15) * 8;
+        bf16x8 v;
+        if (f32) {
+            const float f[8] = {rr.f0[i].x, rr.f0[i].y, rr.f0[i].z, rr.f0[i].w, rr.f1[i].x, rr.f1[i].y, rr.f1[i].z, rr.f1[i].w};
+            v = cvt8(f);
+        } else {
+            v = rr.h[i];
         }
         *reinterpret_cast<bf16x8*>(img + r * TST + c8) = v;
     }
@@ -91,11 +115,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     const int c16 = lane & 15, g = lane >> 4;
     const int bcol = tid & 127, bhalf = tid >> 7;
 
+    const bool dof32 = t.dO_f32 != 0;
+    RowRegs rd, ra;
+    if (cbeg < cend) {
+        load_rows(t.dO, dof32, t.ldo, n8, p.M, cbeg * MC, n0, tid, rd);
+        load_rows(t.A, false, t.lda, k8, p.M, cbeg * MC, k0, tid, ra);
+    }
     for (int c = cbeg; c < cend; ++c) {
-        const int m0 = c * MC;
-        lds_barrier();
-        stage_rows(t.dO, t.dO_f32 != 0, t.ldo, n8, p.M, m0, n0, dOt, tid);
-        stage_rows(t.A, false, t.lda, k8, p.M, m0, k0, At, tid);
+        lds_barrier();                                   // everyone is done reading the previous chunk's tiles
+        store_rows(rd, dof32, dOt, tid);
+        store_rows(ra, false, At, tid);
+        if (c + 1 < cend) {                              // next chunk's loads fly during this chunk's MFMAs
+            load_rows(t.dO, dof32, t.ldo, n8, p.M, (c + 1) * MC, n0, tid, rd);
+            load_rows(t.A, false, t.lda, k8, p.M, (c + 1) * MC, k0, tid, ra);
+        }
         lds_barrier();
         if (want_bias) {
 #pragma unroll 8
@@ -128,6 +161,185 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     if (want_bias && n0 + bcol < t.N) atomicAdd(t.db + n0 + bcol, bsum);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// All-bf16 operands: the same 128x128 tile, fed by buffer_load ... lds (16 B per lane straight into LDS, no VGPR
+// staging) through a ring of DS stages of 32 rows.  The register-staged kernel above keeps one chunk in flight per
+// workgroup and measured ~2.4 TB/s with HBM traffic already at the algorithmic minimum: each chunk exposed a full
+// memory round trip.  Here DS-1 chunks per workgroup are always in flight (3 workgroups per CU x 2 x 16 KB).
+//
+// LDS stage = dO[32 rows][128 cols] | A[32 rows][128 cols], rows unpadded (256 B: the DMA writes 1 KB = 4 rows per
+// wave instruction, lane i -> bytes [16 i, 16 i + 16)).  Bank conflicts of the transpose reads are avoided by
+// permuting which 16-byte column chunk each lane FETCHES: slot s of row r holds column chunk s ^ swz(r).
+constexpr int DC = 32;                     // rows per stage (one MFMA k-step)
+constexpr int DS = 3;                      // ring stages
+constexpr int STAGE_ELEMS = 2 * DC * 128;  // bf16 elements per stage (16 KB)
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
+
+// The transpose reads of the DMA kernel are issued as inline asm: for a ds_read the compiler can see, it inserts
+// `s_waitcnt vmcnt(0)` first (the LDS-DMA loads might alias it), which would drain the whole prefetch ring every
+// chunk.  Arrival of a stage is tracked by hand instead (wait_vm + s_barrier), and so is lgkmcnt (wait_lds).
+__device__ __forceinline__ uint32_t frag_sw_addr(uint32_t tile_bytes, int col0, int lane) {
+    // element j of lane l = tile[8 (l>>4) + j][col0 + (l&15)] of a swizzled [32][128] stage tile (see frag_tr_rows)
+    const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+    const int row = 8 * g + q;
+    const int chunk = ((col0 >> 3) + (pq >> 1)) ^ swz(row);
+    return tile_bytes + (uint32_t)(row * 256 + chunk * 16 + (pq & 1) * 8);       // rows +4: +1024 B, same swizzle
+}
+struct Frag2 { bf16x4 lo, hi; };
+__device__ __forceinline__ void tr_read2(uint32_t addr, Frag2& f) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"
+                 : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ bf16x8 join(const Frag2& f) { return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+// lgkmcnt(0), tied to the fragments so that nothing that uses them is scheduled above it
+__device__ __forceinline__ void wait_lds(Frag2 (&x)[2], Frag2 (&y)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(x[0].lo), "+v"(x[0].hi), "+v"(x[1].lo), "+v"(x[1].hi), "+v"(y[0].lo), "+v"(y[0].hi), "+v"(y[1].lo),
+                   "+v"(y[1].hi), "+v"(y[2].lo), "+v"(y[2].hi), "+v"(y[3].lo), "+v"(y[3].hi) :: "memory");
+}
+__device__ __forceinline__ void wait_lds(Frag2 (&y)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(y[0].lo), "+v"(y[0].hi), "+v"(y[1].lo), "+v"(y[1].hi), "+v"(y[2].lo), "+v"(y[2].hi), "+v"(y[3].lo),
+                   "+v"(y[3].hi) :: "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    int tiles = 0;
+    for (int i = 0; i < p.ntasks; ++i) tiles += ((p.t[i].N + 127) / 128) * ((p.t[i].K + 127) / 128);
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    int w = li % tiles;
+    const int ms = xcd + 8 * (li / tiles);
+    if (ms >= p.msplit) return;
+    int ti = 0, ns = 0, ks = 0;
+    for (; ti < p.ntasks; ++ti) {
+        const int nsl = (p.t[ti].N + 127) / 128, ksl = (p.t[ti].K + 127) / 128;
+        if (w < nsl * ksl) { ns = w / ksl; ks = w % ksl; break; }
+        w -= nsl * ksl;
+    }
+    if (ti >= p.ntasks) return;
+    const WgradTask t = p.t[ti];
+    const int n0 = ns * 128, k0 = ks * 128;
+    const int nchunks = (p.M + DC - 1) / DC;
+    const int cpw = (nchunks + p.msplit - 1) / p.msplit;
+    const int cbeg = ms * cpw, cend = min(nchunks, cbeg + cpw);
+    const int nch = cend - cbeg;
+    const bool want_bias = (t.db != nullptr) && (ks == 0);
+
+    // Out-of-range rows (last chunk) come back as zeros from the buffer bounds check.  Columns past N / K of a slab
+    // are whatever follows in the row: they only reach dW rows / columns that are never committed.
+    const uint32_t bytes_d = (uint32_t)min((int64_t)p.M * t.ldo * 2, (int64_t)0xffffffffu);
+    const uint32_t bytes_a = (uint32_t)min((int64_t)p.M * t.lda * 2, (int64_t)0xffffffffu);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(t.dO), 0, bytes_d, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)t.A, 0, bytes_a, 0x00020000);
+    // this wave's two DMA instructions per operand and chunk: rows 4 (2 wave + i) + (lane >> 4), slot lane & 15
+    uint32_t vd[2], va[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 4 * (2 * wave + i) + (lane >> 4);
+        const int chunk = (lane & 15) ^ swz(row);
+        vd[i] = (uint32_t)(row * t.ldo + n0 + 8 * chunk) * 2u;
+        va[i] = (uint32_t)(row * t.lda + k0 + 8 * chunk) * 2u;
+    }
+    auto issue = [&](int c, int stage) {
+        bf16_t* st = smem + stage * STAGE_ELEMS;
+        const uint32_t od = (uint32_t)c * DC * t.ldo * 2u, oa = (uint32_t)c * DC * t.lda * 2u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_vptr)(st + (2 * wave + i) * 512), 16, vd[i], od, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)(st + DC * 128 + (2 * wave + i) * 512), 16, va[i], oa, 0, 0);
+    };
+
+    f32x4 acc[2][8], accb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+
+#pragma unroll
+    for (int i = 0; i < DS - 1; ++i)
+        if (i < nch) issue(cbeg + i, i);
+    int stage = 0;
+    for (int i = 0; i < nch; ++i) {
+        // chunk i has landed once at most the DS-2 younger chunks (4 instructions each) are still outstanding
+        if (i + DS - 2 < nch) wait_vm<(DS - 2) * 4>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();          // every wave's part of chunk i is in LDS; everyone is done with stage i-1
+        if (i + DS - 1 < nch) issue(cbeg + i + DS - 1, stage == 0 ? DS - 1 : stage - 1);
+        const uint32_t dOt = lds_base + (uint32_t)stage * (STAGE_ELEMS * 2), At = dOt + DC * 256;
+        Frag2 fa[2], fb0[4], fb1[4];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) tr_read2(frag_sw_addr(dOt, (wave * 2 + ii) * 16, lane), fa[ii]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tr_read2(frag_sw_addr(At, j * 16, lane), fb0[j]);
+        wait_lds(fa, fb0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tr_read2(frag_sw_addr(At, (4 + j) * 16, lane), fb1[j]);
+        const bf16x8 a[2] = {join(fa[0]), join(fa[1])};
+        if (want_bias) {                       // column sums of dO as one more MFMA against ones: no extra LDS traffic
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) accb[ii] = mfma16(a[ii], ones, accb[ii]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16x8 b = join(fb0[j]);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) acc[ii][j] = mfma16(a[ii], b, acc[ii][j]);
+        }
+        wait_lds(fb1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16x8 b = join(fb1[j]);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) acc[ii][4 + j] = mfma16(a[ii], b, acc[ii][4 + j]);
+        }
+        stage = stage == DS - 1 ? 0 : stage + 1;
+    }
+
+    const int c16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + (wave * 2 + i) * 16 + g * 4 + r;
+                const int k = k0 + j * 16 + c16;
+                if (n < t.N && k < t.K) atomicAdd(t.dW + (size_t)n * t.ldw + k, acc[i][j][r]);
+            }
+    if (want_bias && c16 == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + (wave * 2 + i) * 16 + g * 4 + r;
+                if (n < t.N) atomicAdd(t.db + n, accb[i][r]);
+            }
+    }
+}
+
 }  // namespace
 
 int hs_wgrad(const WgradParams& p, hipStream_t s) {
@@ -138,6 +350,26 @@ int hs_wgrad(const WgradParams& p, hipStream_t s) {
         if (p.t[i].ldo % 8 || p.t[i].lda % 8) return HS_EDIMS;
         tiles += ((p.t[i].N + 127) / 128) * ((p.t[i].K + 127) / 128);
     }
-    hipLaunchKernelGGL(wgrad_kernel, dim3(8 * tiles * ((p.msplit + 7) / 8)), dim3(256), 0, s, p);
+    // all operands bf16 and addressable with 32-bit buffer offsets -> LDS-DMA kernel (HSIMAE_WGRAD_DMA=0 disables it)
+    static int dma_ok = -1;
+    if (dma_ok < 0) { const char* e = getenv("HSIMAE_WGRAD_DMA"); dma_ok = !(e && e[0] == '0'); }
+    bool dma = dma_ok != 0;
+    for (int i = 0; i < p.ntasks; ++i) {
+        const WgradTask& t = p.t[i];
+        if (t.dO_f32 || (int64_t)(p.M + DC) * t.ldo * 2 >= (1ll << 32) || (int64_t)(p.M + DC) * t.lda * 2 >= (1ll << 32)) dma = false;
+        if ((reinterpret_cast<uintptr_t>(t.dO) | reinterpret_cast<uintptr_t>(t.A)) & 15) dma = false;
+    }
+    const dim3 grid(8 * tiles * ((p.msplit + 7) / 8));
+    if (dma) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      DS * STAGE_ELEMS * 2);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(wgrad_dma_kernel, grid, dim3(256), DS * STAGE_ELEMS * 2, s, p);
+    } else {
+        hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, p);
+    }
     return (int)hipGetLastError();
 }

@@ -181,6 +181,9 @@ typedef struct {
 } hsimae_wgrad_task;
 typedef struct { hsimae_wgrad_task t[8]; int32_t ntasks; int32_t M; int32_t msplit; } hsimae_wgrad_params;
 int hsimae_wgrad(const hsimae_wgrad_params* p, void* stream);
+/* The row split (msplit) hsimae_backward uses for a launch of `tiles` 128x128 dW tiles over M rows: one resident
+   wave of workgroups, whole groups of 8 (row slice ms runs on XCD ms % 8). */
+int32_t hsimae_wgrad_msplit(int32_t tiles, int64_t M);
 
 /* LayerNorm backward (autograd of Models.py:288/299/399/419), residual grad fused. */
 typedef struct {
