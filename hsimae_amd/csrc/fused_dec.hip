@@ -187,8 +187,21 @@ __device__ __forceinline__ void ln_rows(const float* src, int Ts, const float* g
     float gm[8], bt[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gm[e] = gamma[c8 + e]; bt[e] = beta[c8 + e]; }
+    constexpr int NI = (R * 8 + NTHR - 1) / NTHR;
+    float4 ga[FROM_LDS ? 1 : NI], gb[FROM_LDS ? 1 : NI];
+    if constexpr (!FROM_LDS) {                       // all global loads of the sample first: one exposed round trip
 #pragma unroll
-    for (int i = 0; i < (R * 8 + NTHR - 1) / NTHR; ++i) {
+        for (int i = 0; i < NI; ++i) {
+            const int p = threadIdx.x + NTHR * i, row = p >> 3;
+            ga[i] = make_float4(0.f, 0.f, 0.f, 0.f); gb[i] = ga[i];
+            if (p < R * 8 && row < Ts) {
+                ga[i] = *reinterpret_cast<const float4*>(src + (size_t)row * D + c8);
+                gb[i] = *reinterpret_cast<const float4*>(src + (size_t)row * D + c8 + 4);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
         const int p = threadIdx.x + NTHR * i;
         if (p < R * 8) {
             const int row = p >> 3;
@@ -202,11 +215,7 @@ __device__ __forceinline__ void ln_rows(const float* src, int Ts, const float* g
                     *reinterpret_cast<float4*>(copy_out + (size_t)row * D + c8 + 4) = b;
                 }
             } else {
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-                if (row < Ts) {
-                    a = *reinterpret_cast<const float4*>(src + (size_t)row * D + c8);
-                    b = *reinterpret_cast<const float4*>(src + (size_t)row * D + c8 + 4);
-                }
+                const float4 a = ga[i], b = gb[i];
                 f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
                 if (XS) {
                     *reinterpret_cast<float4*>(XS + row * LX + c8) = a;
@@ -702,16 +711,23 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
         f2.load(w2T, 2, q.wn * 2, 0, q);
         const float* n2w = launder(p.w.n2w);
         const float* n2b = launder(p.w.n2b);
+        float fa[NPW][8], dya[NPW][8];                // the sample's loads all in flight at once
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int row = (threadIdx.x + NT_ * i) >> 3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { fa[i][e] = 0.f; dya[i][e] = 0.f; }
+            if (row < p.Ts) { ld8(p.x1 + (rb + row) * D + c8, fa[i]); ld8(p.dy + (rb + row) * D + c8, dya[i]); }
+        }
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pc = threadIdx.x + NT_ * i;
             if (pc < R * 8) {
                 const int row = pc >> 3;
-                float f[8], dyv[8], gm[8], bt[8];
+                float gm[8], bt[8];
+                float (&f)[8] = fa[i];
+                float (&dyv)[8] = dya[i];
                 ld8(n2w + c8, gm); ld8(n2b + c8, bt);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { f[e] = 0.f; dyv[e] = 0.f; }
-                if (row < p.Ts) { ld8(p.x1 + (rb + row) * D + c8, f); ld8(p.dy + (rb + row) * D + c8, dyv); }
                 const float mean = red8(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
                 float v = 0.f;
 #pragma unroll
@@ -827,6 +843,14 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
         }
         acc_to_xs<L::MH>(XS, mt0, MT, q, du2);
         asm volatile("" :: "v"(touch0), "v"(touch1));
+        float xe[NPW][8], dye[NPW][8];                // L2-hot re-reads for the LayerNorm backward, in flight over the barrier
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int row = (threadIdx.x + NT_ * i) >> 3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xe[i][e] = 0.f; dye[i][e] = 0.f; }
+            if (row < p.Ts) { ld8(p.x1 + (rb + row) * D + c8, xe[i]); ld8(p.dy + (rb + row) * D + c8, dye[i]); }
+        }
         lds_barrier();
         PH(3)
 #pragma unroll
@@ -834,12 +858,11 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             const int pc = threadIdx.x + NT_ * i;
             if (pc < R * 8) {
                 const int row = pc >> 3;
-                float du[8], t[8], xh[8], dyv[8], gm[8];
+                float du[8], t[8], gm[8];
+                float (&xh)[8] = xe[i];
+                float (&dyv)[8] = dye[i];
                 ld8(XS + row * LX + c8, du);
                 ld8(n2w + c8, gm);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { xh[e] = 0.f; dyv[e] = 0.f; }
-                if (row < p.Ts) { ld8(p.x1 + (rb + row) * D + c8, xh); ld8(p.dy + (rb + row) * D + c8, dyv); }   // L2-hot re-read
                 const float mean = red8(xh[0] + xh[1] + xh[2] + xh[3] + xh[4] + xh[5] + xh[6] + xh[7]) * (1.f / D);
                 float v = 0.f;
 #pragma unroll
@@ -1072,20 +1095,30 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         const bf16_t* WPl = WP + wl;
         const float* CBl = CB + wl;
         // x, dx1, O and logsumexp of this sample: the only exposed HBM round trip of the iteration
+        float fa[NPW][8], d1a[NPW][8], l8a[NPW][8];
+        bf16x8 ova[NPW];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {               // every load of the sample in flight before the first use
+            const int row = (threadIdx.x + NT_ * i) >> 3;
+            ova[i] = zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { fa[i][e] = 0.f; d1a[i][e] = 0.f; l8a[i][e] = 1e30f; }   // rows past Ts: exp2(s - 1e30) = 0
+            if (row < p.Ts) {
+                ld8(p.x + (rb + row) * D + c8, fa[i]); ld8(p.dx1 + (rb + row) * D + c8, d1a[i]);
+                ova[i] = *reinterpret_cast<const bf16x8*>(p.o + (rb + row) * D + c8);
+                if (c8 == 0) ld8(p.lse_g + (rb + row) * 8, l8a[i]);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pc = threadIdx.x + NT_ * i;
             if (pc < R * 8) {
                 const int row = pc >> 3;
-                float f[8], d1[8], gm[8], bt[8], l8[8];
-                bf16x8 ov = zero8();
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { f[e] = 0.f; d1[e] = 0.f; l8[e] = 1e30f; }   // rows past Ts: exp2(s - 1e30) = 0
-                if (row < p.Ts) {
-                    ld8(p.x + (rb + row) * D + c8, f); ld8(p.dx1 + (rb + row) * D + c8, d1);
-                    ov = *reinterpret_cast<const bf16x8*>(p.o + (rb + row) * D + c8);
-                    if (c8 == 0) ld8(p.lse_g + (rb + row) * 8, l8);
-                }
+                float gm[8], bt[8];
+                float (&f)[8] = fa[i];
+                float (&d1)[8] = d1a[i];
+                float (&l8)[8] = l8a[i];
+                const bf16x8 ov = ova[i];
                 ld8(CBl + 3 * D + c8, gm); ld8(CBl + 4 * D + c8, bt);
                 *reinterpret_cast<bf16x8*>(Ob + row * LU + c8) = ov;
                 if (c8 == 0) {
@@ -1232,6 +1265,14 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             }
         }
         acc_to_xs<L::MH>(XS, mt0, MT, q, du);
+        float xe[NPW][8], d1e[NPW][8];                // L2-hot re-reads for the LayerNorm backward, in flight over the barrier
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int row = (threadIdx.x + NT_ * i) >> 3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xe[i][e] = 0.f; d1e[i][e] = 0.f; }
+            if (row < p.Ts) { ld8(p.x + (rb + row) * D + c8, xe[i]); ld8(p.dx1 + (rb + row) * D + c8, d1e[i]); }
+        }
         lds_barrier();
         PH(6)
 #pragma unroll
@@ -1239,12 +1280,11 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             const int pc = threadIdx.x + NT_ * i;
             if (pc < R * 8) {
                 const int row = pc >> 3;
-                float dv[8], t[8], xh[8], d1[8], gm[8];
+                float dv[8], t[8], gm[8];
+                float (&xh)[8] = xe[i];
+                float (&d1)[8] = d1e[i];
                 ld8(XS + row * LX + c8, dv);
                 ld8(CBl + 3 * D + c8, gm);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { xh[e] = 0.f; d1[e] = 0.f; }
-                if (row < p.Ts) { ld8(p.x + (rb + row) * D + c8, xh); ld8(p.dx1 + (rb + row) * D + c8, d1); }     // L2-hot re-read
                 const float mean = red8(xh[0] + xh[1] + xh[2] + xh[3] + xh[4] + xh[5] + xh[6] + xh[7]) * (1.f / D);
                 float v = 0.f;
 #pragma unroll

@@ -10,6 +10,23 @@
 #include "common.h"
 #include "kernels.h"
 
+// Per-phase cycle accounting for scripts/phase_timing.py (compiled only with -DHS_PHASE_TIMING; never in the shipped library)
+#ifdef HS_PHASE_TIMING
+__device__ unsigned long long hs_phase_cycles_enc[32];
+extern "C" int hsimae_debug_phases_enc(unsigned long long* out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hs_phase_cycles_enc), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(hs_phase_cycles_enc), z, sizeof(z)); }
+    return rc;
+}
+#define PH_DECL unsigned long long ph_t0 = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PH(i) { const unsigned long long ph_t = __builtin_readcyclecounter(); ph_acc[i] += ph_t - ph_t0; ph_t0 = ph_t; }
+#define PH_FLUSH(base) if (threadIdx.x == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&hs_phase_cycles_enc[(base) + i], ph_acc[i]); }
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_FLUSH(base)
+#endif
+
 namespace {
 
 constexpr int R = 64, MH = 2, NTH = 256;   // 64-row panels: several independent 4-wave workgroups per CU
@@ -115,13 +132,19 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     {   // LayerNorm-2 in the wide layout (16 lanes per row) + fp32 copy for the residual
         float gm[8], bt[8];
         ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
+        constexpr int NI = R * LPR / NTH;
+        float fa[NI][8];
 #pragma unroll
-        for (int i = 0; i < R * LPR / NTH; ++i) {
+        for (int i = 0; i < NI; ++i) {                 // the whole panel in flight at once
+            const int row = (threadIdx.x + NTH * i) / LPR;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fa[i][e] = 0.f;
+            if (row0 + row < p.M) ld8(p.x1 + (size_t)(row0 + row) * D + c8, fa[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
             const int pc = threadIdx.x + NTH * i, row = pc / LPR;
-            float f[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = 0.f;
-            if (row0 + row < p.M) ld8(p.x1 + (size_t)(row0 + row) * D + c8, f);
+            float (&f)[8] = fa[i];
             st8(XS + row * LX + c8, f);
             const float mean = redrow<LPR>(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
             float v = 0.f;
@@ -250,6 +273,7 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     const int nt_h = HPE / 16;
     const int c8 = (threadIdx.x % LPR) * 8;
 
+    PH_DECL
     Fr<KSD> f1, f3, f2;
     f1.load(w.w1, KSD, q.wn * 2, 0, nt_h, q);
     f3.load(w.w3, KSD, q.wn * 2, 0, nt_h, q);
@@ -257,14 +281,22 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     {
         float gm[8], bt[8];
         ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
+        // all of the panel's loads first: one exposed HBM round trip instead of one per row group
+        constexpr int NI = R * LPR / NTH;
+        float fa[NI][8], dya[NI][8];
 #pragma unroll
-        for (int i = 0; i < R * LPR / NTH; ++i) {
+        for (int i = 0; i < NI; ++i) {
+            const int row = (threadIdx.x + NTH * i) / LPR;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { fa[i][e] = 0.f; dya[i][e] = 0.f; }
+            if (row0 + row < p.M) { ld8(p.x1 + (size_t)(row0 + row) * D + c8, fa[i]); ld8(p.dy + (size_t)(row0 + row) * D + c8, dya[i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
             const int pc = threadIdx.x + NTH * i, row = pc / LPR;
             const bool ok = row0 + row < p.M;
-            float f[8], dyv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { f[e] = 0.f; dyv[e] = 0.f; }
-            if (ok) { ld8(p.x1 + (size_t)(row0 + row) * D + c8, f); ld8(p.dy + (size_t)(row0 + row) * D + c8, dyv); }
+            float (&f)[8] = fa[i];
+            float (&dyv)[8] = dya[i];
             const float mean = redrow<LPR>(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
             float v = 0.f;
 #pragma unroll
@@ -283,6 +315,7 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
         }
     }
     lds_barrier();
+    PH(0)
     f32x4 du2[NCC][MH][2];
 #pragma unroll
     for (int cc = 0; cc < NCC; ++cc)
@@ -329,6 +362,15 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
                 }
         }
         lds_barrier();
+        PH(1)
+        // W1^T | W3^T fragments of this chunk's data gradient: issued before the operand stores so that their L2 round
+        // trip overlaps them (they were fetched right at their use, twice per chunk)
+        Fr<2> wa[NCC], wb[NCC];
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) {
+            wa[cc].load(w.w13T, 2 * KSH, cc * 4 + q.wn * 2, 2 * c, D / 16, q);
+            wb[cc].load(w.w13T, 2 * KSH, cc * 4 + q.wn * 2, KSH + 2 * c, D / 16, q);
+        }
         // weight-gradient operands of this chunk to HBM (row-contiguous 16-B stores), columns < 352 only
         {
             const int ncol = (c * 64 + 64 <= HPE) ? 64 : HPE - c * 64;       // 64 or 32
@@ -342,27 +384,26 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
                 }
             }
         }
+        PH(2)
         // data gradient through W1 / W3:  du2 += dh1_c W1[c] + dh3_c W3[c]   (packed [N=128][K=704], W3 at k-step 11)
         if (c < NCH - 1 || HPE % 64 == 0) {
 #pragma unroll
             for (int cc = 0; cc < NCC; ++cc) {
-                Fr<2> a, b;
-                a.load(w.w13T, 2 * KSH, cc * 4 + q.wn * 2, 2 * c, D / 16, q);
-                b.load(w.w13T, 2 * KSH, cc * 4 + q.wn * 2, KSH + 2 * c, D / 16, q);
-                mm_f<2>(DH1, LC, 0, a, q, du2[cc]);
-                mm_f<2>(DH3, LC, 0, b, q, du2[cc]);
+                mm_f<2>(DH1, LC, 0, wa[cc], q, du2[cc]);
+                mm_f<2>(DH3, LC, 0, wb[cc], q, du2[cc]);
             }
-        } else {
+        } else {                                    // half chunk: the second k-step is past the hidden width (zero images)
 #pragma unroll
             for (int cc = 0; cc < NCC; ++cc) {
                 Fr<1> a, b;
-                a.load(w.w13T, 2 * KSH, cc * 4 + q.wn * 2, 2 * c, D / 16, q);
-                b.load(w.w13T, 2 * KSH, cc * 4 + q.wn * 2, KSH + 2 * c, D / 16, q);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { a.b[0][j] = wa[cc].b[0][j]; b.b[0][j] = wb[cc].b[0][j]; }
                 mm_f<1>(DH1, LC, 0, a, q, du2[cc]);
                 mm_f<1>(DH3, LC, 0, b, q, du2[cc]);
             }
         }
         lds_barrier();
+        PH(3)
     }
 #pragma unroll
     for (int cc = 0; cc < NCC; ++cc)
@@ -380,15 +421,23 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     {
         float gm[8];
         ld8(w.n2w + c8, gm);
+        constexpr int NI = R * LPR / NTH;
+        float xa[NI][8], dya[NI][8];
 #pragma unroll
-        for (int i = 0; i < R * LPR / NTH; ++i) {
+        for (int i = 0; i < NI; ++i) {                 // L2-hot re-reads, all in flight at once
+            const int row = (threadIdx.x + NTH * i) / LPR;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xa[i][e] = 0.f; dya[i][e] = 0.f; }
+            if (row0 + row < p.M) { ld8(p.x1 + (size_t)(row0 + row) * D + c8, xa[i]); ld8(p.dy + (size_t)(row0 + row) * D + c8, dya[i]); }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
             const int pc = threadIdx.x + NTH * i, row = pc / LPR;
             const bool ok = row0 + row < p.M;
-            float du[8], xh[8], dyv[8], t[8];
+            float du[8], t[8];
+            float (&xh)[8] = xa[i];
+            float (&dyv)[8] = dya[i];
             ld8(XS + row * LX + c8, du);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { xh[e] = 0.f; dyv[e] = 0.f; }
-            if (ok) { ld8(p.x1 + (size_t)(row0 + row) * D + c8, xh); ld8(p.dy + (size_t)(row0 + row) * D + c8, dyv); }
             const float mean = redrow<LPR>(xh[0] + xh[1] + xh[2] + xh[3] + xh[4] + xh[5] + xh[6] + xh[7]) * (1.f / D);
             float v = 0.f;
 #pragma unroll
@@ -413,6 +462,7 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     }
     // LayerNorm-2 parameter grads: reduce the 32 threads that share a column octet, one atomic per column
     lds_barrier();
+    PH(4)
     float* red = reinterpret_cast<float*>(smem);            // [512][8] x 2 fits in the U2 + DYb panels
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[threadIdx.x * 8 + e] = dgam[e]; red[NTH * 8 + threadIdx.x * 8 + e] = dbet[e]; }
@@ -423,6 +473,8 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
         for (int t = o8; t < NTH; t += LPR) s += red[which * NTH * 8 + t * 8 + e];
         atomicAdd((which ? p.g_n2b : p.g_n2w) + c, s);
     }
+    PH(5)
+    PH_FLUSH(0)
 }
 
 }  // namespace

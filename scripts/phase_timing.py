@@ -21,9 +21,10 @@ def build_variant() -> str:
     objs = []
     for u in B.UNITS:
         obj = os.path.join(tmp, u + ".o")
-        flags = B.FLAGS + (["-DHS_PHASE_TIMING"] if u == "fused_dec" else [])
+        timed = u in ("fused_dec", "fused_enc")
+        flags = B.FLAGS + (["-DHS_PHASE_TIMING"] if timed else [])
         src_obj = os.path.join(B.HERE, "build", u + ".o")
-        if u != "fused_dec" and os.path.exists(src_obj):
+        if not timed and os.path.exists(src_obj):
             shutil.copy(src_obj, obj)
         else:
             subprocess.run([B.HIPCC] + flags + ["-c", os.path.join(B.CSRC, u + ".hip"), "-o", obj], check=True)
@@ -49,17 +50,22 @@ def main():
     lib.hsimae_debug_phases.restype = ctypes.c_int
     lib.hsimae_debug_phases.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
     buf = (ctypes.c_uint64 * 32)()
+    buf2 = (ctypes.c_uint64 * 32)()
+    lib.hsimae_debug_phases_enc.restype = ctypes.c_int
+    lib.hsimae_debug_phases_enc.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
     for it in range(3):
         loss, _, _ = m(x, 0.75)
         loss.backward()
         torch.cuda.synchronize()
         lib.hsimae_debug_phases(buf, 1)
-    v = list(buf)
+        lib.hsimae_debug_phases_enc(buf2, 1)
+    v = list(buf) + list(buf2)
     names = {
         "dec_bwd_attn": (0, ["prologue (x dx1 O lse) + LN", "qkv mm", "-", "dO mm + dWp + delta", "dO store", "attention",
                              "du mm + dWqkv", "epilogue LN bwd"]),
         "dec_bwd_mlp": (8, ["prologue LN", "gate mm + silu", "wgrad", "du2 stage", "epilogue LN bwd", "du2 mm", "-", "-"]),
         "dec_fwd": (16, ["LN1 + residual", "qkv", "attention", "o store + proj", "LN2", "gate chunks", "w2 mm", "store"]),
+        "enc_mlp_bwd": (32, ["prologue LN", "gate mm + silu", "operand stores", "du2 mm", "epilogue LN bwd", "LN grads", "-", "-"]),
     }
     for k, (base, ph) in names.items():
         tot = sum(v[base:base + 8]) or 1
