@@ -132,6 +132,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
     const int arow = lane & 15, ag = lane >> 4;
 
+    // Weight fragments are fetched one group of G k-steps ahead of the MFMAs that use them, across k-chunk and
+    // n-chunk boundaries: the group for the next n-chunk is in flight during this chunk's epilogue and the first
+    // group overlaps the staging of A.  (Fetched at their use, every k-step exposed an L2 round trip.)
+    constexpr int G = (DUAL || AK == A_F32_LN) ? 2 : 4;       // the LN prologue holds 64 staging registers: stay at 2 waves/SIMD
+    struct Grp { bf16x8 b[G][2]; bf16x8 b2[DUAL ? G : 1][2]; };
+    auto fetch = [&](int nc_, int kc_, int gb_, Grp& gr) {
+        const int ks0_ = kc_ * (KC / 32);
+        const int nks_ = min(KC / 32, KS_total - ks0_);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nt = nc_ * 8 + wave * 2 + j, ks = gb_ + i;
+                if (nc_ < n_chunks && ks < nks_ && nt < NT_total) {
+                    const size_t off = (((size_t)nt * KS_total + ks0_ + ks) * 64 + lane) * 8;
+                    gr.b[i][j] = *reinterpret_cast<const bf16x8*>(p.W + off);
+                    if constexpr (DUAL) gr.b2[i][j] = *reinterpret_cast<const bf16x8*>(p.W2 + off);
+                } else {
+                    gr.b[i][j] = zero8();
+                    if constexpr (DUAL) gr.b2[i][j] = zero8();
+                }
+            }
+    };
+    Grp cur;
+    fetch(0, 0, 0, cur);
+
     for (int nc = 0; nc < n_chunks; ++nc) {
         f32x4 acc[8][2];
         f32x4 acc2[DUAL ? 8 : 1][2];
@@ -142,7 +168,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                 acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (DUAL) acc2[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-        const int nt0 = nc * 8 + wave * 2;
 
         for (int kc = 0; kc < k_chunks; ++kc) {
             if (k_chunks > 1 || nc == 0) {
@@ -152,29 +177,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             }
             const int ks0 = kc * (KC / 32);
             const int nks = min(KC / 32, KS_total - ks0);
-            for (int ks = 0; ks < nks; ++ks) {
-                bf16x8 b[2], b2[2];
+            for (int gb = 0; gb < nks; gb += G) {
+                int nnc = nc, nkc = kc, ngb = gb + G;
+                if (ngb >= nks) { ngb = 0; if (++nkc >= k_chunks) { nkc = 0; ++nnc; } }
+                Grp nxt;
+                fetch(nnc, nkc, ngb, nxt);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int nt = nt0 + j;
-                    if (nt < NT_total) {
-                        const size_t off = (((size_t)nt * KS_total + ks0 + ks) * 64 + lane) * 8;
-                        b[j] = *reinterpret_cast<const bf16x8*>(p.W + off);
-                        if constexpr (DUAL) b2[j] = *reinterpret_cast<const bf16x8*>(p.W2 + off);
-                    } else {
-                        b[j] = zero8();
-                        if constexpr (DUAL) b2[j] = zero8();
+                for (int i = 0; i < G; ++i) {
+                    const int ks = gb + i;
+                    if (ks < nks) {
+#pragma unroll
+                        for (int mt = 0; mt < 8; ++mt) {
+                            const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (mt * 16 + arow) * LDA + ks * 32 + ag * 8);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                acc[mt][j] = mfma16(a, cur.b[i][j], acc[mt][j]);
+                                if constexpr (DUAL) acc2[mt][j] = mfma16(a, cur.b2[i][j], acc2[mt][j]);
+                            }
+                        }
                     }
                 }
-#pragma unroll
-                for (int mt = 0; mt < 8; ++mt) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (mt * 16 + arow) * LDA + ks * 32 + ag * 8);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[mt][j] = mfma16(a, b[j], acc[mt][j]);
-                        if constexpr (DUAL) acc2[mt][j] = mfma16(a, b2[j], acc2[mt][j]);
-                    }
-                }
+                cur = nxt;
             }
         }
 
