@@ -121,6 +121,38 @@ def optimizer_step_ms(model, iters=10):
     return res
 
 
+def input_pipeline_ms(bands, N, iters=10):
+    """Not part of the metric (inputs are resident when timing starts): SURVEY 8f row N2, one batch of N cubes
+    assembled on the device from HBM-resident synthetic scenes (hsimae_cube_gather through hsimae_amd.data).
+    HBM-bound byte kernel: algorithmic bytes = read + write 324*bands B per cube."""
+    import numpy as np
+    from hsimae_amd.data import HSIdataset4PT
+    rng = np.random.default_rng(0)
+    scenes = [rng.random((145, 145, bands), dtype=np.float32) for _ in range(4)]         # Indian-Pines-sized scenes
+    cut = np.array([(0, h, w, s, 1, 0) for s in range(4) for h in range(0, 136, 3) for w in range(0, 136, 3)], dtype=np.int16)
+    ds = HSIdataset4PT([scenes, cut], train=True)
+    idx = rng.integers(0, len(cut), N).tolist()
+    flips = rng.integers(0, 4, N).astype(np.uint8)
+    for _ in range(2):
+        ds.gather(idx, flips)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ds.gather(idx, flips)
+    e1.record()
+    torch.cuda.synchronize()
+    dev_ms = e0.elapsed_time(e1) / iters               # includes the index / flip uploads of each call
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ds.batch(idx)                                   # + 2 python random() draws per cube, as the reference consumes them
+    torch.cuda.synchronize()
+    call_ms = (time.perf_counter() - t0) / iters * 1e3
+    nbytes = 2.0 * N * 81 * bands * 4
+    return {"device_ms_per_batch": round(dev_ms, 4), "host_call_ms_per_batch": round(call_ms, 3),
+            "cubes_per_s": round(N / (call_ms * 1e-3), 0), "algorithmic_GBps": round(nbytes / (dev_ms * 1e-3) / 1e9, 1)}
+
+
 def cpu_baseline(bands, n_sample=64, steps=4):
     """The CPU oracle (a port of the reference's algorithm, validated against it) on the host cores."""
     from oracle import hsimae_oracle as O
@@ -232,6 +264,7 @@ def main():
         }
         out["roofline"] = dominant_kernel_roofline(model, N, 27)
         out["optimizer_step_ms"] = optimizer_step_ms(model)
+        out["input_pipeline"] = input_pipeline_ms(bands, N)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(bands)
         print(json.dumps(out), flush=True)

@@ -5,5 +5,6 @@
 """
 from .model import HSIMAE, swiglu_hidden, sincos_table  # noqa: F401
 from .optim import FusedAdamW  # noqa: F401
+from .data import HSIdataset4PT, DeviceLoader  # noqa: F401
 
 __version__ = "0.1.0"

@@ -85,6 +85,12 @@ class LossParams(C.Structure):
                 ("sum_mask", f32), ("dpred", vp), ("pred_img", vp), ("mask_img", vp)]
 
 
+class CubeParams(C.Structure):
+    _fields_ = [("scenes", vp), ("scene_f64", i32), ("scene_off", vp), ("scene_w", vp), ("bands", i32),
+                ("cut", vp), ("index", vp), ("flips", vp), ("N", i32),
+                ("out", vp), ("sn", i64), ("sb", i64), ("sh", i64), ("sw", i64)]
+
+
 BUCKET_CB = C.CFUNCTYPE(None, i32, i64, i64, vp)
 
 # name -> (restype, argtypes); also the list the CPU test checks against include/hsimae_hip.h
@@ -114,6 +120,7 @@ SYMBOLS = {
     "hsimae_loss_partials": (C.c_int, [i32, i32]),
     "hsimae_loss": (C.c_int, [C.POINTER(LossParams), vp]),
     "hsimae_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
+    "hsimae_cube_gather": (C.c_int, [C.POINTER(CubeParams), vp]),
 }
 
 A_BF16, A_F32, A_F32_LN = 0, 1, 2

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhsimae_hip.so")
-UNITS = ["gemm", "attn", "wgrad", "elem", "pack", "fused_dec", "fused_enc", "api"]
+UNITS = ["gemm", "attn", "wgrad", "elem", "pack", "fused_dec", "fused_enc", "loader", "api"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
 

@@ -675,6 +675,12 @@ int hsimae_attn_fwd(const hsimae_attn_params* p, void* stream) { return p ? hs_a
 int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream) { return p ? hs_attn_bwd(*p, S(stream)) : HSIMAE_ENULL; }
 int hsimae_wgrad(const hsimae_wgrad_params* p, void* stream) { return p ? hs_wgrad(*p, S(stream)) : HSIMAE_ENULL; }
 int32_t hsimae_wgrad_msplit(int32_t tiles, int64_t M) { return wgrad_msplit(tiles, M); }
+int hsimae_cube_gather(const hsimae_cube_params* p, void* stream) {
+    if (!p) return HSIMAE_ENULL;
+    if (p->N <= 0) return HSIMAE_OK;
+    if (!p->scenes || !p->scene_off || !p->scene_w || !p->cut || !p->index || !p->out) return HSIMAE_ENULL;
+    return hs_cube_gather(*p, S(stream));
+}
 int hsimae_ln_bwd(const hsimae_lnbwd_params* p, void* stream) { return p ? hs_ln_bwd(*p, S(stream)) : HSIMAE_ENULL; }
 int hsimae_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int32_t M, int32_t d, void* stream) {
     return (x && gamma && beta && out) ? hs_ln_fwd(x, gamma, beta, out, M, d, S(stream)) : HSIMAE_ENULL;

@@ -18,6 +18,7 @@ typedef hsimae_mask_params MaskParams;
 typedef hsimae_patch_params PatchParams;
 typedef hsimae_assemble_params AssembleParams;
 typedef hsimae_loss_params LossParams;
+typedef hsimae_cube_params CubeParams;
 
 int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s);
 int hs_pack(const PackDesc* descs_dev, int ndesc, int max_elems, hipStream_t s);
@@ -32,6 +33,7 @@ int hs_assemble_fwd(const AssembleParams& p, hipStream_t s);
 int hs_assemble_bwd(const AssembleParams& p, hipStream_t s);
 int hs_loss(const LossParams& p, hipStream_t s);
 int hs_loss_partials(int N, int T);
+int hs_cube_gather(const CubeParams& p, hipStream_t s);
 int hs_add2(const float* a, const float* b, float* out, int64_t n, hipStream_t s);
 
 // ------------------------------------------------------------------ fused_dec.hip (decoder Block, one workgroup per sample)

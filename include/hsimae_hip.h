@@ -219,6 +219,21 @@ int hsimae_loss(const hsimae_loss_params* p, void* stream);
 int hsimae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* group, int64_t n,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
+/* ------------------------------------------------------------------ next row N2: input pipeline */
+/* One batch of training cubes assembled on the device from HBM-resident scenes (Model_Pretraining.py:40-51
+ * `HSIdataset4PT.__getitem__`): window [h:h+9, w:w+9, :] of scene `num`, (x - min) / (max - min) in the scenes'
+ * dtype, optional flips along w (bit 0, np.flip(data, 1)) and h (bit 1, np.flip(data, 0)), written as
+ * out[n, 0, b, i, j] through the given element strides (band-fastest: sb = 1, sw = bands, sh = 9 * bands).
+ * scenes: all scenes concatenated, each [h][w][bands] row-major; scene_off[s] element offset, scene_w[s] = w.
+ * cut: the reference's int16 table, rows (c, h, w, scene, max, min) (Utils/Preprocessing.py:69-117); like the
+ * reference, `c` is ignored and all bands are taken.  Bit-exact with the numpy arithmetic for fp32 / fp64 scenes. */
+typedef struct {
+    const void* scenes; int32_t scene_f64; const int64_t* scene_off; const int32_t* scene_w; int32_t bands;
+    const int16_t* cut; const int64_t* index; const uint8_t* flips; int32_t N;
+    float* out; int64_t sn, sb, sh, sw;
+} hsimae_cube_params;
+int hsimae_cube_gather(const hsimae_cube_params* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
