@@ -46,7 +46,8 @@ class GemmParams(C.Structure):
                 ("W", vp), ("W2", vp), ("bias", vp), ("bias2", vp), ("gamma", vp), ("beta", vp),
                 ("stats", vp), ("u_out", vp), ("ldu", i32), ("out", vp), ("ldo", i32),
                 ("res", vp), ("res2", vp), ("ldr", i32), ("pos", vp), ("ids", vp), ("ldpos", i32),
-                ("h13", vp), ("ldh", i32), ("hoff", i32)]
+                ("h13", vp), ("ldh", i32), ("hoff", i32),
+                ("lnx", vp), ("dgamma", vp), ("dbeta", vp), ("accumulate", i32)]
 
 
 class PackDesc(C.Structure):
@@ -124,7 +125,7 @@ SYMBOLS = {
 }
 
 A_BF16, A_F32, A_F32_LN = 0, 1, 2
-E_BF16, E_F32, E_RES_F32, E_POS_F32, E_SWIGLU, E_SWIGLU_BWD = 0, 1, 2, 3, 4, 5
+E_BF16, E_F32, E_RES_F32, E_POS_F32, E_SWIGLU, E_SWIGLU_BWD, E_LN_BWD = 0, 1, 2, 3, 4, 5, 6
 
 _lib = None
 

@@ -343,10 +343,7 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     a.qkv = b.qkv; a.ld = 3 * d; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
     a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = d; a.lse = b.lse; a.dout = w.dob; a.lddo = d; a.dqkv = w.dqkv;
     CK(hs_attn_bwd(a, s));
-    p = gp();
-    p.A = w.dqkv; p.lda = 3 * d; p.M = (int)M; p.N = d; p.K = 3 * d; p.n_valid = d; p.W = P.qkvT; p.out = w.du; p.ldo = d;
-    CK(hs_gemm(p, A_BF16, E_F32, s));
-
+    // Weight gradients first: the LayerNorm-backward GEMM below writes dx over G0 / G1 when the caller runs in place
     WgradParams g; std::memset(&g, 0, sizeof(g));
     auto task = [&](const void* dO, int f32, int ldo, const hs_bf16* A, int lda, int N, int K, int64_t dW, int64_t db) {
         WgradTask& t = g.t[g.ntasks++];
@@ -368,9 +365,27 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     g.msplit = wgrad_msplit(tiles, M);
     CK(hs_wgrad(g, s));
 
-    l.du = w.du; l.x = x_in; l.gamma = P.n1w; l.dres = G1; l.dx = dx_out; l.accumulate = accumulate;
-    l.dgamma = grads + o.n1w; l.dbeta = grads + o.n1b;
-    CK(hs_ln_bwd(l, s));
+    // du = dqkv * Wqkv and the LayerNorm-1 backward: one kernel at d = 128 (LN backward as the GEMM's epilogue,
+    // du never goes to HBM), two otherwise.  HSIMAE_FUSED_LNBWD=0 forces the two-kernel form.
+    static int fuse_ln = -1;
+    if (fuse_ln < 0) { const char* e = getenv("HSIMAE_FUSED_LNBWD"); fuse_ln = !(e && e[0] == '0'); }
+    const bool ln_fused = fuse_ln && d == 128;
+    p = gp();
+    p.A = w.dqkv; p.lda = 3 * d; p.M = (int)M; p.N = d; p.K = 3 * d; p.n_valid = d; p.W = P.qkvT;
+    if (ln_fused) {
+        p.out = dx_out; p.ldo = d; p.res = G1; p.ldr = d; p.lnx = x_in; p.gamma = P.n1w; p.accumulate = accumulate;
+        p.dgamma = grads + o.n1w; p.dbeta = grads + o.n1b;
+        CK(hs_gemm(p, A_BF16, E_LN_BWD, s));
+    } else {
+        p.out = w.du; p.ldo = d;
+        CK(hs_gemm(p, A_BF16, E_F32, s));
+    }
+
+    if (!ln_fused) {
+        l.du = w.du; l.x = x_in; l.gamma = P.n1w; l.dres = G1; l.dx = dx_out; l.accumulate = accumulate;
+        l.dgamma = grads + o.n1w; l.dbeta = grads + o.n1b;
+        CK(hs_ln_bwd(l, s));
+    }
     return HSIMAE_OK;
 }
 

@@ -22,7 +22,7 @@ template <int KC> struct EpiRows { static constexpr int v = KC >= 512 ? 16 : 32;
 constexpr int TS = 132;            // fp32 LDS tile row stride (floats): conflict-free b32 writes
 
 template <int AK, int EPI, int KC>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LDA = KC + 8;                       // LDS row stride (elements): 16-B pad => conflict-free b128 reads
     constexpr bool DUAL = (EPI == E_SWIGLU);
@@ -203,6 +203,102 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
         // ---------------------------------------------------------------- epilogue for this 128-column chunk
         const int ccols = min(128, p.N - nc * 128);            // valid columns in this chunk (multiple of 16)
+        if constexpr (EPI == E_LN_BWD) {
+            // LayerNorm backward on the product (N = 128: a row is the 16 adjacent lanes of one piece row).
+            // The row's x and residual-gradient loads are issued before the tile exchange so they overlap it.
+            const int c8 = (tid & 15) * 8;
+            float gm[8], dgam[8], dbet[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gm[e] = p.gamma[c8 + e]; dgam[e] = 0.f; dbet[e] = 0.f; }
+#pragma unroll
+            for (int ps = 0; ps < BM / PR; ++ps) {
+                constexpr int NPC = PR * 16 / 256;
+                __builtin_amdgcn_sched_barrier(0);         // keep each pass's loads in its pass (hoisted, they cost a wave of occupancy)
+                float xr[NPC][8], rs[NPC][8];
+#pragma unroll
+                for (int i = 0; i < NPC; ++i) {
+                    const int row = row0 + ps * PR + ((tid + 256 * i) >> 4);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { xr[i][e] = 0.f; rs[i][e] = 0.f; }
+                    if (row < p.M) {
+                        const float* xp = p.lnx + (size_t)row * p.ldr + c8;
+                        const float* rp = p.res + (size_t)row * p.ldr + c8;
+                        const float4 a0 = *reinterpret_cast<const float4*>(xp), a1 = *reinterpret_cast<const float4*>(xp + 4);
+                        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                        xr[i][0] = a0.x; xr[i][1] = a0.y; xr[i][2] = a0.z; xr[i][3] = a0.w;
+                        xr[i][4] = a1.x; xr[i][5] = a1.y; xr[i][6] = a1.z; xr[i][7] = a1.w;
+                        rs[i][0] = r0.x; rs[i][1] = r0.y; rs[i][2] = r0.z; rs[i][3] = r0.w;
+                        rs[i][4] = r1.x; rs[i][5] = r1.y; rs[i][6] = r1.z; rs[i][7] = r1.w;
+                        if (p.accumulate) {
+                            const float* op = reinterpret_cast<const float*>(p.out) + (size_t)row * p.ldo + c8;
+                            const float4 o0 = *reinterpret_cast<const float4*>(op), o1 = *reinterpret_cast<const float4*>(op + 4);
+                            rs[i][0] += o0.x; rs[i][1] += o0.y; rs[i][2] += o0.z; rs[i][3] += o0.w;
+                            rs[i][4] += o1.x; rs[i][5] += o1.y; rs[i][6] += o1.z; rs[i][7] += o1.w;
+                        }
+                    }
+                }
+                lds_barrier();
+#pragma unroll
+                for (int mi = 0; mi < PR / 16; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            T1[(mi * 16 + ag * 4 + r) * TS + wave * 32 + j * 16 + arow] = acc[ps * (PR / 16) + mi][j][r];
+                lds_barrier();
+#pragma unroll
+                for (int i = 0; i < NPC; ++i) {
+                    const int rl = (tid + 256 * i) >> 4;
+                    const int row = row0 + ps * PR + rl;
+                    const float4 t0 = *reinterpret_cast<const float4*>(T1 + rl * TS + c8);
+                    const float4 t1 = *reinterpret_cast<const float4*>(T1 + rl * TS + c8 + 4);
+                    const float du[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                    float sm = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sm += xr[i][e];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+                    const float mean = sm * (1.f / 128.f);
+                    float q = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { xr[i][e] -= mean; q += xr[i][e] * xr[i][e]; }
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+                    const float rstd = rsqrtf(q * (1.f / 128.f) + 1e-5f);
+                    float a = 0.f, b = 0.f, t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { xr[i][e] *= rstd; t[e] = du[e] * gm[e]; a += t[e]; b += t[e] * xr[i][e]; }
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                    a *= (1.f / 128.f); b *= (1.f / 128.f);
+                    if (row < p.M) {
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            v[e] = rs[i][e] + rstd * (t[e] - a - xr[i][e] * b);
+                            dgam[e] += du[e] * xr[i][e];
+                            dbet[e] += du[e];
+                        }
+                        float* op = reinterpret_cast<float*>(p.out) + (size_t)row * p.ldo + c8;
+                        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                }
+            }
+            // dgamma / dbeta: 16 threads per octet in this workgroup -> LDS, one atomic per column
+            lds_barrier();
+            float* red = T1;                                   // [2][256][8] floats = 16 KB <= PR * TS * 4
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { red[tid * 8 + e] = dgam[e]; red[2048 + tid * 8 + e] = dbet[e]; }
+            lds_barrier();
+            {
+                const int which = tid >> 7, c = tid & 127, o8 = c >> 3, e = c & 7;
+                float sacc = 0.f;
+                for (int t2 = o8; t2 < 256; t2 += 16) sacc += red[which * 2048 + t2 * 8 + e];
+                atomicAdd((which ? p.dbeta : p.dgamma) + c, sacc);
+            }
+            continue;
+        }
 #pragma unroll
         for (int ps = 0; ps < BM / PR; ++ps) {
             lds_barrier();                                   // previous pass fully consumed
@@ -352,6 +448,11 @@ int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s) {
     CASE(A_BF16, E_POS_F32)
     CASE(A_BF16, E_F32)
     CASE(A_BF16, E_BF16)
+    if (akind == A_BF16 && epi == E_LN_BWD) {
+        if (p.N != 128 || p.n_valid != 128 || !p.lnx || !p.res || !p.gamma || !p.dgamma || !p.dbeta || p.ldr % 4 || p.ldo % 4)
+            return HS_EUNSUPPORTED;
+        return launch_kc<A_BF16, E_LN_BWD>(p, s);
+    }
     CASE(A_F32, E_SWIGLU_BWD)
     CASE(A_F32, E_BF16)
     CASE(A_F32, E_F32)

@@ -6,7 +6,8 @@
 
 enum AKind { A_BF16 = HSIMAE_A_BF16, A_F32 = HSIMAE_A_F32, A_F32_LN = HSIMAE_A_F32_LN };
 enum Epi { E_BF16 = HSIMAE_E_BF16, E_F32 = HSIMAE_E_F32, E_RES_F32 = HSIMAE_E_RES_F32,
-           E_POS_F32 = HSIMAE_E_POS_F32, E_SWIGLU = HSIMAE_E_SWIGLU, E_SWIGLU_BWD = HSIMAE_E_SWIGLU_BWD };
+           E_POS_F32 = HSIMAE_E_POS_F32, E_SWIGLU = HSIMAE_E_SWIGLU, E_SWIGLU_BWD = HSIMAE_E_SWIGLU_BWD,
+           E_LN_BWD = HSIMAE_E_LN_BWD };
 
 typedef hsimae_gemm_params GemmParams;
 typedef hsimae_pack_desc PackDesc;

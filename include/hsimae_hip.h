@@ -129,7 +129,11 @@ int hsimae_patch_gather(const hsimae_patch_params* p, void* stream);
  * as prologue and bias / residual / SiLU-gate (Models.py:232, 304-305) as epilogue. */
 enum { HSIMAE_A_BF16 = 0, HSIMAE_A_F32 = 1, HSIMAE_A_F32_LN = 2 };
 enum { HSIMAE_E_BF16 = 0, HSIMAE_E_F32 = 1, HSIMAE_E_RES_F32 = 2, HSIMAE_E_POS_F32 = 3, HSIMAE_E_SWIGLU = 4,
-       HSIMAE_E_SWIGLU_BWD = 5 };
+       HSIMAE_E_SWIGLU_BWD = 5,
+       /* E_LN_BWD: the product is dL/d(LayerNorm output); the epilogue applies the LayerNorm backward (autograd of
+          Models.py:304 `x + attn(norm1(x))` w.r.t. x) in place of a separate pass: out = res + LNbwd(acc; lnx, gamma)
+          (+ out when `accumulate`), dgamma / dbeta accumulated with atomics.  Needs N == n_valid == 128 (one chunk). */
+       HSIMAE_E_LN_BWD = 6 };
 typedef struct {
     const void* A; int32_t lda;
     int32_t M, N, K;
@@ -143,6 +147,7 @@ typedef struct {
     const float* res; const float* res2; int32_t ldr;
     const float* pos; const int32_t* ids; int32_t ldpos;
     hs_bf16* h13; int32_t ldh; int32_t hoff;
+    const float* lnx; float* dgamma; float* dbeta; int32_t accumulate;    /* E_LN_BWD only (lnx: the LayerNorm's input, ld = ldr) */
 } hsimae_gemm_params;
 int hsimae_gemm(const hsimae_gemm_params* p, int32_t a_kind, int32_t epilogue, void* stream);
 

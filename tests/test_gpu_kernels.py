@@ -126,6 +126,36 @@ def test_gemm_layernorm_prologue_bias_bf16_out(M, d, N):
     assert float((out.float() - ref).abs().max()) <= 2 ** -8 * float(ref.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("M,acc", [(300, 0), (129, 1), (1000, 0)])
+def test_gemm_layernorm_backward_epilogue(M, acc):
+    """E_LN_BWD: dx = dres (+ dx) + LayerNormBackward(dqkv @ [Wq;Wk;Wv]) with dgamma / dbeta, against autograd."""
+    torch.manual_seed(12)
+    d = 128
+    W = torch.randn(3 * d, d, device=DEV) * 0.1
+    imgT = pack([(W[:d], 1, 0, 0), (W[d:2 * d], 1, 0, d), (W[2 * d:], 1, 0, 2 * d)], d, 3 * d)
+    dqkv = torch.randn(M, 3 * d, device=DEV).to(torch.bfloat16)
+    x = (torch.randn(M, d, device=DEV) * 2 + 0.5).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(d, device=DEV)).requires_grad_(True)
+    beta = torch.zeros(d, device=DEV, requires_grad=True)
+    dres = torch.randn(M, d, device=DEV)
+    du = dqkv.float() @ bf(W)
+    torch.nn.functional.layer_norm(x, (d,), gamma, beta, 1e-5).backward(du)
+    prev = torch.randn(M, d, device=DEV)
+    dx = prev.clone()
+    dg, dbt = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    gemm(_lib.A_BF16, _lib.E_LN_BWD, A=dqkv, lda=3 * d, M=M, N=d, K=3 * d, n_valid=d, W=imgT, out=dx, ldo=d,
+         res=dres, ldr=d, lnx=x.detach(), gamma=gamma.detach(), dgamma=dg, dbeta=dbt, accumulate=acc)
+    ref = x.grad + dres + (prev if acc else 0)
+    assert rel_err(dx, ref) < 2e-5
+    assert rel_err(dg, gamma.grad) < 1e-4 and rel_err(dbt, beta.grad) < 1e-4
+    # in place over the residual gradient (how hsimae_backward calls it)
+    g1 = dres.clone()
+    dg.zero_(); dbt.zero_()
+    gemm(_lib.A_BF16, _lib.E_LN_BWD, A=dqkv, lda=3 * d, M=M, N=d, K=3 * d, n_valid=d, W=imgT, out=g1, ldo=d,
+         res=g1, ldr=d, lnx=x.detach(), gamma=gamma.detach(), dgamma=dg, dbeta=dbt, accumulate=0)
+    assert rel_err(g1, x.grad + dres) < 2e-5
+
+
 def test_gemm_residual_and_pos_epilogues():
     torch.manual_seed(3)
     M, d, K = 333, 128, 352
