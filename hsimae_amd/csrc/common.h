@@ -47,6 +47,16 @@ __device__ __forceinline__ bf16x8 cvt8(const float* v) {
 
 __device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
 
+// a * sigmoid(a) with the reciprocal taken as v_rcp_f32 + one Newton step (<= 1 ulp): the forward kernels' SiLU.
+// A plain v_rcp (1 ulp, biased) moved the loss by 1e-4 at stress weights; IEEE division costs ~10 VALU slots per
+// element (scale / fmas / fixup), which made the gate the largest VALU item of the fused forward kernels.
+__device__ __forceinline__ float silu_nr(float a) {
+    const float d = 1.f + __expf(-a);
+    float r = __builtin_amdgcn_rcpf(d);
+    r = fmaf(fmaf(-d, r, 1.f), r, r);
+    return a * r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

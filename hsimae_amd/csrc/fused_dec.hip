@@ -13,6 +13,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <type_traits>
+#include <cstdlib>
 
 // Per-phase cycle accounting for scripts/phase_timing.py (compiled only with -DHS_PHASE_TIMING; never in the shipped library)
 #ifdef HS_PHASE_TIMING
@@ -427,7 +428,7 @@ __device__ __forceinline__ void qkv_stage(const bf16_t* U, const DecW& w, const 
     }
 }
 
-__device__ __forceinline__ float silu_f(float a) { return a / (1.f + __expf(-a)); }   // forward: exact division (loss gate 1e-4)
+__device__ __forceinline__ float silu_f(float a) { return silu_nr(a); }   // forward: Newton-refined reciprocal (loss gate 1e-4)
 
 template <int MT>
 __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
@@ -463,8 +464,16 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
         fp.load(w.p, 2, q.wn * 2, 0, q);
         lds_barrier();
         PH(1)
+        // persistent grid: warm L2 / TLB with the next sample's rows while the attention runs (its only other
+        // global traffic is the already-issued proj fragments)
+        float touchx = 0.f;
+        {
+            const int nxt = sample + gridDim.x;
+            if (nxt < p.nsamples && threadIdx.x * 32 < p.Ts * D) touchx = p.x[(size_t)nxt * p.Ts * D + threadIdx.x * 32];
+        }
 #pragma unroll 1
         for (int hh = 0; hh < 2; ++hh) attn_head_fwd<MT>(Qb, Kb, Vt, U, q.wave * 2 + hh, p.Ts, q, p.lse + rb * 8);
+        asm volatile("" :: "v"(touchx));
         lds_barrier();
         PH(2)
         // attention output kept for the backward (dWp operand; saves it the softmax recompute), 16-B row pieces
@@ -1350,7 +1359,9 @@ int launch_fwd(const DecFwdArgs& a, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, L::FWD_TOTAL);
         attr_set = true;
     }
-    hipLaunchKernelGGL((dec_block_fwd_kernel<MT>), dim3(a.nsamples), dim3(256), L::FWD_TOTAL, s, a);
+    static int wgs = 0;                       // workgroups: 2 per CU walking the samples (HSIMAE_DEC_FWD_WGS overrides)
+    if (!wgs) { const char* e = getenv("HSIMAE_DEC_FWD_WGS"); wgs = e ? atoi(e) : 512; if (wgs < 1) wgs = 512; }
+    hipLaunchKernelGGL((dec_block_fwd_kernel<MT>), dim3(a.nsamples < wgs ? a.nsamples : wgs), dim3(256), L::FWD_TOTAL, s, a);
     return (int)hipGetLastError();
 }
 

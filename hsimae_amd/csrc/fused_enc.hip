@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float a1 = h1[mi][j][r];
-                            const float gv = col < w.h ? a1 / (1.f + __expf(-a1)) * h3[mi][j][r] : 0.f;
+                            const float gv = col < w.h ? silu_nr(a1) * h3[mi][j][r] : 0.f;
                             Gb[((q.wm * MH + mi) * 16 + q.g * 4 + r) * LG + col] = (bf16_t)gv;
                         }
                     }

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float a1 = bf2f(h1[e]), a3 = bf2f(h3[e]);       // the values the backward will see
-                        g[e] = a1 / (1.f + __expf(-a1)) * a3;
+                        g[e] = silu_nr(a1) * a3;
                     }
                     *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)row * p.ldo + col) = cvt8(g);
                 } else if constexpr (EPI == E_SWIGLU_BWD) {
