@@ -93,7 +93,7 @@ template <int HD, int NT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     using L = Lay<HD, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hgroups = (p.heads + 3) / 4;
     const int sample = blockIdx.x / hgroups, head = (blockIdx.x % hgroups) * 4 + wave;
     const bool active = head < p.heads;
@@ -180,7 +180,7 @@ template <int HD, int NT>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     using L = Lay<HD, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hgroups = (p.heads + 3) / 4;
     const int sample = blockIdx.x / hgroups, head = (blockIdx.x % hgroups) * 4 + wave;
     const bool active = head < p.heads;

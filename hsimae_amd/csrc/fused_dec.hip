@@ -62,10 +62,14 @@ constexpr int TT_WAVE = 2 * 16 * TTS;      // per wave: [P | dS][16 queries][TTS
 
 struct Geo4 { int lane, c16, g, wave, wm, wn; };
 
+// SCALAR_WAVE: the wave index goes through readfirstlane, so everything derived from it is scalar (uniform branches,
+// SALU address math).
+template <bool SCALAR_WAVE = true>
 __device__ __forceinline__ Geo4 geo() {
     Geo4 q;
     q.lane = threadIdx.x & 63; q.c16 = q.lane & 15; q.g = q.lane >> 4;
-    q.wave = threadIdx.x >> 6; q.wm = q.wave >> 1; q.wn = q.wave & 1;
+    q.wave = SCALAR_WAVE ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
+    q.wm = q.wave >> 1; q.wn = q.wave & 1;
     return q;
 }
 

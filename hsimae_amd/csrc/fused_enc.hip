@@ -55,7 +55,8 @@ struct G8 { int lane, c16, g, wave, wm, wn; };
 __device__ __forceinline__ G8 geo8() {
     G8 q;
     q.lane = threadIdx.x & 63; q.c16 = q.lane & 15; q.g = q.lane >> 4;
-    q.wave = threadIdx.x >> 6; q.wm = q.wave >> 1; q.wn = q.wave & 1;
+    q.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: SGPR, scalar branches
+    q.wm = q.wave >> 1; q.wn = q.wave & 1;
     return q;
 }
 

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
     float* T1 = rstat + 2 * BM;                       // [PR][TS]
     float* T2 = T1 + PR * TS;                         // second tile (SwiGLU pair)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * BM;
     const int KS_total = p.K / 32;
     const int NT_total = p.N / 16;

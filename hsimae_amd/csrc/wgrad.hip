@@ -79,7 +79,7 @@ __device__ __forceinline__ void store_rows(const RowRegs& rr, bool f32, bf16_t* 
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t dOt[MC * TST];
     __shared__ __attribute__((aligned(16))) bf16_t At[MC * TST];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // decode (task, n-slab, k-slab, m-split).  Workgroups go round-robin over the 8 XCDs (blockIdx % 8) and each XCD
     // has its own L2: all tiles of one row slice are placed on the same XCD, next to each other in launch order, so
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     int tiles = 0;
     for (int i = 0; i < p.ntasks; ++i) tiles += ((p.t[i].N + 127) / 128) * ((p.t[i].K + 127) / 128);
