@@ -11,7 +11,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhsimae_hip.so")
 UNITS = ["gemm", "attn", "wgrad", "elem", "pack", "fused_dec", "fused_enc", "loader", "api"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
+# HSIMAE_HIPCC_EXTRA: extra hipcc flags for experiments (e.g. "-Xclang -target-feature -Xclang -packed-fp32-ops",
+# which removes the v_pk_*_f32 forms: measured neutral on the step, so not the default)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"] + os.environ.get("HSIMAE_HIPCC_EXTRA", "").split()
 
 
 def _stale(target: str, deps: list[str]) -> bool:

@@ -994,19 +994,25 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
         // cycles of latency) are consumed after the score MFMAs of tile kt have been issued, and those MFMAs' own
         // latency is covered by the dk/dv MFMAs of tile kt-1.
         bf16x4 Bp = zero4(), Bds = zero4();
+        // K / V row fragments one tile ahead as well: their LDS latency is off the per-tile dependency chain
+        bf16x4 Kn = *reinterpret_cast<const bf16x4*>(Kb + q.c16 * LU + colw);
+        bf16x4 Vn = *reinterpret_cast<const bf16x4*>(Vb + q.c16 * LU + colw);
 #pragma unroll
         for (int kt = 0; kt < MT; ++kt) {
-            const bf16x4 Kf = *reinterpret_cast<const bf16x4*>(Kb + (kt * 16 + q.c16) * LU + colw);
-            const bf16x4 Vf = *reinterpret_cast<const bf16x4*>(Vb + (kt * 16 + q.c16) * LU + colw);
+            const bf16x4 Kf = Kn, Vf = Vn;
+            if (kt + 1 < MT) {
+                Kn = *reinterpret_cast<const bf16x4*>(Kb + ((kt + 1) * 16 + q.c16) * LU + colw);
+                Vn = *reinterpret_cast<const bf16x4*>(Vb + ((kt + 1) * 16 + q.c16) * LU + colw);
+            }
             const f32x4 s = mfma16k16(Kf, bq, z4);
             const f32x4 dp = mfma16k16(Vf, bdo, z4);
-            if (kt > 0) {
-                dkT[kt - 1] = mfma16k16(QT, Bds, dkT[kt - 1]);
-                dvT[kt - 1] = mfma16k16(dOT, Bp, dvT[kt - 1]);
-            }
             f32x4 pv, ds;
 #pragma unroll
+#ifdef HS_EXPERIMENT_NOEXP      /* timing experiment only (scripts/phase_timing.py): what the exps cost */
+            for (int r = 0; r < 4; ++r) pv[r] = fmaf(s[r], sc, lqn);
+#else
             for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn));
+#endif
             if (kt == MT - 1) {                 // only the last key tile can hold rows past Ts
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -1014,6 +1020,10 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) ds[r] = pv[r] * (dp[r] - dl);
+            if (kt > 0) {                       // previous tile's transposed operands, a VALU phase after their reads were issued
+                dkT[kt - 1] = mfma16k16(QT, Bds, dkT[kt - 1]);
+                dvT[kt - 1] = mfma16k16(dOT, Bp, dvT[kt - 1]);
+            }
             const bf16x4 pb = cvt4(pv), dsb = cvt4(ds);
             dqT = mfma16k16(KT[kt], dsb, dqT);
             bf16_t* tp = T;                     // one tile pair per wave: LDS executes a wave's accesses in order

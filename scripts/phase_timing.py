@@ -22,7 +22,7 @@ def build_variant() -> str:
     for u in B.UNITS:
         obj = os.path.join(tmp, u + ".o")
         timed = u in ("fused_dec", "fused_enc")
-        flags = B.FLAGS + (["-DHS_PHASE_TIMING"] if timed else [])
+        flags = B.FLAGS + (["-DHS_PHASE_TIMING"] + os.environ.get("HS_EXTRA_FLAGS", "").split() if timed else [])
         src_obj = os.path.join(B.HERE, "build", u + ".o")
         if not timed and os.path.exists(src_obj):
             shutil.copy(src_obj, obj)
