@@ -90,7 +90,7 @@ def dominant_kernel_roofline(model, N, K_tok, iters=20):
     ms = e0.elapsed_time(e1) / iters
     nbytes = float(M) * (3 * d * 2 + d * 2 + d * 2 + d * 2 + 2 * hp * 2 + d * 2 + d * 2 + hp * 2)
     achieved = nbytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "wgrad_kernel (encoder block: dW/db of q,k,v,proj,w1,w3,w2 in one launch)",
+    return {"bound": "hbm", "kernel": "wgrad_dma_kernel (encoder block: dW/db of q,k,v,proj,w1,w3,w2 in one launch)",
             "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": WGRAD_TRAFFIC_BYTES, "launch_ms": round(ms, 4),
             "bytes_per_launch": nbytes}

@@ -1248,6 +1248,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             }
         }
         // attention backward, one head per wave, dq/dk/dv written in place over q/k/v
+        // (a half-tile start stagger of waves 4-7, MI355X_MICROARCH.md "two waves per SIMD" item 9, measured neutral here)
         attn_head_bwd<MT>(Qb, Kb, Vb, Ob, lse + q.wave * R, dlt + q.wave * R, TT + q.wave * TT_WAVE, q.wave, p.Ts, q,
                           dbq, dbk, dbv);
         lds_barrier();
