@@ -122,6 +122,8 @@ SYMBOLS = {
     "hsimae_loss": (C.c_int, [C.POINTER(LossParams), vp]),
     "hsimae_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "hsimae_cube_gather": (C.c_int, [C.POINTER(CubeParams), vp]),
+    "hsimae_encode": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp]),
+    "hsimae_agg_pool": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
 }
 
 A_BF16, A_F32, A_F32_LN = 0, 1, 2

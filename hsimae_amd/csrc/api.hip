@@ -480,10 +480,11 @@ int64_t hsimae_workspace_bytes(const hsimae_config* cfg, int32_t N, int32_t len_
     return w.bytes;
 }
 
-int hsimae_forward(const hsimae_config* cfg, const hsimae_io* io, void* stream) {
+static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* stream, bool encoder_only) {
     Ctx c; CK(make_ctx(cfg, io, c, true));
-    if (!io->x || !io->noise1 || !io->noise2 || !io->loss || !io->mask || !io->ids_keep || !io->ids_restore) return HSIMAE_ENULL;
-    if (io->want_recons && (!io->pred_img || !io->mask_img)) return HSIMAE_ENULL;
+    if (!io->x || !io->noise1 || !io->noise2 || !io->mask || !io->ids_keep || !io->ids_restore) return HSIMAE_ENULL;
+    if (encoder_only ? !io->latent : !io->loss) return HSIMAE_ENULL;
+    if (!encoder_only && io->want_recons && (!io->pred_img || !io->mask_img)) return HSIMAE_ENULL;
     hipStream_t s = S(stream);
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w;
 
@@ -531,6 +532,10 @@ int hsimae_forward(const hsimae_config* cfg, const hsimae_io* io, void* stream) 
         CK(block_fwd(bp, x, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, nullptr, s));
         x = w.bf[i].x2;
     }
+    if (encoder_only) {                       // `norm` only (Models.py:570 / 892): the latent the fine-tuning head reads
+        CK(hs_ln_fwd(x, P + c.L.nw, P + c.L.nb, io->latent, (int)c.Me, g.D, s));
+        return HSIMAE_OK;
+    }
     // norm + decoder_embed (Models.py:570, 579)
     p = gp();
     p.A = x; p.lda = g.D; p.M = (int)c.Me; p.N = g.Dd; p.K = g.D; p.n_valid = g.Dd; p.W = io->wpk + c.W.de; p.bias = P + c.L.deb;
@@ -564,6 +569,9 @@ int hsimae_forward(const hsimae_config* cfg, const hsimae_io* io, void* stream) 
     if (io->latent) CK(hs_ln_fwd(x, P + c.L.nw, P + c.L.nb, io->latent, (int)c.Me, g.D, s));
     return HSIMAE_OK;
 }
+
+int hsimae_forward(const hsimae_config* cfg, const hsimae_io* io, void* stream) { return forward_impl(cfg, io, stream, false); }
+int hsimae_encode(const hsimae_config* cfg, const hsimae_io* io, void* stream) { return forward_impl(cfg, io, stream, true); }
 
 int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads, hsimae_bucket_cb cb, void* user,
                     void* stream) {
@@ -690,6 +698,11 @@ int hsimae_attn_fwd(const hsimae_attn_params* p, void* stream) { return p ? hs_a
 int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream) { return p ? hs_attn_bwd(*p, S(stream)) : HSIMAE_ENULL; }
 int hsimae_wgrad(const hsimae_wgrad_params* p, void* stream) { return p ? hs_wgrad(*p, S(stream)) : HSIMAE_ENULL; }
 int32_t hsimae_wgrad_msplit(int32_t tiles, int64_t M) { return wgrad_msplit(tiles, M); }
+int hsimae_agg_pool(const float* latent, float* pooled, int32_t N, int32_t T, int32_t L, int32_t D, void* stream) {
+    if (N <= 0) return HSIMAE_OK;
+    if (!latent || !pooled) return HSIMAE_ENULL;
+    return hs_agg_pool(latent, pooled, N, T, L, D, S(stream));
+}
 int hsimae_cube_gather(const hsimae_cube_params* p, void* stream) {
     if (!p) return HSIMAE_ENULL;
     if (p->N <= 0) return HSIMAE_OK;

@@ -423,6 +423,25 @@ int hs_loss(const LossParams& p, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// 'AGG' pooling of the fine-tuning head (Models.py:962-970, 1150-1156): latent [N, T*L, D] -> [N, T*D], mean over the
+// L spatial tokens of each spectral group (x.reshape(N,T,L,C).permute(0,2,1,3).reshape(N,L,T*C).mean(1)).
+__global__ __launch_bounds__(256) void agg_pool_kernel(const float* __restrict__ latent, float* __restrict__ pooled, int T, int L,
+                                                        int D) {
+    const int n = blockIdx.x;
+    for (int e = threadIdx.x; e < T * D; e += 256) {
+        const int t = e / D, c = e - t * D;
+        const float* src = latent + ((size_t)n * T * L + (size_t)t * L) * D + c;
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s += src[(size_t)l * D];
+        pooled[(size_t)n * T * D + e] = s / (float)L;
+    }
+}
+
+int hs_agg_pool(const float* latent, float* pooled, int N, int T, int L, int D, hipStream_t s) {
+    hipLaunchKernelGGL(agg_pool_kernel, dim3(N), dim3(256), 0, s, latent, pooled, T, L, D);
+    return (int)hipGetLastError();
+}
+
 int hs_loss_partials(int N, int T) {
     const int64_t M = (int64_t)N * T * 9;
     return (int)((M + LOSS_ROWS_PER_WG - 1) / LOSS_ROWS_PER_WG);

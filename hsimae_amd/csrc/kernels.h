@@ -35,6 +35,7 @@ int hs_assemble_bwd(const AssembleParams& p, hipStream_t s);
 int hs_loss(const LossParams& p, hipStream_t s);
 int hs_loss_partials(int N, int T);
 int hs_cube_gather(const CubeParams& p, hipStream_t s);
+int hs_agg_pool(const float* latent, float* pooled, int N, int T, int L, int D, hipStream_t s);
 int hs_add2(const float* a, const float* b, float* out, int64_t n, hipStream_t s);
 
 // ------------------------------------------------------------------ fused_dec.hip (decoder Block, one workgroup per sample)

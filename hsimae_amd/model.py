@@ -149,6 +149,8 @@ class HSIMAE(nn.Module):
         if s_depth < 12:                                   # the reference hard-codes 12 here (Models.py:385)
             self.blocks = stack(max(0, depth - s_depth), embed_dim, num_heads)
         self.norm = norm_layer(embed_dim)
+        if kwargs.get("_num_class") is not None:           # DualViT registers its head here (Models.py:742)
+            self.cls_head = nn.Linear(embed_dim * self.patch_embed.b_grid_size, kwargs["_num_class"])
         self.mask_token = nn.Parameter(torch.zeros(1, 1, decoder_embed_dim))   # kept for the wire format; unused
         self.decoder_embed = nn.Linear(embed_dim, decoder_embed_dim, bias=True)
         self.decoder_pos_embed = nn.Parameter(torch.zeros(1, n_tok, decoder_embed_dim))
@@ -252,7 +254,7 @@ class HSIMAE(nn.Module):
         return self._cfg
 
     def _plist(self):
-        return [p for _, p in self.named_parameters()]
+        return [p for n, p in self.named_parameters() if not n.startswith("cls_head.")]
 
     def _ensure_flat(self, device):
         """Re-home every Parameter as a view of one flat fp32 buffer in registration order (the layout
@@ -308,7 +310,7 @@ class HSIMAE(nn.Module):
         return self._ws
 
     # ------------------------------------------------------------------ forward / backward drivers
-    def _run_forward(self, imgs, mask_ratio, noise, grid, want_latent):
+    def _run_forward(self, imgs, mask_ratio, noise, grid, want_latent, encoder_only=False):
         if not imgs.is_cuda:
             raise RuntimeError("hsimae_amd.HSIMAE runs on MI355X only (no CPU fallback): move the model and inputs to a GPU")
         if imgs.dim() != 5 or imgs.shape[1] != 1 or imgs.shape[2] != self.patch_embed.bands or imgs.shape[3:] != (9, 9):
@@ -356,7 +358,10 @@ class HSIMAE(nn.Module):
             grad_scale=1.0 / world, want_recons=int(self.want_recons), loss=loss.data_ptr(),
             pred_img=_lib.ptr(pred_img), mask_img=_lib.ptr(mask_img), mask=mask.data_ptr(),
             ids_keep=ids_keep.data_ptr(), ids_restore=ids_restore.data_ptr(), latent=_lib.ptr(latent), pred=None)
-        _lib.check(lib.hsimae_forward(C.byref(cfg), C.byref(io), stream), "hsimae_forward")
+        if encoder_only:
+            _lib.check(lib.hsimae_encode(C.byref(cfg), C.byref(io), stream), "hsimae_encode")
+        else:
+            _lib.check(lib.hsimae_forward(C.byref(cfg), C.byref(io), stream), "hsimae_forward")
         state = {"io": io, "keep": (imgs, n1, n2, mask, ids_keep, ids_restore, ws), "latent": latent,
                  "ids_keep": ids_keep, "ids_restore": ids_restore, "mask": mask}
         if pred_img is None:

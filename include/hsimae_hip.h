@@ -224,6 +224,15 @@ int hsimae_loss(const hsimae_loss_params* p, void* stream);
 int hsimae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* group, int64_t n,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
+/* ------------------------------------------------------------------ next row N3: fine-tuning forward (inference) */
+/* Encoder only, through `norm` (DualViT / HSIViT `forward_encoder`, Models.py:869-894, 1119-1146): same io as
+ * hsimae_forward; io->latent [N, len_t*len_l, embed_dim] is required, loss / pred / recons outputs are not touched.
+ * For the unmasked encoder pass len_t = T, len_l = 9 and increasing noise (ids_keep = identity). */
+int hsimae_encode(const hsimae_config* cfg, const hsimae_io* io, void* stream);
+/* 'AGG' pooling of the classification head (Models.py:962-970): [N, T*L, D] -> [N, T*D], mean over the L tokens of
+ * each spectral group; the Linear that follows is hsimae_gemm(A_F32, E_F32). */
+int hsimae_agg_pool(const float* latent, float* pooled, int32_t N, int32_t T, int32_t L, int32_t D, void* stream);
+
 /* ------------------------------------------------------------------ next row N2: input pipeline */
 /* One batch of training cubes assembled on the device from HBM-resident scenes (Model_Pretraining.py:40-51
  * `HSIdataset4PT.__getitem__`): window [h:h+9, w:w+9, :] of scene `num`, (x - min) / (max - min) in the scenes'

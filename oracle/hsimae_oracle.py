@@ -321,6 +321,26 @@ def forward(P: dict, cfg: OracleConfig, imgs: torch.Tensor, noise_1, noise_2, le
     return loss, pred_img, mask_img
 
 
+def encode_unmasked(P: dict, cfg: OracleConfig, imgs: torch.Tensor) -> torch.Tensor:
+    """DualViT / HSIViT `forward_encoder` (Models.py:869-894, 1119-1146): every token kept, natural order.
+    Same arithmetic as the masked encoder with the full (T, L) grid; increasing noise makes ids_keep the identity."""
+    N = imgs.shape[0]
+    taps = {}
+    n1 = np.tile(np.arange(cfg.T, dtype=np.float32), (N, 1))
+    n2 = np.tile(np.arange(cfg.L, dtype=np.float32), (N, 1))
+    forward(P, cfg, imgs, n1, n2, cfg.T, cfg.L, taps)           # decoder / loss results are unused (nothing is masked)
+    assert bool((taps["ids_keep"] == torch.arange(cfg.T * cfg.L)).all())
+    return taps["latent"]
+
+
+def dualvit_classify(P: dict, cfg: OracleConfig, imgs: torch.Tensor):
+    """DualViT.forward(imgs) in eval mode (Models.py:975-977, head 'AGG' :962-970) -> (class_pred, pooled)."""
+    lat = encode_unmasked(P, cfg, imgs)
+    N = lat.shape[0]
+    x = lat.reshape(N, cfg.T, cfg.L, cfg.embed_dim).permute(0, 2, 1, 3).reshape(N, cfg.L, -1).mean(1)
+    return F.linear(x, P["cls_head.weight"], P["cls_head.bias"]), x
+
+
 def forward_backward(P: dict, cfg: OracleConfig, imgs, noise_1, noise_2, len_t, len_l, taps=None):
     """Forward + autograd backward of the restatement. Returns (loss, pred, mask, grads)."""
     frozen = ("pos_embed", "decoder_pos_embed")
