@@ -312,14 +312,15 @@ __device__ __forceinline__ void attn_head_fwd(const bf16_t* Qb, const bf16_t* Kb
                                               int Ts, const Geo4& q, float* lse_out) {
     using L = DL<MT>;
     const float sc = 0.35355339059327373f * 1.4426950408889634f;     // 8^-0.5 * log2(e)
-    const bf16_t* vth = Vt + head * HD * L::VST;
+    const bf16_t* vrow = Vt + ((head * HD + q.c16) & 63) * L::VST;
+    const int kcol = (head * HD + 8 * q.g) & 63;
     for (int qt = 0; qt * 16 < Ts; ++qt) {
         const int query = qt * 16 + q.c16;
         const bf16x8 bq = rowfrag8(Qb, LU, query, head * HD, q.g);
         f32x4 s[MT];
 #pragma unroll
-        for (int kt = 0; kt < MT; ++kt)
-            s[kt] = mfma16(rowfrag8(Kb, LU, kt * 16 + q.c16, head * HD, q.g), bq, f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int kt = 0; kt < MT; ++kt)       // K side unmasked: lane groups 1-3 read other heads' (finite) columns against bq's zeros
+            s[kt] = mfma16(*reinterpret_cast<const bf16x8*>(Kb + (kt * 16 + q.c16) * LU + kcol), bq, f32x4{0.f, 0.f, 0.f, 0.f});
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < MT; ++kt) {
@@ -352,7 +353,11 @@ __device__ __forceinline__ void attn_head_fwd(const bf16_t* Qb, const bf16_t* Kb
             const int ta = 2 * pp, tb = 2 * pp + 1;
             const bool tb_ok = tb < MT;
             const bf16x8 bp = pack2(s[ta], tb_ok ? s[tb_ok ? tb : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
-            o = mfma16(trfrag8(vth, L::VST, q.c16, ta, tb, tb_ok, q.g), bp, o);
+            // V^T rows past the head's 8 (c16 >= 8) are other heads' rows: they only reach output rows nobody stores
+            const u32x2 vlo = *reinterpret_cast<const u32x2*>(vrow + ta * 16 + q.g * 4);
+            const u32x2 vhi = *reinterpret_cast<const u32x2*>(vrow + (tb_ok ? tb : ta) * 16 + q.g * 4);
+            const u32x4 vv = {vlo[0], vlo[1], vhi[0], vhi[1]};
+            o = mfma16(__builtin_bit_cast(bf16x8, vv), bp, o);
         }
         if (q.g < 2) {
             bf16x4 ov;
