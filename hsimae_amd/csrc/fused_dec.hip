@@ -295,17 +295,6 @@ __device__ __forceinline__ bf16x8 rowfrag8(const bf16_t* img, int ld, int row, i
     return zero8();
 }
 
-__device__ __forceinline__ bf16x8 trfrag8(const bf16_t* vt, int vst, int drow, int ta, int tb, bool tb_ok, int g) {
-    if (drow < HD) {
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(vt + drow * vst + ta * 16 + g * 4);
-        u32x2 hi = {0u, 0u};
-        if (tb_ok) hi = *reinterpret_cast<const u32x2*>(vt + drow * vst + tb * 16 + g * 4);
-        u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-        return __builtin_bit_cast(bf16x8, v);
-    }
-    return zero8();
-}
-
 // One head of full (unmasked) attention over the sample's Ts tokens; writes O (bf16) into `O` columns head*8..
 template <int MT>
 __device__ __forceinline__ void attn_head_fwd(const bf16_t* Qb, const bf16_t* Kb, const bf16_t* Vt, bf16_t* O, int head,
@@ -575,49 +564,8 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
 // Everything else (u, q, k, v, P, o, h1, h3, g) is recomputed from x / x1 inside the tile.
 typedef __attribute__((address_space(3))) bf16x4* lds_b64;
 
-// MFMA operand whose k index runs over image ROWS (tokens): element j<4 = img[rowa + 4g + j][col0 + c16],
-// j>=4 = img[rowb + 4g + (j-4)][col0 + c16], via two transpose reads (EXEC must be full).
-__device__ __forceinline__ bf16x8 trfrag(const bf16_t* img, int ld, int rowa, int rowb, bool b_ok, int col0, bool lane_ok,
-                                         const Geo4& q) {
-    const int q4 = q.c16 >> 2, p4 = q.c16 & 3;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + (rowa + 4 * q.g + q4) * ld + col0 + 4 * p4));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + ((b_ok ? rowb : rowa) + 4 * q.g + q4) * ld + col0 + 4 * p4));
-    bf16x8 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        r[e] = lane_ok ? lo[e] : (bf16_t)0.f;
-        r[4 + e] = (lane_ok && b_ok) ? hi[e] : (bf16_t)0.f;
-    }
-    return r;
-}
-
-// 16x16 tile of  dO[:, n0..n0+15]^T * A[:, k0..k0+15]  summed over the R image rows (32 per MFMA).
-template <int MT>
-__device__ __forceinline__ void wg_tile(const bf16_t* dO, int n0, const bf16_t* A, int k0, const Geo4& q, f32x4& acc) {
-    constexpr int R = MT * 16;
-#pragma unroll
-    for (int kk = 0; kk < (R + 31) / 32; ++kk) {
-        const bool b_ok = kk * 32 + 16 < R;              // second 16-row half exists
-        // element j of lane group g is row kk*32 + 8g + j: as two 4-row reads at rows kk*32+8g and kk*32+8g+4
-        const int q4 = q.c16 >> 2, p4 = q.c16 & 3;
-        const bool ok = kk * 32 + 8 * q.g < R;
-        const int rb = ok ? kk * 32 + 8 * q.g : kk * 32;
-        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(dO + (rb + q4) * LU + n0 + 4 * p4));
-        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(dO + (rb + 4 + q4) * LU + n0 + 4 * p4));
-        const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(A + (rb + q4) * LU + k0 + 4 * p4));
-        const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(A + (rb + 4 + q4) * LU + k0 + 4 * p4));
-        (void)b_ok;
-        bf16x8 a, b;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a[e] = ok ? a0[e] : (bf16_t)0.f; a[4 + e] = ok ? a1[e] : (bf16_t)0.f;
-            b[e] = ok ? b0[e] : (bf16_t)0.f; b[4 + e] = ok ? b1[e] : (bf16_t)0.f;
-        }
-        acc = mfma16(a, b, acc);
-    }
-}
-
-// Row (token) fragment pair for one k-step of a weight-gradient product (see wg_tile), zeroed past row R.
+// Row (token) fragment pair for one k-step of a weight-gradient product  dO[:, n0..]^T * A[:, k0..]  (contraction over
+// the image rows, 32 per MFMA): element j of lane group g = img[kk*32 + 8g + j][col0 + c16], zeroed past row R.
 // TAIL = the k-step that runs past row R (R % 32 == 16): lane groups 2,3 would read rows >= R and supply zeros
 // instead.  Full k-steps skip the per-element selects (they were ~40 % of the backward kernels' VALU work).
 template <int MT, bool TAIL>
@@ -1408,42 +1356,9 @@ int launch_bwd(const DecBwdMlpArgs& a, const DecBwdAttnArgs& b, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <int MT>
-int launch_bwd_attn(const DecBwdAttnArgs& b, hipStream_t s) {
-    using L = DL<MT>;
-    constexpr int IMG = L::R * LU * 2;
-    constexpr int LDS_B = L::BWD_ATTN_LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_attn_kernel<MT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
-        attr_set = true;
-    }
-    const int grid = b.nsamples < 256 ? b.nsamples : 256;
-    hipLaunchKernelGGL((dec_bwd_attn_kernel<MT>), dim3(grid), dim3(NT_), LDS_B, s, b);
-    return (int)hipGetLastError();
-}
-
 bool hs_dec_fused_supported(int d, int heads, int hidden, int Ts) {
     // the backward kernels keep 5-6 bf16 images + an fp32 tile of the sample in LDS: up to 7 m-tiles (112 tokens)
     return d == D && heads == 8 && hidden <= HPD && hidden % 4 == 0 && Ts <= 112 && Ts >= 16;
-}
-
-int hs_dec_bwd_attn(const float* x, const float* dx1, float* dx, const hs_bf16* o, const float* lse, int nsamples, int Ts,
-                    const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s) {
-    DecW w;
-    w.n1w = bp.n1w; w.n1b = bp.n1b; w.bqkv = bp.bqkv; w.pb = bp.pb; w.n2w = bp.n2w; w.n2b = bp.n2b;
-    w.w1b = bp.w1b; w.w3b = bp.w3b; w.w2b = bp.w2b;
-    w.qkv = bp.qkv; w.p = bp.p; w.w1 = bp.w1; w.w3 = bp.w3; w.w2 = bp.w2; w.h = bp.h;
-    DecBwdAttnArgs b;
-    b.x = x; b.dx1 = dx1; b.dx = dx; b.o = o; b.lse_g = lse; b.nsamples = nsamples; b.Ts = Ts; b.w = w; b.qkvT = bp.qkvT; b.pT = bp.pT;
-    b.qf = bp.qf; b.kf = bp.kf; b.vf = bp.vf; b.pf = bp.pf;
-    b.g_n1w = g.n1w; b.g_n1b = g.n1b; b.g_qw = g.qw; b.g_qb = g.qb; b.g_kw = g.kw; b.g_kb = g.kb; b.g_vw = g.vw;
-    b.g_vb = g.vb; b.g_pw = g.pw; b.g_pb = g.pb;
-    const int mt = (Ts + 15) / 16;
-    if (mt <= 4) return launch_bwd_attn<4>(b, s);
-    if (mt <= 7) return launch_bwd_attn<7>(b, s);
-    return HS_EUNSUPPORTED;
 }
 
 int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o,
