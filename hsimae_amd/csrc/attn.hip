@@ -13,6 +13,7 @@
 // recomputes the scores in both orientations instead of transposing dS through LDS.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -317,6 +318,259 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Head dim 16 (every encoder attention): second-generation kernels.
+//   * K = 16 MFMAs (`v_mfma_f32_16x16x16_bf16`): the head dim fills the contraction exactly, no zero-padded half;
+//   * row-major LDS images only: the operands that need the token index on the contraction axis (V^T, K^T, Q^T, dO^T)
+//     are read with `ds_read_b64_tr_b16` instead of being stored a second time transposed with 2-byte writes
+//     (1,300 ds_write_b16 per wave in the first backward kernel);
+//   * backward in ONE pass over the (query tile, key tile) grid: scores key-major (directly the B operand of dq^T),
+//     P and dS transposed through a 1.5 KB per-wave LDS tile for dk^T / dv^T — no second score / exp pass.
+// Same work decomposition: one workgroup = one sample x 4 heads, one wave per head.
+typedef __attribute__((ext_vector_type(4))) short s16x4_;
+typedef __attribute__((address_space(3))) bf16x4* lds_b64_p;
+__device__ __forceinline__ f32x4 mfma_k16(bf16x4 a, bf16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_, a), __builtin_bit_cast(s16x4_, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4 tr4(const bf16_t* a) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_p)(a)); }
+__device__ __forceinline__ bf16x4 cvt4(f32x4 v) {
+    bf16x4 r;
+    r[0] = (bf16_t)v[0]; r[1] = (bf16_t)v[1]; r[2] = (bf16_t)v[2]; r[3] = (bf16_t)v[3];
+    return r;
+}
+
+constexpr int RS16 = 24;          // image row stride (elements): 16 + 8 pad => conflict-free 8-byte row reads
+
+template <int NT>
+struct Lay16 {
+    static constexpr int ROWS = NT * 16;
+    static constexpr int IMG = ROWS * RS16;                               // elements per image
+    static constexpr int CLS = ROWS * 4;
+    static constexpr int FWD_WAVE = 3 * IMG * 2;                          // Q K V
+    static constexpr int BWD_WAVE = 4 * IMG * 2 + 2 * ROWS * 4 + 2 * 16 * RS16 * 2;   // Q K V dO | lse delta | T(P, dS)
+};
+
+// rows [0, Ts) of one head's slice -> row-major image; rows [Ts, ROWS) zero (finite: P = 0 there, but 0 * NaN = NaN)
+template <int NT>
+__device__ __forceinline__ void load16(const bf16_t* src, int ld, int Ts, int lane, bf16_t* img) {
+    for (int idx = lane; idx < NT * 16 * 2; idx += 64) {
+        const int tok = idx >> 1, pc = idx & 1;
+        bf16x8 v = zero8();
+        if (tok < Ts) v = *reinterpret_cast<const bf16x8*>(src + (size_t)tok * ld + pc * 8);
+        *reinterpret_cast<bf16x8*>(img + tok * RS16 + pc * 8) = v;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void attn16_fwd_kernel(AttnParams p) {
+    using L = Lay16<NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hgroups = (p.heads + 3) / 4;
+    const int sample = blockIdx.x / hgroups, head = (blockIdx.x % hgroups) * 4 + wave;
+    const bool active = head < p.heads;
+    int* cls = reinterpret_cast<int*>(smem);
+    bf16_t* Qi = reinterpret_cast<bf16_t*>(smem + L::CLS + wave * L::FWD_WAVE);
+    bf16_t* Ki = Qi + L::IMG;
+    bf16_t* Vi = Ki + L::IMG;
+    for (int i = threadIdx.x; i < L::ROWS; i += 256) {
+        int c = -1;
+        if (i < p.Ts) c = (p.mode == 1) ? i / p.len_l : (p.mode == 2) ? i % p.len_l : 0;
+        cls[i] = c;
+    }
+    const size_t row_base = (size_t)sample * p.Ts;
+    if (active) {
+        const bf16_t* base = p.qkv + row_base * p.ld + head * 16;
+        load16<NT>(base, p.ld, p.Ts, lane, Qi);
+        load16<NT>(base + p.d, p.ld, p.Ts, lane, Ki);
+        load16<NT>(base + 2 * p.d, p.ld, p.Ts, lane, Vi);
+    }
+    lds_barrier();
+    if (!active) return;
+
+    const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3;
+    const float sc = 0.25f * 1.4426950408889634f;               // 16^-0.5 * log2(e)
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < NT; ++qt) {
+        if (qt * 16 >= p.Ts) break;
+        const int query = qt * 16 + c16;
+        const int qcls = cls[query];
+        const bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qi + query * RS16 + 4 * g);
+        f32x4 s[NT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Ki + (kt * 16 + c16) * RS16 + 4 * g);
+            s[kt] = mfma_k16(ak, bq, z4);
+            const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
+            const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
+                s[kt][r] = ok ? s[kt][r] * sc : -INFINITY;
+                m = fmaxf(m, s[kt][r]);
+            }
+        }
+        m = group_max(m);
+        if (m == -INFINITY) m = 0.f;
+        float lsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - m);
+                s[kt][r] = e;
+                lsum += e;
+            }
+        lsum = group_sum(lsum);
+        const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+        f32x4 o = z4;                                           // o^T[d = 4g + r][query c16]
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const bf16x4 av = tr4(Vi + (kt * 16 + 4 * g + q4) * RS16 + 4 * p4);      // V^T[d = c16][key 4g + j]
+            o = mfma_k16(av, cvt4(s[kt]), o);
+        }
+        if (query < p.Ts) {
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
+            *reinterpret_cast<bf16x4*>(p.o + (row_base + query) * p.ldo + head * 16 + g * 4) = ov;
+            if (g == 0 && p.lse) p.lse[(row_base + query) * p.heads + head] = m + __builtin_amdgcn_logf(fmaxf(lsum, 1e-30f));
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void attn16_bwd_kernel(AttnParams p) {
+    using L = Lay16<NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hgroups = (p.heads + 3) / 4;
+    const int sample = blockIdx.x / hgroups, head = (blockIdx.x % hgroups) * 4 + wave;
+    const bool active = head < p.heads;
+    int* cls = reinterpret_cast<int*>(smem);
+    bf16_t* Qi = reinterpret_cast<bf16_t*>(smem + L::CLS + wave * L::BWD_WAVE);
+    bf16_t* Ki = Qi + L::IMG;
+    bf16_t* Vi = Ki + L::IMG;
+    bf16_t* Di = Vi + L::IMG;
+    float* lse = reinterpret_cast<float*>(Di + L::IMG);
+    float* delta = lse + L::ROWS;
+    bf16_t* Tp = reinterpret_cast<bf16_t*>(delta + L::ROWS);
+    bf16_t* Td = Tp + 16 * RS16;
+    for (int i = threadIdx.x; i < L::ROWS; i += 256) {
+        int c = -1;
+        if (i < p.Ts) c = (p.mode == 1) ? i / p.len_l : (p.mode == 2) ? i % p.len_l : 0;
+        cls[i] = c;
+    }
+    const size_t row_base = (size_t)sample * p.Ts;
+    if (active) {
+        const bf16_t* base = p.qkv + row_base * p.ld + head * 16;
+        load16<NT>(base, p.ld, p.Ts, lane, Qi);
+        load16<NT>(base + p.d, p.ld, p.Ts, lane, Ki);
+        load16<NT>(base + 2 * p.d, p.ld, p.Ts, lane, Vi);
+        load16<NT>(p.dout + row_base * p.lddo + head * 16, p.lddo, p.Ts, lane, Di);
+        for (int tok = lane; tok < L::ROWS; tok += 64) {
+            float acc = 0.f, l = 1e30f;                          // rows past Ts: exp2(s - 1e30) = 0
+            if (tok < p.Ts) {
+                const bf16_t* orow = p.o + (row_base + tok) * p.ldo + head * 16;
+                const bf16_t* drow = p.dout + (row_base + tok) * p.lddo + head * 16;
+#pragma unroll
+                for (int e = 0; e < 16; e += 8) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(orow + e);
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(drow + e);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc += bf2f(a[i]) * bf2f(b[i]);
+                }
+                l = p.lse[(row_base + tok) * p.heads + head];
+            }
+            delta[tok] = acc;
+            lse[tok] = l;
+        }
+    }
+    lds_barrier();
+    if (!active) return;
+
+    const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3;
+    const float scale = 0.25f, sc = 0.25f * 1.4426950408889634f;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int troff = (4 * g + q4) * RS16 + 4 * p4;
+    bf16_t* dq_base = p.dqkv + row_base * p.ld + head * 16;
+    f32x4 dkT[NT], dvT[NT];                       // [d = 4g + r][key c16], accumulated over the query tiles
+    bf16x4 KT[NT];                                // K^T[d = c16][key 4g + j]
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) { dkT[kt] = z4; dvT[kt] = z4; KT[kt] = tr4(Ki + kt * 16 * RS16 + troff); }
+    for (int qt = 0; qt < NT; ++qt) {
+        if (qt * 16 >= p.Ts) break;
+        const int query = qt * 16 + c16;
+        const int qcls = cls[query];
+        const bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qi + query * RS16 + 4 * g);
+        const bf16x4 bdo = *reinterpret_cast<const bf16x4*>(Di + query * RS16 + 4 * g);
+        const float lqn = -lse[query], dl = delta[query];
+        const bf16x4 QT = tr4(Qi + qt * 16 * RS16 + troff);      // Q^T[d = c16][query 4g + j]
+        const bf16x4 DT = tr4(Di + qt * 16 * RS16 + troff);
+        f32x4 dqT = z4;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Ki + (kt * 16 + c16) * RS16 + 4 * g);
+            const bf16x4 av = *reinterpret_cast<const bf16x4*>(Vi + (kt * 16 + c16) * RS16 + 4 * g);
+            const f32x4 s = mfma_k16(ak, bq, z4);                // S^T[key 4g + r][query c16]
+            const f32x4 dp = mfma_k16(av, bdo, z4);
+            const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
+            const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
+            f32x4 pv, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
+                pv[r] = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn)) : 0.f;
+                ds[r] = pv[r] * (dp[r] - dl);
+            }
+            const bf16x4 pb = cvt4(pv), dsb = cvt4(ds);
+            dqT = mfma_k16(KT[kt], dsb, dqT);
+            *reinterpret_cast<bf16x4*>(Tp + c16 * RS16 + 4 * g) = pb;
+            *reinterpret_cast<bf16x4*>(Td + c16 * RS16 + 4 * g) = dsb;
+            asm volatile("" ::: "memory");
+            const bf16x4 Bp = tr4(Tp + troff), Bds = tr4(Td + troff);       // [k = query 4g + j][col key c16]
+            dkT[kt] = mfma_k16(QT, Bds, dkT[kt]);
+            dvT[kt] = mfma_k16(DT, Bp, dvT[kt]);
+        }
+        if (query < p.Ts) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dqT[r] * scale);
+            *reinterpret_cast<bf16x4*>(dq_base + (size_t)query * p.ld + g * 4) = v;
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        const int key = kt * 16 + c16;
+        if (key < p.Ts) {
+            bf16x4 vk, vv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vk[r] = (bf16_t)(dkT[kt][r] * scale); vv[r] = (bf16_t)dvT[kt][r]; }
+            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + p.d + g * 4) = vk;
+            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + 2 * p.d + g * 4) = vv;
+        }
+    }
+}
+
+template <int NT, bool BWD>
+int launch_attn16(const AttnParams& p, hipStream_t s) {
+    using L = Lay16<NT>;
+    const int hgroups = (p.heads + 3) / 4;
+    const size_t lds = L::CLS + 4 * (size_t)(BWD ? L::BWD_WAVE : L::FWD_WAVE);
+    static bool attr_set = false;
+    if constexpr (BWD) {
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<NT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+        hipLaunchKernelGGL((attn16_bwd_kernel<NT>), dim3(p.nsamples * hgroups), dim3(256), lds, s, p);
+    } else {
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_fwd_kernel<NT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+        hipLaunchKernelGGL((attn16_fwd_kernel<NT>), dim3(p.nsamples * hgroups), dim3(256), lds, s, p);
+    }
+    return (int)hipGetLastError();
+}
+
 template <int HD, int NT, bool BWD>
 int launch_attn(const AttnParams& p, hipStream_t s) {
     using L = Lay<HD, NT>;
@@ -341,6 +595,15 @@ int dispatch(const AttnParams& p, hipStream_t s) {
     if (p.nsamples <= 0) return HS_OK;
     if (p.d != p.heads * p.hd || p.ld % 8 || p.ldo % 4) return HS_EDIMS;
     const int nt = (p.Ts + 15) / 16;
+    static int v2 = -1;                      // HSIMAE_ATTN16_V2=0: first-generation head-dim-16 kernels (A/B tests)
+    if (v2 < 0) { const char* e = getenv("HSIMAE_ATTN16_V2"); v2 = !(e && e[0] == '0'); }
+    if (p.hd == 16 && v2 && p.lse) {
+        if (nt <= 1) return launch_attn16<1, BWD>(p, s);
+        if (nt <= 2) return launch_attn16<2, BWD>(p, s);
+        if (nt <= 3) return launch_attn16<3, BWD>(p, s);
+        if (nt <= 4) return launch_attn16<4, BWD>(p, s);
+        if (nt <= 7) return launch_attn16<7, BWD>(p, s);
+    }
     if (p.hd == 16) {
         if (nt <= 1) return launch_attn<16, 1, BWD>(p, s);
         if (nt <= 2) return launch_attn<16, 2, BWD>(p, s);
