@@ -553,6 +553,232 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(AttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// d = 128 (8 heads of 16), sequences of at most 32 tokens (every masked encoder attention of Base): third generation.
+// One workgroup = one SAMPLE, 8 waves = 8 heads.  The sample's q|k|v rows (and dO, O in the backward) are contiguous
+// in HBM (27 x 768 B): they are staged into full-row LDS images with fully coalesced 16-byte loads, each wave works on
+// its 16 columns of the images, results are written back in place and leave as whole rows.  The per-head kernels
+// above fetch 32-byte pieces at a 768-byte stride (one request per row per matrix per wave) and write 8-byte pieces.
+constexpr int FS = 128 + 8;        // full-row image stride (elements)
+
+template <int NT>
+struct LayF {
+    static constexpr int ROWS = NT * 16;
+    static constexpr int IMG = ROWS * FS;
+    static constexpr int FWD = ROWS * 4 + 3 * IMG * 2 + ROWS * 8 * 4;                                   // cls | Q K V | lse
+    static constexpr int BWD = ROWS * 4 + 4 * IMG * 2 + 2 * 8 * ROWS * 4 + 8 * 2 * 16 * RS16 * 2;       // cls | Q K V dO | lse delta | T
+};
+
+template <int NT>
+__device__ __forceinline__ void fill_cls_f(int* cls, const AttnParams& p) {
+    for (int i = threadIdx.x; i < NT * 16; i += 512) {
+        int c = -1;
+        if (i < p.Ts) c = (p.mode == 1) ? i / p.len_l : (p.mode == 2) ? i % p.len_l : 0;
+        cls[i] = c;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void attn128_fwd_kernel(AttnParams p) {
+    using L = LayF<NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int* cls = reinterpret_cast<int*>(smem);
+    bf16_t* Qf = reinterpret_cast<bf16_t*>(smem + L::ROWS * 4);
+    bf16_t* Kf = Qf + L::IMG;
+    bf16_t* Vf = Kf + L::IMG;
+    float* lse_s = reinterpret_cast<float*>(Vf + L::IMG);       // [ROWS][8]
+    const size_t row_base = (size_t)blockIdx.x * p.Ts;
+    fill_cls_f<NT>(cls, p);
+    for (int idx = threadIdx.x; idx < L::ROWS * 48; idx += 512) {
+        const int row = idx / 48, pc = idx - row * 48;
+        bf16x8 v = zero8();
+        if (row < p.Ts) v = *reinterpret_cast<const bf16x8*>(p.qkv + (row_base + row) * p.ld + pc * 8);
+        *reinterpret_cast<bf16x8*>(Qf + (pc >> 4) * L::IMG + row * FS + (pc & 15) * 8) = v;
+    }
+    lds_barrier();
+    const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3, hc = head * 16;
+    const float sc = 0.25f * 1.4426950408889634f;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < NT; ++qt) {
+        if (qt * 16 >= p.Ts) break;
+        const int query = qt * 16 + c16;
+        const int qcls = cls[query];
+        const bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qf + query * FS + hc + 4 * g);
+        f32x4 s[NT];
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (kt * 16 + c16) * FS + hc + 4 * g);
+            s[kt] = mfma_k16(ak, bq, z4);
+            const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
+            const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
+                s[kt][r] = ok ? s[kt][r] * sc : -INFINITY;
+                m = fmaxf(m, s[kt][r]);
+            }
+        }
+        m = group_max(m);
+        if (m == -INFINITY) m = 0.f;
+        float lsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - m);
+                s[kt][r] = e;
+                lsum += e;
+            }
+        lsum = group_sum(lsum);
+        const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+        f32x4 o = z4;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+            o = mfma_k16(tr4(Vf + (kt * 16 + 4 * g + q4) * FS + hc + 4 * p4), cvt4(s[kt]), o);
+        bf16x4 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
+        // in place over this head's q columns of the finished query tile (no other wave reads them)
+        *reinterpret_cast<bf16x4*>(Qf + query * FS + hc + 4 * g) = ov;
+        if (g == 0) lse_s[query * 8 + head] = m + __builtin_amdgcn_logf(fmaxf(lsum, 1e-30f));
+    }
+    lds_barrier();
+    for (int idx = threadIdx.x; idx < p.Ts * 16; idx += 512) {
+        const int row = idx >> 4, pc = idx & 15;
+        *reinterpret_cast<bf16x8*>(p.o + (row_base + row) * p.ldo + pc * 8) = *reinterpret_cast<const bf16x8*>(Qf + row * FS + pc * 8);
+    }
+    for (int idx = threadIdx.x; idx < p.Ts * 2; idx += 512)
+        *reinterpret_cast<float4*>(p.lse + row_base * 8 + idx * 4) = *reinterpret_cast<const float4*>(lse_s + idx * 4);
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void attn128_bwd_kernel(AttnParams p) {
+    using L = LayF<NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int* cls = reinterpret_cast<int*>(smem);
+    bf16_t* Qf = reinterpret_cast<bf16_t*>(smem + L::ROWS * 4);
+    bf16_t* Kf = Qf + L::IMG;
+    bf16_t* Vf = Kf + L::IMG;
+    bf16_t* Df = Vf + L::IMG;
+    float* lse_s = reinterpret_cast<float*>(Df + L::IMG);       // [8][ROWS]
+    float* dlt_s = lse_s + 8 * L::ROWS;                         // [8][ROWS]
+    bf16_t* Tp = reinterpret_cast<bf16_t*>(dlt_s + 8 * L::ROWS) + head * (2 * 16 * RS16);
+    bf16_t* Td = Tp + 16 * RS16;
+    const size_t row_base = (size_t)blockIdx.x * p.Ts;
+    fill_cls_f<NT>(cls, p);
+    for (int idx = threadIdx.x; idx < L::ROWS * 48; idx += 512) {
+        const int row = idx / 48, pc = idx - row * 48;
+        bf16x8 v = zero8();
+        if (row < p.Ts) v = *reinterpret_cast<const bf16x8*>(p.qkv + (row_base + row) * p.ld + pc * 8);
+        *reinterpret_cast<bf16x8*>(Qf + (pc >> 4) * L::IMG + row * FS + (pc & 15) * 8) = v;
+    }
+    for (int idx = threadIdx.x; idx < L::ROWS * 16; idx += 512) {       // dO rows + delta = rowsum(dO * O) per head
+        const int row = idx >> 4, pc = idx & 15;
+        bf16x8 d = zero8(), o = zero8();
+        if (row < p.Ts) {
+            d = *reinterpret_cast<const bf16x8*>(p.dout + (row_base + row) * p.lddo + pc * 8);
+            o = *reinterpret_cast<const bf16x8*>(p.o + (row_base + row) * p.ldo + pc * 8);
+        }
+        *reinterpret_cast<bf16x8*>(Df + row * FS + pc * 8) = d;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += bf2f(d[i]) * bf2f(o[i]);
+        acc += __shfl_xor(acc, 1, 64);                                   // the head's two 8-column pieces are adjacent lanes
+        if (!(pc & 1)) dlt_s[(pc >> 1) * L::ROWS + row] = acc;
+    }
+    for (int idx = threadIdx.x; idx < L::ROWS * 8; idx += 512) {
+        const int row = idx >> 3, h = idx & 7;
+        lse_s[h * L::ROWS + row] = row < p.Ts ? p.lse[(row_base + row) * 8 + h] : 1e30f;       // past Ts: exp2(s - 1e30) = 0
+    }
+    lds_barrier();
+
+    const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3, hc = head * 16;
+    const float scale = 0.25f, sc = 0.25f * 1.4426950408889634f;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int troff = (4 * g + q4) * FS + hc + 4 * p4;
+    const int ttoff = (4 * g + q4) * RS16 + 4 * p4;
+    const float* lse_h = lse_s + head * L::ROWS;
+    const float* dlt_h = dlt_s + head * L::ROWS;
+    f32x4 dkT[NT], dvT[NT];
+    bf16x4 KT[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) { dkT[kt] = z4; dvT[kt] = z4; KT[kt] = tr4(Kf + kt * 16 * FS + troff); }
+    for (int qt = 0; qt < NT; ++qt) {
+        if (qt * 16 >= p.Ts) break;
+        const int query = qt * 16 + c16;
+        const int qcls = cls[query];
+        const bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qf + query * FS + hc + 4 * g);
+        const bf16x4 bdo = *reinterpret_cast<const bf16x4*>(Df + query * FS + hc + 4 * g);
+        const float lqn = -lse_h[query], dl = dlt_h[query];
+        const bf16x4 QT = tr4(Qf + qt * 16 * FS + troff);
+        const bf16x4 DT = tr4(Df + qt * 16 * FS + troff);
+        f32x4 dqT = z4;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (kt * 16 + c16) * FS + hc + 4 * g);
+            const bf16x4 av = *reinterpret_cast<const bf16x4*>(Vf + (kt * 16 + c16) * FS + hc + 4 * g);
+            const f32x4 s = mfma_k16(ak, bq, z4);
+            const f32x4 dp = mfma_k16(av, bdo, z4);
+            const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
+            const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
+            f32x4 pv, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
+                pv[r] = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn)) : 0.f;
+                ds[r] = pv[r] * (dp[r] - dl);
+            }
+            const bf16x4 pb = cvt4(pv), dsb = cvt4(ds);
+            dqT = mfma_k16(KT[kt], dsb, dqT);
+            *reinterpret_cast<bf16x4*>(Tp + c16 * RS16 + 4 * g) = pb;
+            *reinterpret_cast<bf16x4*>(Td + c16 * RS16 + 4 * g) = dsb;
+            asm volatile("" ::: "memory");
+            const bf16x4 Bp = tr4(Tp + ttoff), Bds = tr4(Td + ttoff);
+            dkT[kt] = mfma_k16(QT, Bds, dkT[kt]);
+            dvT[kt] = mfma_k16(DT, Bp, dvT[kt]);
+        }
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dqT[r] * scale);
+        *reinterpret_cast<bf16x4*>(Qf + query * FS + hc + 4 * g) = v;       // dq in place (this head's columns, finished tile)
+    }
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {                                        // dk, dv in place: every read of K / V is done
+        const int key = kt * 16 + c16;
+        bf16x4 vk, vv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { vk[r] = (bf16_t)(dkT[kt][r] * scale); vv[r] = (bf16_t)dvT[kt][r]; }
+        *reinterpret_cast<bf16x4*>(Kf + key * FS + hc + 4 * g) = vk;
+        *reinterpret_cast<bf16x4*>(Vf + key * FS + hc + 4 * g) = vv;
+    }
+    lds_barrier();
+    for (int idx = threadIdx.x; idx < p.Ts * 48; idx += 512) {
+        const int row = idx / 48, pc = idx - row * 48;
+        *reinterpret_cast<bf16x8*>(p.dqkv + (row_base + row) * p.ld + pc * 8) =
+            *reinterpret_cast<const bf16x8*>(Qf + (pc >> 4) * L::IMG + row * FS + (pc & 15) * 8);
+    }
+}
+
+template <int NT, bool BWD>
+int launch_attn128(const AttnParams& p, hipStream_t s) {
+    using L = LayF<NT>;
+    const size_t lds = BWD ? L::BWD : L::FWD;
+    static bool attr_set = false;
+    if constexpr (BWD) {
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn128_bwd_kernel<NT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+        hipLaunchKernelGGL((attn128_bwd_kernel<NT>), dim3(p.nsamples), dim3(512), lds, s, p);
+    } else {
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn128_fwd_kernel<NT>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+        hipLaunchKernelGGL((attn128_fwd_kernel<NT>), dim3(p.nsamples), dim3(512), lds, s, p);
+    }
+    return (int)hipGetLastError();
+}
+
 template <int NT, bool BWD>
 int launch_attn16(const AttnParams& p, hipStream_t s) {
     using L = Lay16<NT>;
@@ -597,6 +823,13 @@ int dispatch(const AttnParams& p, hipStream_t s) {
     const int nt = (p.Ts + 15) / 16;
     static int v2 = -1;                      // HSIMAE_ATTN16_V2=0: first-generation head-dim-16 kernels (A/B tests)
     if (v2 < 0) { const char* e = getenv("HSIMAE_ATTN16_V2"); v2 = !(e && e[0] == '0'); }
+    static int v3 = -1;                      // HSIMAE_ATTN128_V3=0: per-head kernels also at d = 128
+    if (v3 < 0) { const char* e = getenv("HSIMAE_ATTN128_V3"); v3 = !(e && e[0] == '0'); }
+    if (v2 && v3 && p.lse && p.d == 128 && p.heads == 8 && p.hd == 16 && nt <= 2 && p.ld == 384 && p.ldo == 128 &&
+        (!BWD || p.lddo == 128)) {
+        if (nt <= 1) return launch_attn128<1, BWD>(p, s);
+        return launch_attn128<2, BWD>(p, s);
+    }
     if (p.hd == 16 && v2 && p.lse) {
         if (nt <= 1) return launch_attn16<1, BWD>(p, s);
         if (nt <= 2) return launch_attn16<2, BWD>(p, s);
