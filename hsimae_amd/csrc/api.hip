@@ -282,11 +282,16 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
     AttnParams a; std::memset(&a, 0, sizeof(a));
     a.qkv = b.qkv; a.ld = 3 * d; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
     a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = d; a.lse = b.lse;
-    CK(hs_attn_fwd(a, s));
-    p = gp();
-    p.A = b.o; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d; p.W = P.p; p.bias = P.pb;
-    p.res = x_in; p.ldr = d; p.out = b.x1; p.ldo = d;
-    CK(hs_gemm(p, A_BF16, E_RES_F32, s));
+    if (hs_attn_proj_fusable(a)) {            // proj + residual inside the attention kernel (x1 = x + o Wp^T + b)
+        a.proj_w = P.p; a.proj_b = P.pb; a.xres = x_in; a.x1 = b.x1;
+        CK(hs_attn_fwd(a, s));
+    } else {
+        CK(hs_attn_fwd(a, s));
+        p = gp();
+        p.A = b.o; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d; p.W = P.p; p.bias = P.pb;
+        p.res = x_in; p.ldr = d; p.out = b.x1; p.ldo = d;
+        CK(hs_gemm(p, A_BF16, E_RES_F32, s));
+    }
     if (fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s);
     p = gp();
     p.A = b.x1; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = h; p.W = P.w1; p.W2 = P.w3; p.bias = P.w1b;

@@ -589,6 +589,10 @@ __global__ __launch_bounds__(512) void attn128_fwd_kernel(AttnParams p) {
     bf16_t* Vf = Kf + L::IMG;
     float* lse_s = reinterpret_cast<float*>(Vf + L::IMG);       // [ROWS][8]
     const size_t row_base = (size_t)blockIdx.x * p.Ts;
+    // output projection fused in (proj_w != NULL): this wave's n-tile of Wp, fetched now, used after the attention
+    bf16x8 bw[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bw[ks] = p.proj_w ? *reinterpret_cast<const bf16x8*>(p.proj_w + ((size_t)(head * 4 + ks) * 64 + lane) * 8) : zero8();
     fill_cls_f<NT>(cls, p);
     for (int idx = threadIdx.x; idx < L::ROWS * 48; idx += 512) {
         const int row = idx / 48, pc = idx - row * 48;
@@ -651,6 +655,28 @@ __global__ __launch_bounds__(512) void attn128_fwd_kernel(AttnParams p) {
     }
     for (int idx = threadIdx.x; idx < p.Ts * 2; idx += 512)
         *reinterpret_cast<float4*>(p.lse + row_base * 8 + idx * 4) = *reinterpret_cast<const float4*>(lse_s + idx * 4);
+    if (!p.proj_w) return;
+    // x1 = xres + O Wp^T + bp (Models.py:216, 304): wave = 16 output columns, A = the O image (full rows, in Qf)
+    constexpr int XS_ = 132;
+    float* XT = reinterpret_cast<float*>(Kf);                   // fp32 staging over the K | V images (dead by now)
+    static_assert(2 * L::IMG * 2 >= L::ROWS * XS_ * 4, "fp32 staging tile must fit over K|V");
+    const float pb = p.proj_b[hc + c16];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        f32x4 acc = {pb, pb, pb, pb};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            acc = mfma16(*reinterpret_cast<const bf16x8*>(Qf + (mt * 16 + c16) * FS + ks * 32 + g * 8), bw[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) XT[(mt * 16 + 4 * g + r) * XS_ + hc + c16] = acc[r];
+    }
+    lds_barrier();
+    for (int idx = threadIdx.x; idx < p.Ts * 32; idx += 512) {
+        const int row = idx >> 5, c4 = (idx & 31) * 4;
+        const float4 t = *reinterpret_cast<const float4*>(XT + row * XS_ + c4);
+        const float4 x = *reinterpret_cast<const float4*>(p.xres + (row_base + row) * 128 + c4);
+        *reinterpret_cast<float4*>(p.x1 + (row_base + row) * 128 + c4) = make_float4(t.x + x.x, t.y + x.y, t.z + x.z, t.w + x.w);
+    }
 }
 
 template <int NT>
@@ -823,6 +849,7 @@ int dispatch(const AttnParams& p, hipStream_t s) {
     const int nt = (p.Ts + 15) / 16;
     static int v2 = -1;                      // HSIMAE_ATTN16_V2=0: first-generation head-dim-16 kernels (A/B tests)
     if (v2 < 0) { const char* e = getenv("HSIMAE_ATTN16_V2"); v2 = !(e && e[0] == '0'); }
+    if ((p.proj_w || p.projT_w) && !hs_attn_proj_fusable(p)) return HS_EUNSUPPORTED;
     static int v3 = -1;                      // HSIMAE_ATTN128_V3=0: per-head kernels also at d = 128
     if (v3 < 0) { const char* e = getenv("HSIMAE_ATTN128_V3"); v3 = !(e && e[0] == '0'); }
     if (v2 && v3 && p.lse && p.d == 128 && p.heads == 8 && p.hd == 16 && nt <= 2 && p.ld == 384 && p.ldo == 128 &&
@@ -857,4 +884,12 @@ int dispatch(const AttnParams& p, hipStream_t s) {
 }  // namespace
 
 int hs_attn_fwd(const AttnParams& p, hipStream_t s) { return dispatch<false>(p, s); }
+bool hs_attn_proj_fusable(const AttnParams& p) {
+    static int v3 = -1;
+    if (v3 < 0) {
+        const char* e = getenv("HSIMAE_ATTN128_V3"); const char* e2 = getenv("HSIMAE_ATTN16_V2"); const char* e3 = getenv("HSIMAE_FUSED_PROJ");
+        v3 = !(e && e[0] == '0') && !(e2 && e2[0] == '0') && !(e3 && e3[0] == '0');
+    }
+    return v3 && p.lse && p.d == 128 && p.heads == 8 && p.hd == 16 && p.Ts <= 32 && p.ld == 384 && p.ldo == 128;
+}
 int hs_attn_bwd(const AttnParams& p, hipStream_t s) { return dispatch<true>(p, s); }

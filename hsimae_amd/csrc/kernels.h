@@ -25,6 +25,7 @@ int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s);
 int hs_pack(const PackDesc* descs_dev, int ndesc, int max_elems, hipStream_t s);
 int hs_attn_fwd(const AttnParams& p, hipStream_t s);
 int hs_attn_bwd(const AttnParams& p, hipStream_t s);
+bool hs_attn_proj_fusable(const AttnParams& p);      // proj_w / projT_w fusion available for this shape (d=128, 8 heads, Ts<=32)
 int hs_wgrad(const WgradParams& p, hipStream_t s);
 int hs_ln_bwd(const LnBwdParams& p, hipStream_t s);
 int hs_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int M, int d, hipStream_t s);

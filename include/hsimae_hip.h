@@ -172,6 +172,13 @@ typedef struct {
     float* lse;
     const hs_bf16* dout; int32_t lddo;
     hs_bf16* dqkv;
+    /* optional fusion of the output projection + residual (Models.py:216, 304), forward, d = 128 / 8 heads / Ts <= 32
+       only: x1 = xres + o * Wp^T + bp.  proj_w: packed [128][128] image; NULL = attention only. */
+    const hs_bf16* proj_w; const float* proj_b; const float* xres; float* x1;
+    /* optional fusion of the projection's data gradient, backward, same shapes: dout is then taken as
+       dO = dx1 * Wp with dx1 the bf16 [rows][128] gradient of x1 (Models.py:216 backward) and projT_w the packed
+       transposed image; NULL = dout is dO itself. */
+    const hs_bf16* projT_w;
 } hsimae_attn_params;
 int hsimae_attn_fwd(const hsimae_attn_params* p, void* stream);
 int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream);
