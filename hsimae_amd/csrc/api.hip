@@ -340,13 +340,17 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         l.dgamma = grads + o.n2w; l.dbeta = grads + o.n2b;
         CK(hs_ln_bwd(l, s));
     }
-    p = gp();
-    p.A = fmlp ? (const void*)w.g1b : (const void*)G1; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d;
-    p.W = P.pT; p.out = w.dob; p.ldo = d;
-    CK(hs_gemm(p, fmlp ? A_BF16 : A_F32, E_BF16, s));
     AttnParams a; std::memset(&a, 0, sizeof(a));
     a.qkv = b.qkv; a.ld = 3 * d; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
     a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = d; a.lse = b.lse; a.dout = w.dob; a.lddo = d; a.dqkv = w.dqkv;
+    if (fmlp && hs_attn_proj_fusable(a)) {    // dO = dx1 Wp inside the attention backward (dx1 = the bf16 copy from enc_mlp_bwd)
+        a.dout = w.g1b; a.projT_w = P.pT;
+    } else {
+        p = gp();
+        p.A = fmlp ? (const void*)w.g1b : (const void*)G1; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d;
+        p.W = P.pT; p.out = w.dob; p.ldo = d;
+        CK(hs_gemm(p, fmlp ? A_BF16 : A_F32, E_BF16, s));
+    }
     CK(hs_attn_bwd(a, s));
     // Weight gradients first: the LayerNorm-backward GEMM below writes dx over G0 / G1 when the caller runs in place
     WgradParams g; std::memset(&g, 0, sizeof(g));

@@ -566,7 +566,7 @@ struct LayF {
     static constexpr int ROWS = NT * 16;
     static constexpr int IMG = ROWS * FS;
     static constexpr int FWD = ROWS * 4 + 3 * IMG * 2 + ROWS * 8 * 4;                                   // cls | Q K V | lse
-    static constexpr int BWD = ROWS * 4 + 4 * IMG * 2 + 2 * 8 * ROWS * 4 + 8 * 2 * 16 * RS16 * 2;       // cls | Q K V dO | lse delta | T
+    static constexpr int BWD = ROWS * 4 + 5 * IMG * 2 + 2 * 8 * ROWS * 4 + 8 * 2 * 16 * RS16 * 2;       // cls | Q K V dO dX | lse delta | T
 };
 
 template <int NT>
@@ -689,7 +689,8 @@ __global__ __launch_bounds__(512) void attn128_bwd_kernel(AttnParams p) {
     bf16_t* Kf = Qf + L::IMG;
     bf16_t* Vf = Kf + L::IMG;
     bf16_t* Df = Vf + L::IMG;
-    float* lse_s = reinterpret_cast<float*>(Df + L::IMG);       // [8][ROWS]
+    bf16_t* Xf = Df + L::IMG;                                   // dx1 rows (fused projection gradient only)
+    float* lse_s = reinterpret_cast<float*>(Xf + L::IMG);       // [8][ROWS]
     float* dlt_s = lse_s + 8 * L::ROWS;                         // [8][ROWS]
     bf16_t* Tp = reinterpret_cast<bf16_t*>(dlt_s + 8 * L::ROWS) + head * (2 * 16 * RS16);
     bf16_t* Td = Tp + 16 * RS16;
@@ -701,6 +702,10 @@ __global__ __launch_bounds__(512) void attn128_bwd_kernel(AttnParams p) {
         if (row < p.Ts) v = *reinterpret_cast<const bf16x8*>(p.qkv + (row_base + row) * p.ld + pc * 8);
         *reinterpret_cast<bf16x8*>(Qf + (pc >> 4) * L::IMG + row * FS + (pc & 15) * 8) = v;
     }
+    const bool fuse_proj = p.projT_w != nullptr;
+    bf16x8 bw[4];                                                         // this wave's n-tile (= its head's 16 columns) of Wp^T
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bw[ks] = fuse_proj ? *reinterpret_cast<const bf16x8*>(p.projT_w + ((size_t)(head * 4 + ks) * 64 + lane) * 8) : zero8();
     for (int idx = threadIdx.x; idx < L::ROWS * 16; idx += 512) {       // dO rows + delta = rowsum(dO * O) per head
         const int row = idx >> 4, pc = idx & 15;
         bf16x8 d = zero8(), o = zero8();
@@ -708,12 +713,17 @@ __global__ __launch_bounds__(512) void attn128_bwd_kernel(AttnParams p) {
             d = *reinterpret_cast<const bf16x8*>(p.dout + (row_base + row) * p.lddo + pc * 8);
             o = *reinterpret_cast<const bf16x8*>(p.o + (row_base + row) * p.ldo + pc * 8);
         }
-        *reinterpret_cast<bf16x8*>(Df + row * FS + pc * 8) = d;
-        float acc = 0.f;
+        if (fuse_proj) {                                                 // `dout` is dx1: dO = dx1 Wp comes below; O waits in Df
+            *reinterpret_cast<bf16x8*>(Xf + row * FS + pc * 8) = d;
+            *reinterpret_cast<bf16x8*>(Df + row * FS + pc * 8) = o;
+        } else {
+            *reinterpret_cast<bf16x8*>(Df + row * FS + pc * 8) = d;
+            float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc += bf2f(d[i]) * bf2f(o[i]);
-        acc += __shfl_xor(acc, 1, 64);                                   // the head's two 8-column pieces are adjacent lanes
-        if (!(pc & 1)) dlt_s[(pc >> 1) * L::ROWS + row] = acc;
+            for (int i = 0; i < 8; ++i) acc += bf2f(d[i]) * bf2f(o[i]);
+            acc += __shfl_xor(acc, 1, 64);                               // the head's two 8-column pieces are adjacent lanes
+            if (!(pc & 1)) dlt_s[(pc >> 1) * L::ROWS + row] = acc;
+        }
     }
     for (int idx = threadIdx.x; idx < L::ROWS * 8; idx += 512) {
         const int row = idx >> 3, h = idx & 7;
@@ -726,6 +736,28 @@ __global__ __launch_bounds__(512) void attn128_bwd_kernel(AttnParams p) {
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const int troff = (4 * g + q4) * FS + hc + 4 * p4;
     const int ttoff = (4 * g + q4) * RS16 + 4 * p4;
+    if (fuse_proj) {
+        // dO[:, this head's 16 columns] = dx1 Wp (autograd of Models.py:216): only this wave ever touches these columns
+        // of Df, so O is read, delta formed and dO written in place without a workgroup barrier
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            f32x4 acc = z4;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc = mfma16(*reinterpret_cast<const bf16x8*>(Xf + (mt * 16 + c16) * FS + ks * 32 + g * 8), bw[ks], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = mt * 16 + 4 * g + r;
+                bf16_t* cell = Df + row * FS + hc + c16;
+                const bf16_t dob = (bf16_t)acc[r];
+                float v = bf2f(dob) * bf2f(*cell);
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (c16 == 0) dlt_s[head * L::ROWS + row] = v;
+                *cell = dob;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // own LDS writes visible to own later reads
+    }
     const float* lse_h = lse_s + head * L::ROWS;
     const float* dlt_h = dlt_s + head * L::ROWS;
     f32x4 dkT[NT], dvT[NT];
