@@ -343,7 +343,9 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     AttnParams a; std::memset(&a, 0, sizeof(a));
     a.qkv = b.qkv; a.ld = 3 * d; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
     a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = d; a.lse = b.lse; a.dout = w.dob; a.lddo = d; a.dqkv = w.dqkv;
-    if (fmlp && hs_attn_proj_fusable(a)) {    // dO = dx1 Wp inside the attention backward (dx1 = the bf16 copy from enc_mlp_bwd)
+    static int fuse_pb = -1;                  // HSIMAE_FUSED_PROJ_BWD=0: keep the projection's data gradient a separate GEMM
+    if (fuse_pb < 0) { const char* e = getenv("HSIMAE_FUSED_PROJ_BWD"); fuse_pb = !(e && e[0] == '0'); }
+    if (fuse_pb && fmlp && hs_attn_proj_fusable(a)) {    // dO = dx1 Wp inside the attention backward (dx1 = the bf16 copy from enc_mlp_bwd)
         a.dout = w.g1b; a.projT_w = P.pT;
     } else {
         p = gp();
