@@ -15,6 +15,23 @@
 #include "common.h"
 #include "kernels.h"
 
+// Per-phase cycle accounting for scripts/phase_timing.py (compiled only with -DHS_PHASE_TIMING; never in the shipped library)
+#ifdef HS_PHASE_TIMING
+__device__ unsigned long long hs_phase_cycles_gemm[64];
+extern "C" int hsimae_debug_phases_gemm(unsigned long long* out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hs_phase_cycles_gemm), sizeof(unsigned long long) * 64);
+    if (reset) { unsigned long long z[64] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(hs_phase_cycles_gemm), z, sizeof(z)); }
+    return rc;
+}
+#define PH_DECL unsigned long long ph_t0 = __builtin_readcyclecounter(), ph_acc[4] = {0, 0, 0, 0};
+#define PH(i) { const unsigned long long ph_t = __builtin_readcyclecounter(); ph_acc[i] += ph_t - ph_t0; ph_t0 = ph_t; }
+#define PH_FLUSH(base) if (threadIdx.x == 0) { for (int i = 0; i < 4; ++i) atomicAdd(&hs_phase_cycles_gemm[(base) + i], ph_acc[i]); }
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_FLUSH(base)
+#endif
+
 namespace {
 
 constexpr int BM = 128;
@@ -157,6 +174,7 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
     };
     Grp cur;
     fetch(0, 0, 0, cur);
+    PH_DECL
 
     for (int nc = 0; nc < n_chunks; ++nc) {
         f32x4 acc[8][2];
@@ -174,6 +192,7 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
                 if (!(nc == 0 && kc == 0)) lds_barrier();
                 if constexpr (AK == A_F32_LN) stage_ln(); else stage(kc);
                 lds_barrier();
+                PH(0)
             }
             const int ks0 = kc * (KC / 32);
             const int nks = min(KC / 32, KS_total - ks0);
@@ -201,6 +220,7 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
             }
         }
 
+        PH(1)
         // ---------------------------------------------------------------- epilogue for this 128-column chunk
         const int ccols = min(128, p.N - nc * 128);            // valid columns in this chunk (multiple of 16)
         if constexpr (EPI == E_LN_BWD) {
@@ -297,6 +317,7 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
                 for (int t2 = o8; t2 < 256; t2 += 16) sacc += red[which * 2048 + t2 * 8 + e];
                 atomicAdd((which ? p.dbeta : p.dgamma) + c, sacc);
             }
+            PH(2)
             continue;
         }
 #pragma unroll
@@ -404,7 +425,9 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
                 }
             }
         }
+        PH(2)
     }
+    PH_FLUSH(((AK * 3 + (EPI == E_LN_BWD ? 2 : (EPI == E_BF16 ? 0 : 1))) * 4) % 64)
 }
 
 template <int AK, int EPI, int KC>

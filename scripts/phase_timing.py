@@ -21,7 +21,7 @@ def build_variant() -> str:
     objs = []
     for u in B.UNITS:
         obj = os.path.join(tmp, u + ".o")
-        timed = u in ("fused_dec", "fused_enc")
+        timed = u in ("fused_dec", "fused_enc", "gemm")
         flags = B.FLAGS + (["-DHS_PHASE_TIMING"] + os.environ.get("HS_EXTRA_FLAGS", "").split() if timed else [])
         src_obj = os.path.join(B.HERE, "build", u + ".o")
         if not timed and os.path.exists(src_obj):
@@ -59,7 +59,16 @@ def main():
         torch.cuda.synchronize()
         lib.hsimae_debug_phases(buf, 1)
         lib.hsimae_debug_phases_enc(buf2, 1)
+    buf3 = (ctypes.c_uint64 * 64)()
+    lib.hsimae_debug_phases_gemm.restype = ctypes.c_int
+    lib.hsimae_debug_phases_gemm.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+    lib.hsimae_debug_phases_gemm(buf3, 1)          # accumulated over the 3 iterations
     v = list(buf) + list(buf2)
+    g = list(buf3)
+    for name, base in (("gemm A_BF16 -> bf16 (dO / misc)", 0), ("gemm A_BF16 -> f32 family (proj+res, pos)", 4), ("gemm A_BF16 E_LN_BWD (du + LN1 bwd)", 8),
+                       ("gemm A_F32_LN -> bf16 (LN1 + qkv)", 24), ("gemm A_F32_LN -> f32 family", 28)):
+        tot = sum(g[base:base + 3]) or 1
+        print(f"{name}: wave-0 cycles {tot}: stage {100.0 * g[base] / tot:.1f} %  k-loop {100.0 * g[base + 1] / tot:.1f} %  epilogue {100.0 * g[base + 2] / tot:.1f} %")
     names = {
         "dec_bwd_attn": (0, ["prologue (x dx1 O lse) + LN", "qkv mm", "-", "dO mm + dWp + delta", "dO store", "attention",
                              "du mm + dWqkv", "epilogue LN bwd"]),
