@@ -386,7 +386,7 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     if (ln_fused) {
         p.out = dx_out; p.ldo = d; p.res = G1; p.ldr = d; p.lnx = x_in; p.gamma = P.n1w; p.accumulate = accumulate;
         p.dgamma = grads + o.n1w; p.dbeta = grads + o.n1b;
-        CK(hs_gemm(p, A_BF16, E_LN_BWD, s));
+        CK(hs_gemm(p, A_BF16, E_LN_BWD, s));       // K = 384: the persistent LDS-DMA kernel of gemm_dma.hip
     } else {
         p.out = w.du; p.ldo = d;
         CK(hs_gemm(p, A_BF16, E_F32, s));

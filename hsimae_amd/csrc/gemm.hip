@@ -474,6 +474,7 @@ int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s) {
     if (akind == A_BF16 && epi == E_LN_BWD) {
         if (p.N != 128 || p.n_valid != 128 || !p.lnx || !p.res || !p.gamma || !p.dgamma || !p.dbeta || p.ldr % 4 || p.ldo % 4)
             return HS_EUNSUPPORTED;
+        if (hs_lnbwd_dma_supported(p)) return hs_lnbwd_dma(p, s);      // persistent, LDS-DMA fed (gemm_dma.hip)
         return launch_kc<A_BF16, E_LN_BWD>(p, s);
     }
     CASE(A_F32, E_SWIGLU_BWD)

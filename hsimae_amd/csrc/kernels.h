@@ -22,6 +22,8 @@ typedef hsimae_loss_params LossParams;
 typedef hsimae_cube_params CubeParams;
 
 int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s);
+bool hs_lnbwd_dma_supported(const GemmParams& p);     // persistent LDS-DMA form of (A_BF16, E_LN_BWD) at N = 128, K = 384
+int hs_lnbwd_dma(const GemmParams& p, hipStream_t s);
 int hs_pack(const PackDesc* descs_dev, int ndesc, int max_elems, hipStream_t s);
 int hs_attn_fwd(const AttnParams& p, hipStream_t s);
 int hs_attn_bwd(const AttnParams& p, hipStream_t s);
