@@ -182,7 +182,131 @@ __global__ __launch_bounds__(256, 2) void lnbwd_dma_kernel(GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent LayerNorm-1 + q|k|v kernel of the encoder forward (d = 128):
+//     u = LN(x) (bf16, kept for the weight gradients),  qkv = u * [Wq;Wk;Wv]^T + b   (Models.py:194-208, 304)
+// Same arithmetic as gemm_kernel<A_F32_LN, E_BF16>, which spends 39 % of a workgroup's life on the panel load and
+// 40 % in the epilogue.  Here 512 workgroups walk 32-row chunks: the next chunks' x rows are already in flight in
+// registers, the 24 weight fragments per wave stay in registers, and the 32 x 384 result leaves through an LDS tile as
+// whole 768-byte rows.
+constexpr int LQU = 128 + 8;           // LN-output tile row stride (elements)
+constexpr int LQO = 384 + 8;           // result tile row stride (elements)
+
+__global__ __launch_bounds__(256, 2) void lnqkv_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ut[DC * LQU];
+    __shared__ __attribute__((aligned(16))) bf16_t Ot[DC * LQO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g = lane >> 4;
+    const int nchunks = (p.M + DC - 1) / DC;
+    const float* X = reinterpret_cast<const float*>(p.A);
+    bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
+
+    bf16x8 bw[4][6];                   // this wave's 6 n-tiles (96 columns), 4 k-steps
+    float bias[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        bias[j] = p.bias[(wave * 6 + j) * 16 + c16];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            bw[ks][j] = *reinterpret_cast<const bf16x8*>(p.W + (((size_t)(wave * 6 + j) * 4 + ks) * 64 + lane) * 8);
+    }
+    const int c8 = (tid & 15) * 8;
+    float gm[8], bt[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gm[e] = p.gamma[c8 + e]; bt[e] = p.beta[c8 + e]; }
+
+    auto fetch = [&](int chunk, float (&xo)[2][8]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = chunk * DC + (tid >> 4) + 16 * i;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xo[i][e] = 0.f;
+            if (chunk < nchunks && row < p.M) {
+                const float* xp = X + (size_t)row * p.lda + c8;
+                const float4 a0 = *reinterpret_cast<const float4*>(xp), a1 = *reinterpret_cast<const float4*>(xp + 4);
+                xo[i][0] = a0.x; xo[i][1] = a0.y; xo[i][2] = a0.z; xo[i][3] = a0.w; xo[i][4] = a1.x; xo[i][5] = a1.y; xo[i][6] = a1.z; xo[i][7] = a1.w;
+            }
+        }
+    };
+    float xa[2][8], xb[2][8];          // two chunks ahead
+    fetch(blockIdx.x, xa);
+    fetch(blockIdx.x + gridDim.x, xb);
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        // LayerNorm of the chunk's rows (16 lanes per row) -> bf16 tile + HBM copy
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rl = (tid >> 4) + 16 * i, row = chunk * DC + rl;
+            float sm = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm += xa[i][e];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            const float mean = sm * (1.f / 128.f);
+            float q = 0.f, f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[e] = xa[i][e] - mean; q += f[e] * f[e]; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            const float rstd = rsqrtf(q * (1.f / 128.f) + 1e-5f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
+            const bf16x8 u8 = cvt8(f);
+            *reinterpret_cast<bf16x8*>(Ut + rl * LQU + c8) = u8;
+            if (row < p.M && p.u_out) *reinterpret_cast<bf16x8*>(p.u_out + (size_t)row * p.ldu + c8) = u8;
+        }
+        // rotate the prefetch registers and put the chunk after next in flight
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xa[i][e] = xb[i][e];
+        fetch(chunk + 2 * (int)gridDim.x, xb);
+        lds_barrier();
+        f32x4 acc[2][6];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[mt][j] = f32x4{bias[j], bias[j], bias[j], bias[j]};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ut + (mt * 16 + c16) * LQU + ks * 32 + g * 8);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[mt][j] = mfma16(a, bw[ks][j], acc[mt][j]);
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ot[(mt * 16 + 4 * g + r) * LQO + (wave * 6 + j) * 16 + c16] = (bf16_t)acc[mt][j][r];
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int idx = tid + 256 * i, rl = idx / 48, pc = idx - rl * 48;
+            const int row = chunk * DC + rl;
+            if (row < p.M) *reinterpret_cast<bf16x8*>(out + (size_t)row * p.ldo + pc * 8) = *reinterpret_cast<const bf16x8*>(Ot + rl * LQO + pc * 8);
+        }
+        lds_barrier();
+    }
+}
+
 }  // namespace
+
+bool hs_lnqkv_supported(const GemmParams& p) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("HSIMAE_LNQKV_PERSISTENT"); on = !(e && e[0] == '0'); }
+    return on && p.K == 128 && p.N == 384 && p.n_valid == 384 && p.bias && p.gamma && p.beta && p.lda % 4 == 0 && p.ldo % 8 == 0 &&
+           (!p.u_out || p.ldu % 8 == 0);
+}
+
+int hs_lnqkv(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0) return HS_OK;
+    if (!hs_lnqkv_supported(p)) return HS_EUNSUPPORTED;
+    const int nchunks = (p.M + DC - 1) / DC;
+    hipLaunchKernelGGL(lnqkv_kernel, dim3(nchunks < 512 ? nchunks : 512), dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
 
 bool hs_lnbwd_dma_supported(const GemmParams& p) {
     static int on = -1;

@@ -108,7 +108,7 @@ def test_pack_transposed_and_offset_placement():
     assert rel_err(du, ref) < 2e-5
 
 
-@pytest.mark.parametrize("M,d,N", [(300, 128, 384), (150, 64, 192), (260, 256, 768), (129, 512, 128), (90, 32, 96)])
+@pytest.mark.parametrize("M,d,N", [(300, 128, 384), (20001, 128, 384), (150, 64, 192), (260, 256, 768), (129, 512, 128), (90, 32, 96)])
 def test_gemm_layernorm_prologue_bias_bf16_out(M, d, N):
     torch.manual_seed(2)
     x = torch.randn(M, d, device=DEV) * 2 + 0.3
