@@ -86,6 +86,23 @@ __device__ __forceinline__ void mm_f(const bf16_t* A, int lda, int kofs, const F
         }
 }
 
+// Column-split decomposition (forward kernel): the 4 waves split the COLUMNS of every product and each covers all
+// 4 m-tiles of the 64-row panel, so no weight fragment is fetched by two waves.  (In the 2 x 2 split each wave
+// pulled half of every weight matrix: 528 KB of L2 -> register traffic per 64-row panel, 0.9 GB per launch.)
+template <int KS, int NJ>
+struct FrN {
+    bf16x8 b[KS][NJ];
+    __device__ __forceinline__ void load(const bf16_t* W, int KS_total, int nt0, int ks0, int nt_total, int lane) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                b[ks][j] = (nt0 + j < nt_total && ks0 + ks < KS_total)
+                               ? *reinterpret_cast<const bf16x8*>(W + (((size_t)(nt0 + j) * KS_total + ks0 + ks) * 64 + lane) * 8)
+                               : zero8();
+    }
+};
+
 template <class T>
 __device__ __forceinline__ const T* launder(const T* p) { asm volatile("" : "+s"(p)); return p; }
 
@@ -115,7 +132,9 @@ struct EncMlpFwdArgs { const float* x1; const float* res2; float* x2; int M; Enc
 template <int D, int HPE>
 __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     using G = MG<D, HPE>;
-    constexpr int LU = G::LU, LX = G::LX, LG = G::LG, NCH = G::NCH, NCC = G::NCC, KSD = G::KSD, LPR = G::LPR;
+    constexpr int LU = G::LU, LX = G::LX, LG = G::LG, NCH = G::NCH, KSD = G::KSD, KSH = G::KSH, LPR = G::LPR;
+    constexpr int MT4 = R / 16;                         // every wave covers all m-tiles of the panel
+    constexpr int NJO = D / 64;                         // output n-tiles per wave (D / 16 over 4 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
     float* XS = reinterpret_cast<float*>(smem + R * LU * 2);
@@ -126,9 +145,10 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     const int nt_h = HPE / 16;
     const int c8 = (threadIdx.x % LPR) * 8;
 
-    Fr<KSD> f1, f3;
-    f1.load(w.w1, KSD, q.wn * 2, 0, nt_h, q);
-    f3.load(w.w3, KSD, q.wn * 2, 0, nt_h, q);
+    PH_DECL
+    FrN<KSD, 1> f1, f3;                                 // this wave's n-tile of the current hidden chunk
+    f1.load(w.w1, KSD, q.wave, 0, nt_h, q.lane);
+    f3.load(w.w3, KSD, q.wave, 0, nt_h, q.lane);
     __builtin_amdgcn_sched_barrier(0);           // keep the fetches here: hipcc otherwise sinks them next to the MFMAs
     {   // LayerNorm-2 in the wide layout (16 lanes per row) + fp32 copy for the residual
         float gm[8], bt[8];
@@ -158,81 +178,79 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
         }
     }
     lds_barrier();
-    f32x4 xr[NCC][MH][2];                          // residual, [output chunk][m-tile][n-tile] in accumulator layout
+    PH(0)
+    f32x4 xr[MT4][NJO];                            // residual + b2, [m-tile][this wave's output n-tile], accumulator layout
 #pragma unroll
-    for (int cc = 0; cc < NCC; ++cc)
+    for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
-        for (int mi = 0; mi < MH; ++mi)
+        for (int j = 0; j < NJO; ++j) {
+            const int col = (q.wave * NJO + j) * 16 + q.c16;
+            const float b = w.w2b[col];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = cc * 64 + (q.wn * 2 + j) * 16 + q.c16;
-                const float b = w.w2b[col];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xr[cc][mi][j][r] = XS[((q.wm * MH + mi) * 16 + q.g * 4 + r) * LX + col] + b;
-            }
+            for (int r = 0; r < 4; ++r) xr[mt][j][r] = XS[(mt * 16 + q.g * 4 + r) * LX + col] + b;
+        }
     lds_barrier();                             // XS consumed: the gate image may overwrite it
+    PH(1)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const bool live = c * 4 + q.wn * 2 < nt_h;                      // last chunk: only wn == 0 has columns
-        f32x4 h1[MH][2], h3[MH][2];
+        const int nt = c * 4 + q.wave;                                  // this wave's n-tile of the chunk
+        const bool live = nt < nt_h;                                    // last chunk: only waves 0, 1 have columns
+        const int col = nt * 16 + q.c16;
+        f32x4 h1[MT4], h3[MT4];
+        {
+            const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
 #pragma unroll
-        for (int mi = 0; mi < MH; ++mi)
+            for (int mt = 0; mt < MT4; ++mt) { h1[mt] = f32x4{b1, b1, b1, b1}; h3[mt] = f32x4{b3, b3, b3, b3}; }
+        }
+        if (live) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
-                const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
-                h1[mi][j] = f32x4{b1, b1, b1, b1};
-                h3[mi][j] = f32x4{b3, b3, b3, b3};
-            }
-        if (live) { mm_f<KSD>(U2, LU, 0, f1, q, h1); mm_f<KSD>(U2, LU, 0, f3, q, h3); }
+            for (int ks = 0; ks < KSD; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < MT4; ++mt) {                      // one A fragment feeds both products
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(U2 + (mt * 16 + q.c16) * LU + ks * 32 + q.g * 8);
+                    h1[mt] = mfma16(a, f1.b[ks][0], h1[mt]);
+                    h3[mt] = mfma16(a, f3.b[ks][0], h3[mt]);
+                }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < NCH) {
-            f1.load(w.w1, KSD, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
-            f3.load(w.w3, KSD, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
+            f1.load(w.w1, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+            f3.load(w.w3, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (live) {
 #pragma unroll
-            for (int mi = 0; mi < MH; ++mi)
+            for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
-                    if (col < HPE) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float a1 = h1[mi][j][r];
-                            const float gv = col < w.h ? silu_nr(a1) * h3[mi][j][r] : 0.f;
-                            Gb[((q.wm * MH + mi) * 16 + q.g * 4 + r) * LG + col] = (bf16_t)gv;
-                        }
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const float gv = col < w.h ? silu_nr(h1[mt][r]) * h3[mt][r] : 0.f;
+                    Gb[(mt * 16 + q.g * 4 + r) * LG + col] = (bf16_t)gv;
                 }
         }
     }
-    // x2 = x1 + b2 + g W2^T : K = 352 = 11 k-steps, two 64-column output chunks
-    Fr<G::KA> fa[NCC];
-    Fr<(G::KB > 0 ? G::KB : 1)> fb[NCC];
-#pragma unroll
-    for (int cc = 0; cc < NCC; ++cc) {
-        fa[cc].load(w.w2, G::KSH, cc * 4 + q.wn * 2, 0, D / 16, q);
-        if constexpr (G::KB > 0) fb[cc].load(w.w2, G::KSH, cc * 4 + q.wn * 2, G::KA, D / 16, q);
-    }
+    PH(2)
+    // x2 = x1 + b2 + g W2^T : K = 352 = 11 k-steps; this wave's NJO output n-tiles, all 4 m-tiles
+    FrN<KSH, NJO> f2;
+    f2.load(w.w2, KSH, q.wave * NJO, 0, D / 16, q.lane);
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
 #pragma unroll
-    for (int cc = 0; cc < NCC; ++cc) {
-        mm_f<G::KA>(Gb, LG, 0, fa[cc], q, xr[cc]);
-        if constexpr (G::KB > 0) mm_f<G::KB>(Gb, LG, G::KA * 32, fb[cc], q, xr[cc]);
-    }
+    for (int ks = 0; ks < KSH; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < MT4; ++mt) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(Gb + (mt * 16 + q.c16) * LG + ks * 32 + q.g * 8);
+#pragma unroll
+            for (int j = 0; j < NJO; ++j) xr[mt][j] = mfma16(a, f2.b[ks][j], xr[mt][j]);
+        }
     lds_barrier();                             // gate image consumed: reuse the region as the fp32 store tile
+    PH(3)
 #pragma unroll
-    for (int cc = 0; cc < NCC; ++cc)
+    for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
-        for (int mi = 0; mi < MH; ++mi)
+        for (int j = 0; j < NJO; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    XS[((q.wm * MH + mi) * 16 + q.g * 4 + r) * LX + cc * 64 + (q.wn * 2 + j) * 16 + q.c16] = xr[cc][mi][j][r];
+            for (int r = 0; r < 4; ++r)
+                XS[(mt * 16 + q.g * 4 + r) * LX + (q.wave * NJO + j) * 16 + q.c16] = xr[mt][j][r];
     lds_barrier();
 #pragma unroll
     for (int i = 0; i < R * LPR / NTH; ++i) {
@@ -249,6 +267,8 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
             st8(p.x2 + (size_t)(row0 + row) * D + c8, f);
         }
     }
+    PH(4)
+    PH_FLUSH(8)
 }
 
 struct EncMlpBwdArgs {
