@@ -280,7 +280,7 @@ struct EncMlpBwdArgs {
 template <int D, int HPE>
 __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     using G = MG<D, HPE>;
-    constexpr int LU = G::LU, LX = G::LX, NCH = G::NCH, NCC = G::NCC, KSD = G::KSD, KSH = G::KSH, LPR = G::LPR;
+    constexpr int LU = G::LU, LX = G::LX, NCH = G::NCH, KSD = G::KSD, KSH = G::KSH, LPR = G::LPR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
     bf16_t* DYb = U2 + R * LU;
@@ -295,10 +295,13 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     const int c8 = (threadIdx.x % LPR) * 8;
 
     PH_DECL
-    Fr<KSD> f1, f3, f2;
-    f1.load(w.w1, KSD, q.wn * 2, 0, nt_h, q);
-    f3.load(w.w3, KSD, q.wn * 2, 0, nt_h, q);
-    f2.load(w.w2T, KSD, q.wn * 2, 0, nt_h, q);
+    // column-split decomposition (see FrN): wave w owns n-tile w of every 64-column hidden chunk and the output
+    // n-tiles {2w, 2w+1} of the data gradient, each for all 4 m-tiles of the panel
+    constexpr int MT4 = R / 16, NJO = D / 64;
+    FrN<KSD, 1> f1, f3, f2;
+    f1.load(w.w1, KSD, q.wave, 0, nt_h, q.lane);
+    f3.load(w.w3, KSD, q.wave, 0, nt_h, q.lane);
+    f2.load(w.w2T, KSD, q.wave, 0, nt_h, q.lane);
     {
         float gm[8], bt[8];
         ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
@@ -337,61 +340,60 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     }
     lds_barrier();
     PH(0)
-    f32x4 du2[NCC][MH][2];
+    f32x4 du2[MT4][NJO];
 #pragma unroll
-    for (int cc = 0; cc < NCC; ++cc)
+    for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
-        for (int mi = 0; mi < MH; ++mi) { du2[cc][mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; du2[cc][mi][1] = du2[cc][mi][0]; }
+        for (int j = 0; j < NJO; ++j) du2[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const bool live = c * 4 + q.wn * 2 < nt_h;
+        const int nt = c * 4 + q.wave;
+        const bool live = nt < nt_h;
         {
-            f32x4 h1[MH][2], h3[MH][2], dg[MH][2];
+            const int col = nt * 16 + q.c16, lc = q.wave * 16 + q.c16;
+            const bool ok = live && col < w.h;
+            f32x4 h1[MT4], h3[MT4], dg[MT4];
+            const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
 #pragma unroll
-            for (int mi = 0; mi < MH; ++mi)
+            for (int mt = 0; mt < MT4; ++mt) { h1[mt] = f32x4{b1, b1, b1, b1}; h3[mt] = f32x4{b3, b3, b3, b3}; dg[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            if (live) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
-                    const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
-                    h1[mi][j] = f32x4{b1, b1, b1, b1};
-                    h3[mi][j] = f32x4{b3, b3, b3, b3};
-                    dg[mi][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            if (live) { mm_f<KSD>(U2, LU, 0, f1, q, h1); mm_f<KSD>(U2, LU, 0, f3, q, h3); mm_f<KSD>(DYb, LU, 0, f2, q, dg); }
+                for (int ks = 0; ks < KSD; ++ks)
+#pragma unroll
+                    for (int mt = 0; mt < MT4; ++mt) {
+                        const bf16x8 au = *reinterpret_cast<const bf16x8*>(U2 + (mt * 16 + q.c16) * LU + ks * 32 + q.g * 8);
+                        const bf16x8 ad = *reinterpret_cast<const bf16x8*>(DYb + (mt * 16 + q.c16) * LU + ks * 32 + q.g * 8);
+                        h1[mt] = mfma16(au, f1.b[ks][0], h1[mt]);
+                        h3[mt] = mfma16(au, f3.b[ks][0], h3[mt]);
+                        dg[mt] = mfma16(ad, f2.b[ks][0], dg[mt]);
+                    }
+            }
             if (c + 1 < NCH) {
-                f1.load(w.w1, KSD, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
-                f3.load(w.w3, KSD, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
-                f2.load(w.w2T, KSD, (c + 1) * 4 + q.wn * 2, 0, nt_h, q);
+                f1.load(w.w1, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+                f3.load(w.w3, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+                f2.load(w.w2T, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
             }
 #pragma unroll
-            for (int mi = 0; mi < MH; ++mi)
+            for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int lc = (q.wn * 2 + j) * 16 + q.c16;
-                    const bool ok = live && (c * 64 + lc < w.h);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float a1 = h1[mi][j][r], a3 = h3[mi][j][r], dv = dg[mi][j][r];
-                        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-a1));
-                        const float sl = a1 * sg;
-                        const int o = ((q.wm * MH + mi) * 16 + q.g * 4 + r) * LC + lc;
-                        Gc[o] = (bf16_t)(ok ? sl * a3 : 0.f);
-                        DH1[o] = (bf16_t)(ok ? dv * a3 * sg * (1.f + a1 * (1.f - sg)) : 0.f);
-                        DH3[o] = (bf16_t)(ok ? dv * sl : 0.f);
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const float a1 = h1[mt][r], a3 = h3[mt][r], dv = dg[mt][r];
+                    const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-a1));
+                    const float sl = a1 * sg;
+                    const int o = (mt * 16 + q.g * 4 + r) * LC + lc;
+                    Gc[o] = (bf16_t)(ok ? sl * a3 : 0.f);
+                    DH1[o] = (bf16_t)(ok ? dv * a3 * sg * (1.f + a1 * (1.f - sg)) : 0.f);
+                    DH3[o] = (bf16_t)(ok ? dv * sl : 0.f);
                 }
         }
         lds_barrier();
         PH(1)
-        // W1^T | W3^T fragments of this chunk's data gradient: issued before the operand stores so that their L2 round
-        // trip overlaps them (they were fetched right at their use, twice per chunk)
-        Fr<2> wa[NCC], wb[NCC];
-#pragma unroll
-        for (int cc = 0; cc < NCC; ++cc) {
-            wa[cc].load(w.w13T, 2 * KSH, cc * 4 + q.wn * 2, 2 * c, D / 16, q);
-            wb[cc].load(w.w13T, 2 * KSH, cc * 4 + q.wn * 2, KSH + 2 * c, D / 16, q);
-        }
+        // W1^T | W3^T fragments of this chunk's data gradient (this wave's output n-tiles): issued before the operand
+        // stores so that their L2 round trip overlaps them
+        FrN<2, NJO> wa, wb;
+        wa.load(w.w13T, 2 * KSH, q.wave * NJO, 2 * c, D / 16, q.lane);
+        wb.load(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * c, D / 16, q.lane);
         // weight-gradient operands of this chunk to HBM (row-contiguous 16-B stores), columns < 352 only
         {
             const int ncol = (c * 64 + 64 <= HPE) ? 64 : HPE - c * 64;       // 64 or 32
@@ -406,35 +408,33 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
             }
         }
         PH(2)
-        // data gradient through W1 / W3:  du2 += dh1_c W1[c] + dh3_c W3[c]   (packed [N=128][K=704], W3 at k-step 11)
-        if (c < NCH - 1 || HPE % 64 == 0) {
+        // data gradient through W1 / W3:  du2 += dh1_c W1[c] + dh3_c W3[c]   (packed [N=128][K=704], W3 at k-step 11);
+        // the last chunk of HPE = 352 is half full: its second k-step is past the hidden width
+        constexpr bool kHalfLast = (HPE % 64) != 0;
 #pragma unroll
-            for (int cc = 0; cc < NCC; ++cc) {
-                mm_f<2>(DH1, LC, 0, wa[cc], q, du2[cc]);
-                mm_f<2>(DH3, LC, 0, wb[cc], q, du2[cc]);
-            }
-        } else {                                    // half chunk: the second k-step is past the hidden width (zero images)
+        for (int ks = 0; ks < 2; ++ks) {
+            if (kHalfLast && c == NCH - 1 && ks == 1) continue;
 #pragma unroll
-            for (int cc = 0; cc < NCC; ++cc) {
-                Fr<1> a, b;
+            for (int mt = 0; mt < MT4; ++mt) {
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(DH1 + (mt * 16 + q.c16) * LC + ks * 32 + q.g * 8);
+                const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(DH3 + (mt * 16 + q.c16) * LC + ks * 32 + q.g * 8);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) { a.b[0][j] = wa[cc].b[0][j]; b.b[0][j] = wb[cc].b[0][j]; }
-                mm_f<1>(DH1, LC, 0, a, q, du2[cc]);
-                mm_f<1>(DH3, LC, 0, b, q, du2[cc]);
+                for (int j = 0; j < NJO; ++j) {
+                    du2[mt][j] = mfma16(a1, wa.b[ks][j], du2[mt][j]);
+                    du2[mt][j] = mfma16(a3, wb.b[ks][j], du2[mt][j]);
+                }
             }
         }
         lds_barrier();
         PH(3)
     }
 #pragma unroll
-    for (int cc = 0; cc < NCC; ++cc)
+    for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
-        for (int mi = 0; mi < MH; ++mi)
+        for (int j = 0; j < NJO; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    XS[((q.wm * MH + mi) * 16 + q.g * 4 + r) * LX + cc * 64 + (q.wn * 2 + j) * 16 + q.c16] = du2[cc][mi][j][r];
+            for (int r = 0; r < 4; ++r)
+                XS[(mt * 16 + q.g * 4 + r) * LX + (q.wave * NJO + j) * 16 + q.c16] = du2[mt][j][r];
     lds_barrier();
     float dgam[8], dbet[8];
 #pragma unroll
