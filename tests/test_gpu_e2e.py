@@ -389,7 +389,8 @@ def test_fused_adamw_matches_torch_adamw_and_training_step():
             continue      # true gradient is exactly zero (softmax shift invariance): Adam turns rounding noise into +-lr
         worst = max(worst, rms_rel(pb, pa))
     print(f"[adamw] worst parameter rms-rel after 6 steps {worst:.2e}")
-    assert worst < 5e-2       # chaotic bound only; the arithmetic itself is pinned to 1e-6 below
+    assert worst < 0.15       # chaotic bound only (two independent runs, Adam amplifies last-bit gradient noise of
+    #                           near-zero gradients to +-lr): measured 2e-2..5e-2; the arithmetic itself is pinned to 1e-6 below
     # exactness of the arithmetic itself: identical gradients in, one step
     mc, md = build(cfg, state), build(cfg, state)
     for m_ in (mc, md):
