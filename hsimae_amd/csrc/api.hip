@@ -305,13 +305,14 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
     return HSIMAE_OK;
 }
 
-int wgrad_msplit(int tiles, int64_t M) {
+int wgrad_msplit(int tiles, int64_t M, int concurrent = 1) {
     const int chunks = (int)((M + 63) / 64);
     // the kernel holds 2 workgroups per CU (196 registers: 64 accumulators + the prefetched next chunk): keep the
     // launch to one resident wave of workgroups (HSIMAE_WGRAD_WGS overrides the 512 for experiments)
     static int budget = 0;
     if (!budget) { const char* e = getenv("HSIMAE_WGRAD_WGS"); budget = e ? std::max(8, atoi(e)) : 512; }
-    int ms = std::max(1, budget / std::max(1, tiles));
+    // two launches resident at once (the forked axis stacks) share the budget
+    int ms = std::max(1, budget / std::max(1, concurrent) / std::max(1, tiles));
     if (ms >= 8) ms &= ~7;              // whole XCD groups (wgrad.hip places row slice ms on XCD ms % 8)
     return std::min(ms, chunks);
 }
@@ -319,7 +320,7 @@ int wgrad_msplit(int tiles, int64_t M) {
 // One Block backward: data grads (7 launches) + all weight/bias grads of the block (1 launch).
 int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, const BlkBuf& b, int64_t M, int d,
               int heads, int h, int hp, int Ts, int nsamples, int mode, int len_l, float* G0, const Scr& w,
-              float* dx_out, int accumulate, hipStream_t s) {
+              float* dx_out, int accumulate, hipStream_t s, int concurrent = 1) {
     float* G1 = w.G1;
     GemmParams p = gp();
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
@@ -373,7 +374,7 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     g.M = (int)M;
     int tiles = 0;
     for (int i = 0; i < g.ntasks; ++i) tiles += ((g.t[i].N + 127) / 128) * ((g.t[i].K + 127) / 128);
-    g.msplit = wgrad_msplit(tiles, M);
+    g.msplit = wgrad_msplit(tiles, M, concurrent);
     CK(hs_wgrad(g, s));
 
     // du = dqkv * Wqkv and the LayerNorm-1 backward: one kernel at d = 128 (LN backward as the GEMM's epilogue,
@@ -671,7 +672,7 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
         for (int i = g.sdepth - 1; i >= 0; --i) {
             BlkP b2 = resolve(L.b2[i], c.W.b2[i], P, io->wpk, c.W);
             const float* xin2 = (i > 0) ? w.b2[i - 1].x2 : w.x0;
-            CK(block_bwd(b2, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, scr2, w.G0, 0, s2));
+            CK(block_bwd(b2, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, scr2, w.G0, 0, s2, forked ? 2 : 1));
             if (i == 0 && forked) {                 // the spatial stack's last step accumulates onto the spectral dX
                 CK((int)hipEventRecord(sd.join, sd.s));
                 CK((int)hipStreamWaitEvent(s, sd.join, 0));
@@ -679,7 +680,7 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
             BlkP b1 = resolve(L.b1[i], c.W.b1[i], P, io->wpk, c.W);
             const float* xin1 = (i > 0) ? w.b1[i - 1].x2 : w.x0;
             float* out = (i == 0) ? w.G0 : w.G2;
-            CK(block_bwd(b1, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, out, i == 0, s));
+            CK(block_bwd(b1, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, out, i == 0, s, forked ? 2 : 1));
         }
         // gradient ranges in back-to-front order, all complete on the caller's stream by now
         for (int i = g.sdepth - 1; i >= 0; --i) emit(L.b2[i].n1w, L.b2[i].end);

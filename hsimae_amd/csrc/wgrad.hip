@@ -172,7 +172,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 // wave instruction, lane i -> bytes [16 i, 16 i + 16)).  Bank conflicts of the transpose reads are avoided by
 // permuting which 16-byte column chunk each lane FETCHES: slot s of row r holds column chunk s ^ swz(r).
 constexpr int DC = 32;                     // rows per stage (one MFMA k-step)
-constexpr int DS = 3;                      // ring stages
 constexpr int STAGE_ELEMS = 2 * DC * 128;  // bf16 elements per stage (16 KB)
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
@@ -208,13 +207,9 @@ __device__ __forceinline__ void wait_lds(Frag2 (&y)[4]) {
 }
 
 template <int N>
-__device__ __forceinline__ void wait_vm() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-}
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <int DS>                        // ring stages
 __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
@@ -361,13 +356,22 @@ int hs_wgrad(const WgradParams& p, hipStream_t s) {
     }
     const dim3 grid(8 * tiles * ((p.msplit + 7) / 8));
     if (dma) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      DS * STAGE_ELEMS * 2);
-            attr_set = true;
+        // ring depth: a launch of at most one workgroup per CU has the LDS to itself (6 stages = 96 KB); larger
+        // launches keep 3 stages so that three workgroups fit a CU.  HSIMAE_WGRAD_DS=3..6 forces one.
+        static int ds_env = -1;
+        if (ds_env < 0) {
+            const char* e = getenv("HSIMAE_WGRAD_DS");
+            ds_env = e ? atoi(e) : 0;
+            if (ds_env < 3 || ds_env > 6) ds_env = 0;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_ELEMS * 2);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * STAGE_ELEMS * 2);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * STAGE_ELEMS * 2);
         }
-        hipLaunchKernelGGL(wgrad_dma_kernel, grid, dim3(256), DS * STAGE_ELEMS * 2, s, p);
+        const int ds = ds_env ? ds_env : (grid.x <= 256 ? 6 : 3);
+        if (ds == 3) hipLaunchKernelGGL(wgrad_dma_kernel<3>, grid, dim3(256), 3 * STAGE_ELEMS * 2, s, p);
+        else if (ds == 4) hipLaunchKernelGGL(wgrad_dma_kernel<4>, grid, dim3(256), 4 * STAGE_ELEMS * 2, s, p);
+        else if (ds == 5) hipLaunchKernelGGL(wgrad_dma_kernel<5>, grid, dim3(256), 5 * STAGE_ELEMS * 2, s, p);
+        else hipLaunchKernelGGL(wgrad_dma_kernel<6>, grid, dim3(256), 6 * STAGE_ELEMS * 2, s, p);
     } else {
         hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, p);
     }
