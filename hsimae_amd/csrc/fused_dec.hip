@@ -117,7 +117,9 @@ struct Fr {
     }
 };
 
-template <int MH, int KS>
+// SW: operands swapped -> the accumulator holds the TRANSPOSED tile: acc[r] = C[row c16][column 4 g + r], so a lane owns
+// four consecutive columns of one row and tiles go to LDS as one 8-byte (bf16) / 16-byte (fp32) access instead of four
+template <int MH, int KS, bool SW = false>
 __device__ __forceinline__ void mm_f(const bf16_t* A, int lda, int kofs, const Fr<KS>& f, int mt0, int MT, const Geo4& q,
                                      f32x4 (&acc)[MH][2]) {
 #pragma unroll
@@ -128,7 +130,7 @@ __device__ __forceinline__ void mm_f(const bf16_t* A, int lda, int kofs, const F
             if (mt < MT) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + q.c16) * lda + kofs + ks * 32 + q.g * 8);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[mi][j] = mfma16(a, f.b[ks][j], acc[mi][j]);
+                for (int j = 0; j < 2; ++j) acc[mi][j] = SW ? mfma16(f.b[ks][j], a, acc[mi][j]) : mfma16(a, f.b[ks][j], acc[mi][j]);
             }
         }
 }
@@ -244,12 +246,17 @@ __device__ __forceinline__ void ln_rows(const float* src, int Ts, const float* g
     }
 }
 
-template <int MH>
+template <int MH, bool SW = false>
 __device__ __forceinline__ void acc_from_xs(const float* XS, int mt0, int MT, const Geo4& q, f32x4 (&x)[MH][2]) {
 #pragma unroll
     for (int mi = 0; mi < MH; ++mi)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
+            if constexpr (SW) {
+                const int mt = mt0 + mi;
+                x[mi][j] = (mt < MT) ? *reinterpret_cast<const f32x4*>(XS + (mt * 16 + q.c16) * LX + (q.wn * 2 + j) * 16 + q.g * 4)
+                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int mt = mt0 + mi;
@@ -257,12 +264,16 @@ __device__ __forceinline__ void acc_from_xs(const float* XS, int mt0, int MT, co
             }
 }
 
-template <int MH>
+template <int MH, bool SW = false>
 __device__ __forceinline__ void acc_to_xs(float* XS, int mt0, int MT, const Geo4& q, const f32x4 (&x)[MH][2]) {
 #pragma unroll
     for (int mi = 0; mi < MH; ++mi)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
+            if constexpr (SW) {
+                const int mt = mt0 + mi;
+                if (mt < MT) *reinterpret_cast<f32x4*>(XS + (mt * 16 + q.c16) * LX + (q.wn * 2 + j) * 16 + q.g * 4) = x[mi][j];
+            } else
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int mt = mt0 + mi;
@@ -280,6 +291,12 @@ __device__ __forceinline__ void store_rows(const float* XS, int R, int Ts, float
             *reinterpret_cast<float4*>(dst + (size_t)row * D + c8 + 4) = *reinterpret_cast<const float4*>(XS + row * LX + c8 + 4);
         }
     }
+}
+
+__device__ __forceinline__ bf16x4 cvt4(f32x4 v) {
+    bf16x4 r;
+    r[0] = (bf16_t)v[0]; r[1] = (bf16_t)v[1]; r[2] = (bf16_t)v[2]; r[3] = (bf16_t)v[3];
+    return r;
 }
 
 __device__ __forceinline__ bf16x8 pack2(f32x4 a, f32x4 b) {
@@ -303,36 +320,42 @@ __device__ __forceinline__ void attn_head_fwd(const bf16_t* Qb, const bf16_t* Kb
     const float sc = 0.35355339059327373f * 1.4426950408889634f;     // 8^-0.5 * log2(e)
     const bf16_t* vrow = Vt + ((head * HD + q.c16) & 63) * L::VST;
     const int kcol = (head * HD + 8 * q.g) & 63;
+    // Padding keys are masked through the MFMA's C operand (-inf rows; padded K rows are finite: LN of zero rows).
+    // The launchers use MT = 7 for 65..112 tokens, so key tiles 0..3 are always full there.
+    constexpr int KMIN = (MT > 4) ? 4 : 0;
+    f32x4 cinit[MT - KMIN];
+#pragma unroll
+    for (int kt = KMIN; kt < MT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cinit[kt - KMIN][r] = (kt * 16 + q.g * 4 + r >= Ts) ? -INFINITY : 0.f;
     for (int qt = 0; qt * 16 < Ts; ++qt) {
         const int query = qt * 16 + q.c16;
         const bf16x8 bq = rowfrag8(Qb, LU, query, head * HD, q.g);
         f32x4 s[MT];
 #pragma unroll
         for (int kt = 0; kt < MT; ++kt)       // K side unmasked: lane groups 1-3 read other heads' (finite) columns against bq's zeros
-            s[kt] = mfma16(*reinterpret_cast<const bf16x8*>(Kb + (kt * 16 + q.c16) * LU + kcol), bq, f32x4{0.f, 0.f, 0.f, 0.f});
+            s[kt] = mfma16(*reinterpret_cast<const bf16x8*>(Kb + (kt * 16 + q.c16) * LU + kcol), bq,
+                           kt < KMIN ? f32x4{0.f, 0.f, 0.f, 0.f} : cinit[kt < KMIN ? 0 : kt - KMIN]);
         float m = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < MT; ++kt) {
-            if ((kt + 1) * 16 > Ts) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kt * 16 + q.g * 4 + r >= Ts) s[kt][r] = -INFINITY;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
-        }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        const float nm = -m * sc;
-        float lsum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < MT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc, nm));
-                s[kt][r] = e;
-                lsum += e;
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float nm = -m * sc;
+        const f32x2 sc2 = {sc, sc}, nm2 = {nm, nm};
+        f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {          // packed fp32: two scores per v_pk_fma / v_pk_add
+                const f32x2 t = __builtin_elementwise_fma(f32x2{s[kt][r], s[kt][r + 1]}, sc2, nm2);
+                const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                s[kt][r] = e[0]; s[kt][r + 1] = e[1];
+                ls2 += e;
             }
+        float lsum = ls2[0] + ls2[1];
         lsum += __shfl_xor(lsum, 16, 64);
         lsum += __shfl_xor(lsum, 32, 64);
         const float inv = 1.f / lsum;
@@ -395,31 +418,41 @@ __device__ __forceinline__ void qkv_stage(const bf16_t* U, const DecW& w, const 
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         f32x4 acc[MHX][2];
-#pragma unroll
-        for (int mi = 0; mi < MHX; ++mi)
+        if (c < 2) {                        // q, k: transposed accumulators -> one 8-byte LDS write per tile
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float b = w.bqkv[c * D + (q.wn * 2 + j) * 16 + q.c16];
-                acc[mi][j] = f32x4{b, b, b, b};
+                const f32x4 b = *reinterpret_cast<const f32x4*>(w.bqkv + c * D + (q.wn * 2 + j) * 16 + q.g * 4);
+#pragma unroll
+                for (int mi = 0; mi < MHX; ++mi) acc[mi][j] = b;
             }
-        mm_f<MHX, 2>(U, LU, 0, fq[c], mt0, MT, q, acc);
+            mm_f<MHX, 2, true>(U, LU, 0, fq[c], mt0, MT, q, acc);
+            bf16_t* dst = (c == 0 ? Qb : Kb);
 #pragma unroll
-        for (int mi = 0; mi < MHX; ++mi) {
-            const int mt = mt0 + mi;
-            if (mt >= MT) continue;
+            for (int mi = 0; mi < MHX; ++mi) {
+                const int mt = mt0 + mi;
+                if (mt >= MT) continue;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = (q.wn * 2 + j) * 16 + q.c16;
-                const int row = mt * 16 + q.g * 4;
-                if (c < 2) {
-                    bf16_t* dst = (c == 0 ? Qb : Kb);
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<bf16x4*>(dst + (mt * 16 + q.c16) * LU + (q.wn * 2 + j) * 16 + q.g * 4) = cvt4(acc[mi][j]);
+            }
+        } else {                            // v: row-major accumulators are what the V^T image wants
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[(row + r) * LU + col] = (bf16_t)acc[mi][j][r];
-                } else {
-                    bf16x4 v;
+            for (int mi = 0; mi < MHX; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[mi][j][r];
-                    *reinterpret_cast<bf16x4*>(Vt + col * L::VST + row) = v;
+                for (int j = 0; j < 2; ++j) {
+                    const float b = w.bqkv[c * D + (q.wn * 2 + j) * 16 + q.c16];
+                    acc[mi][j] = f32x4{b, b, b, b};
+                }
+            mm_f<MHX, 2>(U, LU, 0, fq[c], mt0, MT, q, acc);
+#pragma unroll
+            for (int mi = 0; mi < MHX; ++mi) {
+                const int mt = mt0 + mi;
+                if (mt >= MT) continue;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = (q.wn * 2 + j) * 16 + q.c16;
+                    const int row = mt * 16 + q.g * 4;
+                    *reinterpret_cast<bf16x4*>(Vt + col * L::VST + row) = cvt4(acc[mi][j]);
                 }
             }
         }
@@ -454,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
         lds_barrier();
         PH(0)
         f32x4 xr[L::MHF][2];
-        acc_from_xs<L::MHF>(XS, mt0, MT, q, xr);
+        acc_from_xs<L::MHF, true>(XS, mt0, MT, q, xr);
         lds_barrier();
         PH(0)
         qkv_stage<MT, L::MHF>(U, w, fq, Qb, Kb, Vt, mt0, q);
@@ -479,20 +512,18 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
             const int row = pc >> 3, k8 = (pc & 7) * 8;
             if (row < p.Ts) *reinterpret_cast<bf16x8*>(p.o + (rb + row) * D + k8) = *reinterpret_cast<const bf16x8*>(U + row * LU + k8);
         }
-        // proj accumulates onto the residual
+        // proj accumulates onto the residual (transposed accumulators: see mm_f)
 #pragma unroll
-        for (int mi = 0; mi < L::MHF; ++mi)
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(w.pb + (q.wn * 2 + j) * 16 + q.g * 4);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float b = w.pb[(q.wn * 2 + j) * 16 + q.c16];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xr[mi][j][r] += b;
-            }
-        mm_f<L::MHF, 2>(U, LU, 0, fp, mt0, MT, q, xr);
+            for (int mi = 0; mi < L::MHF; ++mi) xr[mi][j] += b;
+        }
+        mm_f<L::MHF, 2, true>(U, LU, 0, fp, mt0, MT, q, xr);
         Fr<2> f1, f3;
         f1.load(w.w1, 2, q.wn * 2, 0, q);
         f3.load(w.w3, 2, q.wn * 2, 0, q);
-        acc_to_xs<L::MHF>(XS, mt0, MT, q, xr);
+        acc_to_xs<L::MHF, true>(XS, mt0, MT, q, xr);
         lds_barrier();
         PH(3)
         ln_rows<MT, true, 256>(nullptr, p.Ts, w.n2w, w.n2b, U, XS, p.x1 + rb * D);      // LN2; x1 saved for the backward
@@ -503,16 +534,19 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
         for (int c = 0; c < 3; ++c) {
             f32x4 h1[L::MHF][2], h3[L::MHF][2];
 #pragma unroll
-            for (int mi = 0; mi < L::MHF; ++mi)
+            for (int j = 0; j < 2; ++j) {
+                const int col = c * 64 + (q.wn * 2 + j) * 16 + q.g * 4;
+                f32x4 b1, b3;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
-                    const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
-                    h1[mi][j] = f32x4{b1, b1, b1, b1};
-                    h3[mi][j] = f32x4{b3, b3, b3, b3};
+                for (int r = 0; r < 4; ++r) {
+                    b1[r] = col + r < w.h ? w.w1b[col + r] : 0.f;
+                    b3[r] = col + r < w.h ? w.w3b[col + r] : 0.f;
                 }
-            mm_f<L::MHF, 2>(U, LU, 0, f1, mt0, MT, q, h1);
-            mm_f<L::MHF, 2>(U, LU, 0, f3, mt0, MT, q, h3);
+#pragma unroll
+                for (int mi = 0; mi < L::MHF; ++mi) { h1[mi][j] = b1; h3[mi][j] = b3; }
+            }
+            mm_f<L::MHF, 2, true>(U, LU, 0, f1, mt0, MT, q, h1);
+            mm_f<L::MHF, 2, true>(U, LU, 0, f3, mt0, MT, q, h3);
             if (c < 2) {
                 f1.load(w.w1, 2, (c + 1) * 4 + q.wn * 2, 0, q);
                 f3.load(w.w3, 2, (c + 1) * 4 + q.wn * 2, 0, q);
@@ -525,29 +559,26 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
                 if (mt >= MT) continue;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
+                    const int col = c * 64 + (q.wn * 2 + j) * 16 + q.g * 4;
+                    f32x4 gv;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float gv = col < w.h ? silu_f(h1[mi][j][r]) * h3[mi][j][r] : 0.f;
-                        Gb[(mt * 16 + q.g * 4 + r) * LG + col] = (bf16_t)gv;
-                    }
+                    for (int r = 0; r < 4; ++r) gv[r] = col + r < w.h ? silu_f(h1[mi][j][r]) * h3[mi][j][r] : 0.f;
+                    *reinterpret_cast<bf16x4*>(Gb + (mt * 16 + q.c16) * LG + col) = cvt4(gv);
                 }
             }
         }
         lds_barrier();
         PH(5)
 #pragma unroll
-        for (int mi = 0; mi < L::MHF; ++mi)
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(w.w2b + (q.wn * 2 + j) * 16 + q.g * 4);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float b = w.w2b[(q.wn * 2 + j) * 16 + q.c16];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xr[mi][j][r] += b;
-            }
-        mm_f<L::MHF, 6>(Gb, LG, 0, f2, mt0, MT, q, xr);
+            for (int mi = 0; mi < L::MHF; ++mi) xr[mi][j] += b;
+        }
+        mm_f<L::MHF, 6, true>(Gb, LG, 0, f2, mt0, MT, q, xr);
         lds_barrier();
         PH(6)
-        acc_to_xs<L::MHF>(XS, mt0, MT, q, xr);
+        acc_to_xs<L::MHF, true>(XS, mt0, MT, q, xr);
         lds_barrier();
         store_rows<256>(XS, L::R, p.Ts, p.x2 + rb * D);
         lds_barrier();
@@ -898,11 +929,6 @@ __device__ __forceinline__ f32x4 mfma16k16(bf16x4 a, bf16x4 b, f32x4 c) {
 __device__ __forceinline__ bf16x4 zero4() {
     u32x2 z = {0u, 0u};
     return __builtin_bit_cast(bf16x4, z);
-}
-__device__ __forceinline__ bf16x4 cvt4(f32x4 v) {
-    bf16x4 r;
-    r[0] = (bf16_t)v[0]; r[1] = (bf16_t)v[1]; r[2] = (bf16_t)v[2]; r[3] = (bf16_t)v[3];
-    return r;
 }
 // 4 consecutive image rows of one column per lane: element j of lane (c16, g) = img[row0(g) + j][col0 + c16];
 // `a` is the lane's own 8-byte piece img[row0(g) + (c16 >> 2)][col0 + 4 (c16 & 3) ..].
