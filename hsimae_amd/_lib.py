@@ -28,7 +28,7 @@ class IO(C.Structure):
                 ("workspace", vp), ("workspace_bytes", i64),
                 ("grad_scale", f32), ("want_recons", i32),
                 ("loss", vp), ("pred_img", vp), ("mask_img", vp), ("mask", vp),
-                ("ids_keep", vp), ("ids_restore", vp), ("latent", vp), ("pred", vp)]
+                ("ids_keep", vp), ("ids_restore", vp), ("latent", vp), ("pred", vp), ("drop_scale", vp)]
 
 
 class MaskParams(C.Structure):
@@ -47,7 +47,8 @@ class GemmParams(C.Structure):
                 ("stats", vp), ("u_out", vp), ("ldu", i32), ("out", vp), ("ldo", i32),
                 ("res", vp), ("res2", vp), ("ldr", i32), ("pos", vp), ("ids", vp), ("ldpos", i32),
                 ("h13", vp), ("ldh", i32), ("hoff", i32),
-                ("lnx", vp), ("dgamma", vp), ("dbeta", vp), ("accumulate", i32)]
+                ("lnx", vp), ("dgamma", vp), ("dbeta", vp), ("accumulate", i32),
+                ("a_rowscale", vp), ("out_rowscale", vp)]
 
 
 class PackDesc(C.Structure):
@@ -58,12 +59,12 @@ class PackDesc(C.Structure):
 class AttnParams(C.Structure):
     _fields_ = [("qkv", vp), ("ld", i32), ("d", i32), ("heads", i32), ("hd", i32), ("Ts", i32), ("nsamples", i32),
                 ("mode", i32), ("len_l", i32), ("o", vp), ("ldo", i32), ("lse", vp), ("dout", vp), ("lddo", i32),
-                ("dqkv", vp), ("proj_w", vp), ("proj_b", vp), ("xres", vp), ("x1", vp), ("projT_w", vp)]
+                ("dqkv", vp), ("proj_w", vp), ("proj_b", vp), ("xres", vp), ("x1", vp), ("projT_w", vp), ("rowscale", vp)]
 
 
 class WgradTask(C.Structure):
     _fields_ = [("dO", vp), ("dO_f32", i32), ("ldo", i32), ("A", vp), ("lda", i32), ("N", i32), ("K", i32),
-                ("dW", vp), ("ldw", i32), ("db", vp)]
+                ("dW", vp), ("ldw", i32), ("db", vp), ("dO_rowscale", vp)]
 
 
 class WgradParams(C.Structure):
@@ -123,6 +124,7 @@ SYMBOLS = {
     "hsimae_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "hsimae_cube_gather": (C.c_int, [C.POINTER(CubeParams), vp]),
     "hsimae_encode": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp]),
+    "hsimae_encode_backward": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp, vp, BUCKET_CB, vp, vp]),
     "hsimae_agg_pool": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
 }
 

@@ -273,8 +273,10 @@ DecBlockPtrs dec_ptrs(const BlkP& b, int h) {
 GemmParams gp() { GemmParams p; std::memset(&p, 0, sizeof(p)); return p; }
 
 // One transformer Block forward (Models.py:303-306): 5 launches.
+// rs_a / rs_m: optional per-row DropPath factors of the attention / MLP branch (Models.py:304-305), NULL = none.
 int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int d, int heads, int h, int hp, int Ts,
-              int nsamples, int mode, int len_l, const float* res2, hipStream_t s) {
+              int nsamples, int mode, int len_l, const float* res2, hipStream_t s, const float* rs_a = nullptr,
+              const float* rs_m = nullptr) {
     GemmParams p = gp();
     p.A = x_in; p.lda = d; p.M = (int)M; p.N = 3 * d; p.K = d; p.n_valid = 3 * d; p.W = P.qkv; p.bias = P.bqkv;
     p.gamma = P.n1w; p.beta = P.n1b; p.u_out = b.u; p.ldu = d; p.out = b.qkv; p.ldo = 3 * d;
@@ -283,16 +285,16 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
     a.qkv = b.qkv; a.ld = 3 * d; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
     a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = d; a.lse = b.lse;
     if (hs_attn_proj_fusable(a)) {            // proj + residual inside the attention kernel (x1 = x + o Wp^T + b)
-        a.proj_w = P.p; a.proj_b = P.pb; a.xres = x_in; a.x1 = b.x1;
+        a.proj_w = P.p; a.proj_b = P.pb; a.xres = x_in; a.x1 = b.x1; a.rowscale = rs_a;
         CK(hs_attn_fwd(a, s));
     } else {
         CK(hs_attn_fwd(a, s));
         p = gp();
         p.A = b.o; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d; p.W = P.p; p.bias = P.pb;
-        p.res = x_in; p.ldr = d; p.out = b.x1; p.ldo = d;
+        p.res = x_in; p.ldr = d; p.out = b.x1; p.ldo = d; p.out_rowscale = rs_a;
         CK(hs_gemm(p, A_BF16, E_RES_F32, s));
     }
-    if (fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s);
+    if (fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
     p = gp();
     p.A = b.x1; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = h; p.W = P.w1; p.W2 = P.w3; p.bias = P.w1b;
     p.bias2 = P.w3b; p.gamma = P.n2w; p.beta = P.n2b; p.u_out = b.u2; p.ldu = d; p.out = b.g; p.ldo = hp;
@@ -300,7 +302,7 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
     CK(hs_gemm(p, A_F32_LN, E_SWIGLU, s));
     p = gp();
     p.A = b.g; p.lda = hp; p.M = (int)M; p.N = d; p.K = hp; p.n_valid = d; p.W = P.w2; p.bias = P.w2b;
-    p.res = b.x1; p.res2 = res2; p.ldr = d; p.out = b.x2; p.ldo = d;
+    p.res = b.x1; p.res2 = res2; p.ldr = d; p.out = b.x2; p.ldo = d; p.out_rowscale = rs_m;
     CK(hs_gemm(p, A_BF16, E_RES_F32, s));
     return HSIMAE_OK;
 }
@@ -320,7 +322,8 @@ int wgrad_msplit(int tiles, int64_t M, int concurrent = 1) {
 // One Block backward: data grads (7 launches) + all weight/bias grads of the block (1 launch).
 int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, const BlkBuf& b, int64_t M, int d,
               int heads, int h, int hp, int Ts, int nsamples, int mode, int len_l, float* G0, const Scr& w,
-              float* dx_out, int accumulate, hipStream_t s, int concurrent = 1) {
+              float* dx_out, int accumulate, hipStream_t s, int concurrent = 1, const float* rs_a = nullptr,
+              const float* rs_m = nullptr) {
     float* G1 = w.G1;
     GemmParams p = gp();
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
@@ -329,10 +332,10 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     if (fmlp) {
         // recompute u2 / h1 / h3 / g inside the tile; emits dx1 and the wgrad operands u2, dh1|dh3, g, bf16 dY and dx1
         CK(hs_enc_mlp_bwd(b.x1, G0, G1, b.u2, w.dh13, b.g, w.g0b, w.g1b, (int)M, d, mlp_ptrs(P, h), grads + o.n2w,
-                          grads + o.n2b, s));
+                          grads + o.n2b, s, rs_m, rs_a));
     } else {
         p.A = G0; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = hp; p.W = P.w2T; p.out = w.dh13; p.ldo = 2 * hp;
-        p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp;
+        p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp; p.a_rowscale = rs_m;        // DropPath: the branch saw rs_m * dY
         CK(hs_gemm(p, A_F32, E_SWIGLU_BWD, s));
         p = gp();
         p.A = w.dh13; p.lda = 2 * hp; p.M = (int)M; p.N = d; p.K = 2 * hp; p.n_valid = d; p.W = P.w13T; p.out = w.du; p.ldo = d;
@@ -352,25 +355,27 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         p = gp();
         p.A = fmlp ? (const void*)w.g1b : (const void*)G1; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d;
         p.W = P.pT; p.out = w.dob; p.ldo = d;
+        if (!fmlp) p.a_rowscale = rs_a;       // (the bf16 copy from enc_mlp_bwd already carries the factor)
         CK(hs_gemm(p, fmlp ? A_BF16 : A_F32, E_BF16, s));
     }
     CK(hs_attn_bwd(a, s));
     // Weight gradients first: the LayerNorm-backward GEMM below writes dx over G0 / G1 when the caller runs in place
     WgradParams g; std::memset(&g, 0, sizeof(g));
-    auto task = [&](const void* dO, int f32, int ldo, const hs_bf16* A, int lda, int N, int K, int64_t dW, int64_t db) {
+    auto task = [&](const void* dO, int f32, int ldo, const hs_bf16* A, int lda, int N, int K, int64_t dW, int64_t db,
+                    const float* rs = nullptr) {
         WgradTask& t = g.t[g.ntasks++];
         t.dO = dO; t.dO_f32 = f32; t.ldo = ldo; t.A = A; t.lda = lda; t.N = N; t.K = K; t.dW = grads + dW; t.ldw = K;
-        t.db = grads + db;
+        t.db = grads + db; t.dO_rowscale = f32 ? rs : nullptr;
     };
     task(w.dqkv, 0, 3 * d, b.u, d, d, d, o.qw, o.qb);
     task(w.dqkv + d, 0, 3 * d, b.u, d, d, d, o.kw, o.kb);
     task(w.dqkv + 2 * d, 0, 3 * d, b.u, d, d, d, o.vw, o.vb);
     if (fmlp) task(w.g1b, 0, d, b.o, d, d, d, o.pw, o.pb);      // all-bf16 operands: wgrad takes its LDS-DMA path
-    else task(G1, 1, d, b.o, d, d, d, o.pw, o.pb);
+    else task(G1, 1, d, b.o, d, d, d, o.pw, o.pb, rs_a);
     task(w.dh13, 0, 2 * hp, b.u2, d, h, d, o.w1w, o.w1b);
     task(w.dh13 + hp, 0, 2 * hp, b.u2, d, h, d, o.w3w, o.w3b);
     if (fmlp) task(w.g0b, 0, d, b.g, hp, d, h, o.w2w, o.w2b);
-    else task(G0, 1, d, b.g, hp, d, h, o.w2w, o.w2b);
+    else task(G0, 1, d, b.g, hp, d, h, o.w2w, o.w2b, rs_m);
     g.M = (int)M;
     int tiles = 0;
     for (int i = 0; i < g.ntasks; ++i) tiles += ((g.t[i].N + 127) / 128) * ((g.t[i].K + 127) / 128);
@@ -492,6 +497,14 @@ int64_t hsimae_workspace_bytes(const hsimae_config* cfg, int32_t N, int32_t len_
     return w.bytes;
 }
 
+// DropPath factors of encoder block `e` (execution order blocks_1, blocks_2, blocks): {attention, MLP} row vectors
+struct DropRs { const float* a; const float* m; };
+static DropRs drop_rs(const hsimae_io* io, int e, int64_t Me) {
+    if (!io->drop_scale) return DropRs{nullptr, nullptr};
+    const float* base = io->drop_scale + (int64_t)e * 2 * Me;
+    return DropRs{base, base + Me};
+}
+
 static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* stream, bool encoder_only) {
     Ctx c; CK(make_ctx(cfg, io, c, true));
     if (!io->x || !io->noise1 || !io->noise2 || !io->mask || !io->ids_keep || !io->ids_restore) return HSIMAE_ENULL;
@@ -524,7 +537,8 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
         for (int i = 0; i < g.sdepth; ++i) {
             // spatial stack: attend within one kept band group (Models.py:553,556)
             BlkP b1 = resolve(c.L.b1[i], c.W.b1[i], P, io->wpk, c.W);
-            CK(block_fwd(b1, xa, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, nullptr, s));
+            const DropRs r1 = drop_rs(io, i, c.Me), r2d = drop_rs(io, g.sdepth + i, c.Me);
+            CK(block_fwd(b1, xa, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, nullptr, s, r1.a, r1.m));
             xa = w.b1[i].x2;
             // spectral stack: attend within one kept position (Models.py:554,559)
             BlkP b2 = resolve(c.L.b2[i], c.W.b2[i], P, io->wpk, c.W);
@@ -534,14 +548,16 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
                 CK((int)hipEventRecord(sd.join, sd.s));
                 CK((int)hipStreamWaitEvent(s, sd.join, 0));
             }
-            CK(block_fwd(b2, xb, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, r2, (forked && !last) ? sd.s : s));
+            CK(block_fwd(b2, xb, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, r2, (forked && !last) ? sd.s : s,
+                         r2d.a, r2d.m));
             xb = w.b2[i].x2;
         }
         x = xb;
     }
     for (int i = 0; i < g.nfus; ++i) {
         BlkP bp = resolve(c.L.bf[i], c.W.bf[i], P, io->wpk, c.W);
-        CK(block_fwd(bp, x, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, nullptr, s));
+        const DropRs rf = drop_rs(io, (g.has_axis ? 2 * g.sdepth : 0) + i, c.Me);
+        CK(block_fwd(bp, x, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, nullptr, s, rf.a, rf.m));
         x = w.bf[i].x2;
     }
     if (encoder_only) {                       // `norm` only (Models.py:570 / 892): the latent the fine-tuning head reads
@@ -584,6 +600,62 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
 
 int hsimae_forward(const hsimae_config* cfg, const hsimae_io* io, void* stream) { return forward_impl(cfg, io, stream, false); }
 int hsimae_encode(const hsimae_config* cfg, const hsimae_io* io, void* stream) { return forward_impl(cfg, io, stream, true); }
+
+// Backward of the encoder stacks + patch embedding, from d(x of the last encoder block) in w.G0.  Shared by
+// hsimae_backward (after the decoder) and hsimae_encode_backward (after `norm`).
+static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hipStream_t s, int stage, hsimae_bucket_cb cb,
+                            void* user) {
+    const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
+    auto emit = [&](int64_t off, int64_t end) { if (cb) cb(stage, off, end - off, user); ++stage; };
+    for (int i = g.nfus - 1; i >= 0; --i) {
+        BlkP bp = resolve(L.bf[i], c.W.bf[i], P, io->wpk, c.W);
+        const float* xin = (i > 0) ? w.bf[i - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
+        const DropRs rf = drop_rs(io, (g.has_axis ? 2 * g.sdepth : 0) + i, c.Me);
+        CK(block_bwd(bp, L.bf[i], grads, xin, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, w.G0, w.sc, w.G0, 0, s, 1,
+                     rf.a, rf.m));
+        emit(L.bf[i].n1w, L.bf[i].end);
+    }
+    if (g.has_axis) {
+        // d(x1 + x2) feeds both stacks (Models.py:564); the spectral stack's backward runs on the side stream
+        Side& sd = side();
+        const bool forked = sd.ok && g.sdepth > 1;
+        CK((int)hipMemcpyAsync(w.G2, w.G0, c.Me * g.D * 4, hipMemcpyDeviceToDevice, s));
+        if (forked) {
+            CK((int)hipEventRecord(sd.fork, s));
+            CK((int)hipStreamWaitEvent(sd.s, sd.fork, 0));
+        }
+        hipStream_t s2 = forked ? sd.s : s;
+        const Scr& scr2 = forked ? w.sc2 : w.sc;
+        for (int i = g.sdepth - 1; i >= 0; --i) {
+            BlkP b2 = resolve(L.b2[i], c.W.b2[i], P, io->wpk, c.W);
+            const DropRs r1 = drop_rs(io, i, c.Me), r2d = drop_rs(io, g.sdepth + i, c.Me);
+            const float* xin2 = (i > 0) ? w.b2[i - 1].x2 : w.x0;
+            CK(block_bwd(b2, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, scr2, w.G0, 0, s2, forked ? 2 : 1,
+                         r2d.a, r2d.m));
+            if (i == 0 && forked) {                 // the spatial stack's last step accumulates onto the spectral dX
+                CK((int)hipEventRecord(sd.join, sd.s));
+                CK((int)hipStreamWaitEvent(s, sd.join, 0));
+            }
+            BlkP b1 = resolve(L.b1[i], c.W.b1[i], P, io->wpk, c.W);
+            const float* xin1 = (i > 0) ? w.b1[i - 1].x2 : w.x0;
+            float* out = (i == 0) ? w.G0 : w.G2;
+            CK(block_bwd(b1, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, out, i == 0, s, forked ? 2 : 1,
+                         r1.a, r1.m));
+        }
+        // gradient ranges in back-to-front order, all complete on the caller's stream by now
+        for (int i = g.sdepth - 1; i >= 0; --i) emit(L.b2[i].n1w, L.b2[i].end);
+        for (int i = g.sdepth - 1; i >= 0; --i) emit(L.b1[i].n1w, L.b1[i].end);
+    }
+    {   // patch_embed.proj: only the kept tokens carry gradient (Models.py:528); no input gradient
+        WgradParams wg; std::memset(&wg, 0, sizeof(wg));
+        WgradTask& t = wg.t[0]; t.dO = w.G0; t.dO_f32 = 1; t.ldo = g.D; t.A = w.a_pe; t.lda = 96; t.N = g.D; t.K = 72;
+        t.dW = grads + L.pew; t.ldw = 72; t.db = grads + L.peb;
+        wg.ntasks = 1; wg.M = (int)c.Me; wg.msplit = wgrad_msplit((g.D + 127) / 128, c.Me);
+        CK(hs_wgrad(wg, s));
+    }
+    emit(0, L.peb + g.D);
+    return HSIMAE_OK;
+}
 
 int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads, hsimae_bucket_cb cb, void* user,
                     void* stream) {
@@ -652,49 +724,25 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
     CK(hs_ln_bwd(l, s));
     emit(L.nw, L.deb + g.Dd);
 
-    for (int i = g.nfus - 1; i >= 0; --i) {
-        BlkP bp = resolve(L.bf[i], c.W.bf[i], P, io->wpk, c.W);
-        const float* xin = (i > 0) ? w.bf[i - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
-        CK(block_bwd(bp, L.bf[i], grads, xin, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, w.G0, w.sc, w.G0, 0, s));
-        emit(L.bf[i].n1w, L.bf[i].end);
-    }
-    if (g.has_axis) {
-        // d(x1 + x2) feeds both stacks (Models.py:564); the spectral stack's backward runs on the side stream
-        Side& sd = side();
-        const bool forked = sd.ok && g.sdepth > 1;
-        CK((int)hipMemcpyAsync(w.G2, w.G0, c.Me * g.D * 4, hipMemcpyDeviceToDevice, s));
-        if (forked) {
-            CK((int)hipEventRecord(sd.fork, s));
-            CK((int)hipStreamWaitEvent(sd.s, sd.fork, 0));
-        }
-        hipStream_t s2 = forked ? sd.s : s;
-        const Scr& scr2 = forked ? w.sc2 : w.sc;
-        for (int i = g.sdepth - 1; i >= 0; --i) {
-            BlkP b2 = resolve(L.b2[i], c.W.b2[i], P, io->wpk, c.W);
-            const float* xin2 = (i > 0) ? w.b2[i - 1].x2 : w.x0;
-            CK(block_bwd(b2, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, scr2, w.G0, 0, s2, forked ? 2 : 1));
-            if (i == 0 && forked) {                 // the spatial stack's last step accumulates onto the spectral dX
-                CK((int)hipEventRecord(sd.join, sd.s));
-                CK((int)hipStreamWaitEvent(s, sd.join, 0));
-            }
-            BlkP b1 = resolve(L.b1[i], c.W.b1[i], P, io->wpk, c.W);
-            const float* xin1 = (i > 0) ? w.b1[i - 1].x2 : w.x0;
-            float* out = (i == 0) ? w.G0 : w.G2;
-            CK(block_bwd(b1, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, out, i == 0, s, forked ? 2 : 1));
-        }
-        // gradient ranges in back-to-front order, all complete on the caller's stream by now
-        for (int i = g.sdepth - 1; i >= 0; --i) emit(L.b2[i].n1w, L.b2[i].end);
-        for (int i = g.sdepth - 1; i >= 0; --i) emit(L.b1[i].n1w, L.b1[i].end);
-    }
-    {   // patch_embed.proj: only the kept tokens carry gradient (Models.py:528); no input gradient
-        WgradParams wg; std::memset(&wg, 0, sizeof(wg));
-        WgradTask& t = wg.t[0]; t.dO = w.G0; t.dO_f32 = 1; t.ldo = g.D; t.A = w.a_pe; t.lda = 96; t.N = g.D; t.K = 72;
-        t.dW = grads + L.pew; t.ldw = 72; t.db = grads + L.peb;
-        wg.ntasks = 1; wg.M = (int)c.Me; wg.msplit = wgrad_msplit((g.D + 127) / 128, c.Me);
-        CK(hs_wgrad(wg, s));
-    }
-    emit(0, L.peb + g.D);
-    return HSIMAE_OK;
+    return encoder_backward(c, io, grads, s, stage, cb, user);
+}
+
+int hsimae_encode_backward(const hsimae_config* cfg, const hsimae_io* io, const float* dlatent, float* grads,
+                           hsimae_bucket_cb cb, void* user, void* stream) {
+    Ctx c; CK(make_ctx(cfg, io, c, true));
+    if (!grads || !dlatent) return HSIMAE_ENULL;
+    hipStream_t s = S(stream);
+    const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
+    // `norm` (Models.py:892): dlatent -> d(x of the last encoder block) in G0
+    const float* xf = g.nfus ? w.bf[g.nfus - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
+    LnBwdParams l; std::memset(&l, 0, sizeof(l));
+    l.du = dlatent; l.x = xf; l.gamma = P + L.nw; l.dres = nullptr; l.dx = w.G0; l.dgamma = grads + L.nw; l.dbeta = grads + L.nb;
+    l.M = (int)c.Me; l.d = g.D;
+    CK(hs_ln_bwd(l, s));
+    int stage = 0;
+    if (cb) cb(stage, L.nw, L.nb + g.D - L.nw, user);
+    ++stage;
+    return encoder_backward(c, io, grads, s, stage, cb, user);
 }
 
 // ---------------------------------------------------------------------- per-kernel entry points

@@ -673,8 +673,12 @@ __global__ __launch_bounds__(512) void attn128_fwd_kernel(AttnParams p) {
     lds_barrier();
     for (int idx = threadIdx.x; idx < p.Ts * 32; idx += 512) {
         const int row = idx >> 5, c4 = (idx & 31) * 4;
-        const float4 t = *reinterpret_cast<const float4*>(XT + row * XS_ + c4);
+        float4 t = *reinterpret_cast<const float4*>(XT + row * XS_ + c4);
         const float4 x = *reinterpret_cast<const float4*>(p.xres + (row_base + row) * 128 + c4);
+        if (p.rowscale) {                                       // DropPath: x + scale * attn(x)
+            const float q = p.rowscale[row_base + row];
+            t.x *= q; t.y *= q; t.z *= q; t.w *= q;
+        }
         *reinterpret_cast<float4*>(p.x1 + (row_base + row) * 128 + c4) = make_float4(t.x + x.x, t.y + x.y, t.z + x.z, t.w + x.w);
     }
 }

@@ -127,7 +127,7 @@ struct EncMlpW {
     int h;
 };
 
-struct EncMlpFwdArgs { const float* x1; const float* res2; float* x2; int M; EncMlpW w; };
+struct EncMlpFwdArgs { const float* x1; const float* res2; float* x2; int M; EncMlpW w; const float* rowscale; };
 
 template <int D, int HPE>
 __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
             const int col = (q.wave * NJO + j) * 16 + q.c16;
             const float b = w.w2b[col];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xr[mt][j][r] = XS[(mt * 16 + q.g * 4 + r) * LX + col] + b;
+            for (int r = 0; r < 4; ++r) xr[mt][j][r] = (p.rowscale ? 0.f : XS[(mt * 16 + q.g * 4 + r) * LX + col]) + b;
         }
     lds_barrier();                             // XS consumed: the gate image may overwrite it
     PH(1)
@@ -258,6 +258,13 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
         if (row0 + row < p.M) {
             float f[8];
             ld8(XS + row * LX + c8, f);
+            if (p.rowscale) {                  // DropPath: x1 + scale * mlp(x1); the accumulators hold the branch alone
+                float t[8];
+                const float rs = p.rowscale[row0 + row];
+                ld8(p.x1 + (size_t)(row0 + row) * D + c8, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], rs, t[e]);
+            }
             if (p.res2) {
                 float t[8];
                 ld8(p.res2 + (size_t)(row0 + row) * D + c8, t);
@@ -275,6 +282,9 @@ struct EncMlpBwdArgs {
     const float* x1; const float* dy; float* dx1; bf16_t* u2; bf16_t* dh13; bf16_t* g; int M; EncMlpW w;
     float* g_n2w; float* g_n2b;
     bf16_t* dyb; bf16_t* dx1b;       // bf16 copies of dY and dx1: the dO operands of dW2 / dWproj (and proj's data gradient)
+    // DropPath (NULL = none): the MLP branch saw rs_mlp * dY, so dyb and everything derived from it carry the factor;
+    // dx1b is what the attention branch sees, rs_attn * dx1.  dx1 itself (the residual path) is unscaled.
+    const float* rs_mlp; const float* rs_attn;
 };
 
 template <int D, int HPE>
@@ -330,6 +340,14 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
             for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
             const bf16x8 ub = cvt8(f);
             *reinterpret_cast<bf16x8*>(U2 + row * LU + c8) = ub;
+            if (p.rs_mlp && ok) {
+                const float rs = p.rs_mlp[row0 + row];
+                float sv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sv[e] = dyv[e] * rs;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dyv[e] = sv[e];
+            }
             const bf16x8 dyb8 = cvt8(dyv);
             *reinterpret_cast<bf16x8*>(DYb + row * LU + c8) = dyb8;
             if (ok) {
@@ -477,6 +495,11 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
                     dbet[e] += du[e];
                 }
                 st8(p.dx1 + (size_t)(row0 + row) * D + c8, o);
+                if (p.rs_attn) {
+                    const float rs = p.rs_attn[row0 + row];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] *= rs;
+                }
                 *reinterpret_cast<bf16x8*>(p.dx1b + (size_t)(row0 + row) * D + c8) = cvt8(o);
             }
         }
@@ -522,9 +545,10 @@ static void set_attrs() {
     done = true;
 }
 
-int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, const EncMlpPtrs& b, hipStream_t s) {
+int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, const EncMlpPtrs& b, hipStream_t s,
+                   const float* rowscale) {
     if (M <= 0) return HS_OK;
-    EncMlpFwdArgs a; a.x1 = x1; a.res2 = res2; a.x2 = x2; a.M = M; a.w = mkw(b);
+    EncMlpFwdArgs a; a.x1 = x1; a.res2 = res2; a.x2 = x2; a.M = M; a.w = mkw(b); a.rowscale = rowscale;
     if (d == 128) {
         set_attrs<128, 352>();
         hipLaunchKernelGGL((enc_mlp_fwd_kernel<128, 352>), dim3((M + R - 1) / R), dim3(NTH), (MG<128, 352>::LDS_FWD), s, a);
@@ -535,10 +559,11 @@ int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, 
 }
 
 int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
-                   hs_bf16* dx1b, int M, int d, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s) {
+                   hs_bf16* dx1b, int M, int d, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s,
+                   const float* rs_mlp, const float* rs_attn) {
     if (M <= 0) return HS_OK;
     EncMlpBwdArgs a; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.u2 = u2; a.dh13 = dh13; a.g = g; a.M = M; a.w = mkw(b);
-    a.g_n2w = g_n2w; a.g_n2b = g_n2b; a.dyb = dyb; a.dx1b = dx1b;
+    a.g_n2w = g_n2w; a.g_n2b = g_n2b; a.dyb = dyb; a.dx1b = dx1b; a.rs_mlp = rs_mlp; a.rs_attn = rs_attn;
     if (d == 128) {
         set_attrs<128, 352>();
         hipLaunchKernelGGL((enc_mlp_bwd_kernel<128, 352>), dim3((M + R - 1) / R), dim3(NTH), (MG<128, 352>::LDS_BWD), s, a);

@@ -125,6 +125,13 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
                     const float4 x0 = *reinterpret_cast<const float4*>(A + (size_t)row * p.lda + kcol);
                     const float4 x1 = *reinterpret_cast<const float4*>(A + (size_t)row * p.lda + kcol + 4);
                     float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    if constexpr (AK == A_F32) {
+                        if (p.a_rowscale) {                       // DropPath: the branch gradient is scale * dY
+                            const float rs = p.a_rowscale[row];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) f[i] *= rs;
+                        }
+                    }
                     if constexpr (AK == A_F32_LN) {
                         const float mean = rstat[2 * r], rstd = rstat[2 * r + 1];
                         const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + kcol);
@@ -362,6 +369,11 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
                 } else if constexpr (EPI == E_F32 || EPI == E_RES_F32 || EPI == E_POS_F32) {
                     if (!cvalid) continue;
                     if constexpr (EPI == E_RES_F32) {
+                        if (p.out_rowscale) {                     // DropPath: x + scale * branch
+                            const float rs = p.out_rowscale[row];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] *= rs;
+                        }
                         const float* rp = p.res + (size_t)row * p.ldr + col;
                         const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
                         v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;

@@ -64,9 +64,11 @@ struct EncMlpPtrs {
     int h;
 };
 bool hs_enc_mlp_fused_supported(int d, int hidden);
-int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, const EncMlpPtrs& b, hipStream_t s);
+int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, const EncMlpPtrs& b, hipStream_t s,
+                   const float* rowscale = nullptr);
 int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
-                   hs_bf16* dx1b, int M, int d, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s);
+                   hs_bf16* dx1b, int M, int d, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s,
+                   const float* rs_mlp = nullptr, const float* rs_attn = nullptr);
 
 int hs_adamw(float* p, const float* g, float* m, float* v, const unsigned char* group, int64_t n, float lr, float b1, float b2,
              float eps, float wd, int step, hipStream_t s);

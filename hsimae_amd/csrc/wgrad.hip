@@ -38,7 +38,7 @@ struct RowRegs {
 };
 
 __device__ __forceinline__ void load_rows(const void* src, bool f32, int ld, int ncols8, int M, int m0, int c0, int tid,
-                                          RowRegs& rr) {
+                                          RowRegs& rr, const float* rowscale = nullptr) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + 256 * i;
@@ -51,6 +51,11 @@ __device__ __forceinline__ void load_rows(const void* src, bool f32, int ld, int
                 const float* s = reinterpret_cast<const float*>(src) + (size_t)row * ld + col;
                 rr.f0[i] = *reinterpret_cast<const float4*>(s);
                 rr.f1[i] = *reinterpret_cast<const float4*>(s + 4);
+                if (rowscale) {                          // DropPath: this linear saw scale * dO
+                    const float q = rowscale[row];
+                    rr.f0[i].x *= q; rr.f0[i].y *= q; rr.f0[i].z *= q; rr.f0[i].w *= q;
+                    rr.f1[i].x *= q; rr.f1[i].y *= q; rr.f1[i].z *= q; rr.f1[i].w *= q;
+                }
             }
         } else {
             rr.h[i] = zero8();
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     const bool dof32 = t.dO_f32 != 0;
     RowRegs rd, ra;
     if (cbeg < cend) {
-        load_rows(t.dO, dof32, t.ldo, n8, p.M, cbeg * MC, n0, tid, rd);
+        load_rows(t.dO, dof32, t.ldo, n8, p.M, cbeg * MC, n0, tid, rd, t.dO_rowscale);
         load_rows(t.A, false, t.lda, k8, p.M, cbeg * MC, k0, tid, ra);
     }
     for (int c = cbeg; c < cend; ++c) {
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
         store_rows(rd, dof32, dOt, tid);
         store_rows(ra, false, At, tid);
         if (c + 1 < cend) {                              // next chunk's loads fly during this chunk's MFMAs
-            load_rows(t.dO, dof32, t.ldo, n8, p.M, (c + 1) * MC, n0, tid, rd);
+            load_rows(t.dO, dof32, t.ldo, n8, p.M, (c + 1) * MC, n0, tid, rd, t.dO_rowscale);
             load_rows(t.A, false, t.lda, k8, p.M, (c + 1) * MC, k0, tid, ra);
         }
         lds_barrier();

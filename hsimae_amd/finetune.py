@@ -1,14 +1,19 @@
-"""Row N3: the dual-branch fine-tuning model's FORWARD (`Models.DualViT`, Models.py:637-993) on the
-MI355X-native kernels — inference only.
+"""Row N3: the dual-branch fine-tuning model (`Models.DualViT`, Models.py:637-993) on the MI355X-native
+kernels — inference AND the fine-tuning step (Model_Finetuning.py:150-156).
 
   class_pred = cls_head(AGG(norm(encoder(imgs))))                      (forward_encoder :869-894, head :962-970)
   with imgs_u: the masked-autoencoder path on concat(imgs, imgs_u)      (forward :975-993) — the pretraining hot path
+  training mode: DropPath (stochastic depth, Models.py:235-263) on both residual branches of every encoder block,
+  rate linspace(0, drop_path, depth)[i] (:687), one Bernoulli factor per sequence of the block's input.
 
 Same constructor keywords, same parameter names / order / init stream as the reference (the head is registered
-between `norm` and `decoder_embed`), so fine-tuned checkpoints load both ways.  Everything runs through the HIP
-library: `hsimae_encode` (unmasked encoder = the masked schedule with the full token grid and identity order),
-`hsimae_agg_pool`, `hsimae_gemm` for the head.  NOT built: the fine-tuning BACKWARD (classification loss through
-the head and the unmasked encoder, DropPath); calling the model in training mode raises.
+between `norm` and `decoder_embed`), so checkpoints load both ways.  Everything on the encoder / decoder runs through
+the HIP library: `hsimae_encode` (+ `hsimae_encode_backward`) = the masked schedule with the full token grid and
+identity order, `hsimae_forward` / `hsimae_backward` for the reconstruction branch, DropPath as per-row factor vectors
+(`hsimae_io.drop_scale`), `hsimae_agg_pool` + `hsimae_gemm` for the head's forward.  The head's backward (an
+[N, T*D] x [classes, T*D] product) is three torch matmuls on the device.
+RNG: DropPath factors are drawn from torch's generator of the input's device in the reference's order (classification
+pass, then grid / masking noise, then reconstruction pass); `drop_factors=` replaces the draws (parity tests).
 """
 from __future__ import annotations
 
@@ -21,6 +26,26 @@ from . import _lib
 from .model import HSIMAE
 
 
+class _FineTuneStep(torch.autograd.Function):
+    """DualViT.forward in training as one autograd node: encoder / decoder parameter gradients are written by the kernels
+    into the model's flat gradient buffer; the head's two parameters are ordinary autograd inputs."""
+
+    @staticmethod
+    def forward(ctx, anchor, head_w, head_b, model, imgs, imgs_u, ratio, noise, grid, drop_factors):
+        out = model._train_forward(imgs, imgs_u, ratio, noise, grid, drop_factors)
+        ctx.model, ctx.saved = model, out["saved"]
+        if imgs_u is None:
+            return out["class_pred"]
+        ctx.mark_non_differentiable(out["pred_rec"], out["mask"])
+        return out["loss_rec"], out["pred_rec"], out["mask"], out["class_pred"]
+
+    @staticmethod
+    def backward(ctx, *gs):
+        g_loss, g_cls = (None, gs[0]) if len(gs) == 1 else (gs[0], gs[3])
+        gw, gb = ctx.model._train_backward(ctx.saved, g_loss, g_cls)
+        return None, gw, gb, None, None, None, None, None, None, None
+
+
 class DualViT(HSIMAE):
     def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, s_depth=6, num_heads=16,
                  mlp_ratio=4.0, norm_layer=nn.LayerNorm, bands=32, b_patch_size=8, num_class=100, no_qkv_bias=False,
@@ -31,7 +56,7 @@ class DualViT(HSIMAE):
                          decoder_num_heads=decoder_num_heads, mlp_ratio=mlp_ratio, norm_layer=norm_layer,
                          norm_pix_loss=norm_pix_loss, bands=bands, b_patch_size=b_patch_size, no_qkv_bias=no_qkv_bias,
                          trunc_init=trunc_init, s_depth=s_depth, _num_class=num_class)
-        self.drop_path = drop_path            # stochastic depth is a training-time op: identity in this (eval) forward
+        self.drop_path = drop_path            # stochastic depth: active in training mode only (Models.py:244)
         self.num_class = num_class
         self._head_pack = None
 
@@ -83,15 +108,135 @@ class DualViT(HSIMAE):
         _lib.check(lib.hsimae_gemm(C.byref(p), _lib.A_F32, _lib.E_F32, stream), "hsimae_gemm")
         return out[:, :self.num_class], pooled
 
-    def forward(self, imgs, imgs_u=None, mask_ratio=0.75, noise=None, grid=None):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("hsimae_amd.DualViT is the inference forward (row N3); fine-tuning backward / "
-                                      "DropPath are not built — call .eval() or wrap in torch.no_grad()")
-        latent = self.forward_encoder(imgs)
-        class_pred, _ = self.head(latent)
-        if imgs_u is None:
-            return class_pred
-        imgs_all = torch.concat([imgs, imgs_u], dim=0)
+    # ------------------------------------------------------------------ stochastic depth (Models.py:235-263, 687-731)
+    def drop_rates(self):
+        """DropPath probability of every encoder block in execution order (blocks_1, blocks_2, blocks)."""
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path, self.depth)]
+        out = []
+        if self.s_depth > 0:
+            out += dpr[:self.s_depth] + dpr[:self.s_depth]
+        if self.s_depth < 12:
+            out += dpr[self.s_depth:self.depth]
+        return out
+
+    def draw_drop_factors(self, N, len_t, len_l, device):
+        """Per-sequence factors (0 or 1/keep) of one encoder pass, drawn in the reference's order: attention then MLP of
+        every block; a block with rate 0 holds nn.Identity and draws nothing (Models.py:298)."""
+        s, nf = self.s_depth, (self.depth - self.s_depth if self.s_depth < 12 else 0)
+        nseq = ([N * len_t] * s + [N * len_l] * s if s > 0 else []) + [N] * nf
+        out = []
+        for p, n in zip(self.drop_rates(), nseq):
+            if p == 0.0:
+                out.append((None, None))
+                continue
+            keep = 1 - p
+            pair = []
+            for _ in range(2):
+                m = torch.empty(n, 1, 1, device=device).bernoulli_(keep)
+                if keep > 0.0:
+                    m.div_(keep)
+                pair.append(m.reshape(-1))
+            out.append(tuple(pair))
+        return out
+
+    def _row_scales(self, factors, N, len_t, len_l, device):
+        """[n_blocks, 2, N*K] fp32 per-row factors for hsimae_io.drop_scale, rows in the kernels' (n, t, l) order:
+        a spatial block's sequence is (n, t) ('b (t l) c -> (b t) l c'), a spectral block's (n, l), a fusion block's n."""
+        if factors is None or all(a is None and b is None for a, b in factors):
+            return None
+        s = self.s_depth
+        rows = torch.ones(len(factors), 2, N, len_t, len_l, dtype=torch.float32, device=device)
+        for e, pair in enumerate(factors):
+            for j, m in enumerate(pair):
+                if m is None:
+                    continue
+                m = m.to(device=device, dtype=torch.float32)
+                if s > 0 and e < s:
+                    rows[e, j] = m.view(N, len_t, 1)
+                elif s > 0 and e < 2 * s:
+                    rows[e, j] = m.view(N, 1, len_l)
+                else:
+                    rows[e, j] = m.view(N, 1, 1)
+        return rows.reshape(len(factors), 2, N * len_t * len_l).contiguous()
+
+    # ------------------------------------------------------------------ training step
+    def _train_forward(self, imgs, imgs_u, mask_ratio, noise, grid, drop_factors):
+        dev = imgs.device
+        T, L = self.input_size[0], self.input_size[1] ** 2
+        N = imgs.shape[0]
+        use_drop = self.training and self.drop_path > 0.0
+        f_cls = f_rec = None
+        if drop_factors is not None:
+            f_cls, f_rec = drop_factors
+        elif use_drop:
+            f_cls = self.draw_drop_factors(N, T, L, dev)              # forward_encoder's draws come first (Models.py:976)
+        n1 = torch.arange(T, dtype=torch.float32).expand(N, T)
+        n2 = torch.arange(L, dtype=torch.float32).expand(N, L)
+        _, _, _, st_cls = self._run_forward(imgs, 0.0, (n1, n2), (T, L), want_latent=True, encoder_only=True,
+                                            drop_scale=self._row_scales(f_cls, N, T, L, dev), ws_slot=1)
+        class_pred, pooled = self.head(st_cls["latent"])
+        saved = {"cls": st_cls, "pooled": pooled, "N": N, "rec": None}
+        out = {"class_pred": class_pred, "saved": saved}
+        if imgs_u is not None:
+            imgs_all = torch.concat([imgs, imgs_u], dim=0)
+            Na = imgs_all.shape[0]
+            # RNG order of forward_mask_encoder: grid (python random), noise_1, noise_2, then the blocks' DropPaths
+            len_t, len_l = grid if grid is not None else self.get_dim_patches(T, L, mask_ratio)
+            if noise is None:
+                noise = (torch.rand(Na, T, device=dev), torch.rand(Na, L, device=dev))
+            if drop_factors is None and use_drop:
+                f_rec = self.draw_drop_factors(Na, int(len_t), int(len_l), dev)
+            loss_rec, pred_rec, mask, st_rec = self._run_forward(
+                imgs_all, mask_ratio, noise, (int(len_t), int(len_l)), want_latent=False,
+                drop_scale=self._row_scales(f_rec, Na, int(len_t), int(len_l), dev), ws_slot=0)
+            saved["rec"] = st_rec
+            out.update(loss_rec=loss_rec, pred_rec=pred_rec, mask=mask)
+        return out
+
+    def _train_backward(self, saved, g_loss, g_cls):
+        lib, cfg = _lib.load(), self._config()
+        dev = self._flat.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        params, scratch = self._params_cache, self._flat_scratch
+        scratch.zero_()                                   # weight grads are accumulated with atomics
+        nocb = _lib.BUCKET_CB(0)
+        if saved["rec"] is not None and g_loss is not None:
+            _lib.check(lib.hsimae_backward(C.byref(cfg), C.byref(saved["rec"]["io"]), scratch.data_ptr(), nocb, None, stream),
+                       "hsimae_backward")
+            scratch.mul_(g_loss)                          # chain rule with d/d(loss_rec) (lamda in the reference's loop)
+        gw = gb = None
+        if g_cls is not None:
+            # head (Models.py:962-970): class_pred = pooled W^T + b, pooled[n, t*D + c] = mean_l latent[n, t, l, c]
+            N, T, L, D = saved["N"], self.input_size[0], self.input_size[1] ** 2, self.dim
+            g_cls = g_cls.to(torch.float32)
+            w = self.cls_head.weight.detach()
+            gw = g_cls.t() @ saved["pooled"]
+            gb = g_cls.sum(0)
+            dlat = ((g_cls @ w) / L).view(N, T, 1, D).expand(N, T, L, D).contiguous()
+            _lib.check(lib.hsimae_encode_backward(C.byref(cfg), C.byref(saved["cls"]["io"]), dlat.data_ptr(),
+                                                  scratch.data_ptr(), nocb, None, stream), "hsimae_encode_backward")
+        if params[self._trainable[0]].grad is None:
+            self._flat_grad.copy_(scratch)
+            for i in self._trainable:
+                params[i].grad = self._grad_views[i]
+        else:
+            self._flat_grad.add_(scratch)
+        return gw, gb
+
+    def forward(self, imgs, imgs_u=None, mask_ratio=0.75, noise=None, grid=None, drop_factors=None):
+        """-> class_pred, or (loss_rec, pred_rec, mask, class_pred) with imgs_u (Models.py:975-991).
+        `noise`, `grid` as in HSIMAE.forward; `drop_factors=(classification pass, reconstruction pass)`, each a list of
+        (attn, mlp) per-sequence factor vectors per encoder block (None entries = no DropPath), replaces the draws."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if imgs.is_cuda:
+                self._ensure_flat(imgs.device)
+            if self._reducer is not None:
+                raise NotImplementedError("data-parallel fine-tuning is not built (pretraining only)")
+            anchor = self._anchor if self._anchor is not None else torch.zeros((), requires_grad=True)
+            return _FineTuneStep.apply(anchor, self.cls_head.weight, self.cls_head.bias, self, imgs, imgs_u, mask_ratio,
+                                       noise, grid, drop_factors)
         with torch.no_grad():
-            loss_rec, pred_rec, mask, _ = self._run_forward(imgs_all, mask_ratio, noise, grid, want_latent=False)
-        return loss_rec, pred_rec, mask, class_pred
+            out = self._train_forward(imgs, imgs_u, mask_ratio, noise, grid, drop_factors)
+        if imgs_u is None:
+            return out["class_pred"]
+        return out["loss_rec"], out["pred_rec"], out["mask"], out["class_pred"]

@@ -161,6 +161,7 @@ class HSIMAE(nn.Module):
 
         # runtime state (not part of the state_dict)
         self._flat = self._flat_grad = self._wpk = self._pack_table = self._ws = None
+        self._ws_slots = None
         self._cfg = None
         self._packed_version = -1
         self._anchor = None
@@ -303,14 +304,21 @@ class HSIMAE(nn.Module):
                        "hsimae_pack_params")
             self._packed_version = ver
 
-    def _workspace(self, nbytes, device):
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = None
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        return self._ws
+    def _workspace(self, nbytes, device, slot=0):
+        """slot 1: a second workspace for the pass whose activations must outlive the next forward (DualViT keeps the
+        unmasked encoder's and the masked path's activations until the backward)."""
+        if self._ws_slots is None:
+            self._ws_slots = {}
+        ws = self._ws_slots.get(slot)
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            self._ws_slots[slot] = None
+            ws = self._ws_slots[slot] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if slot == 0:
+            self._ws = ws
+        return ws
 
     # ------------------------------------------------------------------ forward / backward drivers
-    def _run_forward(self, imgs, mask_ratio, noise, grid, want_latent, encoder_only=False):
+    def _run_forward(self, imgs, mask_ratio, noise, grid, want_latent, encoder_only=False, drop_scale=None, ws_slot=0):
         if not imgs.is_cuda:
             raise RuntimeError("hsimae_amd.HSIMAE runs on MI355X only (no CPU fallback): move the model and inputs to a GPU")
         if imgs.dim() != 5 or imgs.shape[1] != 1 or imgs.shape[2] != self.patch_embed.bands or imgs.shape[3:] != (9, 9):
@@ -339,7 +347,7 @@ class HSIMAE(nn.Module):
         nbytes = lib.hsimae_workspace_bytes(C.byref(cfg), N, self.len_t, self.len_l)
         if nbytes < 0:
             raise RuntimeError("hsimae_workspace_bytes: unsupported configuration")
-        ws = self._workspace(nbytes + 256, dev)
+        ws = self._workspace(nbytes + 256, dev, ws_slot)
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
         loss = torch.empty((), dtype=torch.float32, device=dev)
         mask = torch.empty(N, TL, dtype=torch.float32, device=dev)
@@ -357,12 +365,13 @@ class HSIMAE(nn.Module):
             params=self._flat.data_ptr(), wpk=self._wpk.data_ptr(), workspace=ws_ptr, workspace_bytes=nbytes,
             grad_scale=1.0 / world, want_recons=int(self.want_recons), loss=loss.data_ptr(),
             pred_img=_lib.ptr(pred_img), mask_img=_lib.ptr(mask_img), mask=mask.data_ptr(),
-            ids_keep=ids_keep.data_ptr(), ids_restore=ids_restore.data_ptr(), latent=_lib.ptr(latent), pred=None)
+            ids_keep=ids_keep.data_ptr(), ids_restore=ids_restore.data_ptr(), latent=_lib.ptr(latent), pred=None,
+            drop_scale=_lib.ptr(drop_scale))
         if encoder_only:
             _lib.check(lib.hsimae_encode(C.byref(cfg), C.byref(io), stream), "hsimae_encode")
         else:
             _lib.check(lib.hsimae_forward(C.byref(cfg), C.byref(io), stream), "hsimae_forward")
-        state = {"io": io, "keep": (imgs, n1, n2, mask, ids_keep, ids_restore, ws), "latent": latent,
+        state = {"io": io, "keep": (imgs, n1, n2, mask, ids_keep, ids_restore, ws, drop_scale), "latent": latent,
                  "ids_keep": ids_keep, "ids_restore": ids_restore, "mask": mask}
         if pred_img is None:
             pred_img = torch.empty(0, device=dev)

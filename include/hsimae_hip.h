@@ -94,6 +94,11 @@ typedef struct {
     int32_t* ids_restore;         /* [N,T*9] */
     float* latent;                /* optional [N*K, D] fp32 copy of the encoder output (may be NULL) */
     float* pred;                  /* optional [N*T*9, 72] fp32 copy of decoder_pred output (may be NULL) */
+    /* optional stochastic depth of the encoder blocks (DropPath, Models.py:235-263, 304-305; fine-tuning only):
+       per-ROW factors (0 or 1/keep_prob, equal within a sequence) for the attention branch and the MLP branch of
+       every encoder block, [n_enc_blocks][2][N*K] fp32 in execution order blocks_1[0..], blocks_2[0..], blocks[0..];
+       x += scale * branch(x).  NULL = no DropPath.  Must be the same array in forward and backward. */
+    const float* drop_scale;
 } hsimae_io;
 
 int64_t hsimae_workspace_bytes(const hsimae_config* cfg, int32_t N, int32_t len_t, int32_t len_l);
@@ -148,6 +153,9 @@ typedef struct {
     const float* pos; const int32_t* ids; int32_t ldpos;
     hs_bf16* h13; int32_t ldh; int32_t hoff;
     const float* lnx; float* dgamma; float* dbeta; int32_t accumulate;    /* E_LN_BWD only (lnx: the LayerNorm's input, ld = ldr) */
+    /* optional per-row factors [M] (DropPath): a_rowscale multiplies the rows of an A_F32 operand as it is staged;
+       out_rowscale multiplies (product + bias) before the residual is added in E_RES_F32.  NULL = 1. */
+    const float* a_rowscale; const float* out_rowscale;
 } hsimae_gemm_params;
 int hsimae_gemm(const hsimae_gemm_params* p, int32_t a_kind, int32_t epilogue, void* stream);
 
@@ -179,6 +187,8 @@ typedef struct {
        dO = dx1 * Wp with dx1 the bf16 [rows][128] gradient of x1 (Models.py:216 backward) and projT_w the packed
        transposed image; NULL = dout is dO itself. */
     const hs_bf16* projT_w;
+    /* optional per-row factor [rows] on the fused projection branch (DropPath): x1 = xres + rowscale * (o Wp^T + bp) */
+    const float* rowscale;
 } hsimae_attn_params;
 int hsimae_attn_fwd(const hsimae_attn_params* p, void* stream);
 int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream);
@@ -190,6 +200,7 @@ typedef struct {
     int32_t N, K;
     float* dW; int32_t ldw;
     float* db;
+    const float* dO_rowscale;     /* optional per-row factor [M] on an fp32 dO (DropPath); NULL = 1 */
 } hsimae_wgrad_task;
 typedef struct { hsimae_wgrad_task t[8]; int32_t ntasks; int32_t M; int32_t msplit; } hsimae_wgrad_params;
 int hsimae_wgrad(const hsimae_wgrad_params* p, void* stream);
@@ -231,11 +242,16 @@ int hsimae_loss(const hsimae_loss_params* p, void* stream);
 int hsimae_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const uint8_t* group, int64_t n,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
-/* ------------------------------------------------------------------ next row N3: fine-tuning forward (inference) */
+/* ------------------------------------------------------------------ next row N3: fine-tuning (DualViT) */
 /* Encoder only, through `norm` (DualViT / HSIViT `forward_encoder`, Models.py:869-894, 1119-1146): same io as
  * hsimae_forward; io->latent [N, len_t*len_l, embed_dim] is required, loss / pred / recons outputs are not touched.
  * For the unmasked encoder pass len_t = T, len_l = 9 and increasing noise (ids_keep = identity). */
 int hsimae_encode(const hsimae_config* cfg, const hsimae_io* io, void* stream);
+/* Backward of hsimae_encode (fine-tuning, Model_Finetuning.py:156 `loss.backward()` through the classification
+ * branch): dlatent [N*K, D] fp32 is dL/d(latent); the activations hsimae_encode left in io->workspace are consumed.
+ * Accumulates into `grads` like hsimae_backward (the decoder's entries are not touched), same bucket callback. */
+int hsimae_encode_backward(const hsimae_config* cfg, const hsimae_io* io, const float* dlatent, float* grads,
+                           hsimae_bucket_cb cb, void* user, void* stream);
 /* 'AGG' pooling of the classification head (Models.py:962-970): [N, T*L, D] -> [N, T*D], mean over the L tokens of
  * each spectral group; the Linear that follows is hsimae_gemm(A_F32, E_F32). */
 int hsimae_agg_pool(const float* latent, float* pooled, int32_t N, int32_t T, int32_t L, int32_t D, void* stream);

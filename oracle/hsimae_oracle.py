@@ -227,17 +227,27 @@ def swiglu(x, P, pre):
     return F.linear(F.silu(h1) * h3, P[f"{pre}.w2.weight"], P[f"{pre}.w2.bias"])
 
 
-def block(x, P, pre, heads):
-    """Models.py:303-306 (drop_path is Identity in HSIMAE, Models.py:298)."""
-    x = x + attention(layer_norm(x, P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"]), P, f"{pre}.attn", heads)
-    x = x + swiglu(layer_norm(x, P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"]), P, f"{pre}.mlp")
-    return x
+def block(x, P, pre, heads, drop=None):
+    """Models.py:303-306.  drop_path is Identity in HSIMAE (Models.py:298); DualViT in training mode multiplies each
+    residual branch by a per-sequence factor (0 or 1/keep_prob, Models.py:235-250): `drop` = (attn, mlp) vectors of
+    length x.shape[0], either may be None."""
+    a = attention(layer_norm(x, P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"]), P, f"{pre}.attn", heads)
+    if drop is not None and drop[0] is not None:
+        a = a * drop[0].to(a.dtype).reshape(-1, 1, 1)
+    x = x + a
+    m = swiglu(layer_norm(x, P[f"{pre}.norm2.weight"], P[f"{pre}.norm2.bias"]), P, f"{pre}.mlp")
+    if drop is not None and drop[1] is not None:
+        m = m * drop[1].to(m.dtype).reshape(-1, 1, 1)
+    return x + m
 
 
 # --------------------------------------------------------------------------- full forward
 def forward(P: dict, cfg: OracleConfig, imgs: torch.Tensor, noise_1, noise_2, len_t: int, len_l: int,
-            taps: dict | None = None):
+            taps: dict | None = None, drops: list | None = None):
     """Full pretraining forward, Models.py:627-634, given the replayed noise.
+
+    drops (DualViT training only): per encoder block, in execution order blocks_1[0..], blocks_2[0..], blocks[0..],
+    a pair (attn, mlp) of per-sequence DropPath factors (see `block`); None = no stochastic depth.
 
     P: name -> tensor (reference state_dict layout), all of one float dtype.
     Returns (loss, pred_img, mask_img); optional `taps` dict collects stage outputs.
@@ -272,9 +282,9 @@ def forward(P: dict, cfg: OracleConfig, imgs: torch.Tensor, noise_1, noise_2, le
         x1 = X.reshape(N, len_t, len_l, D).reshape(N * len_t, len_l, D)
         x2 = X.reshape(N, len_t, len_l, D).permute(0, 2, 1, 3).reshape(N * len_l, len_t, D)
         for i in range(cfg.s_depth):
-            x1 = block(x1, P, f"blocks_1.{i}", cfg.num_heads)
+            x1 = block(x1, P, f"blocks_1.{i}", cfg.num_heads, drops[i] if drops else None)
         for i in range(cfg.s_depth):
-            x2 = block(x2, P, f"blocks_2.{i}", cfg.num_heads)
+            x2 = block(x2, P, f"blocks_2.{i}", cfg.num_heads, drops[cfg.s_depth + i] if drops else None)
         x1 = x1.reshape(N, K, D)
         x2 = x2.reshape(N, len_l, len_t, D).permute(0, 2, 1, 3).reshape(N, K, D)
         tap("x1", x1); tap("x2", x2)
@@ -282,7 +292,8 @@ def forward(P: dict, cfg: OracleConfig, imgs: torch.Tensor, noise_1, noise_2, le
     # 8. fusion (Models.py:566-570)
     if cfg.s_depth < 12:
         for i in range(cfg.depth - cfg.s_depth):
-            X = block(X, P, f"blocks.{i}", cfg.num_heads)
+            X = block(X, P, f"blocks.{i}", cfg.num_heads,
+                      drops[(2 * cfg.s_depth if cfg.s_depth > 0 else 0) + i] if drops else None)
     tap("fused", X)
     latent = layer_norm(X, P["norm.weight"], P["norm.bias"])
     tap("latent", latent)
@@ -339,6 +350,70 @@ def dualvit_classify(P: dict, cfg: OracleConfig, imgs: torch.Tensor):
     N = lat.shape[0]
     x = lat.reshape(N, cfg.T, cfg.L, cfg.embed_dim).permute(0, 2, 1, 3).reshape(N, cfg.L, -1).mean(1)
     return F.linear(x, P["cls_head.weight"], P["cls_head.bias"]), x
+
+
+def drop_rates(cfg: OracleConfig, drop_path: float) -> list:
+    """DropPath probability of every encoder block in execution order (Models.py:687-731: dpr = linspace(0, p, depth);
+    blocks_1[i] and blocks_2[i] use dpr[i], blocks[j] uses dpr[s_depth + j])."""
+    dpr = [x.item() for x in torch.linspace(0, drop_path, cfg.depth)]
+    out = []
+    if cfg.s_depth > 0:
+        out += dpr[:cfg.s_depth] + dpr[:cfg.s_depth]
+    if cfg.s_depth < 12:
+        out += dpr[cfg.s_depth:cfg.depth]
+    return out
+
+
+def draw_drop_factors(cfg: OracleConfig, drop_path: float, N: int, len_t: int, len_l: int, generator=None) -> list:
+    """The DropPath factors one encoder pass draws, in the reference's order (attn then mlp of every block; blocks
+    with probability 0 are nn.Identity and draw nothing, Models.py:298): bernoulli_(keep) / keep on a
+    [sequences, 1, 1] tensor (Models.py:245-249)."""
+    nseq = ([N * len_t] * cfg.s_depth + [N * len_l] * cfg.s_depth if cfg.s_depth > 0 else []) + \
+           ([N] * (cfg.depth - cfg.s_depth) if cfg.s_depth < 12 else [])
+    out = []
+    for p, n in zip(drop_rates(cfg, drop_path), nseq):
+        if p == 0.0:
+            out.append((None, None))
+            continue
+        keep = 1 - p
+        pair = []
+        for _ in range(2):
+            m = torch.empty(n, 1, 1).bernoulli_(keep, generator=generator)
+            if keep > 0.0:
+                m.div_(keep)
+            pair.append(m.reshape(-1))
+        out.append(tuple(pair))
+    return out
+
+
+def dualvit_train_step(P: dict, cfg: OracleConfig, imgs, imgs_u, targets, lamda, noise_1, noise_2, len_t, len_l,
+                       drops_cls=None, drops_rec=None):
+    """One fine-tuning step of the reference (Model_Finetuning.py:150-156) up to `loss.backward()`:
+    DualViT.forward(imgs, imgs_u) (Models.py:975-991) = classification branch on the unmasked encoder +
+    reconstruction branch on concat(imgs, imgs_u); loss = lamda * loss_rec + CrossEntropy(ignore_index=0).
+    Returns (loss_rec, class_pred, loss, grads)."""
+    frozen = ("pos_embed", "decoder_pos_embed")
+    Pg = {}
+    for k, v in P.items():
+        t = v.detach().clone()
+        if k not in frozen and k != "mask_token":
+            t.requires_grad_(True)
+        Pg[k] = t
+    N = imgs.shape[0]
+    taps = {}
+    n1 = np.tile(np.arange(cfg.T, dtype=np.float32), (N, 1))
+    n2 = np.tile(np.arange(cfg.L, dtype=np.float32), (N, 1))
+    forward(Pg, cfg, imgs, n1, n2, cfg.T, cfg.L, taps, drops_cls)
+    lat = taps["latent"]
+    x = lat.reshape(N, cfg.T, cfg.L, cfg.embed_dim).permute(0, 2, 1, 3).reshape(N, cfg.L, -1).mean(1)
+    class_pred = F.linear(x, Pg["cls_head.weight"], Pg["cls_head.bias"])
+    imgs_all = torch.cat([imgs, imgs_u], dim=0)
+    loss_rec, _, _ = forward(Pg, cfg, imgs_all, noise_1, noise_2, len_t, len_l, None, drops_rec)
+    loss_cls = F.cross_entropy(class_pred, targets, reduction="mean", ignore_index=0)
+    loss = lamda * loss_rec + loss_cls
+    loss.backward()
+    grads = {k: v.grad for k, v in Pg.items() if v.grad is not None}
+    return loss_rec.detach(), class_pred.detach(), loss.detach(), grads
 
 
 def forward_backward(P: dict, cfg: OracleConfig, imgs, noise_1, noise_2, len_t, len_l, taps=None):

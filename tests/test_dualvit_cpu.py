@@ -47,3 +47,66 @@ def test_dualvit_mirror_state_dict_matches_reference_manifest():
         t = DualViT(img_size=9, patch_size=3, in_chans=1, num_class=11, trunc_init=True, drop_path=0.2, norm_pix_loss=True,
                     b_patch_size=8, **{k: v for k, v in CFG.items()})
     t.load_state_dict(tiny_state())
+
+
+# ------------------------------------------------------------------ training step (DropPath, both branches, backward)
+FXT = np.load(os.path.join(ROOT, "tests", "golden", "dualvit_train_tiny.npz"))
+
+
+def fixture_drops(tag, n_blocks=5):
+    out = []
+    for e in range(n_blocks):
+        k = f"drop_{tag}/{e}/attn"
+        out.append((torch.from_numpy(FXT[k]), torch.from_numpy(FXT[f"drop_{tag}/{e}/mlp"])) if k in FXT.files else (None, None))
+    return out
+
+
+def test_oracle_finetune_step_matches_reference_fixture():
+    """loss_rec, class_pred and every parameter gradient of one reference fine-tuning step (train mode, DropPath 0.2,
+    lamda * loss_rec + CE(ignore_index=0)) from the recorded draws."""
+    cfg = O.OracleConfig(norm_pix_loss=True, **CFG)
+    P = tiny_state()
+    rec, pred, loss, grads = O.dualvit_train_step(
+        P, cfg, torch.from_numpy(FXT["x"]), torch.from_numpy(FXT["x_u"]), torch.from_numpy(FXT["y"]), float(FXT["lamda"]),
+        FXT["noise_1"], FXT["noise_2"], int(FXT["grid"][0]), int(FXT["grid"][1]), fixture_drops("cls"), fixture_drops("rec"))
+    assert abs(float(rec) - float(FXT["loss_rec"])) < 1e-6
+    assert abs(float(loss) - float(FXT["loss"])) < 1e-5
+    assert float((pred - torch.from_numpy(FXT["class_pred"])).abs().max()) < 1e-5
+    names = [k[5:] for k in FXT.files if k.startswith("grad/")]
+    assert len(names) == 138
+    for n in names:
+        ref = torch.from_numpy(FXT["grad/" + n])
+        assert float((grads[n] - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-9, n
+
+
+def test_drop_rates_and_draw_order_match_reference_layout():
+    cfg = O.OracleConfig(norm_pix_loss=True, **CFG)
+    rates = O.drop_rates(cfg, 0.2)                       # depth 3, s_depth 2: blocks_1[0,1], blocks_2[0,1], blocks[0]
+    assert np.allclose(rates, [0.0, 0.1, 0.0, 0.1, 0.2])
+    assert [a is None for a, _ in fixture_drops("cls")] == [True, False, True, False, False]
+    torch.manual_seed(21)
+    d = O.draw_drop_factors(cfg, 0.2, 4, cfg.T, cfg.L)
+    for e, (a, b) in enumerate(fixture_drops("cls")):    # the first draws after the seed are the classification pass's
+        if a is not None:
+            assert torch.equal(d[e][0], a) and torch.equal(d[e][1], b)
+    from hsimae_amd import DualViT
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = DualViT(img_size=9, patch_size=3, in_chans=1, bands=32, b_patch_size=8, embed_dim=32, depth=3, s_depth=2,
+                    num_heads=2, num_class=11, trunc_init=True, drop_path=0.2, decoder_embed_dim=32, decoder_depth=2,
+                    decoder_num_heads=4, norm_pix_loss=True)
+    assert np.allclose(m.drop_rates(), rates)
+    torch.manual_seed(21)
+    dm = m.draw_drop_factors(4, cfg.T, cfg.L, torch.device("cpu"))     # same stream as the reference on CPU
+    for e, (a, b) in enumerate(d):
+        assert (a is None) == (dm[e][0] is None)
+        if a is not None:
+            assert torch.equal(dm[e][0], a) and torch.equal(dm[e][1], b)
+    # per-row expansion: a spatial block's sequence is (n, t), a spectral block's (n, l), a fusion block's n
+    N, t, l = 4, cfg.T, cfg.L
+    rows = m._row_scales(dm, N, t, l, torch.device("cpu")).view(5, 2, N, t, l)
+    assert torch.all(rows[0] == 1) and torch.all(rows[2] == 1)
+    assert torch.equal(rows[1, 0], dm[1][0].view(N, t, 1).expand(N, t, l))
+    assert torch.equal(rows[3, 1], dm[3][1].view(N, 1, l).expand(N, t, l))
+    assert torch.equal(rows[4, 0], dm[4][0].view(N, 1, 1).expand(N, t, l))

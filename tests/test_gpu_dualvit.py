@@ -1,5 +1,6 @@
-"""Row N3 on the GPU: hsimae_amd.DualViT inference forward (hsimae_encode + hsimae_agg_pool + head GEMM) against the
-fixture recorded from the reference DualViT and against the oracle at Base width."""
+"""Row N3 on the GPU: hsimae_amd.DualViT — inference forward (hsimae_encode + hsimae_agg_pool + head GEMM) and the
+fine-tuning step (DropPath, both branches, hsimae_encode_backward + hsimae_backward) — against the fixtures recorded
+from the reference DualViT and against the oracle at Base width."""
 import contextlib
 import io
 import os
@@ -43,9 +44,6 @@ def test_tiny_dualvit_against_reference_fixture():
     # dual-branch call: the masked path on concat(imgs, imgs_u) plus the same class_pred
     loss, rec, mask, pred2 = m(x, x.flip(0), mask_ratio=0.5)
     assert torch.isfinite(loss) and rec.shape == (12, 1, 32, 9, 9) and mask.shape == rec.shape and torch.equal(pred2.cpu(), pred)
-    m.train()
-    with pytest.raises(NotImplementedError):
-        m(x)
 
 
 def test_base_width_dualvit_against_oracle():
@@ -67,3 +65,113 @@ def test_base_width_dualvit_against_oracle():
     lat = m.forward_encoder(x.cuda())
     _, pooled = m.head(lat)
     assert rms_rel(pooled.cpu(), ref_pool) < 5e-3
+
+
+# ------------------------------------------------------------------ fine-tuning step
+FXT = np.load(os.path.join(ROOT, "tests", "golden", "dualvit_train_tiny.npz"))
+
+
+def fixture_drops(tag, n_blocks=5):
+    out = []
+    for e in range(n_blocks):
+        k = f"drop_{tag}/{e}/attn"
+        out.append((torch.from_numpy(FXT[k]), torch.from_numpy(FXT[f"drop_{tag}/{e}/mlp"])) if k in FXT.files else (None, None))
+    return out
+
+
+def grad_report(model, ref_grads):
+    """-> (worst RMS-relative error, its name) over every parameter with a reference gradient."""
+    worst, wname = 0.0, None
+    for n, p in model.named_parameters():
+        if n not in ref_grads or n.endswith("attn.k.bias"):     # k.bias: the true gradient is exactly zero (softmax shift invariance)
+            continue
+        assert p.grad is not None, n
+        r = ref_grads[n]
+        scale = float(r.double().pow(2).mean().sqrt())
+        if scale < 1e-9:
+            continue
+        e = float((p.grad.detach().cpu().double() - r.double()).pow(2).mean().sqrt()) / scale
+        if e > worst:
+            worst, wname = e, n
+    return worst, wname
+
+
+def test_tiny_finetune_step_against_reference_fixture():
+    """Reference fine-tuning step (train mode, DropPath 0.2, lamda * loss_rec + CE(ignore_index=0), backward) replayed
+    with the recorded draws: losses, logits and all 138 parameter gradients."""
+    from hsimae_amd import DualViT
+    m = quiet(DualViT, img_size=9, patch_size=3, in_chans=1, bands=32, b_patch_size=8, embed_dim=32, depth=3, s_depth=2,
+              num_heads=2, num_class=11, trunc_init=True, drop_path=0.2, decoder_embed_dim=32, decoder_depth=2,
+              decoder_num_heads=4, norm_pix_loss=True)
+    m.load_state_dict({k[3:]: torch.from_numpy(FX[k]) for k in FX.files if k.startswith("sd/")})
+    m = m.cuda().train()
+    x, xu, y = (torch.from_numpy(FXT[k]).cuda() for k in ("x", "x_u", "y"))
+    lam = float(FXT["lamda"])
+    loss_rec, rec, mask, pred = m(x, xu, mask_ratio=float(FXT["mask_ratio"]),
+                                  noise=(torch.from_numpy(FXT["noise_1"]), torch.from_numpy(FXT["noise_2"])),
+                                  grid=(int(FXT["grid"][0]), int(FXT["grid"][1])),
+                                  drop_factors=(fixture_drops("cls"), fixture_drops("rec")))
+    loss = lam * loss_rec + torch.nn.functional.cross_entropy(pred, y, reduction="mean", ignore_index=0)
+    loss.backward()
+    assert abs(float(loss_rec) - float(FXT["loss_rec"])) < 1e-4 * float(FXT["loss_rec"])       # north-star gate
+    assert rms_rel(pred.detach().cpu(), torch.from_numpy(FXT["class_pred"])) < 1e-2
+    assert abs(float(loss) - float(FXT["loss"])) < 2e-3 * abs(float(FXT["loss"]))
+    ref = {k[5:]: torch.from_numpy(FXT[k]) for k in FXT.files if k.startswith("grad/")}
+    worst, wname = grad_report(m, ref)
+    print(f"[finetune tiny] loss_rec {float(loss_rec):.6f} ref {float(FXT['loss_rec']):.6f}  worst grad rms-rel {worst:.2e} ({wname})")
+    assert worst < 5e-2, (worst, wname)         # width 32: same bound as the tiny pretraining fixture (test_gpu_e2e.py)
+    # a dropped sequence contributes nothing: with every factor 0 the blocks are the identity and the encoder's
+    # block parameters get exactly zero gradient from the classification branch
+    m.zero_grad(set_to_none=True)
+    zeros = [(torch.zeros(n), torch.zeros(n)) for n in (4 * 4, 4 * 4, 4 * 9, 4 * 9, 4)]
+    pred0 = m(x, drop_factors=(zeros, None))
+    pred0.sum().backward()
+    assert float(m.blocks[0].mlp.w1.weight.grad.abs().max()) == 0.0
+    assert float(m.blocks_1[1].attn.q.weight.grad.abs().max()) == 0.0
+    assert float(m.patch_embed.proj.weight.grad.abs().max()) > 0.0
+
+
+def test_base_width_finetune_step_against_oracle():
+    """Base width (the fused d = 128 kernels carry the DropPath factors): one step against the oracle."""
+    from hsimae_amd import DualViT
+    cfg = O.OracleConfig(bands=96, norm_pix_loss=True)
+    state = O.init_state(cfg, seed=4, std=0.06)
+    g = torch.Generator().manual_seed(8)
+    state["cls_head.weight"] = torch.randn(16, 128 * 12, generator=g) * 0.02
+    state["cls_head.bias"] = torch.randn(16, generator=g) * 0.05
+    m = quiet(DualViT, img_size=9, patch_size=3, in_chans=1, bands=96, b_patch_size=8, num_class=16, embed_dim=128, depth=12,
+              num_heads=8, s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8, norm_pix_loss=True,
+              trunc_init=True, drop_path=0.2)
+    m.load_state_dict(state)
+    m = m.cuda().train()
+    N, Nu = 6, 10
+    x = torch.rand(N, 1, 96, 9, 9, generator=g)
+    xu = torch.rand(Nu, 1, 96, 9, 9, generator=g)
+    y = torch.tensor([1, 0, 5, 15, 3, 9])
+    n1 = torch.rand(N + Nu, cfg.T, generator=g)
+    n2 = torch.rand(N + Nu, cfg.L, generator=g)
+    len_t, len_l = 6, 9                                   # mask ratio 0.5 at T = 12: (6, 9) or (9, 6)
+    torch.manual_seed(33)
+    d_cls = O.draw_drop_factors(cfg, 0.2, N, cfg.T, cfg.L)
+    d_rec = O.draw_drop_factors(cfg, 0.2, N + Nu, len_t, len_l)
+    lam = 5.0
+    o_rec, o_pred, o_loss, o_grads = O.dualvit_train_step(state, cfg, x, xu, y, lam, n1.numpy(), n2.numpy(), len_t, len_l,
+                                                           d_cls, d_rec)
+    loss_rec, _, _, pred = m(x.cuda(), xu.cuda(), mask_ratio=0.5, noise=(n1, n2), grid=(len_t, len_l), drop_factors=(d_cls, d_rec))
+    loss = lam * loss_rec + torch.nn.functional.cross_entropy(pred, y.cuda(), reduction="mean", ignore_index=0)
+    loss.backward()
+    assert abs(float(loss_rec) - float(o_rec)) < 1e-4 * float(o_rec), (float(loss_rec), float(o_rec))
+    assert rms_rel(pred.detach().cpu(), o_pred) < 1e-2
+    worst, wname = grad_report(m, o_grads)
+    print(f"[finetune base] loss_rec {float(loss_rec):.6f} oracle {float(o_rec):.6f}  worst grad rms-rel {worst:.2e} ({wname})")
+    assert worst < 3e-2, (worst, wname)
+    # drawn (not injected) factors: the step runs and DropPath really is active in training mode
+    m.zero_grad(set_to_none=True)
+    torch.manual_seed(1)
+    a = m(x.cuda())
+    torch.manual_seed(2)
+    b = m(x.cuda())
+    assert not torch.equal(a, b)
+    m.eval()
+    with torch.no_grad():
+        assert torch.equal(m(x.cuda()), m(x.cuda()))
