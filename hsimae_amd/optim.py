@@ -18,15 +18,31 @@ class FusedAdamW:
         self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         decay, nodecay = [], []
         self._groups_of = []
+        # Parameters that do not live in the model's flat buffer (DualViT's cls_head) are stepped by a stock
+        # torch.optim.AdamW with the same hyper-parameters; their lr follows param_groups[0] / [1].
+        in_flat = {id(p) for p in model._plist()} if hasattr(model, "_plist") else None
+        extra_decay, extra_nodecay = [], []
         for n, p in model.named_parameters():
+            is_nd = any(k in n for k in no_decay)
+            if in_flat is not None and id(p) not in in_flat:
+                if p.requires_grad:
+                    (extra_nodecay if is_nd else extra_decay).append(p)
+                    (nodecay if is_nd else decay).append(p)
+                continue
             if not p.requires_grad or n == "mask_token":        # mask_token never receives a gradient
                 self._groups_of.append(2)
-            elif any(k in n for k in no_decay):
+            elif is_nd:
                 self._groups_of.append(1); nodecay.append(p)
             else:
                 self._groups_of.append(0); decay.append(p)
         self.param_groups = [dict(params=decay, lr=lr, weight_decay=weight_decay, betas=tuple(betas), eps=eps),
                              dict(params=nodecay, lr=lr, weight_decay=0.0, betas=tuple(betas), eps=eps)]
+        self._extra = None
+        if extra_decay or extra_nodecay:
+            groups = [(0, dict(params=extra_decay, weight_decay=weight_decay)), (1, dict(params=extra_nodecay, weight_decay=0.0))]
+            groups = [(i, g) for i, g in groups if g["params"]]
+            self._extra_of = [i for i, _ in groups]          # which reference group each extra group follows
+            self._extra = torch.optim.AdamW([g for _, g in groups], lr=lr, betas=tuple(betas), eps=eps)
         self.step_count = 0
         self._flat_id = None
         self.exp_avg = self.exp_avg_sq = self._group = None
@@ -68,14 +84,21 @@ class FusedAdamW:
             self._group.data_ptr(), m._flat.numel(), float(g0["lr"]), float(b1), float(b2), float(g0["eps"]),
             float(g0["weight_decay"]), self.step_count, stream), "hsimae_adamw_step")
         m._packed_version = -1                    # packed bf16 images are stale now
+        if self._extra is not None:
+            for ge, gi in zip(self._extra.param_groups, self._extra_of):
+                ge["lr"] = self.param_groups[gi]["lr"]
+            self._extra.step()
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+                "extra": self._extra.state_dict() if self._extra is not None else None}
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
         self.exp_avg, self.exp_avg_sq = sd["exp_avg"], sd["exp_avg_sq"]
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)
+        if self._extra is not None and sd.get("extra") is not None:
+            self._extra.load_state_dict(sd["extra"])
         self._flat_id = None

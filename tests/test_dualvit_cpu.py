@@ -110,3 +110,23 @@ def test_drop_rates_and_draw_order_match_reference_layout():
     assert torch.equal(rows[1, 0], dm[1][0].view(N, t, 1).expand(N, t, l))
     assert torch.equal(rows[3, 1], dm[3][1].view(N, 1, l).expand(N, t, l))
     assert torch.equal(rows[4, 0], dm[4][0].view(N, 1, 1).expand(N, t, l))
+
+
+def test_finetune_host_helpers_split_and_scores():
+    """spilt_dataset (Utils/Preprocessing.py:276-300) and the OA / AA / kappa restatement against sklearn."""
+    from sklearn import metrics
+    from hsimae_amd.finetune_train import scores, spilt_dataset
+    np.random.seed(3)
+    label = np.array([1, 2, 3] * 10 + [1] * 6)
+    data = list(range(len(label)))
+    tr, tr_y, va, va_y = spilt_dataset(data, label, training_ratio=0.5)
+    assert sorted(tr + va) == data and len(va) == 8 + 5 + 5
+    assert all(label[i] == y for i, y in zip(tr, tr_y)) and all(label[i] == y for i, y in zip(va, va_y))
+    rng = np.random.default_rng(1)
+    gt = rng.integers(0, 5, 400)
+    pred = np.where(rng.random(400) < 0.7, gt, rng.integers(1, 5, 400))
+    oa, aa, kappa, ca = scores(gt, pred)
+    g, p = gt[gt != 0] - 1, pred[gt != 0] - 1
+    assert abs(oa - metrics.accuracy_score(g, p)) < 1e-12
+    assert abs(aa - np.mean(metrics.recall_score(g, p, average=None, labels=np.unique(g)))) < 1e-12
+    assert abs(kappa - metrics.cohen_kappa_score(g, p)) < 1e-12
