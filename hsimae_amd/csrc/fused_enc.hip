@@ -44,7 +44,7 @@ struct MG {
     static constexpr int KSH = HP / 32;         // k-steps over the hidden width
     static constexpr int LPR = D / 8;           // lanes per row in the wide layout
     static constexpr int KA = KSH > 6 ? 6 : KSH, KB = KSH - KA;
-    static constexpr int LDS_FWD = R * LU * 2 + R * LG * 2;
+    static constexpr int LDS_FWD = R * LU * 2 + 2 * R * LC * 2;
     static constexpr int LDS_BWD = 2 * R * LU * 2 + 3 * R * LC * 2;
     static_assert(R * LG * 2 >= R * LX * 4, "gate image region must hold the fp32 staging tile");
     static_assert(R * LU * 2 + 3 * R * LC * 2 >= R * LX * 4, "dY panel + chunk images must hold the fp32 staging tile");
@@ -129,16 +129,21 @@ struct EncMlpW {
 
 struct EncMlpFwdArgs { const float* x1; const float* res2; float* x2; int M; EncMlpW w; const float* rowscale; };
 
+// x2 = x1 + rs * (b2 + (silu(u2 W1^T + b1) * (u2 W3^T + b3)) W2^T)  (+ res2), u2 = LN2(x1), one 64-row panel per workgroup.
+// The W2 product is accumulated per 64-column hidden chunk (the gate lives in two 9-KB chunk images instead of a
+// 46-KB panel image) and the residual is added from an L2-hot re-read in the store loop, so a workgroup needs 36 KB of
+// LDS and ~150 registers: three workgroups per CU instead of two.
 template <int D, int HPE>
-__global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
+__global__ __launch_bounds__(NTH, 3) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     using G = MG<D, HPE>;
-    constexpr int LU = G::LU, LX = G::LX, LG = G::LG, NCH = G::NCH, KSD = G::KSD, KSH = G::KSH, LPR = G::LPR;
+    constexpr int LU = G::LU, LX = G::LX, NCH = G::NCH, KSD = G::KSD, LPR = G::LPR;
     constexpr int MT4 = R / 16;                         // every wave covers all m-tiles of the panel
     constexpr int NJO = D / 64;                         // output n-tiles per wave (D / 16 over 4 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
-    float* XS = reinterpret_cast<float*>(smem + R * LU * 2);
-    bf16_t* Gb = reinterpret_cast<bf16_t*>(smem + R * LU * 2);
+    bf16_t* Gc = U2 + R * LU;                           // two chunk images [64][LC]
+    float* XS = reinterpret_cast<float*>(smem);         // fp32 store tile over U2 | Gc once the products are done
+    static_assert(R * LU * 2 + 2 * R * LC * 2 >= R * LX * 4, "store tile must fit over the panel + chunk images");
     const G8 q = geo8();
     const int row0 = blockIdx.x * R;
     const EncMlpW& w = p.w;
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     f1.load(w.w1, KSD, q.wave, 0, nt_h, q.lane);
     f3.load(w.w3, KSD, q.wave, 0, nt_h, q.lane);
     __builtin_amdgcn_sched_barrier(0);           // keep the fetches here: hipcc otherwise sinks them next to the MFMAs
-    {   // LayerNorm-2 in the wide layout (16 lanes per row) + fp32 copy for the residual
+    {   // LayerNorm-2 in the wide layout (16 lanes per row)
         float gm[8], bt[8];
         ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
         constexpr int NI = R * LPR / NTH;
@@ -166,7 +171,6 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
         for (int i = 0; i < NI; ++i) {
             const int pc = threadIdx.x + NTH * i, row = pc / LPR;
             float (&f)[8] = fa[i];
-            st8(XS + row * LX + c8, f);
             const float mean = redrow<LPR>(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
             float v = 0.f;
 #pragma unroll
@@ -177,25 +181,25 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
             *reinterpret_cast<bf16x8*>(U2 + row * LU + c8) = cvt8(f);
         }
     }
+    FrN<2, NJO> f2;                                     // W2 fragments of the current chunk (k-steps 2c, 2c+1)
+    f2.load(w.w2, G::KSH, q.wave * NJO, 0, D / 16, q.lane);
     lds_barrier();
     PH(0)
-    f32x4 xr[MT4][NJO];                            // residual + b2, [m-tile][this wave's output n-tile], accumulator layout
+    f32x4 xr[MT4][NJO];                            // b2 + the W2 product, [m-tile][this wave's output n-tile]
 #pragma unroll
     for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
         for (int j = 0; j < NJO; ++j) {
-            const int col = (q.wave * NJO + j) * 16 + q.c16;
-            const float b = w.w2b[col];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xr[mt][j][r] = (p.rowscale ? 0.f : XS[(mt * 16 + q.g * 4 + r) * LX + col]) + b;
+            const float b = w.w2b[(q.wave * NJO + j) * 16 + q.c16];
+            xr[mt][j] = f32x4{b, b, b, b};
         }
-    lds_barrier();                             // XS consumed: the gate image may overwrite it
     PH(1)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int nt = c * 4 + q.wave;                                  // this wave's n-tile of the chunk
         const bool live = nt < nt_h;                                    // last chunk: only waves 0, 1 have columns
         const int col = nt * 16 + q.c16;
+        bf16_t* Gi = Gc + (c & 1) * R * LC;
         f32x4 h1[MT4], h3[MT4];
         {
             const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
@@ -218,31 +222,32 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
             f3.load(w.w3, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (live) {
 #pragma unroll
-            for (int mt = 0; mt < MT4; ++mt)
+        for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float gv = col < w.h ? silu_nr(h1[mt][r]) * h3[mt][r] : 0.f;
-                    Gb[(mt * 16 + q.g * 4 + r) * LG + col] = (bf16_t)gv;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const float gv = (live && col < w.h) ? silu_nr(h1[mt][r]) * h3[mt][r] : 0.f;
+                Gi[(mt * 16 + q.g * 4 + r) * LC + q.wave * 16 + q.c16] = (bf16_t)gv;
+            }
+        lds_barrier();                             // chunk image complete; the other image is free again after this barrier
+        // x2 += g_c W2_c^T : this wave's NJO output n-tiles, all 4 m-tiles; the last chunk of 352 is half full
+        constexpr bool kHalfLast = (HPE % 64) != 0;
+        FrN<2, NJO> f2n;
+        if (c + 1 < NCH) f2n.load(w.w2, G::KSH, q.wave * NJO, 2 * (c + 1), D / 16, q.lane);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (kHalfLast && c == NCH - 1 && ks == 1) continue;
+#pragma unroll
+            for (int mt = 0; mt < MT4; ++mt) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Gi + (mt * 16 + q.c16) * LC + ks * 32 + q.g * 8);
+#pragma unroll
+                for (int j = 0; j < NJO; ++j) xr[mt][j] = mfma16(a, f2.b[ks][j], xr[mt][j]);
+            }
         }
+        if (c + 1 < NCH) f2 = f2n;
     }
     PH(2)
-    // x2 = x1 + b2 + g W2^T : K = 352 = 11 k-steps; this wave's NJO output n-tiles, all 4 m-tiles
-    FrN<KSH, NJO> f2;
-    f2.load(w.w2, KSH, q.wave * NJO, 0, D / 16, q.lane);
-    __builtin_amdgcn_sched_barrier(0);
-    lds_barrier();
-#pragma unroll
-    for (int ks = 0; ks < KSH; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < MT4; ++mt) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(Gb + (mt * 16 + q.c16) * LG + ks * 32 + q.g * 8);
-#pragma unroll
-            for (int j = 0; j < NJO; ++j) xr[mt][j] = mfma16(a, f2.b[ks][j], xr[mt][j]);
-        }
-    lds_barrier();                             // gate image consumed: reuse the region as the fp32 store tile
+    lds_barrier();                             // all products done: reuse the panel + chunk images as the fp32 store tile
     PH(3)
 #pragma unroll
     for (int mt = 0; mt < MT4; ++mt)
@@ -256,17 +261,13 @@ __global__ __launch_bounds__(NTH, 2) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     for (int i = 0; i < R * LPR / NTH; ++i) {
         const int pc = threadIdx.x + NTH * i, row = pc / LPR;
         if (row0 + row < p.M) {
-            float f[8];
+            float f[8], t[8];
             ld8(XS + row * LX + c8, f);
-            if (p.rowscale) {                  // DropPath: x1 + scale * mlp(x1); the accumulators hold the branch alone
-                float t[8];
-                const float rs = p.rowscale[row0 + row];
-                ld8(p.x1 + (size_t)(row0 + row) * D + c8, t);
+            ld8(p.x1 + (size_t)(row0 + row) * D + c8, t);              // residual: L2-hot re-read of the panel
+            const float rs = p.rowscale ? p.rowscale[row0 + row] : 1.f;   // DropPath: x1 + scale * mlp(x1)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], rs, t[e]);
-            }
+            for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], rs, t[e]);
             if (p.res2) {
-                float t[8];
                 ld8(p.res2 + (size_t)(row0 + row) * D + c8, t);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] += t[e];

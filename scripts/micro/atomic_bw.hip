@@ -5,7 +5,8 @@
 #include <vector>
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(float* buf, int nfloats, int rot) {
+__global__ __launch_bounds__(256) void k(float* buf0, int nfloats, int rot, int nbuf) {
+    float* buf = buf0 + (size_t)(blockIdx.x % nbuf) * nfloats;       // nbuf partial buffers: contention per address / nbuf
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // start at a per-workgroup rotated offset so that workgroups do not all hit the same line at the same time
     const int per = nfloats / 4;                 // per wave
@@ -21,15 +22,15 @@ __global__ __launch_bounds__(256) void k(float* buf, int nfloats, int rot) {
 
 int main() {
     const int nfloats = 3 * 352 * 128;   // dW1, dW3, dW2 of one encoder block
-    float* buf; hipMalloc(&buf, nfloats * 4); hipMemset(buf, 0, nfloats * 4);
+    float* buf; hipMalloc(&buf, (size_t)nfloats * 4 * 16); hipMemset(buf, 0, (size_t)nfloats * 4 * 16);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int wgs : {256, 512, 1024}) for (int rot : {0, 1}) {
-        k<0><<<wgs, 256>>>(buf, nfloats, rot); hipDeviceSynchronize();
+    for (int wgs : {512}) for (int rot : {1}) for (int nbuf : {1, 2, 4, 8, 16}) {
+        k<0><<<wgs, 256>>>(buf, nfloats, rot, nbuf); hipDeviceSynchronize();
         hipEventRecord(a);
-        for (int r = 0; r < 10; ++r) k<0><<<wgs, 256>>>(buf, nfloats, rot);
+        for (int r = 0; r < 10; ++r) k<0><<<wgs, 256>>>(buf, nfloats, rot, nbuf);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b); ms /= 10;
-        printf("wgs=%d rot=%d: %.1f us, %.1f M atomics, %.2f T atomics/s, %.1f GB/s equivalent\n", wgs, rot, ms * 1e3,
+        printf("wgs=%d rot=%d nbuf=%d: %.1f us, %.1f M atomics, %.2f T atomics/s, %.1f GB/s equivalent\n", wgs, rot, nbuf, ms * 1e3,
                (double)wgs * nfloats / 1e6, (double)wgs * nfloats / ms / 1e9, (double)wgs * nfloats * 4 / ms / 1e6);
     }
     std::vector<float> h(nfloats); hipMemcpy(h.data(), buf, nfloats * 4, hipMemcpyDeviceToHost);
