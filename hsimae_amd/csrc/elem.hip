@@ -203,6 +203,72 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float
 
 // ------------------------------------------------------------------ decoder sequence assembly (Models.py:579-592)
 // yfull[n,i,:] = (ids_restore[n,i] < K ? y[n, ids_restore[n,i], :] : mean_k y[n,k,:]) + decoder_pos_embed[i,:]
+// Fast forms for decoder widths whose row (Dd / 4 float4 lanes) divides the workgroup: a thread owns one float4
+// column group and walks rows, so every access is a coalesced 16-byte piece and the mean token / its gradient is a
+// two-level sum (row groups in registers, then LDS) instead of one serial chain per column.
+template <int LPR>                                        // lanes per row = Dd / 4
+__global__ __launch_bounds__(256) void assemble_fwd_fast_kernel(AssembleParams p) {
+    constexpr int RG = 256 / LPR, Dd = LPR * 4;
+    __shared__ float4 part[RG][LPR];
+    __shared__ int rest[512];
+    const int n = blockIdx.x, c4 = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+    const float4* y = reinterpret_cast<const float4*>(p.y + (size_t)n * p.K * Dd);
+    for (int i = threadIdx.x; i < p.TL; i += 256) rest[i] = p.ids_restore[(size_t)n * p.TL + i];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = rg; k < p.K; k += RG) {
+        const float4 v = y[(size_t)k * LPR + c4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    part[rg][c4] = s;
+    __syncthreads();
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < RG; ++g) { const float4 v = part[g][c4]; m.x += v.x; m.y += v.y; m.z += v.z; m.w += v.w; }
+    const float ik = 1.f / (float)p.K;
+    m.x *= ik; m.y *= ik; m.z *= ik; m.w *= ik;
+    const float4* pos = reinterpret_cast<const float4*>(p.pos);
+    float4* out = reinterpret_cast<float4*>(p.yfull + (size_t)n * p.TL * Dd);
+    for (int i = rg; i < p.TL; i += RG) {
+        const int r = rest[i];
+        const float4 v = (r < p.K) ? y[(size_t)r * LPR + c4] : m;
+        const float4 q = pos[(size_t)i * LPR + c4];
+        out[(size_t)i * LPR + c4] = make_float4(v.x + q.x, v.y + q.y, v.z + q.z, v.w + q.w);
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void assemble_bwd_fast_kernel(AssembleParams p) {
+    constexpr int RG = 256 / LPR, Dd = LPR * 4;
+    __shared__ float4 part[RG][LPR];
+    __shared__ int rest[512];
+    const int n = blockIdx.x, c4 = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+    const float4* dyf = reinterpret_cast<const float4*>(p.dyfull + (size_t)n * p.TL * Dd);
+    for (int i = threadIdx.x; i < p.TL; i += 256) rest[i] = p.ids_restore[(size_t)n * p.TL + i];
+    __syncthreads();
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = rg; i < p.TL; i += RG)
+        if (rest[i] >= p.K) {
+            const float4 v = dyf[(size_t)i * LPR + c4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    part[rg][c4] = s;
+    __syncthreads();
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < RG; ++g) { const float4 v = part[g][c4]; m.x += v.x; m.y += v.y; m.z += v.z; m.w += v.w; }
+    const float ik = 1.f / (float)p.K;
+    m.x *= ik; m.y *= ik; m.z *= ik; m.w *= ik;
+    for (int i = rg; i < p.TL; i += RG) {
+        const int r = rest[i];
+        if (r < p.K) {
+            const float4 v = dyf[(size_t)i * LPR + c4];
+            bf16x4 o;
+            o[0] = (bf16_t)(v.x + m.x); o[1] = (bf16_t)(v.y + m.y); o[2] = (bf16_t)(v.z + m.z); o[3] = (bf16_t)(v.w + m.w);
+            *reinterpret_cast<bf16x4*>(p.dy + ((size_t)n * p.K + r) * Dd + c4 * 4) = o;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void assemble_fwd_kernel(AssembleParams p) {
     __shared__ float meanv[512];
     const int n = blockIdx.x;
@@ -311,6 +377,104 @@ __global__ __launch_bounds__(256) void loss_kernel(LossParams p) {
     if (threadIdx.x == 0) p.partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// One workgroup per sample: the cube is read once, coalesced, into an LDS image (the token view is 24 runs of 3 floats
+// per token: as global accesses that is 4-byte gathers / scatters), the reconstruction image is assembled in LDS and
+// written back as whole rows.  Same arithmetic per token as loss_kernel.
+constexpr int LSN = 1024;                     // threads per sample: 16 waves walk the tokens
+__global__ __launch_bounds__(LSN) void loss_sample_kernel(LossParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    __shared__ float wsum[LSN / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int B = p.T * 8, E = B * 81, TL = p.T * 9;
+    float* X = lsm;
+    float* P = lsm + E;
+    float* MK = P + (p.pred_img ? E : 0);
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < TL; i += LSN) MK[i] = p.mask[(size_t)n * TL + i];
+    const float* base = p.x + (size_t)n * p.sn;
+    if (p.sw == 1 && p.sh == 9 && p.sb == 81 && (p.sn & 3) == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0) {
+        for (int e = threadIdx.x; e < E / 4; e += LSN) reinterpret_cast<float4*>(X)[e] = reinterpret_cast<const float4*>(base)[e];
+    } else if (p.sb == 1) {                         // band-fastest cubes (the loader's layout): bands are the contiguous axis
+        for (int e = threadIdx.x; e < E; e += LSN) {
+            const int ij = e / B, b = e - ij * B;
+            X[b * 81 + ij] = base[(int64_t)b + (int64_t)(ij / 9) * p.sh + (int64_t)(ij % 9) * p.sw];
+        }
+    } else {
+        for (int e = threadIdx.x; e < E; e += LSN) {
+            const int b = e / 81, ij = e - b * 81;
+            X[e] = base[(int64_t)b * p.sb + (int64_t)(ij / 9) * p.sh + (int64_t)(ij % 9) * p.sw];
+        }
+    }
+    __syncthreads();
+    float lacc = 0.f;
+    for (int tok = wave; tok < TL; tok += LSN / 64) {
+        const int64_t row = (int64_t)n * TL + tok;
+        const int tau = tok / 9, sp = tok % 9, gi = sp / 3, gj = sp % 3;
+        float t[2], pr[2];
+        int off[2];
+        float s = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ft = lane + 64 * h;
+            const bool ok = ft < 72;
+            const int u = ft / 9, pq = ft % 9, pp = pq / 3, q = pq % 3;
+            off[h] = (8 * tau + u) * 81 + (3 * gi + pp) * 9 + (3 * gj + q);
+            t[h] = ok ? X[off[h]] : 0.f;
+            pr[h] = ok ? p.pred[row * 72 + ft] : 0.f;
+            s += t[h];
+        }
+        float mean = 0.f, std = 1.f;
+        if (p.norm_pix) {
+            mean = wave_sum(s) * (1.f / 72.f);
+            float q2 = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float dlt = (lane + 64 * h < 72) ? t[h] - mean : 0.f;
+                q2 += dlt * dlt;
+            }
+            std = sqrtf(wave_sum(q2) * (1.f / 71.f) + 1.0e-6f);
+        }
+        const float mk = MK[tok];
+        float e2 = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ft = lane + 64 * h;
+            if (ft < 72) {
+                const float tg = p.norm_pix ? (t[h] - mean) / std : t[h];
+                const float diff = pr[h] - tg;
+                e2 += diff * diff;
+                if (p.dpred) p.dpred[row * 96 + ft] = (bf16_t)(2.f * mk * diff * p.inv_scale);
+                if (p.pred_img) P[off[h]] = p.norm_pix ? pr[h] * std + mean : pr[h];
+            } else if (ft < 96 && p.dpred) {
+                p.dpred[row * 96 + ft] = (bf16_t)0.f;
+            }
+        }
+        e2 = wave_sum(e2);
+        lacc += e2 * (1.f / 72.f) * mk;
+    }
+    if (lane == 0) wsum[wave] = lacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < LSN / 64; ++i) t += wsum[i];
+        p.partial[blockIdx.x] = t;
+    }
+    if (p.pred_img) {                              // contiguous [N,1,B,9,9] images, 16 bytes per lane
+        float4* po = reinterpret_cast<float4*>(p.pred_img + (size_t)n * E);
+        float4* mo = reinterpret_cast<float4*>(p.mask_img + (size_t)n * E);
+        for (int e4 = threadIdx.x; e4 < E / 4; e4 += LSN) {
+            po[e4] = reinterpret_cast<const float4*>(P)[e4];
+            float m[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e4 * 4 + k, b = e / 81, ij = e - b * 81;
+                m[k] = MK[(b >> 3) * 9 + (ij / 27) * 3 + (ij % 9) / 3];
+            }
+            mo[e4] = make_float4(m[0], m[1], m[2], m[3]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void loss_final_kernel(const float* partial, int n, float sum_mask, float* loss) {
     __shared__ double red[256];
     double s = 0.0;
@@ -403,26 +567,42 @@ int hs_ln_fwd(const float* x, const float* gamma, const float* beta, float* out,
 int hs_assemble_fwd(const AssembleParams& p, hipStream_t s) {
     if (p.N <= 0) return HS_OK;
     if (p.Dd > 512) return HS_EUNSUPPORTED;
-    hipLaunchKernelGGL(assemble_fwd_kernel, dim3(p.N), dim3(256), 0, s, p);
+    if (p.TL <= 512 && p.Dd == 64) hipLaunchKernelGGL(assemble_fwd_fast_kernel<16>, dim3(p.N), dim3(256), 0, s, p);
+    else if (p.TL <= 512 && p.Dd == 32) hipLaunchKernelGGL(assemble_fwd_fast_kernel<8>, dim3(p.N), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(assemble_fwd_kernel, dim3(p.N), dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
 
 int hs_assemble_bwd(const AssembleParams& p, hipStream_t s) {
     if (p.N <= 0) return HS_OK;
     if (p.Dd > 512) return HS_EUNSUPPORTED;
-    hipLaunchKernelGGL(assemble_bwd_kernel, dim3(p.N), dim3(256), 0, s, p);
+    if (p.TL <= 512 && p.Dd == 64) hipLaunchKernelGGL(assemble_bwd_fast_kernel<16>, dim3(p.N), dim3(256), 0, s, p);
+    else if (p.TL <= 512 && p.Dd == 32) hipLaunchKernelGGL(assemble_bwd_fast_kernel<8>, dim3(p.N), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(assemble_bwd_kernel, dim3(p.N), dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
 
 int hs_loss(const LossParams& p, hipStream_t s) {
     const int64_t M = (int64_t)p.N * p.T * 9;
     if (M <= 0) return HS_OK;
-    const int grid = (int)((M + LOSS_ROWS_PER_WG - 1) / LOSS_ROWS_PER_WG);
-    hipLaunchKernelGGL(loss_kernel, dim3(grid), dim3(256), 0, s, p);
+    // per-sample form while two cube images + the mask row fit in LDS (T <= 24 with images, T <= 48 without)
+    const size_t lds = ((size_t)p.T * 8 * 81 * (p.pred_img ? 2 : 1) + (size_t)p.T * 9) * 4;
+    int grid;
+    if (lds <= 150 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(loss_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr_set = true;
+        }
+        grid = p.N;
+        hipLaunchKernelGGL(loss_sample_kernel, dim3(grid), dim3(LSN), lds, s, p);
+    } else {
+        grid = (int)((M + LOSS_ROWS_PER_WG - 1) / LOSS_ROWS_PER_WG);
+        hipLaunchKernelGGL(loss_kernel, dim3(grid), dim3(256), 0, s, p);
+    }
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, p.partial, grid, p.sum_mask, p.loss);
     return (int)hipGetLastError();
 }
-
 // 'AGG' pooling of the fine-tuning head (Models.py:962-970, 1150-1156): latent [N, T*L, D] -> [N, T*D], mean over the
 // L spatial tokens of each spectral group (x.reshape(N,T,L,C).permute(0,2,1,3).reshape(N,L,T*C).mean(1)).
 __global__ __launch_bounds__(256) void agg_pool_kernel(const float* __restrict__ latent, float* __restrict__ pooled, int T, int L,
@@ -444,7 +624,7 @@ int hs_agg_pool(const float* latent, float* pooled, int N, int T, int L, int D, 
 
 int hs_loss_partials(int N, int T) {
     const int64_t M = (int64_t)N * T * 9;
-    return (int)((M + LOSS_ROWS_PER_WG - 1) / LOSS_ROWS_PER_WG);
+    return (int)std::max<int64_t>((M + LOSS_ROWS_PER_WG - 1) / LOSS_ROWS_PER_WG, N);     // either kernel form of hs_loss
 }
 
 int hs_add2(const float* a, const float* b, float* out, int64_t n, hipStream_t s) {
