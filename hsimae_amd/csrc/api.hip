@@ -313,8 +313,11 @@ int wgrad_msplit(int tiles, int64_t M, int concurrent = 1) {
     // launch to one resident wave of workgroups (HSIMAE_WGRAD_WGS overrides the 512 for experiments)
     static int budget = 0;
     if (!budget) { const char* e = getenv("HSIMAE_WGRAD_WGS"); budget = e ? std::max(8, atoi(e)) : 512; }
-    // two launches resident at once (the forked axis stacks) share the budget
+    // `concurrent` launches resident at once (the forked axis stacks) share the budget as long as each still gets whole
+    // groups of 8 row slices: slice ms runs on XCD ms % 8, so fewer than 8 slices leave XCDs idle (D = 256: 52 tiles,
+    // sharing made the step 13 % slower; D = 128: 13 tiles, 2 % faster).
     int ms = std::max(1, budget / std::max(1, concurrent) / std::max(1, tiles));
+    if (ms < 8) ms = std::max(1, budget / std::max(1, tiles));
     if (ms >= 8) ms &= ~7;              // whole XCD groups (wgrad.hip places row slice ms on XCD ms % 8)
     return std::min(ms, chunks);
 }
