@@ -566,7 +566,10 @@ struct LayF {
     static constexpr int ROWS = NT * 16;
     static constexpr int IMG = ROWS * FS;
     static constexpr int FWD = ROWS * 4 + 3 * IMG * 2 + ROWS * 8 * 4;                                   // cls | Q K V | lse
-    static constexpr int BWD = ROWS * 4 + 5 * IMG * 2 + 2 * 8 * ROWS * 4 + 8 * 2 * 16 * RS16 * 2;       // cls | Q K V dO dX | lse delta | T
+    // cls | Q K V dO | dX, later the per-wave transposition tiles T (dX is dead once dO = dX Wp is formed) | lse delta:
+    // 49 KB at NT = 2, three workgroups per CU
+    static constexpr int XT = (IMG * 2 > 8 * 2 * 16 * RS16 * 2) ? IMG * 2 : 8 * 2 * 16 * RS16 * 2;
+    static constexpr int BWD = ROWS * 4 + 4 * IMG * 2 + XT + 2 * 8 * ROWS * 4;
 };
 
 template <int NT>
@@ -693,10 +696,10 @@ __global__ __launch_bounds__(512) void attn128_bwd_kernel(AttnParams p) {
     bf16_t* Kf = Qf + L::IMG;
     bf16_t* Vf = Kf + L::IMG;
     bf16_t* Df = Vf + L::IMG;
-    bf16_t* Xf = Df + L::IMG;                                   // dx1 rows (fused projection gradient only)
-    float* lse_s = reinterpret_cast<float*>(Xf + L::IMG);       // [8][ROWS]
+    bf16_t* Xf = Df + L::IMG;                                   // dx1 rows (fused projection gradient only), then T
+    float* lse_s = reinterpret_cast<float*>(reinterpret_cast<char*>(Xf) + L::XT);       // [8][ROWS]
     float* dlt_s = lse_s + 8 * L::ROWS;                         // [8][ROWS]
-    bf16_t* Tp = reinterpret_cast<bf16_t*>(dlt_s + 8 * L::ROWS) + head * (2 * 16 * RS16);
+    bf16_t* Tp = Xf + head * (2 * 16 * RS16);                   // this wave's P / dS transposition tiles (alias dX)
     bf16_t* Td = Tp + 16 * RS16;
     const size_t row_base = (size_t)blockIdx.x * p.Ts;
     fill_cls_f<NT>(cls, p);
@@ -760,7 +763,7 @@ __global__ __launch_bounds__(512) void attn128_bwd_kernel(AttnParams p) {
                 *cell = dob;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // own LDS writes visible to own later reads
+        lds_barrier();                    // every wave is done with dX before any wave's tiles overwrite it (also orders own writes)
     }
     const float* lse_h = lse_s + head * L::ROWS;
     const float* dlt_h = dlt_s + head * L::ROWS;
