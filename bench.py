@@ -45,7 +45,7 @@ def flops_per_sample(bands, D, depth, s_depth, Dd, dec_depth, lt, ll, hidden, de
 PEAK_HBM_GBS = 8000.0              # HBM3E spec, same guide
 # HBM bytes per encoder-block wgrad launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, guide's gfx950
 # correction), see profiles/r01_pmc_wgrad.txt; None until measured
-WGRAD_TRAFFIC_BYTES = 2 * 234524 * 1024 + 25368 * 1024   # 506 MB vs 460 MB algorithmic (profiles/r01_v5_pmc_hbm_traffic.txt)
+WGRAD_TRAFFIC_BYTES = 2 * 235380 * 1024 + 25368 * 1024   # 508 MB vs 460 MB algorithmic (profiles/r01_v11_pmc_hbm_traffic.txt)
 
 
 def dominant_kernel_roofline(model, N, K_tok, iters=20):
