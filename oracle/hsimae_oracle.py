@@ -11,7 +11,10 @@ Parity status: PINNED.  `tests/golden/make_golden.py` imports the reference
 (`/root/reference/Models.py`) in the build container, replays its RNG streams,
 and commits the reference's own outputs as fixtures under `tests/golden/`;
 `tests/test_oracle_golden.py` checks every function below against them
-(ids bit-exact, fp32 loss to 1e-6 rel, activations/grads to 1e-5).
+(ids bit-exact, fp32 loss to 1e-6 rel, activations/grads to 1e-5).  The fine-tuning additions (`encode_unmasked`,
+`dualvit_classify`, `drop_rates`, `draw_drop_factors`, `dualvit_train_step`) are pinned the same way by
+`tests/golden/make_golden_dualvit.py` (eval forward) and `make_golden_dualvit_train.py` (one training step of the
+reference DualViT with DropPath: recorded draws, losses, logits, all gradients), checked in `tests/test_dualvit_cpu.py`.
 
 Each function cites the reference lines it restates (paths relative to the
 reference checkout).  Integer/index work is numpy; floating point is torch CPU
