@@ -278,6 +278,12 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
               int nsamples, int mode, int len_l, const float* res2, hipStream_t s, const float* rs_a = nullptr,
               const float* rs_m = nullptr) {
     GemmParams p = gp();
+    if (hs_attn_block_fusable(d, heads, Ts)) {
+        // LN1 + q|k|v + attention + projection + residual in one persistent kernel (attn.hip blk128_fwd_kernel)
+        CK(hs_attn_block_fwd(x_in, P.n1w, P.n1b, P.qkv, P.bqkv, P.p, P.pb, b.u, b.qkv, b.o, b.lse, b.x1, rs_a, Ts, nsamples, mode,
+                             len_l, s));
+        if (fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
+    } else {
     p.A = x_in; p.lda = d; p.M = (int)M; p.N = 3 * d; p.K = d; p.n_valid = 3 * d; p.W = P.qkv; p.bias = P.bqkv;
     p.gamma = P.n1w; p.beta = P.n1b; p.u_out = b.u; p.ldu = d; p.out = b.qkv; p.ldo = 3 * d;
     CK(hs_gemm(p, A_F32_LN, E_BF16, s));
@@ -293,6 +299,7 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
         p.A = b.o; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d; p.W = P.p; p.bias = P.pb;
         p.res = x_in; p.ldr = d; p.out = b.x1; p.ldo = d; p.out_rowscale = rs_a;
         CK(hs_gemm(p, A_BF16, E_RES_F32, s));
+    }
     }
     if (fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
     p = gp();

@@ -63,6 +63,10 @@ struct EncMlpPtrs {
     const bf16_t *w1, *w3, *w2, *w2T, *w13T;
     int h;
 };
+bool hs_attn_block_fusable(int d, int heads, int Ts);
+int hs_attn_block_fwd(const float* x, const float* n1w, const float* n1b, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* wp,
+                      const float* pb, hs_bf16* u, hs_bf16* qkv, hs_bf16* o, float* lse, float* x1, const float* rowscale, int Ts,
+                      int nsamples, int mode, int len_l, hipStream_t s);
 bool hs_enc_mlp_fused_supported(int d, int hidden);
 int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, const EncMlpPtrs& b, hipStream_t s,
                    const float* rowscale = nullptr);
