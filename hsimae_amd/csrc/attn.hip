@@ -1145,8 +1145,8 @@ int hs_attn_bwd(const AttnParams& p, hipStream_t s) { return dispatch<true>(p, s
 
 // LN1 + q|k|v + attention + projection + residual in one launch (see blk128_fwd_kernel).  HSIMAE_FUSED_ATTN_BLOCK=0 disables.
 bool hs_attn_block_fusable(int d, int heads, int Ts) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("HSIMAE_FUSED_ATTN_BLOCK"); on = !(e && e[0] == '0'); }
+    const char* e = getenv("HSIMAE_FUSED_ATTN_BLOCK");        // read per call: the parity test flips it inside one process
+    const bool on = !(e && e[0] == '0');
     AttnParams q = AttnParams();
     q.d = d; q.heads = heads; q.hd = heads ? d / heads : 0; q.Ts = Ts; q.ld = 384; q.ldo = 128; q.lse = reinterpret_cast<float*>(1);
     return on && hs_attn_proj_fusable(q);

@@ -322,6 +322,43 @@ def test_fused_encoder_mlp_matches_layerwise(bands, grid, N):
     print(f"[fused-mlp {bands}] worst grad rms-rel vs layerwise {worst}")
 
 
+@pytest.mark.parametrize("bands,grid,N", [(48, (2, 7), 37), (96, (3, 9), 24), (96, (9, 3), 24)])
+def test_fused_attention_half_matches_separate_kernels(bands, grid, N):
+    """blk128_fwd_kernel (LN1 -> q|k|v -> attention -> projection + residual in one persistent launch) against
+    lnqkv_kernel + attn128_fwd_kernel on the same inputs: loss, predictions and every gradient (the backward consumes
+    the u / qkv / o / lse / x1 the forward saved, so it checks those too)."""
+    cfg = O.OracleConfig(bands=bands)
+    m = build(cfg, O.init_state(cfg, seed=13, std=0.06))
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand(N, 1, bands, 9, 9, generator=g).to(DEV)
+    n = (torch.rand(N, bands // 8, generator=g), torch.rand(N, 9, generator=g))
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["HSIMAE_FUSED_ATTN_BLOCK"] = mode
+        try:
+            m.zero_grad()
+            loss, pred, _ = m(x, 0.75, noise=n, grid=grid)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = (loss.item(), pred.clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        finally:
+            os.environ.pop("HSIMAE_FUSED_ATTN_BLOCK", None)
+    l0, p0, g0 = res["0"]
+    l1, p1, g1 = res["1"]
+    print(f"[fused-attn-half {bands} {grid}] loss separate {l0:.7f} fused {l1:.7f}")
+    assert abs(l0 - l1) <= 5e-5 * abs(l0)
+    assert rms_rel(p1, p0) < 3e-3
+    worst = ("", 0.0)
+    for k in g0:
+        if k.endswith("attn.k.bias"):
+            continue
+        r = rms_rel(g1[k], g0[k])
+        if r > worst[1]:
+            worst = (k, r)
+        assert r < 3e-2, (k, r)
+    print(f"[fused-attn-half {bands}] worst grad rms-rel vs separate {worst}")
+
+
 @pytest.mark.parametrize("name,bands,dim,grid,N", [("C3-Large", 96, 256, (3, 9), 12), ("C5-Huge@512", 192, 512, (6, 9), 6),
                                                    ("C5-Huge@512", 192, 512, (18, 3), 6)])
 def test_large_and_huge_widths_against_oracle(name, bands, dim, grid, N):
