@@ -7,8 +7,8 @@
 
 A step = one forward + backward of HSIMAE-Base over a per-GPU batch of 4096 synthetic 9x9x96 cubes already
 resident in HBM (mask ratio 0.75), including the RCCL gradient all-reduce when N > 1.  Rank 0 prints ONE JSON
-line; `value` is the whole-job patches/s.  `roofline` prices the dominant kernel against the dense bf16 MFMA
-peak from live HIP-event timings; `cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
+line; `value` is the whole-job patches/s.  `roofline` prices the kernel with the largest share of the step (HBM-bound)
+against the HBM peak from live HIP-event timings (`roofline_wgrad`: the runner-up); `cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
 """
 import argparse
 import ctypes as C
@@ -48,11 +48,65 @@ PEAK_HBM_GBS = 8000.0              # HBM3E spec, same guide
 WGRAD_TRAFFIC_BYTES = 2 * 235380 * 1024 + 25368 * 1024   # 508 MB vs 460 MB algorithmic (profiles/r01_v11_pmc_hbm_traffic.txt)
 
 
+# enc_mlp_bwd_kernel, same source: 2*118358 KB fetched + 399167 KB written = 651 MB vs 488 MB algorithmic (x1 / dY are
+# re-read in the epilogue)
+MLPBWD_TRAFFIC_BYTES = 2 * 118358 * 1024 + 399167 * 1024
+
+
 def dominant_kernel_roofline(model, N, K_tok, iters=20):
-    """Live HIP-event timing of the dominant kernel of the step (profiles/: `wgrad_kernel`, ~18 % of kernel
-    time): the batched weight-gradient launch of one ENCODER block (q, k, v, proj, w1, w3, w2) at the workload's
-    shape (M = N*K kept-token rows), through the C ABI on the current stream.  HBM-bound: algorithmic bytes per
-    launch = every operand read once =
+    """Live HIP-event timing of the kernel with the largest share of the step (profiles/r01_v11_kernel_stats_*:
+    `enc_mlp_bwd_kernel`, 21 launches, 14-15 % of kernel time): the MLP-half backward of one ENCODER block at the
+    workload's shape (M = N*K kept-token rows), through the C ABI on the current stream.  HBM-bound: algorithmic bytes
+    per launch = every operand once = M * (x1 4d + dY 4d  read;  dx1 4d + u2 2d + dY_bf16 2d + dx1_bf16 2d + dh1|dh3
+    2*2hp + g 2hp  written)."""
+    from hsimae_amd import _lib, swiglu_hidden
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = model.dim
+    h = swiglu_hidden(d, model.mlp_ratio)
+    hp = (h + 31) // 32 * 32
+    M = N * K_tok
+    f32 = dict(dtype=torch.float32, device=dev)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    x1, dy = torch.randn(M, d, **f32), torch.randn(M, d, **f32) * 1e-3
+    dx1 = torch.empty(M, d, **f32)
+    u2, dyb, dx1b = (torch.empty(M, d, **bf) for _ in range(3))
+    dh13, g = torch.empty(M, 2 * hp, **bf), torch.empty(M, hp, **bf)
+    # packed weight images: any bf16 content of the right size is a valid image (timing only)
+    w1, w3, w2T = (torch.randn(hp * d, **bf) * 0.05 for _ in range(3))
+    w2, w13T = torch.randn(d * hp, **bf) * 0.05, torch.randn(d * 2 * hp, **bf) * 0.05
+    n2w, n2b, b2 = torch.ones(d, **f32), torch.zeros(d, **f32), torch.zeros(d, **f32)
+    b1, b3 = torch.zeros(hp, **f32), torch.zeros(hp, **f32)
+    gw, gb = torch.zeros(d, **f32), torch.zeros(d, **f32)
+    w = _lib.MlpWeights(n2w=n2w.data_ptr(), n2b=n2b.data_ptr(), w1b=b1.data_ptr(), w3b=b3.data_ptr(), w2b=b2.data_ptr(),
+                        w1=w1.data_ptr(), w3=w3.data_ptr(), w2=w2.data_ptr(), w2T=w2T.data_ptr(), w13T=w13T.data_ptr(), hidden=h)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        _lib.check(lib.hsimae_enc_mlp_bwd(x1.data_ptr(), dy.data_ptr(), dx1.data_ptr(), u2.data_ptr(), dh13.data_ptr(),
+                                          g.data_ptr(), dyb.data_ptr(), dx1b.data_ptr(), M, d, C.byref(w), gw.data_ptr(),
+                                          gb.data_ptr(), None, None, s), "hsimae_enc_mlp_bwd")
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = float(M) * (4 * d + 4 * d + 4 * d + 2 * d + 2 * d + 2 * d + 2 * 2 * hp + 2 * hp)
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "enc_mlp_bwd_kernel<128,352> (encoder block: MLP-half backward, emits dx1 + the weight-gradient operands)",
+            "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": MLPBWD_TRAFFIC_BYTES, "launch_ms": round(ms, 4),
+            "bytes_per_launch": nbytes}
+
+
+def wgrad_kernel_roofline(model, N, K_tok, iters=20):
+    """Second-largest HBM-bound kernel (wgrad_dma_kernel, 23 launches, 12-13 % of kernel time): the batched
+    weight-gradient launch of one ENCODER block (q, k, v, proj, w1, w3, w2) at the workload's shape, timed the same way.
+    Algorithmic bytes per launch = every operand read once =
     M * (dqkv 3d*2 + u d*2 + dx1 d*2 + o d*2 + dh13 2hp*2 + u2 d*2 + dY d*2 + g hp*2)  (all operands bf16)."""
     from hsimae_amd import _lib, swiglu_hidden
     lib = _lib.load()
@@ -262,7 +316,12 @@ def main():
             "step_frac_of_bf16_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
             "gflop_per_patch": round(fl / 1e9, 4),
         }
-        out["roofline"] = dominant_kernel_roofline(model, N, 27)
+        if D == 128:
+            out["roofline"] = dominant_kernel_roofline(model, N, 27)
+            out["roofline_wgrad"] = wgrad_kernel_roofline(model, N, 27)
+        else:                                   # wider encoders run layer-at-a-time: the weight-gradient launch leads there
+            out["roofline"] = wgrad_kernel_roofline(model, N, 27)
+            out["roofline"]["traffic"] = None   # PMC traffic was collected at D = 128 only
         out["optimizer_step_ms"] = optimizer_step_ms(model)
         out["input_pipeline"] = input_pipeline_ms(bands, N)
         if world == 1 and not args.no_cpu_baseline:

@@ -62,6 +62,11 @@ class AttnParams(C.Structure):
                 ("dqkv", vp), ("proj_w", vp), ("proj_b", vp), ("xres", vp), ("x1", vp), ("projT_w", vp), ("rowscale", vp)]
 
 
+class MlpWeights(C.Structure):
+    _fields_ = [("n2w", vp), ("n2b", vp), ("w1b", vp), ("w3b", vp), ("w2b", vp),
+                ("w1", vp), ("w3", vp), ("w2", vp), ("w2T", vp), ("w13T", vp), ("hidden", i32)]
+
+
 class WgradTask(C.Structure):
     _fields_ = [("dO", vp), ("dO_f32", i32), ("ldo", i32), ("A", vp), ("lda", i32), ("N", i32), ("K", i32),
                 ("dW", vp), ("ldw", i32), ("db", vp), ("dO_rowscale", vp)]
@@ -111,6 +116,8 @@ SYMBOLS = {
     "hsimae_patch_gather": (C.c_int, [C.POINTER(PatchParams), vp]),
     "hsimae_gemm": (C.c_int, [C.POINTER(GemmParams), i32, i32, vp]),
     "hsimae_pack_matrix": (C.c_int, [vp, i32, i32, vp]),
+    "hsimae_enc_mlp_fwd": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(MlpWeights), vp, vp]),
+    "hsimae_enc_mlp_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(MlpWeights), vp, vp, vp, vp, vp]),
     "hsimae_attn_fwd": (C.c_int, [C.POINTER(AttnParams), vp]),
     "hsimae_attn_bwd": (C.c_int, [C.POINTER(AttnParams), vp]),
     "hsimae_wgrad": (C.c_int, [C.POINTER(WgradParams), vp]),

@@ -764,6 +764,27 @@ int hsimae_gemm(const hsimae_gemm_params* p, int32_t a_kind, int32_t epilogue, v
 int hsimae_pack_matrix(const hsimae_pack_desc* d, int32_t n, int32_t max_elems, void* stream) {
     return d ? hs_pack(d, n, max_elems, S(stream)) : HSIMAE_ENULL;
 }
+static EncMlpPtrs mlp_from_abi(const hsimae_mlp_weights* w) {
+    EncMlpPtrs m;
+    m.n2w = w->n2w; m.n2b = w->n2b; m.w1b = w->w1b; m.w3b = w->w3b; m.w2b = w->w2b;
+    m.w1 = w->w1; m.w3 = w->w3; m.w2 = w->w2; m.w2T = w->w2T; m.w13T = w->w13T; m.h = w->hidden;
+    return m;
+}
+int hsimae_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int32_t M, int32_t d, const hsimae_mlp_weights* w,
+                       const float* rowscale, void* stream) {
+    if (M <= 0) return HSIMAE_OK;
+    if (!x1 || !x2 || !w) return HSIMAE_ENULL;
+    if (!hs_enc_mlp_fused_supported(d, w->hidden)) return HSIMAE_EUNSUPPORTED;
+    return hs_enc_mlp_fwd(x1, res2, x2, M, d, mlp_from_abi(w), S(stream), rowscale);
+}
+int hsimae_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
+                       hs_bf16* dx1b, int32_t M, int32_t d, const hsimae_mlp_weights* w, float* g_n2w, float* g_n2b,
+                       const float* rs_mlp, const float* rs_attn, void* stream) {
+    if (M <= 0) return HSIMAE_OK;
+    if (!x1 || !dy || !dx1 || !u2 || !dh13 || !g || !dyb || !dx1b || !w || !g_n2w || !g_n2b) return HSIMAE_ENULL;
+    if (!hs_enc_mlp_fused_supported(d, w->hidden)) return HSIMAE_EUNSUPPORTED;
+    return hs_enc_mlp_bwd(x1, dy, dx1, u2, dh13, g, dyb, dx1b, M, d, mlp_from_abi(w), g_n2w, g_n2b, S(stream), rs_mlp, rs_attn);
+}
 int hsimae_attn_fwd(const hsimae_attn_params* p, void* stream) { return p ? hs_attn_fwd(*p, S(stream)) : HSIMAE_ENULL; }
 int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream) { return p ? hs_attn_bwd(*p, S(stream)) : HSIMAE_ENULL; }
 int hsimae_wgrad(const hsimae_wgrad_params* p, void* stream) { return p ? hs_wgrad(*p, S(stream)) : HSIMAE_ENULL; }

@@ -169,6 +169,22 @@ typedef struct {
 } hsimae_pack_desc;
 int hsimae_pack_matrix(const hsimae_pack_desc* desc_dev, int32_t ndesc, int32_t max_elems, void* stream);
 
+/* MLP half of an encoder Block in one kernel each way (Models.py:305 `x + mlp(norm2(x))`, SwiGLU :231-232), d = 128 with
+ * hidden width padded to 352 (Base): forward  x2 = x1 + rowscale * (b2 + (silu(u2 W1^T + b1) * (u2 W3^T + b3)) W2^T) (+ res2),
+ * u2 = LN2(x1); backward recomputes u2 / h1 / h3 and writes dx1 (fp32) plus the bf16 operands of the block's weight
+ * gradients: u2, dh1|dh3 [M, 2*352], g [M, 352], dY and dx1 copies; LayerNorm-2 parameter grads are accumulated.
+ * Weight images as produced by hsimae_pack_params (w13T = W1^T | W3^T along K).  rs_mlp / rs_attn: DropPath row factors. */
+typedef struct {
+    const float* n2w; const float* n2b; const float* w1b; const float* w3b; const float* w2b;
+    const hs_bf16* w1; const hs_bf16* w3; const hs_bf16* w2; const hs_bf16* w2T; const hs_bf16* w13T;
+    int32_t hidden;
+} hsimae_mlp_weights;
+int hsimae_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int32_t M, int32_t d, const hsimae_mlp_weights* w,
+                       const float* rowscale, void* stream);
+int hsimae_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
+                       hs_bf16* dx1b, int32_t M, int32_t d, const hsimae_mlp_weights* w, float* g_n2w, float* g_n2b,
+                       const float* rs_mlp, const float* rs_attn, void* stream);
+
 /* Masked multi-head attention over one sample's tokens (Models.py:192-215) and its backward. */
 typedef struct {
     const hs_bf16* qkv; int32_t ld;
