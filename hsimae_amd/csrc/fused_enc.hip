@@ -29,7 +29,7 @@ extern "C" int hsimae_debug_phases_enc(unsigned long long* out, int reset) {
 
 namespace {
 
-constexpr int R = 64, MH = 2, NTH = 256;   // 64-row panels: several independent 4-wave workgroups per CU
+constexpr int R = 48, MH = 2, NTH = 256;   // 48-row panels: three 4-wave workgroups per CU, 2304 = 3 x 768 workgroups at M = 110,592
 constexpr int LC = 64 + 8;         // 64-column chunk image row stride
 
 // Geometry for model width D and padded hidden width HP (multiples of 64 / 32).
@@ -289,7 +289,7 @@ struct EncMlpBwdArgs {
 };
 
 template <int D, int HPE>
-__global__ __launch_bounds__(NTH, 2) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
+__global__ __launch_bounds__(NTH, 3) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     using G = MG<D, HPE>;
     constexpr int LU = G::LU, LX = G::LX, NCH = G::NCH, KSD = G::KSD, KSH = G::KSH, LPR = G::LPR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
