@@ -215,6 +215,74 @@ def test_gemm_swiglu_forward_and_backward_epilogues(d, h):
     assert float(dh13[:, h:hp].abs().max()) == 0
 
 
+@pytest.mark.parametrize("M,drop", [(210, False), (4133, False), (333, True)])
+def test_fused_encoder_mlp_half_forward_backward(M, drop):
+    """hsimae_enc_mlp_fwd / hsimae_enc_mlp_bwd (one kernel each way, Base width) against a plain PyTorch fp32
+    restatement of `x + rs * mlp(norm2(x))` (Models.py:305, 231-232) and its autograd, ragged row counts, optional
+    DropPath row factors; also the bf16 weight-gradient operands the backward emits."""
+    torch.manual_seed(6)
+    d, h = 128, 344
+    hp = rup(h, 32)
+    lib = _lib.load()
+    x1 = torch.randn(M, d, device=DEV)
+    dy = torch.randn(M, d, device=DEV) * 0.1
+    gamma, beta = 1 + 0.1 * torch.randn(d, device=DEV), 0.1 * torch.randn(d, device=DEV)
+    W1, W3, W2 = (torch.randn(h, d, device=DEV) * 0.1, torch.randn(h, d, device=DEV) * 0.1, torch.randn(d, h, device=DEV) * 0.1)
+    b1, b3, b2 = torch.randn(h, device=DEV) * 0.1, torch.randn(h, device=DEV) * 0.1, torch.randn(d, device=DEV) * 0.1
+    rs_m = rs_a = None
+    if drop:                                               # factors 0 or 1/keep, constant over runs of 9 rows
+        rs_m = (torch.rand((M + 8) // 9, device=DEV) < 0.8).float().div(0.8).repeat_interleave(9)[:M].contiguous()
+        rs_a = (torch.rand((M + 8) // 9, device=DEV) < 0.8).float().div(0.8).repeat_interleave(9)[:M].contiguous()
+    i1, i3 = pack([(W1, 0, 0, 0)], hp, d), pack([(W3, 0, 0, 0)], hp, d)
+    i2 = pack([(W2, 0, 0, 0)], d, hp)
+    i2T = pack([(W2, 1, 0, 0)], hp, d)
+    i13T = pack([(W1, 1, 0, 0), (W3, 1, 0, hp)], d, 2 * hp)
+    b1p, b3p = torch.zeros(hp, device=DEV), torch.zeros(hp, device=DEV)
+    b1p[:h], b3p[:h] = b1, b3
+    w = _lib.MlpWeights(n2w=gamma.data_ptr(), n2b=beta.data_ptr(), w1b=b1p.data_ptr(), w3b=b3p.data_ptr(), w2b=b2.data_ptr(),
+                        w1=i1.data_ptr(), w3=i3.data_ptr(), w2=i2.data_ptr(), w2T=i2T.data_ptr(), w13T=i13T.data_ptr(), hidden=h)
+    x2 = torch.empty(M, d, device=DEV)
+    _lib.check(lib.hsimae_enc_mlp_fwd(x1.data_ptr(), None, x2.data_ptr(), M, d, C.byref(w), _lib.ptr(rs_m), stream()))
+    # reference, fp32 with the bf16-rounded weights the kernel multiplies with
+    xr = x1.clone().requires_grad_(True)
+    u = torch.nn.functional.layer_norm(xr, (d,), gamma, beta, 1e-5)
+    h1, h3 = u @ bf(W1).t() + b1, u @ bf(W3).t() + b3
+    gate = torch.nn.functional.silu(h1) * h3
+    branch = gate @ bf(W2).t() + b2
+    y = xr + (branch * rs_m[:, None] if drop else branch)
+    torch.cuda.synchronize()
+    assert rel_err(x2, y.detach()) < 6e-3                   # bf16 operands (u, gate), fp32 accumulation
+    y.backward(dy)
+    dx1 = torch.empty(M, d, device=DEV)
+    u2, dyb, dx1b = (torch.empty(M, d, dtype=torch.bfloat16, device=DEV) for _ in range(3))
+    dh13 = torch.empty(M, 2 * hp, dtype=torch.bfloat16, device=DEV)
+    g = torch.empty(M, hp, dtype=torch.bfloat16, device=DEV)
+    gw, gb = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    _lib.check(lib.hsimae_enc_mlp_bwd(x1.data_ptr(), dy.data_ptr(), dx1.data_ptr(), u2.data_ptr(), dh13.data_ptr(), g.data_ptr(),
+                                      dyb.data_ptr(), dx1b.data_ptr(), M, d, C.byref(w), gw.data_ptr(), gb.data_ptr(),
+                                      _lib.ptr(rs_m), _lib.ptr(rs_a), stream()))
+    torch.cuda.synchronize()
+    assert rel_err(dx1, xr.grad) < 1.5e-2
+    assert rel_err(u2.float(), u.detach()) < 2 ** -7
+    assert rel_err(g[:, :h].float(), gate.detach()) < 1e-2 and float(g[:, h:].float().abs().max()) == 0
+    dyr = dy * rs_m[:, None] if drop else dy
+    assert rel_err(dyb.float(), dyr) < 2 ** -7                                       # the MLP branch's incoming gradient
+    assert rel_err(dx1b.float(), xr.grad * rs_a[:, None] if drop else xr.grad) < 1.5e-2   # what the attention branch sees
+    # dh1 | dh3: check through the weight gradients they produce (what they are for)
+    dW1 = dh13[:, :h].float().t() @ u2.float()
+    dW3 = dh13[:, hp:hp + h].float().t() @ u2.float()
+    dgate = dyr @ bf(W2)
+    s = torch.sigmoid(h1.detach())
+    r1 = (dgate * h3.detach() * s * (1 + h1.detach() * (1 - s))).t() @ u.detach()
+    r3 = (dgate * h1.detach() * s).t() @ u.detach()
+    assert rel_err(dW1, r1) < 2e-2 and rel_err(dW3, r3) < 2e-2
+    assert float(dh13[:, h:hp].float().abs().max()) == 0
+    # LayerNorm-2 parameter gradients (accumulated with atomics)
+    xh = (x1 - x1.mean(1, keepdim=True)) / torch.sqrt(x1.var(1, unbiased=False, keepdim=True) + 1e-5)
+    dgate_u = (dgate * h3.detach() * s * (1 + h1.detach() * (1 - s))) @ bf(W1) + (dgate * h1.detach() * s) @ bf(W3)
+    assert rel_err(gw, (dgate_u * xh).sum(0)) < 2e-2 and rel_err(gb, dgate_u.sum(0)) < 2e-2
+
+
 # ----------------------------------------------------------------------------------------------- attention
 def attn_reference(qkv, d, heads, Ts, mode, len_l):
     """fp32 masked attention over [nsamples, Ts] tokens; qkv fp32 leaf [rows, 3d] (values already bf16-exact)."""
