@@ -75,7 +75,7 @@ def main():
         "dec_bwd_mlp": (8, ["prologue LN", "gate mm + silu", "wgrad", "du2 stage", "epilogue LN bwd", "du2 mm", "-", "-"]),
         "dec_fwd": (16, ["LN1 + residual", "qkv", "attention", "o store + proj", "LN2", "gate chunks", "w2 mm", "store"]),
         "enc_mlp_bwd": (32, ["prologue LN", "gate mm + silu", "operand stores", "du2 mm", "epilogue LN bwd", "LN grads", "-", "-"]),
-        "enc_mlp_fwd": (40, ["prologue LN", "residual to registers", "gate chunks", "W2 mm", "store", "-", "-", "-"]),
+        "enc_mlp_fwd": (40, ["prologue LN", "bias init", "gate + W2 chunks", "(barrier)", "store", "-", "-", "-"]),
     }
     for k, (base, ph) in names.items():
         tot = sum(v[base:base + 8]) or 1
