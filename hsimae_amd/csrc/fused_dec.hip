@@ -32,6 +32,17 @@ extern "C" int hsimae_debug_phases(unsigned long long* out, int reset) {
 #define PH_FLUSH(base)
 #endif
 
+/* next-sample L2 / TLB warm-up loads in the persistent decoder kernels (forward / MLP backward / attention backward) */
+#ifndef HS_TOUCH_F
+#define HS_TOUCH_F 0
+#endif
+#ifndef HS_TOUCH_M
+#define HS_TOUCH_M 0
+#endif
+#ifndef HS_TOUCH_A
+#define HS_TOUCH_A 0
+#endif
+
 namespace {
 
 constexpr int D = 64, HD = 8, HPD = 192;
@@ -500,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
         float touchx = 0.f;
         {
             const int nxt = sample + gridDim.x;
-            if (nxt < p.nsamples && threadIdx.x * 32 < p.Ts * D) touchx = p.x[(size_t)nxt * p.Ts * D + threadIdx.x * 32];
+            if (HS_TOUCH_F && nxt < p.nsamples && threadIdx.x * 32 < p.Ts * D) touchx = p.x[(size_t)nxt * p.Ts * D + threadIdx.x * 32];
         }
 #pragma unroll 1
         for (int hh = 0; hh < 2; ++hh) attn_head_fwd<MT>(Qb, Kb, Vt, U, q.wave * 2 + hh, p.Ts, q, p.lse + rb * 8);
@@ -747,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
         {
             const int nxt = sample + gridDim.x;
             const size_t o = (size_t)nxt * p.Ts * D + threadIdx.x * 16;
-            if (nxt < p.nsamples && threadIdx.x * 16 < p.Ts * D) { touch0 = p.x1[o]; touch1 = p.dy[o]; }
+            if (HS_TOUCH_M && nxt < p.nsamples && threadIdx.x * 16 < p.Ts * D) { touch0 = p.x1[o]; touch1 = p.dy[o]; }
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -1220,7 +1231,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             const int nxt = sample + gridDim.x;
             const size_t nb = (size_t)nxt * p.Ts;
             const int t16 = threadIdx.x * 16;
-            if (nxt < p.nsamples) {
+            if (HS_TOUCH_A && nxt < p.nsamples) {
                 if (t16 < p.Ts * D) { touch[0] = p.x[nb * D + t16]; touch[1] = p.dx1[nb * D + t16]; }
                 if (2 * t16 < p.Ts * D) touch[2] = bf2f(p.o[nb * D + 2 * t16]);
                 if (t16 < p.Ts * 8) touch[3] = p.lse_g[nb * 8 + t16];
