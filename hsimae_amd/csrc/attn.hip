@@ -843,26 +843,32 @@ struct Blk128Args {
     int Ts, nsamples, mode, len_l;
 };
 
-template <int NT>
+// SPW samples are walked per iteration ("slots" of NT m-tiles each in the images): one sample is a chain of ~30 dependent
+// LDS / MFMA steps, so a wave with a single sample in hand is parked 75 % of the time; two independent chains per wave
+// and half the barriers per sample is what the 2 waves per SIMD can still interleave.
+template <int NT, int SPW>
 struct LayB {
-    static constexpr int ROWS = NT * 16;
-    static constexpr int IMG = ROWS * FS;
-    // cls | U | Q K V | O | lse | vectors
-    static constexpr int TOTAL = ROWS * 4 + 5 * IMG * 2 + ROWS * 8 * 4 + 768 * 4;   // + gamma | beta | bqkv | bp
+    static constexpr int ROWS = NT * 16;                 // rows of one slot
+    static constexpr int RT = SPW * ROWS;                // rows of the images
+    static constexpr int IMG = RT * FS;
+    // cls | U | Q K V | O | lse | vectors (gamma | beta | bqkv | bp)
+    static constexpr int TOTAL = RT * 4 + 5 * IMG * 2 + RT * 8 * 4 + 768 * 4;
 };
 
-template <int NT>
+template <int NT, int SPW>
 __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
-    using L = LayB<NT>;
+    using L = LayB<NT, SPW>;
+    constexpr int ROWS = L::ROWS, RT = L::RT, MTT = SPW * NT;
+    constexpr int PASSES = (RT * 16 + 511) / 512;               // LayerNorm passes: 16 lanes per row, 32 rows per pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int* cls = reinterpret_cast<int*>(smem);
-    bf16_t* Uf = reinterpret_cast<bf16_t*>(smem + L::ROWS * 4);
+    bf16_t* Uf = reinterpret_cast<bf16_t*>(smem + RT * 4);
     bf16_t* Qf = Uf + L::IMG;
     bf16_t* Kf = Qf + L::IMG;
     bf16_t* Vf = Kf + L::IMG;
     bf16_t* Of = Vf + L::IMG;
-    float* lse_s = reinterpret_cast<float*>(Of + L::IMG);       // [ROWS][8]
+    float* lse_s = reinterpret_cast<float*>(Of + L::IMG);       // [RT][8]
     const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3, hc = head * 16;
     const float sc = 0.25f * 1.4426950408889634f;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -875,61 +881,79 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
         for (int ks = 0; ks < 4; ++ks) wq[m][ks] = *reinterpret_cast<const bf16x8*>(p.wqkv + ((size_t)((m * 8 + head) * 4 + ks) * 64 + lane) * 8);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) wpj[ks] = *reinterpret_cast<const bf16x8*>(p.wp + ((size_t)(head * 4 + ks) * 64 + lane) * 8);
-    // vectors every sample needs live in LDS, not in registers (the weights take 64 of the 128)
-    float* vec_s = lse_s + L::ROWS * 8;                           // gamma[128] | beta[128] | bqkv[384] | bp[128]
+    // vectors every sample needs live in LDS, not in registers (the weights take 64)
+    float* vec_s = lse_s + RT * 8;                                // gamma[128] | beta[128] | bqkv[384] | bp[128]
     for (int i = threadIdx.x; i < 768; i += 512)
         vec_s[i] = i < 128 ? p.n1w[i] : i < 256 ? p.n1b[i - 128] : i < 640 ? p.bqkv[i - 256] : p.pb[i - 640];
-    fill_cls_f<NT>(cls, p);
+    for (int i = threadIdx.x; i < RT; i += 512) {                 // class of an image row: -1 = padding; slots never mix
+        const int slot = i / ROWS, r = i - slot * ROWS;
+        int c = -1;
+        if (r < p.Ts) c = slot * 64 + ((p.mode == 1) ? r / p.len_l : (p.mode == 2) ? r % p.len_l : 0);
+        cls[i] = c;
+    }
 
-    // LayerNorm / store mapping: 16 lanes per row, 8 columns each (ROWS * 16 <= 512 threads)
-    const int lrow = threadIdx.x >> 4, lc8 = (threadIdx.x & 15) * 8;
-    const bool lact = lrow < L::ROWS;
-    float xn[8];                                                  // next sample's row piece, in flight during this sample
-    auto fetch = [&](int sample) {
+    const int lc8 = (threadIdx.x & 15) * 8;
+    float xn[PASSES][8];                                          // next group's row pieces, in flight during this group
+    auto fetch = [&](int first) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) xn[e] = 0.f;
-        if (sample < p.nsamples && lact && lrow < p.Ts) {
-            const float* src = p.x + ((size_t)sample * p.Ts + lrow) * 128 + lc8;
-            const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-            xn[0] = a.x; xn[1] = a.y; xn[2] = a.z; xn[3] = a.w; xn[4] = b.x; xn[5] = b.y; xn[6] = b.z; xn[7] = b.w;
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int irow = ps * 32 + (threadIdx.x >> 4), slot = irow / ROWS, r = irow - slot * ROWS;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xn[ps][e] = 0.f;
+            if (irow < RT && first + slot < p.nsamples && r < p.Ts) {
+                const float* src = p.x + ((size_t)(first + slot) * p.Ts + r) * 128 + lc8;
+                const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+                xn[ps][0] = a.x; xn[ps][1] = a.y; xn[ps][2] = a.z; xn[ps][3] = a.w;
+                xn[ps][4] = b.x; xn[ps][5] = b.y; xn[ps][6] = b.z; xn[ps][7] = b.w;
+            }
         }
     };
-    fetch(blockIdx.x);
+    fetch(blockIdx.x * SPW);
     lds_barrier();                                                // vec_s / cls visible
-    for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
-        const size_t row_base = (size_t)sample * p.Ts;
+    for (int first = blockIdx.x * SPW; first < p.nsamples; first += gridDim.x * SPW) {
+        // global row of image row i (slot-major), or -1
+        auto grow = [&](int irow) -> int64_t {
+            const int slot = irow / ROWS, r = irow - slot * ROWS;
+            return (first + slot < p.nsamples && r < p.Ts) ? (int64_t)(first + slot) * p.Ts + r : -1;
+        };
         // ---- LN1 -> U image (+ u to HBM: the q / k / v weight gradients' operand)
-        if (lact) {
-            float sm = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sm += xn[e];
-            sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
-            const float mean = sm * (1.f / 128.f);
-            float vq = 0.f, f[8];
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int irow = ps * 32 + (threadIdx.x >> 4);
+            if (irow < RT) {
+                float sm = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { f[e] = xn[e] - mean; vq += f[e] * f[e]; }
-            vq += __shfl_xor(vq, 1, 64); vq += __shfl_xor(vq, 2, 64); vq += __shfl_xor(vq, 4, 64); vq += __shfl_xor(vq, 8, 64);
-            const float rstd = rsqrtf(vq * (1.f / 128.f) + 1e-5f);
-            {
-                const float4 g0 = *reinterpret_cast<const float4*>(vec_s + lc8), g1 = *reinterpret_cast<const float4*>(vec_s + lc8 + 4);
-                const float4 b0 = *reinterpret_cast<const float4*>(vec_s + 128 + lc8), b1 = *reinterpret_cast<const float4*>(vec_s + 128 + lc8 + 4);
-                const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                for (int e = 0; e < 8; ++e) sm += xn[ps][e];
+                sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
+                const float mean = sm * (1.f / 128.f);
+                float vq = 0.f, f[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
+                for (int e = 0; e < 8; ++e) { f[e] = xn[ps][e] - mean; vq += f[e] * f[e]; }
+                vq += __shfl_xor(vq, 1, 64); vq += __shfl_xor(vq, 2, 64); vq += __shfl_xor(vq, 4, 64); vq += __shfl_xor(vq, 8, 64);
+                const float rstd = rsqrtf(vq * (1.f / 128.f) + 1e-5f);
+                {
+                    const float4 g0 = *reinterpret_cast<const float4*>(vec_s + lc8), g1 = *reinterpret_cast<const float4*>(vec_s + lc8 + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(vec_s + 128 + lc8), b1 = *reinterpret_cast<const float4*>(vec_s + 128 + lc8 + 4);
+                    const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
+                }
+                const int64_t gr = grow(irow);
+                const bf16x8 ub = gr >= 0 ? cvt8(f) : zero8();
+                *reinterpret_cast<bf16x8*>(Uf + irow * FS + lc8) = ub;
+                if (gr >= 0) *reinterpret_cast<bf16x8*>(p.u + gr * 128 + lc8) = ub;
             }
-            const bf16x8 ub = lrow < p.Ts ? cvt8(f) : zero8();
-            *reinterpret_cast<bf16x8*>(Uf + lrow * FS + lc8) = ub;
-            if (lrow < p.Ts) *reinterpret_cast<bf16x8*>(p.u + (row_base + lrow) * 128 + lc8) = ub;
         }
-        fetch(sample + gridDim.x);                                // next sample's rows fly during this one
+        fetch(first + gridDim.x * SPW);                           // next group's rows fly during this one
         lds_barrier();
         // ---- q | k | v of this head: transposed accumulators -> 8-byte writes into the images
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             bf16_t* img = Qf + m * L::IMG;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(vec_s + 256 + m * 128 + hc + 4 * g);
 #pragma unroll
-            for (int mt = 0; mt < NT; ++mt) {
-                f32x4 acc = *reinterpret_cast<const f32x4*>(vec_s + 256 + m * 128 + hc + 4 * g);
+            for (int mt = 0; mt < MTT; ++mt) {
+                f32x4 acc = bias;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
                     acc = mfma16(wq[m][ks], *reinterpret_cast<const bf16x8*>(Uf + (mt * 16 + c16) * FS + ks * 32 + g * 8), acc);
@@ -937,103 +961,116 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // own writes before own reads (only this wave touches these columns)
-        // ---- attention of this head (as attn128_fwd_kernel), O into its own image
-        for (int qt = 0; qt < NT; ++qt) {
-            if (qt * 16 >= p.Ts) break;
-            const int query = qt * 16 + c16;
-            const int qcls = cls[query];
-            const bf16x4 bqf = *reinterpret_cast<const bf16x4*>(Qf + query * FS + hc + 4 * g);
-            f32x4 sv[NT];
-            float m = -INFINITY;
+        // ---- attention of this head (as attn128_fwd_kernel) slot by slot, O into its own image
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-                const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (kt * 16 + c16) * FS + hc + 4 * g);
-                sv[kt] = mfma_k16(ak, bqf, z4);
-                const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
-                const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
+        for (int slot = 0; slot < SPW; ++slot) {
+            const int r0 = slot * ROWS;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
-                    sv[kt][r] = ok ? sv[kt][r] * sc : -INFINITY;
-                    m = fmaxf(m, sv[kt][r]);
+            for (int qt = 0; qt < NT; ++qt) {
+                if (qt * 16 >= p.Ts) break;
+                const int query = r0 + qt * 16 + c16;
+                const int qcls = cls[query];
+                const bf16x4 bqf = *reinterpret_cast<const bf16x4*>(Qf + query * FS + hc + 4 * g);
+                f32x4 sv[NT];
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (r0 + kt * 16 + c16) * FS + hc + 4 * g);
+                    sv[kt] = mfma_k16(ak, bqf, z4);
+                    const int4 kc = *reinterpret_cast<const int4*>(cls + r0 + kt * 16 + g * 4);
+                    const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
+                        sv[kt][r] = ok ? sv[kt][r] * sc : -INFINITY;
+                        m = fmaxf(m, sv[kt][r]);
+                    }
                 }
+                m = group_max(m);
+                if (m == -INFINITY) m = 0.f;
+                float lsum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(sv[kt][r] - m);
+                        sv[kt][r] = e;
+                        lsum += e;
+                    }
+                lsum = group_sum(lsum);
+                const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+                f32x4 o = z4;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+                    o = mfma_k16(tr4(Vf + (r0 + kt * 16 + 4 * g + q4) * FS + hc + 4 * p4), cvt4(sv[kt]), o);
+                bf16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
+                *reinterpret_cast<bf16x4*>(Of + query * FS + hc + 4 * g) = ov;
+                if (g == 0) lse_s[query * 8 + head] = m + __builtin_amdgcn_logf(fmaxf(lsum, 1e-30f));
             }
-            m = group_max(m);
-            if (m == -INFINITY) m = 0.f;
-            float lsum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(sv[kt][r] - m);
-                    sv[kt][r] = e;
-                    lsum += e;
-                }
-            lsum = group_sum(lsum);
-            const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
-            f32x4 o = z4;
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt)
-                o = mfma_k16(tr4(Vf + (kt * 16 + 4 * g + q4) * FS + hc + 4 * p4), cvt4(sv[kt]), o);
-            bf16x4 ov;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
-            *reinterpret_cast<bf16x4*>(Of + query * FS + hc + 4 * g) = ov;
-            if (g == 0) lse_s[query * 8 + head] = m + __builtin_amdgcn_logf(fmaxf(lsum, 1e-30f));
         }
         lds_barrier();
-        // ---- residual pieces of this wave's output tile (L2-hot: the LayerNorm read the same rows)
-        f32x4 xr[NT];
+        // ---- residual pieces of this wave's output tiles (L2-hot: the LayerNorm read the same rows)
+        f32x4 xr[MTT];
+        int64_t orow[MTT];
 #pragma unroll
-        for (int mt = 0; mt < NT; ++mt) {
-            const int row = mt * 16 + c16;
-            xr[mt] = row < p.Ts ? *reinterpret_cast<const f32x4*>(p.x + (row_base + row) * 128 + hc + 4 * g) : z4;
+        for (int mt = 0; mt < MTT; ++mt) {
+            orow[mt] = grow(mt * 16 + c16);
+            xr[mt] = orow[mt] >= 0 ? *reinterpret_cast<const f32x4*>(p.x + orow[mt] * 128 + hc + 4 * g) : z4;
         }
         // ---- saved activations leave as whole rows: q|k|v (48 pieces per row), o, lse
-        for (int idx = threadIdx.x; idx < p.Ts * 48; idx += 512) {
-            const int row = idx / 48, pc = idx - row * 48;
-            *reinterpret_cast<bf16x8*>(p.qkv + (row_base + row) * 384 + pc * 8) =
-                *reinterpret_cast<const bf16x8*>(Qf + (pc >> 4) * L::IMG + row * FS + (pc & 15) * 8);
+        for (int idx = threadIdx.x; idx < RT * 48; idx += 512) {
+            const int irow = idx / 48, pc = idx - irow * 48;
+            const int64_t gr = grow(irow);
+            if (gr >= 0)
+                *reinterpret_cast<bf16x8*>(p.qkv + gr * 384 + pc * 8) =
+                    *reinterpret_cast<const bf16x8*>(Qf + (pc >> 4) * L::IMG + irow * FS + (pc & 15) * 8);
         }
-        for (int idx = threadIdx.x; idx < p.Ts * 16; idx += 512) {
-            const int row = idx >> 4, pc = idx & 15;
-            *reinterpret_cast<bf16x8*>(p.o + (row_base + row) * 128 + pc * 8) = *reinterpret_cast<const bf16x8*>(Of + row * FS + pc * 8);
+        for (int idx = threadIdx.x; idx < RT * 16; idx += 512) {
+            const int irow = idx >> 4, pc = idx & 15;
+            const int64_t gr = grow(irow);
+            if (gr >= 0) *reinterpret_cast<bf16x8*>(p.o + gr * 128 + pc * 8) = *reinterpret_cast<const bf16x8*>(Of + irow * FS + pc * 8);
         }
-        for (int idx = threadIdx.x; idx < p.Ts * 2; idx += 512)
-            *reinterpret_cast<float4*>(p.lse + row_base * 8 + idx * 4) = *reinterpret_cast<const float4*>(lse_s + idx * 4);
+        for (int idx = threadIdx.x; idx < RT * 2; idx += 512) {
+            const int irow = idx >> 1;
+            const int64_t gr = grow(irow);
+            if (gr >= 0) *reinterpret_cast<float4*>(p.lse + gr * 8 + (idx & 1) * 4) = *reinterpret_cast<const float4*>(lse_s + idx * 4);
+        }
         // ---- projection: this wave's 16 output columns; transposed accumulators -> x1 leaves as 16-byte pieces
         //      (rows c16, columns hc + 4 g ..: two heads complete a 128-byte line)
+        const f32x4 pbias = *reinterpret_cast<const f32x4*>(vec_s + 640 + hc + 4 * g);
 #pragma unroll
-        for (int mt = 0; mt < NT; ++mt) {
-            f32x4 pa = *reinterpret_cast<const f32x4*>(vec_s + 640 + hc + 4 * g);
+        for (int mt = 0; mt < MTT; ++mt) {
+            f32x4 pa = pbias;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 pa = mfma16(wpj[ks], *reinterpret_cast<const bf16x8*>(Of + (mt * 16 + c16) * FS + ks * 32 + g * 8), pa);
-            const int row = mt * 16 + c16;
-            if (row < p.Ts) {
-                const float rs = p.rowscale ? p.rowscale[row_base + row] : 1.f;   // DropPath: x + scale * attn(x)
+            if (orow[mt] >= 0) {
+                const float rs = p.rowscale ? p.rowscale[orow[mt]] : 1.f;        // DropPath: x + scale * attn(x)
                 f32x4 ov;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ov[r] = fmaf(pa[r], rs, xr[mt][r]);
-                *reinterpret_cast<f32x4*>(p.x1 + (row_base + row) * 128 + hc + 4 * g) = ov;
+                *reinterpret_cast<f32x4*>(p.x1 + orow[mt] * 128 + hc + 4 * g) = ov;
             }
         }
-        // no barrier here: the next sample's LayerNorm writes only U (its readers passed the barrier above), and its
+        // no barrier here: the next group's LayerNorm writes only U (its readers passed the barrier above), and its
         // q|k|v image writes come after its own first barrier, which every wave reaches after the row stores above
     }
 }
 
-template <int NT>
+template <int NT, int SPW>
 int launch_blk128(const Blk128Args& a, hipStream_t s) {
-    using L = LayB<NT>;
+    using L = LayB<NT, SPW>;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk128_fwd_kernel<NT>),
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk128_fwd_kernel<NT, SPW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::TOTAL); attr_set = true; }
     // persistent, one 8-wave workgroup per CU: the weights (64 registers) + the attention state need ~156 registers;
     // forced to 128 (two workgroups per CU) the kernel spills 24-68 of them and is 20 % slower.  HSIMAE_BLK128_WGS overrides.
     static int wgs = 0;
     if (!wgs) { const char* e = getenv("HSIMAE_BLK128_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 1) wgs = 256; }
-    hipLaunchKernelGGL((blk128_fwd_kernel<NT>), dim3(a.nsamples < wgs ? a.nsamples : wgs), dim3(512), (size_t)L::TOTAL, s, a);
+    const int groups = (a.nsamples + SPW - 1) / SPW;
+    hipLaunchKernelGGL((blk128_fwd_kernel<NT, SPW>), dim3(groups < wgs ? groups : wgs), dim3(512), (size_t)L::TOTAL, s, a);
     return (int)hipGetLastError();
 }
 
@@ -1159,5 +1196,8 @@ int hs_attn_block_fwd(const float* x, const float* n1w, const float* n1b, const 
     Blk128Args a;
     a.x = x; a.n1w = n1w; a.n1b = n1b; a.wqkv = wqkv; a.bqkv = bqkv; a.wp = wp; a.pb = pb; a.u = u; a.qkv = qkv; a.o = o;
     a.lse = lse; a.x1 = x1; a.rowscale = rowscale; a.Ts = Ts; a.nsamples = nsamples; a.mode = mode; a.len_l = len_l;
-    return Ts <= 16 ? launch_blk128<1>(a, s) : launch_blk128<2>(a, s);
+    static int spw = 0;                       // samples in hand per iteration (HSIMAE_BLK128_SPW = 1 | 2; 3 measured 0.5 % slower than 2)
+    if (!spw) { const char* e = getenv("HSIMAE_BLK128_SPW"); spw = (e && e[0] == '1') ? 1 : 2; }
+    if (spw == 1) return Ts <= 16 ? launch_blk128<1, 1>(a, s) : launch_blk128<2, 1>(a, s);
+    return Ts <= 16 ? launch_blk128<1, 2>(a, s) : launch_blk128<2, 2>(a, s);
 }
