@@ -611,6 +611,33 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
 int hsimae_forward(const hsimae_config* cfg, const hsimae_io* io, void* stream) { return forward_impl(cfg, io, stream, false); }
 int hsimae_encode(const hsimae_config* cfg, const hsimae_io* io, void* stream) { return forward_impl(cfg, io, stream, true); }
 
+int hsimae_decode(const hsimae_config* cfg, const hsimae_io* io, const float* latent, float* pred, void* stream) {
+    Ctx c; CK(make_ctx(cfg, io, c, true));
+    if (!latent || !pred || !io->ids_restore) return HSIMAE_ENULL;
+    hipStream_t s = S(stream);
+    const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w;
+    GemmParams p = gp();                      // decoder_embed (Models.py:579)
+    p.A = latent; p.lda = g.D; p.M = (int)c.Me; p.N = g.Dd; p.K = g.D; p.n_valid = g.Dd; p.W = io->wpk + c.W.de; p.bias = P + c.L.deb;
+    p.out = w.y; p.ldo = g.Dd;
+    CK(hs_gemm(p, A_F32, E_F32, s));
+    AssembleParams as; std::memset(&as, 0, sizeof(as));
+    as.y = w.y; as.N = c.N; as.K = c.K; as.TL = g.TL; as.Dd = g.Dd; as.ids_restore = io->ids_restore; as.pos = P + c.L.dpos;
+    as.yfull = w.yfull;
+    CK(hs_assemble_fwd(as, s));
+    const float* z = w.yfull;
+    const bool fdec = fused_dec_enabled(g);
+    for (int i = 0; i < g.ddepth; ++i) {
+        BlkP bp = resolve(c.L.bd[i], c.W.bd[i], P, io->wpk, c.W);
+        if (fdec) CK(hs_dec_block_fwd(z, w.bd[i].x1, w.bd[i].x2, w.bd[i].o, w.bd[i].lse, c.N, g.TL, dec_ptrs(bp, g.hdec), s));
+        else CK(block_fwd(bp, z, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, nullptr, s));
+        z = w.bd[i].x2;
+    }
+    p = gp();                                 // decoder_norm + decoder_pred (Models.py:597-600)
+    p.A = z; p.lda = g.Dd; p.M = (int)c.Md; p.N = 80; p.K = g.Dd; p.n_valid = 72; p.W = io->wpk + c.W.dp; p.bias = P + c.L.dpb;
+    p.gamma = P + c.L.dnw; p.beta = P + c.L.dnb; p.u_out = w.zn; p.ldu = g.Dd; p.out = pred; p.ldo = 72;
+    return hs_gemm(p, A_F32_LN, E_F32, s);
+}
+
 // Backward of the encoder stacks + patch embedding, from d(x of the last encoder block) in w.G0.  Shared by
 // hsimae_backward (after the decoder) and hsimae_encode_backward (after `norm`).
 static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hipStream_t s, int stage, hsimae_bucket_cb cb,

@@ -168,6 +168,7 @@ class HSIMAE(nn.Module):
         self._reducer = None
         self.want_recons = True
         self.len_t = self.len_l = None
+        self._last_imgs = None
         print("model initialized")
 
     # ------------------------------------------------------------------ init (reference Models.py:429-459)
@@ -343,6 +344,7 @@ class HSIMAE(nn.Module):
         K, TL = self.len_t * self.len_l, T * L
         self.patch_embed.output_size = torch.Size([N, T, L, self.dim])
         self.patch_info = (N, imgs.shape[2], 9, 9, 3, 8, T, 3, 3)
+        self._last_imgs = imgs
 
         nbytes = lib.hsimae_workspace_bytes(C.byref(cfg), N, self.len_t, self.len_l)
         if nbytes < 0:
@@ -413,16 +415,76 @@ class HSIMAE(nn.Module):
         return loss, pred, mask
 
     def forward_encoder(self, x, mask_ratio, noise=None, grid=None):
-        """-> (latent [N,K,D], mask [N,TL], ids_restore [N,TL] int64, ids_keep [N,K] int64); inference only."""
+        """-> (latent [N,K,D], mask [N,TL], ids_restore [N,TL] int64, ids_keep [N,K] int64); inference only
+        (Models.py:537-571)."""
         with torch.no_grad():
-            _, _, _, st = self._run_forward(x, mask_ratio, noise, grid, want_latent=True)
+            _, _, _, st = self._run_forward(x, mask_ratio, noise, grid, want_latent=True, encoder_only=True)
         return st["latent"], st["mask"], st["ids_restore"].long(), st["ids_keep"].long()
 
     def forward_decoder(self, x, ids_restore):
-        raise NotImplementedError("stand-alone forward_decoder is not part of the pretraining hot path; use forward()")
+        """latent [N,K,D] + ids_restore [N,TL] -> pred [N,TL,72]; inference only (Models.py:573-601).  K must be the
+        len_t * len_l of the last `forward_encoder` / `forward` call (the kept tokens form that grid)."""
+        if not x.is_cuda:
+            raise RuntimeError("hsimae_amd.HSIMAE runs on MI355X only (no CPU fallback)")
+        N, K, D = x.shape
+        T, L = self.input_size[0], self.input_size[1] ** 2
+        if self.len_t is None or self.len_t * self.len_l != K or D != self.dim or ids_restore.shape != (N, T * L):
+            raise ValueError("forward_decoder: latent does not match the grid of the last encoder call")
+        dev = x.device
+        lib, cfg = _lib.load(), self._config()
+        self._ensure_flat(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        self._ensure_packed(stream)
+        nbytes = lib.hsimae_workspace_bytes(C.byref(cfg), N, self.len_t, self.len_l)
+        ws = self._workspace(nbytes + 256, dev)
+        lat = x.detach().to(torch.float32).contiguous()
+        ids = ids_restore.to(device=dev, dtype=torch.int32).contiguous()
+        pred = torch.empty(N, T * L, 72, dtype=torch.float32, device=dev)
+        io = _lib.IO(N=N, len_t=self.len_t, len_l=self.len_l, params=self._flat.data_ptr(), wpk=self._wpk.data_ptr(),
+                     workspace=(ws.data_ptr() + 255) // 256 * 256, workspace_bytes=nbytes, grad_scale=1.0,
+                     ids_restore=ids.data_ptr())
+        _lib.check(lib.hsimae_decode(C.byref(cfg), C.byref(io), lat.data_ptr(), pred.data_ptr(), stream), "hsimae_decode")
+        return pred
 
     def forward_loss(self, imgs, pred, mask):
-        raise NotImplementedError("stand-alone forward_loss is not part of the pretraining hot path; use forward()")
+        """Masked reconstruction loss of pred [N,TL,72] against the cube (Models.py:603-616); inference only.
+        Like the reference it leaves `mean` / `var` (per-token target statistics) for `recons`."""
+        if not imgs.is_cuda:
+            raise RuntimeError("hsimae_amd.HSIMAE runs on MI355X only (no CPU fallback)")
+        dev = imgs.device
+        lib = _lib.load()
+        imgs = imgs.float()
+        N, T = imgs.shape[0], self.input_size[0]
+        TL = T * self.input_size[1] ** 2
+        pr = pred.detach().to(torch.float32).reshape(N * TL, 72).contiguous()
+        mk = mask.detach().to(torch.float32).reshape(N, TL).contiguous()
+        sum_mask = float(mk.sum().item())
+        partial = torch.empty(lib.hsimae_loss_partials(N, T), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        p = _lib.LossParams(x=imgs.data_ptr(), sn=imgs.stride(0), sb=imgs.stride(2), sh=imgs.stride(3), sw=imgs.stride(4),
+                            N=N, T=T, pred=pr.data_ptr(), mask=mk.data_ptr(), norm_pix=int(bool(self.norm_pix_loss)),
+                            inv_scale=0.0, partial=partial.data_ptr(), loss=loss.data_ptr(), sum_mask=sum_mask)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.hsimae_loss(C.byref(p), stream), "hsimae_loss")
+        self._last_imgs = imgs
+        return loss
+
+    @property
+    def mean(self):
+        """Per-token target mean [N,TL,1] of the last cube batch (the reference stashes it in forward_loss, :609)."""
+        return self.patchify(self._last_imgs).mean(dim=-1, keepdim=True)
+
+    @property
+    def var(self):
+        """sqrt(var + 1e-6) [N,TL,1] of the last cube batch — the reference's `self.var` is the std (:610)."""
+        return (self.patchify(self._last_imgs).var(dim=-1, keepdim=True) + 1.0e-6) ** 0.5
+
+    def recons(self, mask, pred):
+        """Models.py:618-625: token mask and (de-normalised) prediction as [N,1,B,9,9] images."""
+        mask = self.unpatchify(mask.unsqueeze(2).repeat(1, 1, pred.shape[2]))
+        if self.norm_pix_loss:
+            pred = pred * self.var + self.mean
+        return mask, self.unpatchify(pred)
 
     # ------------------------------------------------------------------ data parallel (not in the reference)
     def enable_data_parallel(self, process_group=None, bucket_bytes=4 << 20, broadcast=True):

@@ -322,6 +322,42 @@ def test_fused_encoder_mlp_matches_layerwise(bands, grid, N):
     print(f"[fused-mlp {bands}] worst grad rms-rel vs layerwise {worst}")
 
 
+@pytest.mark.parametrize("bands,grid", [(48, (2, 7)), (96, (9, 3))])
+def test_public_sub_entry_points_against_oracle(bands, grid):
+    """The module's public sub-entry points: forward_encoder -> forward_decoder -> forward_loss -> recons chained
+    by hand reproduce the oracle's latent / pred / loss / images, and `mean` / `var` are the target statistics the
+    reference stashes (Models.py:537-625)."""
+    cfg = O.OracleConfig(bands=bands)
+    state = O.init_state(cfg, seed=5, std=0.05)
+    m = build(cfg, state).eval()
+    N = 12
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(N, 1, bands, 9, 9, generator=g)
+    n1, n2 = torch.rand(N, bands // 8, generator=g), torch.rand(N, 9, generator=g)
+    taps = {}
+    ref_loss, ref_pred_img, ref_mask_img = O.forward(state, cfg, x, n1.numpy(), n2.numpy(), *grid, taps)
+    xd = x.to(DEV)
+    latent, mask, ids_restore, ids_keep = m.forward_encoder(xd, 0.75, noise=(n1, n2), grid=grid)
+    assert torch.equal(ids_keep.cpu(), taps["ids_keep"]) and torch.equal(ids_restore.cpu(), taps["ids_restore"])
+    assert torch.equal(mask.cpu(), taps["mask"]) and ids_restore.dtype == torch.int64
+    assert rms_rel(latent, taps["latent"]) < 5e-3
+    pred = m.forward_decoder(latent, ids_restore)
+    assert pred.shape == taps["pred"].shape and rms_rel(pred, taps["pred"]) < 1e-2
+    loss = m.forward_loss(xd, pred, mask)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-4 * ref_loss.item()
+    # the loss kernel alone on the oracle's own prediction: fp32 arithmetic only
+    loss2 = m.forward_loss(xd, taps["pred"].to(DEV), mask)
+    assert abs(loss2.item() - ref_loss.item()) <= 2e-6 * ref_loss.item()
+    tgt = O.patchify(x, cfg)
+    assert float((m.mean.cpu() - tgt.mean(-1, keepdim=True)).abs().max()) < 1e-6
+    assert float((m.var.cpu() - (tgt.var(-1, keepdim=True) + 1e-6) ** 0.5).abs().max()) < 1e-6
+    mask_img, pred_img = m.recons(mask, pred)
+    assert torch.equal(mask_img.cpu(), ref_mask_img)
+    assert rms_rel(pred_img, ref_pred_img) < 1e-2
+    with pytest.raises(ValueError):
+        m.forward_decoder(latent[:, :-1], ids_restore)
+
+
 @pytest.mark.parametrize("bands,grid,N", [(48, (2, 7), 37), (96, (3, 9), 24), (96, (9, 3), 24)])
 def test_fused_attention_half_matches_separate_kernels(bands, grid, N):
     """blk128_fwd_kernel (LN1 -> q|k|v -> attention -> projection + residual in one persistent launch) against
