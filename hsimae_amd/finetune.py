@@ -71,6 +71,10 @@ class DualViT(HSIMAE):
             _, _, _, st = self._run_forward(x, 0.0, (n1, n2), (T, L), want_latent=True, encoder_only=True)
         return st["latent"]
 
+    def forward_mask_encoder(self, x, mask_ratio, noise=None, grid=None):
+        """DualViT's name for the masked encoder (Models.py:896-921) = HSIMAE.forward_encoder; inference only."""
+        return HSIMAE.forward_encoder(self, x, mask_ratio, noise, grid)
+
     def _packed_head(self, dev):
         w = self.cls_head.weight
         key = (w._version, self.cls_head.bias._version, dev)
