@@ -322,6 +322,27 @@ def test_fused_encoder_mlp_matches_layerwise(bands, grid, N):
     print(f"[fused-mlp {bands}] worst grad rms-rel vs layerwise {worst}")
 
 
+@pytest.mark.parametrize("N", [1, 3, 5])
+def test_tiny_and_odd_batches_against_oracle(N):
+    """Batches smaller than any kernel's panel / sample group (one workgroup mostly padding, a last group with one sample):
+    loss, mask and a deep weight gradient against the oracle at Base width."""
+    cfg = O.OracleConfig(bands=96)
+    state = O.init_state(cfg, seed=2, std=0.04)
+    m = build(cfg, state)
+    g = torch.Generator().manual_seed(N)
+    x = torch.rand(N, 1, 96, 9, 9, generator=g)
+    n1, n2 = torch.rand(N, 12, generator=g), torch.rand(N, 9, generator=g)
+    ref_loss, _, ref_mask, ref_g = O.forward_backward(state, cfg, x, n1.numpy(), n2.numpy(), 3, 9)
+    loss, _, mask = m(x.to(DEV), 0.75, noise=(n1, n2), grid=(3, 9))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(mask.cpu(), ref_mask)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-4 * ref_loss.item()
+    named = dict(m.named_parameters())
+    for k in ("blocks_1.3.mlp.w1.weight", "blocks_2.0.attn.q.weight", "decoder_blocks.2.mlp.w2.weight", "patch_embed.proj.weight"):
+        assert grad_err(named, ref_g, k) < 2e-2, k
+
+
 @pytest.mark.parametrize("bands,grid", [(48, (2, 7)), (96, (9, 3))])
 def test_public_sub_entry_points_against_oracle(bands, grid):
     """The module's public sub-entry points: forward_encoder -> forward_decoder -> forward_loss -> recons chained
