@@ -197,7 +197,7 @@ void carve(const Geo& g, int N, int K, char* base, Ws& w) {
     w.sc2.G1 = (float*)take(Me * g.D * 4); w.sc2.du = (float*)take(Me * g.D * 4);
     w.sc2.dh13 = (hs_bf16*)take(Me * 2 * g.hp * 2); w.sc2.dob = (hs_bf16*)take(Me * g.D * 2);
     w.sc2.dqkv = (hs_bf16*)take(Me * g.D * 3 * 2);
-    w.sc.g0b = (hs_bf16*)take(Me * g.D * 2); w.sc.g1b = (hs_bf16*)take(Me * g.D * 2);
+    w.sc.g0b = (hs_bf16*)take(gmax * 2); w.sc.g1b = (hs_bf16*)take(gmax * 2);     // (also decoder rows on the layer-at-a-time path)
     w.sc2.g0b = (hs_bf16*)take(Me * g.D * 2); w.sc2.g1b = (hs_bf16*)take(Me * g.D * 2);
     w.bytes = cur;
 }
@@ -353,6 +353,10 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         l.du = w.du; l.x = b.x1; l.gamma = P.n2w; l.dres = G0; l.dx = G1; l.accumulate = 0;
         l.dgamma = grads + o.n2w; l.dbeta = grads + o.n2b;
         CK(hs_ln_bwd(l, s));
+        // bf16 copies of dY / dx1 (with the DropPath factors folded in) so that the weight gradients below take the
+        // LDS-DMA kernel: 666 -> ~300 us per block at D = 256
+        CK(hs_rows_to_bf16(G0, w.g0b, M, d, rs_m, s));
+        CK(hs_rows_to_bf16(G1, w.g1b, M, d, rs_a, s));
     }
     AttnParams a; std::memset(&a, 0, sizeof(a));
     a.qkv = b.qkv; a.ld = 3 * d; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
@@ -363,10 +367,9 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         a.dout = w.g1b; a.projT_w = P.pT;
     } else {
         p = gp();
-        p.A = fmlp ? (const void*)w.g1b : (const void*)G1; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d;
+        p.A = w.g1b; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d;      // (the bf16 copy carries the DropPath factor)
         p.W = P.pT; p.out = w.dob; p.ldo = d;
-        if (!fmlp) p.a_rowscale = rs_a;       // (the bf16 copy from enc_mlp_bwd already carries the factor)
-        CK(hs_gemm(p, fmlp ? A_BF16 : A_F32, E_BF16, s));
+        CK(hs_gemm(p, A_BF16, E_BF16, s));
     }
     CK(hs_attn_bwd(a, s));
     // Weight gradients first: the LayerNorm-backward GEMM below writes dx over G0 / G1 when the caller runs in place
@@ -380,12 +383,10 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     task(w.dqkv, 0, 3 * d, b.u, d, d, d, o.qw, o.qb);
     task(w.dqkv + d, 0, 3 * d, b.u, d, d, d, o.kw, o.kb);
     task(w.dqkv + 2 * d, 0, 3 * d, b.u, d, d, d, o.vw, o.vb);
-    if (fmlp) task(w.g1b, 0, d, b.o, d, d, d, o.pw, o.pb);      // all-bf16 operands: wgrad takes its LDS-DMA path
-    else task(G1, 1, d, b.o, d, d, d, o.pw, o.pb, rs_a);
+    task(w.g1b, 0, d, b.o, d, d, d, o.pw, o.pb);                // all-bf16 operands: wgrad takes its LDS-DMA path
     task(w.dh13, 0, 2 * hp, b.u2, d, h, d, o.w1w, o.w1b);
     task(w.dh13 + hp, 0, 2 * hp, b.u2, d, h, d, o.w3w, o.w3b);
-    if (fmlp) task(w.g0b, 0, d, b.g, hp, d, h, o.w2w, o.w2b);
-    else task(G0, 1, d, b.g, hp, d, h, o.w2w, o.w2b, rs_m);
+    task(w.g0b, 0, d, b.g, hp, d, h, o.w2w, o.w2b);
     g.M = (int)M;
     int tiles = 0;
     for (int i = 0; i < g.ntasks; ++i) tiles += ((g.t[i].N + 127) / 128) * ((g.t[i].K + 127) / 128);

@@ -622,6 +622,31 @@ int hs_agg_pool(const float* latent, float* pooled, int N, int T, int L, int D, 
     return (int)hipGetLastError();
 }
 
+// fp32 rows -> bf16 copy (optionally times a per-row factor): the layer-at-a-time backward's dY / dx1 as operands of the
+// LDS-DMA weight-gradient kernel, which takes bf16 only (the register-staged fp32 path runs at half its bandwidth).
+__global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n8, int d8,
+                                                           const float* __restrict__ rowscale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float4 a = *reinterpret_cast<const float4*>(src + i * 8), b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
+        float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        if (rowscale) {
+            const float q = rowscale[i / d8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= q;
+        }
+        *reinterpret_cast<bf16x8*>(dst + i * 8) = cvt8(f);
+    }
+}
+
+int hs_rows_to_bf16(const float* src, hs_bf16* dst, int64_t rows, int d, const float* rowscale, hipStream_t s) {
+    if (rows <= 0) return HS_OK;
+    if (d % 8) return HS_EDIMS;
+    const int64_t n8 = rows * (d / 8);
+    const int grid = (int)std::min<int64_t>((n8 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(rows_to_bf16_kernel, dim3(grid), dim3(256), 0, s, src, dst, n8, d / 8, rowscale);
+    return (int)hipGetLastError();
+}
+
 int hs_loss_partials(int N, int T) {
     const int64_t M = (int64_t)N * T * 9;
     return (int)std::max<int64_t>((M + LOSS_ROWS_PER_WG - 1) / LOSS_ROWS_PER_WG, N);     // either kernel form of hs_loss
