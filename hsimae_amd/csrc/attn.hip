@@ -15,6 +15,13 @@
 #include "kernels.h"
 #include <cstdlib>
 
+#ifndef HS_NT_C
+#define HS_NT_C 1      /* u / q|k|v / o saved by blk128_fwd for the backward: read ~10 ms later (step -0.5 %) */
+#endif
+#ifndef HS_NT_E
+#define HS_NT_E 0      /* dqkv of attn128_bwd */
+#endif
+
 namespace {
 
 template <int HD>
@@ -822,8 +829,8 @@ __global__ __launch_bounds__(512) void attn128_bwd_kernel(AttnParams p) {
     lds_barrier();
     for (int idx = threadIdx.x; idx < p.Ts * 48; idx += 512) {
         const int row = idx / 48, pc = idx - row * 48;
-        *reinterpret_cast<bf16x8*>(p.dqkv + (row_base + row) * p.ld + pc * 8) =
-            *reinterpret_cast<const bf16x8*>(Qf + (pc >> 4) * L::IMG + row * FS + (pc & 15) * 8);
+        HS_NT(HS_NT_E, reinterpret_cast<bf16x8*>(p.dqkv + (row_base + row) * p.ld + pc * 8),
+              *reinterpret_cast<const bf16x8*>(Qf + (pc >> 4) * L::IMG + row * FS + (pc & 15) * 8));
     }
 }
 
@@ -941,7 +948,7 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
                 const int64_t gr = grow(irow);
                 const bf16x8 ub = gr >= 0 ? cvt8(f) : zero8();
                 *reinterpret_cast<bf16x8*>(Uf + irow * FS + lc8) = ub;
-                if (gr >= 0) *reinterpret_cast<bf16x8*>(p.u + gr * 128 + lc8) = ub;
+                if (gr >= 0) HS_NT(HS_NT_C, reinterpret_cast<bf16x8*>(p.u + gr * 128 + lc8), ub);
             }
         }
         fetch(first + gridDim.x * SPW);                           // next group's rows fly during this one
@@ -1024,13 +1031,13 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
             const int irow = idx / 48, pc = idx - irow * 48;
             const int64_t gr = grow(irow);
             if (gr >= 0)
-                *reinterpret_cast<bf16x8*>(p.qkv + gr * 384 + pc * 8) =
-                    *reinterpret_cast<const bf16x8*>(Qf + (pc >> 4) * L::IMG + irow * FS + (pc & 15) * 8);
+                HS_NT(HS_NT_C, reinterpret_cast<bf16x8*>(p.qkv + gr * 384 + pc * 8),
+                      *reinterpret_cast<const bf16x8*>(Qf + (pc >> 4) * L::IMG + irow * FS + (pc & 15) * 8));
         }
         for (int idx = threadIdx.x; idx < RT * 16; idx += 512) {
             const int irow = idx >> 4, pc = idx & 15;
             const int64_t gr = grow(irow);
-            if (gr >= 0) *reinterpret_cast<bf16x8*>(p.o + gr * 128 + pc * 8) = *reinterpret_cast<const bf16x8*>(Of + irow * FS + pc * 8);
+            if (gr >= 0) HS_NT(HS_NT_C, reinterpret_cast<bf16x8*>(p.o + gr * 128 + pc * 8), *reinterpret_cast<const bf16x8*>(Of + irow * FS + pc * 8));
         }
         for (int idx = threadIdx.x; idx < RT * 2; idx += 512) {
             const int irow = idx >> 1;

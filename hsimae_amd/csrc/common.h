@@ -79,3 +79,8 @@ __host__ __device__ inline int64_t wpk_elems(int N, int K) {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Streaming stores (write-once tensors that are read much later, by another kernel): `nt` stores do not allocate in
+// L2 / Infinity Cache, which keeps the lines the next kernels re-read resident.  HS_NT(enabled, ptr, value).
+#define HS_NT(on, ptr, val) do { if constexpr (on) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
+

@@ -463,14 +463,17 @@ __global__ __launch_bounds__(LSN) void loss_sample_kernel(LossParams p) {
         float4* po = reinterpret_cast<float4*>(p.pred_img + (size_t)n * E);
         float4* mo = reinterpret_cast<float4*>(p.mask_img + (size_t)n * E);
         for (int e4 = threadIdx.x; e4 < E / 4; e4 += LSN) {
-            po[e4] = reinterpret_cast<const float4*>(P)[e4];
+            {                                       // the two images are outputs nobody on the GPU reads back: streaming stores
+                const float4 pv = reinterpret_cast<const float4*>(P)[e4];
+                __builtin_nontemporal_store((f32x4{pv.x, pv.y, pv.z, pv.w}), reinterpret_cast<f32x4*>(po) + e4);
+            }
             float m[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int e = e4 * 4 + k, b = e / 81, ij = e - b * 81;
                 m[k] = MK[(b >> 3) * 9 + (ij / 27) * 3 + (ij % 9) / 3];
             }
-            mo[e4] = make_float4(m[0], m[1], m[2], m[3]);
+            __builtin_nontemporal_store((f32x4{m[0], m[1], m[2], m[3]}), reinterpret_cast<f32x4*>(mo) + e4);
         }
     }
 }

@@ -32,6 +32,9 @@ extern "C" int hsimae_debug_phases(unsigned long long* out, int reset) {
 #define PH_FLUSH(base)
 #endif
 
+#ifndef HS_NT_D
+#define HS_NT_D 1      /* x1 / o saved by the decoder forward for the backward as streaming stores (step -0.5 %) */
+#endif
 /* next-sample L2 / TLB warm-up loads in the persistent decoder kernels (forward / MLP backward / attention backward) */
 #ifndef HS_TOUCH_F
 #define HS_TOUCH_F 0
@@ -229,8 +232,8 @@ __device__ __forceinline__ void ln_rows(const float* src, int Ts, const float* g
                 const float4 b = *reinterpret_cast<const float4*>(XS + row * LX + c8 + 4);
                 f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
                 if (copy_out && row < Ts) {
-                    *reinterpret_cast<float4*>(copy_out + (size_t)row * D + c8) = a;
-                    *reinterpret_cast<float4*>(copy_out + (size_t)row * D + c8 + 4) = b;
+                    HS_NT(HS_NT_D, reinterpret_cast<f32x4*>(copy_out + (size_t)row * D + c8), (f32x4{a.x, a.y, a.z, a.w}));   // x1: read again only by the backward
+                    HS_NT(HS_NT_D, reinterpret_cast<f32x4*>(copy_out + (size_t)row * D + c8 + 4), (f32x4{b.x, b.y, b.z, b.w}));
                 }
             } else {
                 const float4 a = ga[i], b = gb[i];
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
         // attention output kept for the backward (dWp operand; saves it the softmax recompute), 16-B row pieces
         for (int pc = threadIdx.x; pc < L::R * 8; pc += 256) {
             const int row = pc >> 3, k8 = (pc & 7) * 8;
-            if (row < p.Ts) *reinterpret_cast<bf16x8*>(p.o + (rb + row) * D + k8) = *reinterpret_cast<const bf16x8*>(U + row * LU + k8);
+            if (row < p.Ts) HS_NT(HS_NT_D, reinterpret_cast<bf16x8*>(p.o + (rb + row) * D + k8), *reinterpret_cast<const bf16x8*>(U + row * LU + k8));
         }
         // proj accumulates onto the residual (transposed accumulators: see mm_f)
 #pragma unroll

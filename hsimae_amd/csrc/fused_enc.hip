@@ -27,6 +27,13 @@ extern "C" int hsimae_debug_phases_enc(unsigned long long* out, int reset) {
 #define PH_FLUSH(base)
 #endif
 
+#ifndef HS_NT_A
+#define HS_NT_A 1      /* dh1|dh3 / g of enc_mlp_bwd as streaming stores: step -1.3 % */
+#endif
+#ifndef HS_NT_B
+#define HS_NT_B 0      /* u2 / dY copy / dx1 / dx1 copy */
+#endif
+
 namespace {
 
 constexpr int R = 48, MH = 2, NTH = 256;   // 48-row panels: three 4-wave workgroups per CU, 2304 = 3 x 768 workgroups at M = 110,592
@@ -352,8 +359,8 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
             const bf16x8 dyb8 = cvt8(dyv);
             *reinterpret_cast<bf16x8*>(DYb + row * LU + c8) = dyb8;
             if (ok) {
-                *reinterpret_cast<bf16x8*>(p.u2 + (size_t)(row0 + row) * D + c8) = ub;     // wgrad operands
-                *reinterpret_cast<bf16x8*>(p.dyb + (size_t)(row0 + row) * D + c8) = dyb8;
+                HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.u2 + (size_t)(row0 + row) * D + c8), ub);     // wgrad operands
+                HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.dyb + (size_t)(row0 + row) * D + c8), dyb8);
             }
         }
     }
@@ -420,9 +427,9 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
                 const int row = pc >> 3, k8 = (pc & 7) * 8;
                 if (row0 + row < p.M && k8 < ncol) {
                     const size_t gr = (size_t)(row0 + row);
-                    *reinterpret_cast<bf16x8*>(p.g + gr * HPE + c * 64 + k8) = *reinterpret_cast<const bf16x8*>(Gc + row * LC + k8);
-                    *reinterpret_cast<bf16x8*>(p.dh13 + gr * 2 * HPE + c * 64 + k8) = *reinterpret_cast<const bf16x8*>(DH1 + row * LC + k8);
-                    *reinterpret_cast<bf16x8*>(p.dh13 + gr * 2 * HPE + HPE + c * 64 + k8) = *reinterpret_cast<const bf16x8*>(DH3 + row * LC + k8);
+                    HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.g + gr * HPE + c * 64 + k8), *reinterpret_cast<const bf16x8*>(Gc + row * LC + k8));
+                    HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.dh13 + gr * 2 * HPE + c * 64 + k8), *reinterpret_cast<const bf16x8*>(DH1 + row * LC + k8));
+                    HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.dh13 + gr * 2 * HPE + HPE + c * 64 + k8), *reinterpret_cast<const bf16x8*>(DH3 + row * LC + k8));
                 }
             }
         }
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] *= rs;
                 }
-                *reinterpret_cast<bf16x8*>(p.dx1b + (size_t)(row0 + row) * D + c8) = cvt8(o);
+                HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.dx1b + (size_t)(row0 + row) * D + c8), cvt8(o));
             }
         }
     }

@@ -10,6 +10,10 @@
 #include "kernels.h"
 #include <cstdlib>
 
+#ifndef HS_NT_W
+#define HS_NT_W 0      /* cache policy of the LDS-DMA operand loads: 2 = nt (streaming) */
+#endif
+
 namespace {
 
 constexpr int MC = 64;            // rows per chunk (2 k-steps)
@@ -262,10 +266,10 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
         const uint32_t od = (uint32_t)c * DC * t.ldo * 2u, oa = (uint32_t)c * DC * t.lda * 2u;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_vptr)(st + (2 * wave + i) * 512), 16, vd[i], od, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_vptr)(st + (2 * wave + i) * 512), 16, vd[i], od, 0, HS_NT_W);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)(st + DC * 128 + (2 * wave + i) * 512), 16, va[i], oa, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)(st + DC * 128 + (2 * wave + i) * 512), 16, va[i], oa, 0, HS_NT_W);
     };
 
     f32x4 acc[2][8], accb[2];
