@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
                 for (int e = 0; e < 8; ++e) f[i][e] = (f[i][e] - mean) * rstd * g[e] + bt[e];
                 const bf16x8 val = cok ? cvt8(f[i]) : zero8();
                 if (cok && p.u_out && row0 + r < p.M)
-                    *reinterpret_cast<bf16x8*>(p.u_out + (size_t)(row0 + r) * p.ldu + c8) = val;
+                    HS_NT(true, reinterpret_cast<bf16x8*>(p.u_out + (size_t)(row0 + r) * p.ldu + c8), val);   // saved for the backward only
                 *reinterpret_cast<bf16x8*>(As + r * LDA + c8) = val;
             }
         }
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
                     val = cvt8(f);
                     if constexpr (AK == A_F32_LN) {
                         if (p.u_out && row0 + r < p.M)
-                            *reinterpret_cast<bf16x8*>(p.u_out + (size_t)(row0 + r) * p.ldu + kcol) = val;
+                            HS_NT(true, reinterpret_cast<bf16x8*>(p.u_out + (size_t)(row0 + r) * p.ldu + kcol), val);
                     }
                 }
             }
@@ -411,8 +411,8 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
 #pragma unroll
                     for (int e = 0; e < 8; ++e) if (e >= nv) { v[e] = 0.f; w[e] = 0.f; }
                     const bf16x8 h1 = cvt8(v), h3 = cvt8(w);
-                    *reinterpret_cast<bf16x8*>(p.h13 + (size_t)row * p.ldh + col) = h1;
-                    *reinterpret_cast<bf16x8*>(p.h13 + (size_t)row * p.ldh + p.hoff + col) = h3;
+                    HS_NT(true, reinterpret_cast<bf16x8*>(p.h13 + (size_t)row * p.ldh + col), h1);             // pre-activations: saved for the backward only
+                    HS_NT(true, reinterpret_cast<bf16x8*>(p.h13 + (size_t)row * p.ldh + p.hoff + col), h3);
                     float g[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
