@@ -51,7 +51,7 @@ struct MG {
     static constexpr int KSH = HP / 32;         // k-steps over the hidden width
     static constexpr int LPR = D / 8;           // lanes per row in the wide layout
     static constexpr int KA = KSH > 6 ? 6 : KSH, KB = KSH - KA;
-    static constexpr int LDS_FWD = R * LU * 2 + 2 * R * LC * 2;
+    static constexpr int LDS_FWD = R * LU * 2 + 2 * R * LC * 2 + R * LX * 4;
     static constexpr int LDS_BWD = 2 * R * LU * 2 + 3 * R * LC * 2;
     static_assert(R * LG * 2 >= R * LX * 4, "gate image region must hold the fp32 staging tile");
     static_assert(R * LU * 2 + 3 * R * LC * 2 >= R * LX * 4, "dY panel + chunk images must hold the fp32 staging tile");
@@ -150,6 +150,8 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Gc = U2 + R * LU;                           // two chunk images [64][LC]
     float* XS = reinterpret_cast<float*>(smem);         // fp32 store tile over U2 | Gc once the products are done
+    float* XR = reinterpret_cast<float*>(smem + R * LU * 2 + 2 * R * LC * 2);   // the panel's x1 in fp32: the residual (25 KB; a re-read from
+                                                                               // L2 missed: 57 MB of extra fetches per launch)
     static_assert(R * LU * 2 + 2 * R * LC * 2 >= R * LX * 4, "store tile must fit over the panel + chunk images");
     const G8 q = geo8();
     const int row0 = blockIdx.x * R;
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
         for (int i = 0; i < NI; ++i) {
             const int pc = threadIdx.x + NTH * i, row = pc / LPR;
             float (&f)[8] = fa[i];
+            st8(XR + row * LX + c8, f);
             const float mean = redrow<LPR>(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
             float v = 0.f;
 #pragma unroll
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
         if (row0 + row < p.M) {
             float f[8], t[8];
             ld8(XS + row * LX + c8, f);
-            ld8(p.x1 + (size_t)(row0 + row) * D + c8, t);              // residual: L2-hot re-read of the panel
+            ld8(XR + row * LX + c8, t);                                // residual from the panel's fp32 copy
             const float rs = p.rowscale ? p.rowscale[row0 + row] : 1.f;   // DropPath: x1 + scale * mlp(x1)
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], rs, t[e]);
