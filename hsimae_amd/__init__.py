@@ -8,7 +8,7 @@ from .optim import FusedAdamW  # noqa: F401
 from .data import HSIdataset4PT, DeviceLoader  # noqa: F401
 from .sched import CosineLRScheduler  # noqa: F401
 from .pretrain import mask_pretraining  # noqa: F401
-from .finetune import DualViT  # noqa: F401
+from .finetune import DualViT, HSIViT  # noqa: F401
 from .finetune_train import dual_branch_finetuning  # noqa: F401
 
 __version__ = "0.1.0"

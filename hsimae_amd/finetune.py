@@ -244,3 +244,48 @@ class DualViT(HSIMAE):
         if imgs_u is None:
             return out["class_pred"]
         return out["loss_rec"], out["pred_rec"], out["mask"], out["class_pred"]
+
+
+class HSIViT(DualViT):
+    """The encoder-only classifier the reference evaluates fine-tuned checkpoints with (`Models.HSIViT`, Models.py:996-1167;
+    `Model_Finetuning.test_model` :243-300): `forward(imgs) -> class logits`, 385-entry state_dict (encoder + `cls_head`),
+    loaded key-filtered from a DualViT checkpoint.  Inference only.  The kernels' parameter layout always has a decoder, so a
+    minimal one exists behind the scenes; it is not part of the module tree (state_dict / named_parameters do not list it).
+    (Its random initialisation differs from the reference's stream: the class exists to load checkpoints.)"""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4.0,
+                 norm_layer=nn.LayerNorm, bands=16, b_patch_size=4, num_class=100, no_qkv_bias=False, trunc_init=False,
+                 drop_rate=0., drop_path=0., s_depth=6, **kwargs):
+        super().__init__(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim, depth=depth,
+                         s_depth=s_depth, num_heads=num_heads, mlp_ratio=mlp_ratio, norm_layer=norm_layer, bands=bands,
+                         b_patch_size=b_patch_size, num_class=num_class, no_qkv_bias=no_qkv_bias, trunc_init=trunc_init,
+                         drop_path=drop_path, decoder_embed_dim=32, decoder_depth=1, decoder_num_heads=4, norm_pix_loss=False)
+        self._config()                                                  # cached while the decoder is still visible
+        full = [p for n, p in self.named_parameters() if not n.startswith("cls_head.")]
+        object.__setattr__(self, "_full_params", full)                  # flat-buffer order, decoder included
+        hidden = {}
+        for name in ("mask_token", "decoder_pos_embed"):
+            hidden[name] = self._parameters.pop(name)
+        for name in ("decoder_embed", "decoder_blocks", "decoder_norm", "decoder_pred"):
+            hidden[name] = self._modules.pop(name)
+        object.__setattr__(self, "_hidden_decoder", hidden)             # keeps them alive, outside the module tree
+
+    def _plist(self):
+        return self._full_params
+
+    def _apply(self, fn, *a, **k):                                       # .to(device) must move the hidden decoder too
+        out = super()._apply(fn, *a, **k)
+        for v in self._hidden_decoder.values():
+            if isinstance(v, nn.Module):
+                v._apply(fn)
+            else:
+                v.data = fn(v.data)
+        return out
+
+    def forward(self, imgs):
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("hsimae_amd.HSIViT is the evaluation model (inference only); fine-tune with DualViT")
+        with torch.no_grad():
+            latent = self.forward_encoder(imgs)
+            pred, _ = self.head(latent)
+        return pred

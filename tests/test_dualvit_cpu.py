@@ -130,3 +130,24 @@ def test_finetune_host_helpers_split_and_scores():
     assert abs(oa - metrics.accuracy_score(g, p)) < 1e-12
     assert abs(aa - np.mean(metrics.recall_score(g, p, average=None, labels=np.unique(g)))) < 1e-12
     assert abs(kappa - metrics.cohen_kappa_score(g, p)) < 1e-12
+
+
+def test_hsivit_mirror_state_dict_matches_reference_manifest():
+    """hsimae_amd.HSIViT (the evaluation model of Model_Finetuning.test_model) exposes the reference HSIViT's 385 keys /
+    shapes, and a DualViT state_dict loads into it key-filtered the way the reference does (:253-261)."""
+    import contextlib
+    import io
+    from hsimae_amd import DualViT, HSIViT
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["HSIViT_base32"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        v = HSIViT(img_size=9, patch_size=3, in_chans=1, bands=32, b_patch_size=8, num_class=16, embed_dim=128, depth=12,
+                   num_heads=8, s_depth=9, trunc_init=True)
+        d = DualViT(img_size=9, patch_size=3, in_chans=1, bands=32, b_patch_size=8, num_class=16, embed_dim=128, depth=12,
+                    num_heads=8, s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8, trunc_init=True)
+    sd = v.state_dict()
+    assert [(k, list(t.shape), str(t.dtype).replace("torch.", "")) for k, t in sd.items()] == [tuple(e) if False else (e[0], e[1], e[2]) for e in man]
+    assert [n for n, _ in v.named_parameters()] == [e[0] for e in man]
+    model_dict = v.state_dict()
+    model_dict.update({k: t for k, t in d.state_dict().items() if k in model_dict})
+    v.load_state_dict(model_dict)
+    assert torch.equal(v.blocks_1[3].mlp.w1.weight, d.blocks_1[3].mlp.w1.weight) and torch.equal(v.cls_head.bias, d.cls_head.bias)

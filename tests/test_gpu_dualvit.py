@@ -202,3 +202,32 @@ def test_dual_branch_finetuning_loop_learns_separable_classes(tmp_path):
     assert val_value[0] > 0.8
     sd = torch.load(os.path.join(str(tmp_path), "ft.pkl"), map_location="cpu")
     assert "cls_head.weight" in sd and "decoder_pred.bias" in sd and "blocks_1.0.attn.q.weight" in sd
+
+
+def test_hsivit_evaluates_a_dualvit_checkpoint():
+    """Model_Finetuning.test_model's flow (:243-300): the fine-tuned DualViT state_dict is loaded key-filtered into HSIViT
+    (encoder + head, 385 keys), whose logits must be DualViT's own eval logits — and the oracle's."""
+    from hsimae_amd import DualViT, HSIViT
+    cfg = O.OracleConfig(bands=96)
+    state = O.init_state(cfg, seed=4, std=0.02)
+    g = torch.Generator().manual_seed(8)
+    state["cls_head.weight"] = torch.randn(16, 128 * 12, generator=g) * 0.02
+    state["cls_head.bias"] = torch.randn(16, generator=g) * 0.05
+    kw = dict(img_size=9, patch_size=3, in_chans=1, bands=96, b_patch_size=8, num_class=16, embed_dim=128, depth=12, num_heads=8,
+              s_depth=9, trunc_init=True)
+    d = quiet(DualViT, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8, norm_pix_loss=True, **kw)
+    d.load_state_dict(state)
+    v = quiet(HSIViT, **kw)
+    model_dict = v.state_dict()
+    model_dict.update({k: t for k, t in d.state_dict().items() if k in model_dict})
+    assert len(model_dict) == 385
+    v.load_state_dict(model_dict)
+    d, v = d.cuda().eval(), v.cuda().eval()
+    x = torch.rand(24, 1, 96, 9, 9, generator=g)
+    ref_pred, _ = O.dualvit_classify(state, cfg, x)
+    pd, pv = d(x.cuda()).cpu(), v(x.cuda()).cpu()
+    assert torch.equal(pd, pv)
+    assert rms_rel(pv, ref_pred) < 1e-2
+    v.train()
+    with pytest.raises(NotImplementedError):
+        v(x.cuda())
