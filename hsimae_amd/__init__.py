@@ -9,6 +9,6 @@ from .data import HSIdataset4PT, DeviceLoader  # noqa: F401
 from .sched import CosineLRScheduler  # noqa: F401
 from .pretrain import mask_pretraining  # noqa: F401
 from .finetune import DualViT, HSIViT  # noqa: F401
-from .finetune_train import dual_branch_finetuning  # noqa: F401
+from .finetune_train import dual_branch_finetuning, test_model  # noqa: F401
 
 __version__ = "0.1.0"

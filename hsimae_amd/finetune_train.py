@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from .data import DeviceLoader
-from .finetune import DualViT
+from .finetune import DualViT, HSIViT
 from .optim import FusedAdamW
 from .pretrain import seed_everything
 from .sched import CosineLRScheduler
@@ -161,3 +161,29 @@ def dual_branch_finetuning(data_list, labeled_index, unlabeled_data, gt, save_di
 
     torch.save(model.state_dict(), os.path.join(save_dir, model_name))
     return val_value, epoch_loss_list, val_loss_list
+
+
+def test_model(data_cubes, test_gt, gt, save_dir, model_name, depth=12, dim=96, s_depth=6, device="cuda:0"):
+    """Model_Finetuning.test_model (:243-300): every cube of the scene through HSIViT loaded key-filtered from the
+    fine-tuned checkpoint, class = 1 + argmax over logits[:, 1:], scores on the labeled test pixels.
+    -> (oa, aa, kappa, per-class recall, prediction map shaped like `gt`).  The colour-map PNGs (:296-298) are not written."""
+    device = torch.device(device)
+    h, w, c = data_cubes[0].shape
+    n_class = int(np.max(gt) + 1)
+    model = HSIViT(img_size=h, patch_size=3, in_chans=1, bands=c, b_patch_size=8, num_class=n_class, embed_dim=dim, depth=depth,
+                   num_heads=dim // 16, s_depth=s_depth, sep_pos_embed=True, use_learnable_pos_emb=False).to(device)
+    model_dict = model.state_dict()
+    loaded = torch.load(os.path.join(save_dir, model_name), map_location=device)
+    model_dict.update({k: v for k, v in loaded.items() if k in model_dict})
+    model.load_state_dict(model_dict)
+    model.eval()
+    dataset = HSIdataset(data_cubes, device=device)
+    preds = []
+    with torch.no_grad():
+        for x in DeviceLoader(dataset, batch_size=256, shuffle=False):
+            preds.append(model(x)[:, 1:].argmax(1))
+    pred = (torch.cat(preds).cpu().numpy() + 1).reshape(np.asarray(gt).shape)
+    pred_all = pred.copy()
+    pred[np.asarray(gt) == 0] = 0
+    oa, aa, kappa, ca = scores(np.asarray(test_gt).reshape(-1), pred.reshape(-1))
+    return oa, aa, kappa, ca, pred_all

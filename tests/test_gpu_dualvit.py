@@ -202,6 +202,14 @@ def test_dual_branch_finetuning_loop_learns_separable_classes(tmp_path):
     assert val_value[0] > 0.8
     sd = torch.load(os.path.join(str(tmp_path), "ft.pkl"), map_location="cpu")
     assert "cls_head.weight" in sd and "decoder_pred.bias" in sd and "blocks_1.0.attn.q.weight" in sd
+    # Model_Finetuning.test_model on the saved checkpoint: HSIViT over fresh cubes of the same classes
+    from hsimae_amd import test_model
+    test_gt = np.tile(np.arange(1, classes + 1), 20).reshape(6, 10)
+    test_cubes = [cube(int(c)) for c in test_gt.reshape(-1)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        oa, aa, kappa, ca, pred_map = test_model(test_cubes, test_gt, test_gt, str(tmp_path), "ft.pkl", depth=4, dim=64, s_depth=2)
+    print(f"[test_model] OA/AA/kappa {oa:.3f}/{aa:.3f}/{kappa:.3f}")
+    assert pred_map.shape == test_gt.shape and oa > 0.8 and len(ca) == classes
 
 
 def test_hsivit_evaluates_a_dualvit_checkpoint():
