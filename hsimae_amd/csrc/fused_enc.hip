@@ -236,7 +236,8 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
         for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float gv = (live && col < w.h) ? silu_nr(h1[mt][r]) * h3[mt][r] : 0.f;
+                // columns past the hidden width: the packed W1 / W3 rows and the biases read as zero -> h1 = h3 = 0 -> g = 0
+                const float gv = silu_nr(h1[mt][r]) * h3[mt][r];
                 Gi[(mt * 16 + q.g * 4 + r) * LC + q.wave * 16 + q.c16] = (bf16_t)gv;
             }
         lds_barrier();                             // chunk image complete; the other image is free again after this barrier
@@ -381,7 +382,6 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
         const bool live = nt < nt_h;
         {
             const int col = nt * 16 + q.c16, lc = q.wave * 16 + q.c16;
-            const bool ok = live && col < w.h;
             f32x4 h1[MT4], h3[MT4], dg[MT4];
             const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
 #pragma unroll
@@ -411,9 +411,11 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
                     const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-a1));
                     const float sl = a1 * sg;
                     const int o = (mt * 16 + q.g * 4 + r) * LC + lc;
-                    Gc[o] = (bf16_t)(ok ? sl * a3 : 0.f);
-                    DH1[o] = (bf16_t)(ok ? dv * a3 * sg * (1.f + a1 * (1.f - sg)) : 0.f);
-                    DH3[o] = (bf16_t)(ok ? dv * sl : 0.f);
+                    // columns past the hidden width: packed W1 / W3 / W2^T rows and the biases are zero -> a1 = a3 = dv = 0 ->
+                    // g = dh1 = dh3 = 0 without a select
+                    Gc[o] = (bf16_t)(sl * a3);
+                    DH1[o] = (bf16_t)(dv * a3 * sg * (1.f + a1 * (1.f - sg)));
+                    DH3[o] = (bf16_t)(dv * sl);
                 }
         }
         lds_barrier();
