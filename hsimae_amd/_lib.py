@@ -18,7 +18,7 @@ i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 class Config(C.Structure):
     _fields_ = [("bands", i32), ("embed_dim", i32), ("depth", i32), ("s_depth", i32), ("num_heads", i32),
                 ("dec_dim", i32), ("dec_depth", i32), ("dec_heads", i32), ("hidden", i32), ("dec_hidden", i32),
-                ("norm_pix_loss", i32)]
+                ("norm_pix_loss", i32), ("precision", i32)]
 
 
 class IO(C.Structure):
@@ -28,7 +28,8 @@ class IO(C.Structure):
                 ("workspace", vp), ("workspace_bytes", i64),
                 ("grad_scale", f32), ("want_recons", i32),
                 ("loss", vp), ("pred_img", vp), ("mask_img", vp), ("mask", vp),
-                ("ids_keep", vp), ("ids_restore", vp), ("latent", vp), ("pred", vp), ("drop_scale", vp)]
+                ("ids_keep", vp), ("ids_restore", vp), ("latent", vp), ("pred", vp), ("drop_scale", vp),
+                ("bucket_stream", vp)]
 
 
 class MaskParams(C.Structure):
@@ -134,8 +135,10 @@ SYMBOLS = {
     "hsimae_encode_backward": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp, vp, BUCKET_CB, vp, vp]),
     "hsimae_agg_pool": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "hsimae_decode": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp, vp, vp]),
+    "hsimae_decode_backward": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp, vp, vp, BUCKET_CB, vp, vp]),
 }
 
+PREC_BF16, PREC_FP8 = 0, 1
 A_BF16, A_F32, A_F32_LN = 0, 1, 2
 E_BF16, E_F32, E_RES_F32, E_POS_F32, E_SWIGLU, E_SWIGLU_BWD, E_LN_BWD = 0, 1, 2, 3, 4, 5, 6
 

@@ -6,8 +6,12 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 
 namespace {
+
+#define CK(expr) do { int _e = (expr); if (_e) return _e; } while (0)
+#define CK0(expr) do { int _e0 = (expr); if (_e0) return _e0; } while (0)
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int rup(int x, int m) { return (x + m - 1) / m * m; }
@@ -219,25 +223,64 @@ BlkP resolve(const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk,
     return b;
 }
 
-#define CK(expr) do { int _e = (expr); if (_e) return _e; } while (0)
 
 // The two axis stacks (blocks_1 / blocks_2, Models.py:556-560) are independent until x1 + x2: the spectral
 // stack runs on a side stream so two kernels are resident at once (a single 864-workgroup launch leaves a
 // ~45 % tail on 256 CUs).  The stream and its two events are created once per process; HSIMAE_TWO_STREAMS=0
 // keeps everything on the caller's stream.
-struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
+struct Side {
+    hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false, init = false;
+    std::vector<hipEvent_t> pool; size_t next = 0;        // events handed to the bucket stream, one per reported range
+};
+// One Side per device, looked up by the device that is current at the call (include/hsimae_hip.h, Contract): a model
+// on cuda:1 gets a side stream on cuda:1.  One host thread per device is assumed (fork / join events are shared).
 Side& side() {
-    static Side sd = [] {
-        Side x;
+    static Side sides[32];
+    static Side none;
+    static std::mutex mu;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return none;
+    std::lock_guard<std::mutex> lk(mu);
+    Side& x = sides[dev];
+    if (!x.init) {
+        x.init = true;
         const char* e = getenv("HSIMAE_TWO_STREAMS");
-        if (e && e[0] == '0') return x;
-        x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
-               hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
-        return x;
-    }();
-    return sd;
+        if (!(e && e[0] == '0'))
+            x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+    }
+    return x;
 }
+// next event of the per-device pool (grown on demand, reused round-robin: a wait captures the record that precedes it)
+hipEvent_t pool_event(Side& sd) {
+    if (sd.pool.size() < 96) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) { sd.pool.push_back(e); return e; }
+    }
+    if (sd.pool.empty()) return nullptr;
+    return sd.pool[sd.next++ % sd.pool.size()];
+}
+
+// Reports gradient ranges to the caller's bucket callback.  With io->bucket_stream the consumer's launch stream is
+// made to wait for the stream the range's kernels were enqueued on (so side-stream ranges can be reported at once);
+// without it a range may only be reported once it is complete on the caller's stream.
+struct Emitter {
+    hsimae_bucket_cb cb; void* user; hipStream_t bucket; int stage;
+    int operator()(int64_t off, int64_t end, hipStream_t done_on) {
+        if (cb) {
+            if (bucket) {
+                hipEvent_t e = pool_event(side());
+                if (!e) return (int)hipErrorOutOfMemory;
+                CK0((int)hipEventRecord(e, done_on));
+                CK0((int)hipStreamWaitEvent(bucket, e, 0));
+            }
+            cb(stage, off, end - off, user);
+        }
+        ++stage;
+        return HSIMAE_OK;
+    }
+};
 
 // HSIMAE_FUSED_DEC=0 forces the layer-at-a-time decoder (A/B testing of the fused decoder kernels)
 bool fused_dec_enabled(const Geo& g) {
@@ -621,6 +664,7 @@ int hsimae_decode(const hsimae_config* cfg, const hsimae_io* io, const float* la
     p.A = latent; p.lda = g.D; p.M = (int)c.Me; p.N = g.Dd; p.K = g.D; p.n_valid = g.Dd; p.W = io->wpk + c.W.de; p.bias = P + c.L.deb;
     p.out = w.y; p.ldo = g.Dd;
     CK(hs_gemm(p, A_F32, E_F32, s));
+    CK(hs_rows_to_bf16(latent, w.lat, c.Me, g.D, nullptr, s));      // decoder_embed's wgrad operand (hsimae_decode_backward)
     AssembleParams as; std::memset(&as, 0, sizeof(as));
     as.y = w.y; as.N = c.N; as.K = c.K; as.TL = g.TL; as.Dd = g.Dd; as.ids_restore = io->ids_restore; as.pos = P + c.L.dpos;
     as.yfull = w.yfull;
@@ -641,17 +685,15 @@ int hsimae_decode(const hsimae_config* cfg, const hsimae_io* io, const float* la
 
 // Backward of the encoder stacks + patch embedding, from d(x of the last encoder block) in w.G0.  Shared by
 // hsimae_backward (after the decoder) and hsimae_encode_backward (after `norm`).
-static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hipStream_t s, int stage, hsimae_bucket_cb cb,
-                            void* user) {
+static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hipStream_t s, Emitter& emit) {
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
-    auto emit = [&](int64_t off, int64_t end) { if (cb) cb(stage, off, end - off, user); ++stage; };
     for (int i = g.nfus - 1; i >= 0; --i) {
         BlkP bp = resolve(L.bf[i], c.W.bf[i], P, io->wpk, c.W);
         const float* xin = (i > 0) ? w.bf[i - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
         const DropRs rf = drop_rs(io, (g.has_axis ? 2 * g.sdepth : 0) + i, c.Me);
         CK(block_bwd(bp, L.bf[i], grads, xin, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, w.G0, w.sc, w.G0, 0, s, 1,
                      rf.a, rf.m));
-        emit(L.bf[i].n1w, L.bf[i].end);
+        CK(emit(L.bf[i].n1w, L.bf[i].end, s));
     }
     if (g.has_axis) {
         // d(x1 + x2) feeds both stacks (Models.py:564); the spectral stack's backward runs on the side stream
@@ -664,12 +706,16 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
         }
         hipStream_t s2 = forked ? sd.s : s;
         const Scr& scr2 = forked ? w.sc2 : w.sc;
+        // with a bucket stream every block's range is reported as soon as its kernels are enqueued (the consumer waits
+        // for the right stream through an event); without one the side stream's ranges wait for the join
+        const bool per_block = emit.bucket != nullptr || !forked;
         for (int i = g.sdepth - 1; i >= 0; --i) {
             BlkP b2 = resolve(L.b2[i], c.W.b2[i], P, io->wpk, c.W);
             const DropRs r1 = drop_rs(io, i, c.Me), r2d = drop_rs(io, g.sdepth + i, c.Me);
             const float* xin2 = (i > 0) ? w.b2[i - 1].x2 : w.x0;
             CK(block_bwd(b2, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, scr2, w.G0, 0, s2, forked ? 2 : 1,
                          r2d.a, r2d.m));
+            if (per_block) CK(emit(L.b2[i].n1w, L.b2[i].end, s2));
             if (i == 0 && forked) {                 // the spatial stack's last step accumulates onto the spectral dX
                 CK((int)hipEventRecord(sd.join, sd.s));
                 CK((int)hipStreamWaitEvent(s, sd.join, 0));
@@ -679,10 +725,12 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
             float* out = (i == 0) ? w.G0 : w.G2;
             CK(block_bwd(b1, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, out, i == 0, s, forked ? 2 : 1,
                          r1.a, r1.m));
+            if (per_block) CK(emit(L.b1[i].n1w, L.b1[i].end, s));
         }
-        // gradient ranges in back-to-front order, all complete on the caller's stream by now
-        for (int i = g.sdepth - 1; i >= 0; --i) emit(L.b2[i].n1w, L.b2[i].end);
-        for (int i = g.sdepth - 1; i >= 0; --i) emit(L.b1[i].n1w, L.b1[i].end);
+        if (!per_block) {     // back-to-front, all complete on the caller's stream by now
+            for (int i = g.sdepth - 1; i >= 0; --i) CK(emit(L.b2[i].n1w, L.b2[i].end, s));
+            for (int i = g.sdepth - 1; i >= 0; --i) CK(emit(L.b1[i].n1w, L.b1[i].end, s));
+        }
     }
     {   // patch_embed.proj: only the kept tokens carry gradient (Models.py:528); no input gradient
         WgradParams wg; std::memset(&wg, 0, sizeof(wg));
@@ -691,20 +739,15 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
         wg.ntasks = 1; wg.M = (int)c.Me; wg.msplit = wgrad_msplit((g.D + 127) / 128, c.Me);
         CK(hs_wgrad(wg, s));
     }
-    emit(0, L.peb + g.D);
+    CK(emit(0, L.peb + g.D, s));
     return HSIMAE_OK;
 }
 
-int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads, hsimae_bucket_cb cb, void* user,
-                    void* stream) {
-    Ctx c; CK(make_ctx(cfg, io, c, true));
-    if (!grads || !io->ids_restore) return HSIMAE_ENULL;
-    hipStream_t s = S(stream);
+// Backward of the decoder from dL/dpred (bf16 [Md][96] in w.dpred) down to dL/d(latent) in w.du [Me][D]
+// (autograd of Models.py:573-601): decoder_pred / decoder_norm, the decoder blocks, the sequence assembly and
+// decoder_embed (its weight gradient included).  Shared by hsimae_backward and hsimae_decode_backward.
+static int decoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hipStream_t s, Emitter& emit) {
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
-    int stage = 0;
-    auto emit = [&](int64_t off, int64_t end) { if (cb) cb(stage, off, end - off, user); ++stage; };
-
-    // decoder_pred / decoder_norm
     const float* zlast = w.bd[g.ddepth - 1].x2;
     GemmParams p = gp();
     p.A = w.dpred; p.lda = 96; p.M = (int)c.Md; p.N = g.Dd; p.K = 96; p.n_valid = g.Dd; p.W = io->wpk + c.W.dpT; p.out = w.du; p.ldo = g.Dd;
@@ -720,7 +763,7 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
     l.du = w.du; l.x = zlast; l.gamma = P + L.dnw; l.dres = nullptr; l.dx = w.G0; l.dgamma = grads + L.dnw; l.dbeta = grads + L.dnb;
     l.M = (int)c.Md; l.d = g.Dd;
     CK(hs_ln_bwd(l, s));
-    emit(L.dnw, L.total);
+    CK(emit(L.dnw, L.total, s));
 
     const bool fdec = fused_dec_enabled(g);
     for (int i = g.ddepth - 1; i >= 0; --i) {
@@ -740,9 +783,9 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
         } else {
             CK(block_bwd(bp, L.bd[i], grads, xin, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, w.G0, w.sc, w.G0, 0, s));
         }
-        emit(L.bd[i].n1w, L.bd[i].end);
+        CK(emit(L.bd[i].n1w, L.bd[i].end, s));
     }
-    // sequence assembly + decoder_embed + norm
+    // sequence assembly + decoder_embed
     AssembleParams as; std::memset(&as, 0, sizeof(as));
     as.N = c.N; as.K = c.K; as.TL = g.TL; as.Dd = g.Dd; as.ids_restore = io->ids_restore; as.dyfull = w.G0; as.dy = w.dyb;
     CK(hs_assemble_bwd(as, s));
@@ -756,13 +799,38 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
         wg.ntasks = 1; wg.M = (int)c.Me; wg.msplit = wgrad_msplit(((g.Dd + 127) / 128) * ((g.D + 127) / 128), c.Me);
         CK(hs_wgrad(wg, s));
     }
+    return HSIMAE_OK;
+}
+
+int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads, hsimae_bucket_cb cb, void* user,
+                    void* stream) {
+    Ctx c; CK(make_ctx(cfg, io, c, true));
+    if (!grads || !io->ids_restore) return HSIMAE_ENULL;
+    hipStream_t s = S(stream);
+    const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
+    Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0};
+    CK(decoder_backward(c, io, grads, s, emit));
+    // norm (Models.py:570)
     const float* xf = g.nfus ? w.bf[g.nfus - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
+    LnBwdParams l; std::memset(&l, 0, sizeof(l));
     l.du = w.du; l.x = xf; l.gamma = P + L.nw; l.dres = nullptr; l.dx = w.G0; l.dgamma = grads + L.nw; l.dbeta = grads + L.nb;
     l.M = (int)c.Me; l.d = g.D;
     CK(hs_ln_bwd(l, s));
-    emit(L.nw, L.deb + g.Dd);
+    CK(emit(L.nw, L.deb + g.Dd, s));
+    return encoder_backward(c, io, grads, s, emit);
+}
 
-    return encoder_backward(c, io, grads, s, stage, cb, user);
+int hsimae_decode_backward(const hsimae_config* cfg, const hsimae_io* io, const float* dpred, float* dlatent, float* grads,
+                           hsimae_bucket_cb cb, void* user, void* stream) {
+    Ctx c; CK(make_ctx(cfg, io, c, true));
+    if (!grads || !dpred || !dlatent || !io->ids_restore) return HSIMAE_ENULL;
+    hipStream_t s = S(stream);
+    const Geo& g = c.g; const Ws& w = c.w; const PLayout& L = c.L;
+    CK(hs_rows_pad_bf16(dpred, w.dpred, c.Md, 72, 96, s));
+    Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0};
+    CK(decoder_backward(c, io, grads, s, emit));
+    CK(emit(L.dew, L.deb + g.Dd, s));
+    return (int)hipMemcpyAsync(dlatent, w.du, c.Me * g.D * 4, hipMemcpyDeviceToDevice, s);
 }
 
 int hsimae_encode_backward(const hsimae_config* cfg, const hsimae_io* io, const float* dlatent, float* grads,
@@ -777,10 +845,9 @@ int hsimae_encode_backward(const hsimae_config* cfg, const hsimae_io* io, const 
     l.du = dlatent; l.x = xf; l.gamma = P + L.nw; l.dres = nullptr; l.dx = w.G0; l.dgamma = grads + L.nw; l.dbeta = grads + L.nb;
     l.M = (int)c.Me; l.d = g.D;
     CK(hs_ln_bwd(l, s));
-    int stage = 0;
-    if (cb) cb(stage, L.nw, L.nb + g.D - L.nw, user);
-    ++stage;
-    return encoder_backward(c, io, grads, s, stage, cb, user);
+    Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0};
+    CK(emit(L.nw, L.nb + g.D, s));
+    return encoder_backward(c, io, grads, s, emit);
 }
 
 // ---------------------------------------------------------------------- per-kernel entry points

@@ -650,6 +650,25 @@ int hs_rows_to_bf16(const float* src, hs_bf16* dst, int64_t rows, int d, const f
     return (int)hipGetLastError();
 }
 
+// fp32 rows [rows][cols] -> bf16 rows [rows][ldd] zero-padded (dL/dpred of a stand-alone decode backward: 72 -> 96)
+__global__ __launch_bounds__(256) void rows_pad_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows, int cols,
+                                                            int ldd) {
+    const int64_t n = rows * ldd;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ldd;
+        const int c = (int)(i - r * ldd);
+        dst[i] = c < cols ? (bf16_t)src[r * cols + c] : (bf16_t)0.f;
+    }
+}
+
+int hs_rows_pad_bf16(const float* src, hs_bf16* dst, int64_t rows, int cols, int ldd, hipStream_t s) {
+    if (rows <= 0) return HS_OK;
+    if (cols > ldd) return HS_EDIMS;
+    const int grid = (int)std::min<int64_t>((rows * ldd + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(rows_pad_bf16_kernel, dim3(grid), dim3(256), 0, s, src, dst, rows, cols, ldd);
+    return (int)hipGetLastError();
+}
+
 int hs_loss_partials(int N, int T) {
     const int64_t M = (int64_t)N * T * 9;
     return (int)std::max<int64_t>((M + LOSS_ROWS_PER_WG - 1) / LOSS_ROWS_PER_WG, N);     // either kernel form of hs_loss

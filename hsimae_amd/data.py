@@ -20,15 +20,26 @@ import torch
 from . import _lib
 
 
-def random_sampler_order(n: int) -> list[int]:
-    """Index order of one epoch: torch.utils.data.RandomSampler (replacement=False, generator=None)."""
-    # DataLoader.__iter__ first draws the iterator's `_base_seed` (one int64 from the default generator, used only
-    # by worker processes), then the sampler draws its own seed when the first batch is requested
+def draw_base_seed() -> None:
+    """`DataLoader.__iter__` draws the iterator's `_base_seed` (one int64 from the default generator, used only by worker
+    processes) when the iterator is CREATED — before any batch is requested."""
     torch.empty((), dtype=torch.int64).random_()
+
+
+def sampler_order(n: int) -> list[int]:
+    """torch.utils.data.RandomSampler (replacement=False, generator=None): its seed is drawn from the default generator
+    when the FIRST batch is requested, then `randperm` runs on a private generator."""
     seed = int(torch.empty((), dtype=torch.int64).random_().item())
     g = torch.Generator()
     g.manual_seed(seed)
     return torch.randperm(n, generator=g).tolist()
+
+
+def random_sampler_order(n: int) -> list[int]:
+    """Index order of one epoch when nothing else touches the default generator between `iter()` and the first
+    `next()`: base seed, then the sampler's seed and permutation."""
+    draw_base_seed()
+    return sampler_order(n)
 
 
 def draw_flips(n: int, train: bool) -> np.ndarray:
@@ -120,22 +131,59 @@ class HSIdataset4PT:
 class DeviceLoader:
     """`DataLoader(dataset, batch_size=bs, shuffle=True, num_workers=0)` (Model_Pretraining.py:75) on the device."""
 
-    def __init__(self, dataset: HSIdataset4PT, batch_size=1, shuffle=False, drop_last=False):
+    def __init__(self, dataset: HSIdataset4PT, batch_size=1, shuffle=False, drop_last=False, rank=0, world=1):
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, batch_size, shuffle, drop_last
+        if not 0 <= rank < world:
+            raise ValueError("rank must be in [0, world)")
+        self.rank, self.world = rank, world               # data parallel: per-rank batch_size, see _LoaderIter
 
     def __len__(self):
-        n = len(self.dataset)
-        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        n, gb = len(self.dataset), self.batch_size * self.world
+        return n // gb if self.drop_last else (n + gb - 1) // gb
 
     def __iter__(self):
-        n = len(self.dataset)
-        if self.shuffle:
-            order = random_sampler_order(n)
-        else:
-            torch.empty((), dtype=torch.int64).random_()     # the iterator's base seed is drawn either way
-            order = list(range(n))
-        for i in range(0, n, self.batch_size):
-            idx = order[i:i + self.batch_size]
-            if self.drop_last and len(idx) < self.batch_size:
-                return
-            yield self.dataset.batch(idx)
+        return _LoaderIter(self)
+
+
+class _LoaderIter:
+    """One epoch.  RNG consumption follows `_SingleProcessDataLoaderIter`: the base seed is drawn here, at `iter()`; the
+    sampler's seed and permutation at the first `next()` — so two loaders created back to back and then advanced in turn
+    (Model_Finetuning.py:142-149) see the default generator in the reference's order.
+
+    `rank` / `world` (data parallel, not in the reference): every rank draws the SAME permutation (same seeds) and takes
+    the rank-th contiguous slice of each global batch of `batch_size * world` indices, so the union over ranks is the
+    reference's single-process batch sequence at a global batch of `batch_size * world`."""
+
+    def __init__(self, loader):
+        self.loader = loader
+        self.order = None
+        self.pos = 0
+        draw_base_seed()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        ld = self.loader
+        n = len(ld.dataset)
+        if self.order is None:
+            self.order = sampler_order(n) if ld.shuffle else list(range(n))
+        gb = ld.batch_size * ld.world
+        if self.pos >= n:
+            raise StopIteration
+        idx = self.order[self.pos:self.pos + gb]
+        if ld.drop_last and len(idx) < gb:
+            raise StopIteration
+        self.pos += gb
+        if ld.world > 1:
+            # every rank consumes the flips' python-random draws of the WHOLE global batch, in the reference's order, and
+            # keeps its own slice: the python-random stream (which also picks the masking grid) stays identical on all ranks.
+            # Equal shares only (equal sum(mask) per rank makes the mean of rank means the global mean): the last, ragged
+            # global batch drops its < world leftover cubes.
+            flips = draw_flips(len(idx), ld.dataset.train)
+            per = len(idx) // ld.world
+            if per == 0:
+                raise StopIteration
+            sl = slice(ld.rank * per, (ld.rank + 1) * per)
+            return ld.dataset.gather(idx[sl], flips[sl])
+        return ld.dataset.batch(idx)

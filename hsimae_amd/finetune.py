@@ -177,7 +177,7 @@ class DualViT(HSIMAE):
         n1 = torch.arange(T, dtype=torch.float32).expand(N, T)
         n2 = torch.arange(L, dtype=torch.float32).expand(N, L)
         _, _, _, st_cls = self._run_forward(imgs, 0.0, (n1, n2), (T, L), want_latent=True, encoder_only=True,
-                                            drop_scale=self._row_scales(f_cls, N, T, L, dev), ws_slot=1)
+                                            drop_scale=self._row_scales(f_cls, N, T, L, dev))
         class_pred, pooled = self.head(st_cls["latent"])
         saved = {"cls": st_cls, "pooled": pooled, "N": N, "rec": None}
         out = {"class_pred": class_pred, "saved": saved}
@@ -192,7 +192,7 @@ class DualViT(HSIMAE):
                 f_rec = self.draw_drop_factors(Na, int(len_t), int(len_l), dev)
             loss_rec, pred_rec, mask, st_rec = self._run_forward(
                 imgs_all, mask_ratio, noise, (int(len_t), int(len_l)), want_latent=False,
-                drop_scale=self._row_scales(f_rec, Na, int(len_t), int(len_l), dev), ws_slot=0)
+                drop_scale=self._row_scales(f_rec, Na, int(len_t), int(len_l), dev))
             saved["rec"] = st_rec
             out.update(loss_rec=loss_rec, pred_rec=pred_rec, mask=mask)
         return out
@@ -200,31 +200,34 @@ class DualViT(HSIMAE):
     def _train_backward(self, saved, g_loss, g_cls):
         lib, cfg = _lib.load(), self._config()
         dev = self._flat.device
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        params, scratch = self._params_cache, self._flat_scratch
-        scratch.zero_()                                   # weight grads are accumulated with atomics
-        nocb = _lib.BUCKET_CB(0)
-        if saved["rec"] is not None and g_loss is not None:
-            _lib.check(lib.hsimae_backward(C.byref(cfg), C.byref(saved["rec"]["io"]), scratch.data_ptr(), nocb, None, stream),
-                       "hsimae_backward")
-            scratch.mul_(g_loss)                          # chain rule with d/d(loss_rec) (lamda in the reference's loop)
         gw = gb = None
-        if g_cls is not None:
-            # head (Models.py:962-970): class_pred = pooled W^T + b, pooled[n, t*D + c] = mean_l latent[n, t, l, c]
-            N, T, L, D = saved["N"], self.input_size[0], self.input_size[1] ** 2, self.dim
-            g_cls = g_cls.to(torch.float32)
-            w = self.cls_head.weight.detach()
-            gw = g_cls.t() @ saved["pooled"]
-            gb = g_cls.sum(0)
-            dlat = ((g_cls @ w) / L).view(N, T, 1, D).expand(N, T, L, D).contiguous()
-            _lib.check(lib.hsimae_encode_backward(C.byref(cfg), C.byref(saved["cls"]["io"]), dlat.data_ptr(),
-                                                  scratch.data_ptr(), nocb, None, stream), "hsimae_encode_backward")
-        if params[self._trainable[0]].grad is None:
-            self._flat_grad.copy_(scratch)
-            for i in self._trainable:
-                params[i].grad = self._grad_views[i]
-        else:
-            self._flat_grad.add_(scratch)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            scratch = self._flat_scratch
+            scratch.zero_()                                   # weight grads are accumulated with atomics
+            nocb = _lib.BUCKET_CB(0)
+            if saved["rec"] is not None and g_loss is not None:
+                saved["rec"].check_alive()
+                saved["rec"]["_done"] = True
+                _lib.check(lib.hsimae_backward(C.byref(cfg), C.byref(saved["rec"]["io"]), scratch.data_ptr(), nocb, None, stream),
+                           "hsimae_backward")
+                scratch.mul_(g_loss)                          # chain rule with d/d(loss_rec) (lamda in the reference's loop)
+            if g_cls is not None:
+                # head (Models.py:962-970): class_pred = pooled W^T + b, pooled[n, t*D + c] = mean_l latent[n, t, l, c]
+                N, T, L, D = saved["N"], self.input_size[0], self.input_size[1] ** 2, self.dim
+                g_cls = g_cls.to(torch.float32)
+                w = self.cls_head.weight.detach()
+                gw = g_cls.t() @ saved["pooled"]
+                gb = g_cls.sum(0)
+                dlat = ((g_cls @ w) / L).view(N, T, 1, D).expand(N, T, L, D).contiguous()
+                saved["cls"].check_alive()
+                saved["cls"]["_done"] = True
+                _lib.check(lib.hsimae_encode_backward(C.byref(cfg), C.byref(saved["cls"]["io"]), dlat.data_ptr(),
+                                                      scratch.data_ptr(), nocb, None, stream), "hsimae_encode_backward")
+        self._apply_grads(scratch, 1.0)
+        for st in (saved["rec"], saved["cls"]):
+            if st is not None:
+                st.release()
         return gw, gb
 
     def forward(self, imgs, imgs_u=None, mask_ratio=0.75, noise=None, grid=None, drop_factors=None):

@@ -102,6 +102,66 @@ class Block(nn.Module):
         self.mlp = SwiGLU(dim, swiglu_hidden(dim, mlp_ratio))
 
 
+class _FwdState(dict):
+    """What one forward pass leaves behind for its backward: the `hsimae_io` block, the tensors it points to, and a
+    lease on the workspace arena that holds the saved activations.  The arena goes back to the model's pool when the
+    state is released (after the backward) or dropped; every arena carries a generation number, so a backward whose
+    arena has been handed to a later forward raises instead of reading someone else's activations."""
+
+    def release(self):
+        ws, pool = self.pop("_ws", None), self.pop("_pool", None)
+        if ws is not None and pool is not None:
+            pool.give_back(ws)
+
+    def check_alive(self):
+        if self.get("_done"):
+            raise RuntimeError("hsimae_amd: this forward pass has already been back-propagated; its saved activations are "
+                               "consumed in place by the backward kernels (run the forward again instead of retain_graph)")
+        ws = self.get("_ws_ref")
+        if ws is None or getattr(ws, "_hs_gen", None) != self.get("_gen"):
+            raise RuntimeError(
+                "hsimae_amd: the activations of this forward pass are gone (its workspace was released by an earlier "
+                "backward and reused by a later forward).  Call backward once per forward, or keep the graph's forward "
+                "and backward adjacent when using retain_graph.")
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class _WorkspacePool:
+    """Workspace arenas (hsimae_workspace_bytes each, 19.7 GB at C2) leased per forward pass.  A training step reuses one
+    arena forever; `(m(x1)[0] + m(x2)[0]).backward()`, a monitoring forward between forward and backward, or deferred
+    backwards simply hold several at once, as the reference's autograd graph would hold several sets of activations."""
+
+    MAX_FREE = 2
+
+    def __init__(self):
+        self.free, self.gen = [], 0
+
+    def lease(self, nbytes, device):
+        best = None
+        for t in self.free:
+            if t.device == device and t.numel() >= nbytes and (best is None or t.numel() < best.numel()):
+                best = t
+        if best is not None:
+            self.free = [t for t in self.free if t is not best]
+        else:
+            if self.free:                                  # too small / other device: let the allocator have it back first
+                self.free.pop(0)
+            best = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.gen += 1
+        best._hs_gen = self.gen
+        return best
+
+    def give_back(self, t):
+        self.free.append(t)
+        while len(self.free) > self.MAX_FREE:
+            self.free.pop(0)
+
+
 class _Step(torch.autograd.Function):
     """Whole forward / whole backward as one autograd node; parameter grads are written by the kernels
     into the model's flat gradient buffer and attached to the Parameters directly."""
@@ -117,6 +177,53 @@ class _Step(torch.autograd.Function):
     def backward(ctx, g_loss, g_pred, g_mask):
         ctx.model._run_backward(ctx.state, g_loss)
         return None, None, None, None, None, None
+
+
+class _EncodeFn(torch.autograd.Function):
+    """forward_encoder (Models.py:537-571) as an autograd node: hsimae_encode / hsimae_encode_backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, x, ratio, noise, grid):
+        _, _, _, st = model._run_forward(x, ratio, noise, grid, want_latent=True, encoder_only=True)
+        ctx.model, ctx.state = model, st
+        ids_r, ids_k = st["ids_restore"].long(), st["ids_keep"].long()
+        ctx.mark_non_differentiable(st["mask"], ids_r, ids_k)
+        return st["latent"], st["mask"], ids_r, ids_k
+
+    @staticmethod
+    def backward(ctx, g_lat, *_):
+        ctx.model._encode_backward(ctx.state, g_lat)
+        return None, None, None, None, None, None
+
+
+class _DecodeFn(torch.autograd.Function):
+    """forward_decoder (Models.py:573-601) as an autograd node: hsimae_decode / hsimae_decode_backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, latent, model, ids_restore):
+        pred, st = model._run_decode(latent, ids_restore)
+        ctx.model, ctx.state = model, st
+        return pred
+
+    @staticmethod
+    def backward(ctx, g_pred):
+        return None, ctx.model._decode_backward(ctx.state, g_pred), None, None
+
+
+class _LossFn(torch.autograd.Function):
+    """forward_loss (Models.py:603-616) as an autograd node: the loss kernel also emits dLoss/dpred."""
+
+    @staticmethod
+    def forward(ctx, pred, model, imgs, mask):
+        loss, dpred = model._run_loss(imgs, pred, mask, want_grad=True)
+        ctx.save_for_backward(dpred)
+        ctx.shape = pred.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return (dpred[:, :72].float() * g).view(ctx.shape), None, None, None
 
 
 class HSIMAE(nn.Module):
@@ -160,9 +267,10 @@ class HSIMAE(nn.Module):
         self.initialize_weights()
 
         # runtime state (not part of the state_dict)
-        self._flat = self._flat_grad = self._wpk = self._pack_table = self._ws = None
-        self._ws_slots = None
+        self._flat = self._flat_grad = self._wpk = self._pack_table = None
+        self._pool = _WorkspacePool()
         self._cfg = None
+        self._precision = _lib.PREC_BF16
         self._packed_version = -1
         self._anchor = None
         self._reducer = None
@@ -252,8 +360,20 @@ class HSIMAE(nn.Module):
                 bands=self.patch_embed.bands, embed_dim=self.dim, depth=depth, s_depth=self.s_depth,
                 num_heads=self.num_heads, dec_dim=self.dec_dim, dec_depth=len(self.decoder_blocks),
                 dec_heads=self.decoder_num_heads, hidden=swiglu_hidden(self.dim, self.mlp_ratio),
-                dec_hidden=swiglu_hidden(self.dec_dim, self.mlp_ratio), norm_pix_loss=int(bool(self.norm_pix_loss)))
+                dec_hidden=swiglu_hidden(self.dec_dim, self.mlp_ratio), norm_pix_loss=int(bool(self.norm_pix_loss)),
+                precision=self._precision)
         return self._cfg
+
+    def set_precision(self, precision="bf16"):
+        """GEMM operand type of the encoder blocks' linears: "bf16" (default) or "fp8" (MX block-scaled e4m3 MFMA,
+        include/hsimae_hip.h `hsimae_config.precision`).  Compute copies only: parameters, gradients and the state_dict
+        stay fp32."""
+        prec = {"bf16": _lib.PREC_BF16, "fp8": _lib.PREC_FP8}[precision]
+        if prec != self._precision:
+            self._precision, self._cfg = prec, None
+            self._wpk = self._pack_table = None          # the packed images are laid out per precision
+            self._packed_version = -1
+        return self
 
     def _plist(self):
         return [p for n, p in self.named_parameters() if not n.startswith("cls_head.")]
@@ -265,6 +385,8 @@ class HSIMAE(nn.Module):
         if (self._flat is not None and self._flat.device == device and
                 params[0].data_ptr() == self._flat.data_ptr() and
                 params[-1].data_ptr() == self._flat.data_ptr() + 4 * (self._flat.numel() - params[-1].numel())):
+            if self._wpk is None:
+                self._ensure_pack_buffers(device)
             return
         lib, cfg = _lib.load(), self._config()
         n = len(params)
@@ -287,16 +409,30 @@ class HSIMAE(nn.Module):
         self._flat_scratch = torch.zeros_like(flat)
         self._grad_views = [self._flat_grad[o: o + s].view(p.shape) for o, s, p in zip(self._offs, self._sizes, params)]
         self._trainable = [i for i, p in enumerate(params) if p.requires_grad and i != 1]   # 1 = mask_token (never used)
+        # the encoder's / decoder's parameters are two contiguous ranges of the flat buffer (stand-alone backward passes)
+        names = [n_ for n_, _ in self.named_parameters() if not n_.startswith("cls_head.")]
+        dec0 = names.index("decoder_embed.weight")
+        self._enc_idx = [i for i in self._trainable if i < dec0]
+        self._dec_idx = [i for i in self._trainable if i >= dec0]
+        self._enc_range = (self._offs[self._enc_idx[0]], self._offs[dec0])
+        self._dec_range = (self._offs[dec0], total)
         self._params_cache = params
+        self._anchor = torch.zeros((), device=device, requires_grad=True)
+        self._ensure_pack_buffers(device)
+
+    def _ensure_pack_buffers(self, device):
+        lib, cfg = _lib.load(), self._config()
         wpk_elems = lib.hsimae_wpk_elems(C.byref(cfg))
+        if wpk_elems < 0:
+            raise NotImplementedError("hsimae_amd: this configuration is not supported by the gfx950 kernels "
+                                      "(widths must be multiples of 8 up to 512, head dim 8 or 16)")
         self._wpk = torch.zeros(wpk_elems, dtype=torch.bfloat16, device=device)
         tb = lib.hsimae_pack_table_bytes(C.byref(cfg))
         host = torch.empty(tb, dtype=torch.uint8)
-        _lib.check(lib.hsimae_build_pack_table(C.byref(cfg), flat.data_ptr(), self._wpk.data_ptr(), host.data_ptr()),
+        _lib.check(lib.hsimae_build_pack_table(C.byref(cfg), self._flat.data_ptr(), self._wpk.data_ptr(), host.data_ptr()),
                    "hsimae_build_pack_table")
         self._pack_table = host.to(device)
         self._packed_version = -1
-        self._anchor = torch.zeros((), device=device, requires_grad=True)
 
     def _ensure_packed(self, stream):
         ver = sum(p._version for p in self._params_cache)
@@ -305,21 +441,10 @@ class HSIMAE(nn.Module):
                        "hsimae_pack_params")
             self._packed_version = ver
 
-    def _workspace(self, nbytes, device, slot=0):
-        """slot 1: a second workspace for the pass whose activations must outlive the next forward (DualViT keeps the
-        unmasked encoder's and the masked path's activations until the backward)."""
-        if self._ws_slots is None:
-            self._ws_slots = {}
-        ws = self._ws_slots.get(slot)
-        if ws is None or ws.numel() < nbytes or ws.device != device:
-            self._ws_slots[slot] = None
-            ws = self._ws_slots[slot] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        if slot == 0:
-            self._ws = ws
-        return ws
-
     # ------------------------------------------------------------------ forward / backward drivers
     def _run_forward(self, imgs, mask_ratio, noise, grid, want_latent, encoder_only=False, drop_scale=None, ws_slot=0):
+        """One hsimae_forward / hsimae_encode call.  Returns (loss, pred_img, mask_img, state); `state` holds the lease on
+        the workspace arena with the saved activations until `state.release()` or until it is dropped."""
         if not imgs.is_cuda:
             raise RuntimeError("hsimae_amd.HSIMAE runs on MI355X only (no CPU fallback): move the model and inputs to a GPU")
         if imgs.dim() != 5 or imgs.shape[1] != 1 or imgs.shape[2] != self.patch_embed.bands or imgs.shape[3:] != (9, 9):
@@ -327,6 +452,10 @@ class HSIMAE(nn.Module):
         if imgs.dtype != torch.float32:
             imgs = imgs.float()
         dev = imgs.device
+        with torch.cuda.device(dev):                  # the library's side stream / events belong to the current device
+            return self._run_forward_on(dev, imgs, mask_ratio, noise, grid, want_latent, encoder_only, drop_scale)
+
+    def _run_forward_on(self, dev, imgs, mask_ratio, noise, grid, want_latent, encoder_only, drop_scale):
         lib, cfg = _lib.load(), self._config()
         self._ensure_flat(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -349,14 +478,14 @@ class HSIMAE(nn.Module):
         nbytes = lib.hsimae_workspace_bytes(C.byref(cfg), N, self.len_t, self.len_l)
         if nbytes < 0:
             raise RuntimeError("hsimae_workspace_bytes: unsupported configuration")
-        ws = self._workspace(nbytes + 256, dev, ws_slot)
+        ws = self._pool.lease(nbytes + 256, dev)
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
         loss = torch.empty((), dtype=torch.float32, device=dev)
         mask = torch.empty(N, TL, dtype=torch.float32, device=dev)
         ids_keep = torch.empty(N, K, dtype=torch.int32, device=dev)
         ids_restore = torch.empty(N, TL, dtype=torch.int32, device=dev)
         pred_img = mask_img = None
-        if self.want_recons:
+        if self.want_recons and not encoder_only:
             pred_img = torch.empty(N, 1, imgs.shape[2], 9, 9, dtype=torch.float32, device=dev)
             mask_img = torch.empty_like(pred_img)
         latent = torch.empty(N, K, self.dim, dtype=torch.float32, device=dev) if want_latent else None
@@ -365,65 +494,86 @@ class HSIMAE(nn.Module):
             x=imgs.data_ptr(), sn=imgs.stride(0), sb=imgs.stride(2), sh=imgs.stride(3), sw=imgs.stride(4),
             N=N, len_t=self.len_t, len_l=self.len_l, noise1=n1.data_ptr(), noise2=n2.data_ptr(),
             params=self._flat.data_ptr(), wpk=self._wpk.data_ptr(), workspace=ws_ptr, workspace_bytes=nbytes,
-            grad_scale=1.0 / world, want_recons=int(self.want_recons), loss=loss.data_ptr(),
+            grad_scale=1.0 / world, want_recons=int(pred_img is not None), loss=loss.data_ptr(),
             pred_img=_lib.ptr(pred_img), mask_img=_lib.ptr(mask_img), mask=mask.data_ptr(),
             ids_keep=ids_keep.data_ptr(), ids_restore=ids_restore.data_ptr(), latent=_lib.ptr(latent), pred=None,
-            drop_scale=_lib.ptr(drop_scale))
+            drop_scale=_lib.ptr(drop_scale), bucket_stream=None)
+        state = _FwdState(io=io, keep=(imgs, n1, n2, mask, ids_keep, ids_restore, drop_scale, self._flat, self._wpk),
+                          latent=latent, ids_keep=ids_keep, ids_restore=ids_restore, mask=mask,
+                          _ws=ws, _ws_ref=ws, _gen=ws._hs_gen, _pool=self._pool, grid=(self.len_t, self.len_l))
         if encoder_only:
             _lib.check(lib.hsimae_encode(C.byref(cfg), C.byref(io), stream), "hsimae_encode")
         else:
             _lib.check(lib.hsimae_forward(C.byref(cfg), C.byref(io), stream), "hsimae_forward")
-        state = {"io": io, "keep": (imgs, n1, n2, mask, ids_keep, ids_restore, ws, drop_scale), "latent": latent,
-                 "ids_keep": ids_keep, "ids_restore": ids_restore, "mask": mask}
         if pred_img is None:
             pred_img = torch.empty(0, device=dev)
             mask_img = torch.empty(0, device=dev)
         return loss, pred_img, mask_img, state
 
-    def _run_backward(self, state, g_loss):
+    def _apply_grads(self, scratch, scale, idxs=None, rng=None):
+        """`.grad` semantics for the parameters `idxs` (flat range `rng`): scratch * scale is ASSIGNED where the gradient
+        was cleared (None) and ACCUMULATED where one exists — per parameter, whatever tensor `.grad` currently is."""
+        params, views = self._params_cache, self._grad_views
+        idxs = self._trainable if idxs is None else idxs
+        lo, hi = (0, scratch.numel()) if rng is None else rng
+        cur = [params[i].grad for i in idxs]
+        if all(g is None for g in cur):
+            torch.mul(scratch[lo:hi], scale, out=self._flat_grad[lo:hi])
+            for i in idxs:
+                params[i].grad = views[i]
+        elif all(g is not None and g.data_ptr() == views[i].data_ptr() and g.shape == views[i].shape
+                 for g, i in zip(cur, idxs)):
+            self._flat_grad[lo:hi].addcmul_(scratch[lo:hi], torch.as_tensor(scale, device=scratch.device, dtype=torch.float32))
+        else:                                             # mixed: some cleared, some replaced by the caller
+            for g, i in zip(cur, idxs):
+                o, n = self._offs[i], self._sizes[i]
+                upd = (scratch[o:o + n] * scale).view(params[i].shape)
+                if g is None:
+                    views[i].copy_(upd)
+                    params[i].grad = views[i]
+                else:
+                    g.add_(upd)
+
+    def _call_backward(self, fn, what, state, *args):
+        """Shared driver of the three backward entry points: zeroed scratch, bucket callback, reducer hand-shake."""
+        state.check_alive()
         lib, cfg = _lib.load(), self._config()
         dev = self._flat.device
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        params = self._params_cache
-        scratch = self._flat_scratch
-        scratch.zero_()                       # weight grads are accumulated with atomics
-        red = self._reducer
-        cb = red.make_callback(scratch) if red is not None else _lib.BUCKET_CB(0)
-        _lib.check(lib.hsimae_backward(C.byref(cfg), C.byref(state["io"]), scratch.data_ptr(), cb, None, stream),
-                   "hsimae_backward")
-        if red is not None:
-            red.finish()
-        # chain rule with d/d(loss) handed in by autograd (1.0 for loss.backward()), then .grad semantics:
-        # assign when the grads were cleared, accumulate otherwise.
-        if params[self._trainable[0]].grad is None:
-            torch.mul(scratch, g_loss, out=self._flat_grad)
-            for i in self._trainable:
-                params[i].grad = self._grad_views[i]
-        else:
-            self._flat_grad.addcmul_(scratch, g_loss)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            scratch = self._flat_scratch
+            scratch.zero_()                       # weight grads are accumulated with atomics
+            red = self._reducer
+            io = state["io"]
+            if red is not None:
+                io.bucket_stream = red.launch_stream_handle(dev)
+                cb = red.make_callback(scratch)
+            else:
+                cb = _lib.BUCKET_CB(0)
+                io.bucket_stream = None
+            state["_done"] = True
+            try:
+                _lib.check(fn(C.byref(cfg), C.byref(io), *args, scratch.data_ptr(), cb, None, stream), what)
+            finally:
+                if red is not None:
+                    red.finish()
+        return scratch
 
-    # ------------------------------------------------------------------ public API (reference Models.py:537-634)
-    def forward(self, imgs, mask_ratio=0.75, noise=None, grid=None):
-        """-> (loss, pred [N,1,B,9,9], mask [N,1,B,9,9]).  `noise=(noise_1 [N,T], noise_2 [N,9])` and
-        `grid=(len_t, len_l)` optionally replace the RNG draws (parity tests)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if imgs.is_cuda:
-                self._ensure_flat(imgs.device)
-            anchor = self._anchor if self._anchor is not None else torch.zeros((), requires_grad=True)
-            return _Step.apply(anchor, self, imgs, mask_ratio, noise, grid)
-        loss, pred, mask, _ = self._run_forward(imgs, mask_ratio, noise, grid, want_latent=False)
-        return loss, pred, mask
+    def _run_backward(self, state, g_loss):
+        lib = _lib.load()
+        scratch = self._call_backward(lib.hsimae_backward, "hsimae_backward", state)
+        # chain rule with d/d(loss) handed in by autograd (1.0 for loss.backward())
+        self._apply_grads(scratch, g_loss)
+        state.release()
 
-    def forward_encoder(self, x, mask_ratio, noise=None, grid=None):
-        """-> (latent [N,K,D], mask [N,TL], ids_restore [N,TL] int64, ids_keep [N,K] int64); inference only
-        (Models.py:537-571)."""
-        with torch.no_grad():
-            _, _, _, st = self._run_forward(x, mask_ratio, noise, grid, want_latent=True, encoder_only=True)
-        return st["latent"], st["mask"], st["ids_restore"].long(), st["ids_keep"].long()
+    def _encode_backward(self, state, g_latent):
+        lib = _lib.load()
+        dlat = g_latent.to(torch.float32).contiguous()
+        scratch = self._call_backward(lib.hsimae_encode_backward, "hsimae_encode_backward", state, dlat.data_ptr())
+        self._apply_grads(scratch, 1.0, self._enc_idx, self._enc_range)
+        state.release()
 
-    def forward_decoder(self, x, ids_restore):
-        """latent [N,K,D] + ids_restore [N,TL] -> pred [N,TL,72]; inference only (Models.py:573-601).  K must be the
-        len_t * len_l of the last `forward_encoder` / `forward` call (the kept tokens form that grid)."""
+    def _run_decode(self, x, ids_restore):
         if not x.is_cuda:
             raise RuntimeError("hsimae_amd.HSIMAE runs on MI355X only (no CPU fallback)")
         N, K, D = x.shape
@@ -432,23 +582,36 @@ class HSIMAE(nn.Module):
             raise ValueError("forward_decoder: latent does not match the grid of the last encoder call")
         dev = x.device
         lib, cfg = _lib.load(), self._config()
-        self._ensure_flat(dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        self._ensure_packed(stream)
-        nbytes = lib.hsimae_workspace_bytes(C.byref(cfg), N, self.len_t, self.len_l)
-        ws = self._workspace(nbytes + 256, dev)
-        lat = x.detach().to(torch.float32).contiguous()
-        ids = ids_restore.to(device=dev, dtype=torch.int32).contiguous()
-        pred = torch.empty(N, T * L, 72, dtype=torch.float32, device=dev)
-        io = _lib.IO(N=N, len_t=self.len_t, len_l=self.len_l, params=self._flat.data_ptr(), wpk=self._wpk.data_ptr(),
-                     workspace=(ws.data_ptr() + 255) // 256 * 256, workspace_bytes=nbytes, grad_scale=1.0,
-                     ids_restore=ids.data_ptr())
-        _lib.check(lib.hsimae_decode(C.byref(cfg), C.byref(io), lat.data_ptr(), pred.data_ptr(), stream), "hsimae_decode")
-        return pred
+        with torch.cuda.device(dev):
+            self._ensure_flat(dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            self._ensure_packed(stream)
+            nbytes = lib.hsimae_workspace_bytes(C.byref(cfg), N, self.len_t, self.len_l)
+            ws = self._pool.lease(nbytes + 256, dev)
+            lat = x.detach().to(torch.float32).contiguous()
+            ids = ids_restore.to(device=dev, dtype=torch.int32).contiguous()
+            pred = torch.empty(N, T * L, 72, dtype=torch.float32, device=dev)
+            world = self._reducer.world_size if self._reducer is not None else 1
+            io = _lib.IO(N=N, len_t=self.len_t, len_l=self.len_l, params=self._flat.data_ptr(), wpk=self._wpk.data_ptr(),
+                         workspace=(ws.data_ptr() + 255) // 256 * 256, workspace_bytes=nbytes, grad_scale=1.0 / world,
+                         ids_restore=ids.data_ptr(), bucket_stream=None)
+            state = _FwdState(io=io, keep=(lat, ids, self._flat, self._wpk), _ws=ws, _ws_ref=ws, _gen=ws._hs_gen,
+                              _pool=self._pool, shape=(N, K, D))
+            _lib.check(lib.hsimae_decode(C.byref(cfg), C.byref(io), lat.data_ptr(), pred.data_ptr(), stream), "hsimae_decode")
+        return pred, state
 
-    def forward_loss(self, imgs, pred, mask):
-        """Masked reconstruction loss of pred [N,TL,72] against the cube (Models.py:603-616); inference only.
-        Like the reference it leaves `mean` / `var` (per-token target statistics) for `recons`."""
+    def _decode_backward(self, state, g_pred):
+        lib = _lib.load()
+        N, K, D = state["shape"]
+        dpred = g_pred.to(torch.float32).contiguous()
+        dlat = torch.empty(N, K, D, dtype=torch.float32, device=dpred.device)
+        scratch = self._call_backward(lib.hsimae_decode_backward, "hsimae_decode_backward", state, dpred.data_ptr(),
+                                      dlat.data_ptr())
+        self._apply_grads(scratch, 1.0, self._dec_idx, self._dec_range)
+        state.release()
+        return dlat
+
+    def _run_loss(self, imgs, pred, mask, want_grad=False):
         if not imgs.is_cuda:
             raise RuntimeError("hsimae_amd.HSIMAE runs on MI355X only (no CPU fallback)")
         dev = imgs.device
@@ -459,15 +622,66 @@ class HSIMAE(nn.Module):
         pr = pred.detach().to(torch.float32).reshape(N * TL, 72).contiguous()
         mk = mask.detach().to(torch.float32).reshape(N, TL).contiguous()
         sum_mask = float(mk.sum().item())
-        partial = torch.empty(lib.hsimae_loss_partials(N, T), dtype=torch.float32, device=dev)
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        p = _lib.LossParams(x=imgs.data_ptr(), sn=imgs.stride(0), sb=imgs.stride(2), sh=imgs.stride(3), sw=imgs.stride(4),
-                            N=N, T=T, pred=pr.data_ptr(), mask=mk.data_ptr(), norm_pix=int(bool(self.norm_pix_loss)),
-                            inv_scale=0.0, partial=partial.data_ptr(), loss=loss.data_ptr(), sum_mask=sum_mask)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(lib.hsimae_loss(C.byref(p), stream), "hsimae_loss")
+        with torch.cuda.device(dev):
+            partial = torch.empty(lib.hsimae_loss_partials(N, T), dtype=torch.float32, device=dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            dpred = torch.empty(N * TL, 96, dtype=torch.bfloat16, device=dev) if want_grad else None
+            p = _lib.LossParams(x=imgs.data_ptr(), sn=imgs.stride(0), sb=imgs.stride(2), sh=imgs.stride(3), sw=imgs.stride(4),
+                                N=N, T=T, pred=pr.data_ptr(), mask=mk.data_ptr(), norm_pix=int(bool(self.norm_pix_loss)),
+                                inv_scale=(1.0 / (72.0 * sum_mask)) if want_grad else 0.0, partial=partial.data_ptr(),
+                                loss=loss.data_ptr(), sum_mask=sum_mask, dpred=_lib.ptr(dpred))
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.hsimae_loss(C.byref(p), stream), "hsimae_loss")
         self._last_imgs = imgs
-        return loss
+        return loss, dpred
+
+    def _wants_grad(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    # ------------------------------------------------------------------ public API (reference Models.py:537-634)
+    def forward(self, imgs, mask_ratio=0.75, noise=None, grid=None):
+        """-> (loss, pred [N,1,B,9,9], mask [N,1,B,9,9]).  `noise=(noise_1 [N,T], noise_2 [N,9])` and
+        `grid=(len_t, len_l)` optionally replace the RNG draws (parity tests)."""
+        if self._wants_grad():
+            if imgs.is_cuda:
+                self._ensure_flat(imgs.device)
+            anchor = self._anchor if self._anchor is not None else torch.zeros((), requires_grad=True)
+            return _Step.apply(anchor, self, imgs, mask_ratio, noise, grid)
+        loss, pred, mask, st = self._run_forward(imgs, mask_ratio, noise, grid, want_latent=False)
+        st.release()
+        return loss, pred, mask
+
+    def forward_encoder(self, x, mask_ratio, noise=None, grid=None):
+        """-> (latent [N,K,D], mask [N,TL], ids_restore [N,TL] int64, ids_keep [N,K] int64)  (Models.py:537-571).
+        Differentiable w.r.t. the encoder's parameters (hsimae_encode_backward)."""
+        if self._wants_grad():
+            if x.is_cuda:
+                self._ensure_flat(x.device)
+            anchor = self._anchor if self._anchor is not None else torch.zeros((), requires_grad=True)
+            return _EncodeFn.apply(anchor, self, x, mask_ratio, noise, grid)
+        _, _, _, st = self._run_forward(x, mask_ratio, noise, grid, want_latent=True, encoder_only=True)
+        st.release()
+        return st["latent"], st["mask"], st["ids_restore"].long(), st["ids_keep"].long()
+
+    def forward_decoder(self, x, ids_restore):
+        """latent [N,K,D] + ids_restore [N,TL] -> pred [N,TL,72]  (Models.py:573-601).  K must be the len_t * len_l of the
+        last `forward_encoder` / `forward` call (the kept tokens form that grid).  Differentiable w.r.t. the latent and
+        the decoder's parameters (hsimae_decode_backward)."""
+        if self._wants_grad() or (torch.is_grad_enabled() and x.requires_grad):
+            if x.is_cuda:
+                self._ensure_flat(x.device)
+            anchor = self._anchor if self._anchor is not None else torch.zeros((), requires_grad=True)
+            return _DecodeFn.apply(anchor, x, self, ids_restore)
+        pred, st = self._run_decode(x, ids_restore)
+        st.release()
+        return pred
+
+    def forward_loss(self, imgs, pred, mask):
+        """Masked reconstruction loss of pred [N,TL,72] against the cube (Models.py:603-616); differentiable w.r.t. pred.
+        Like the reference it leaves `mean` / `var` (per-token target statistics) for `recons`."""
+        if torch.is_grad_enabled() and pred.requires_grad:
+            return _LossFn.apply(pred, self, imgs, mask)
+        return self._run_loss(imgs, pred, mask)[0]
 
     @property
     def mean(self):
@@ -487,11 +701,11 @@ class HSIMAE(nn.Module):
         return mask, self.unpatchify(pred)
 
     # ------------------------------------------------------------------ data parallel (not in the reference)
-    def enable_data_parallel(self, process_group=None, bucket_bytes=4 << 20, broadcast=True):
+    def enable_data_parallel(self, process_group=None, bucket_bytes=4 << 20, broadcast=True, force_collectives=False):
         """One process per GPU: average gradients over the group with bucketed RCCL all-reduce launched from
         inside the backward schedule (overlapped with the remaining backward kernels)."""
         from .parallel import GradReducer
-        self._reducer = GradReducer(process_group, bucket_bytes)
+        self._reducer = GradReducer(process_group, bucket_bytes, force_collectives)
         if broadcast:
             dev = next(self.parameters()).device
             if dev.type == "cuda":

@@ -30,10 +30,38 @@ def seed_everything(seed):
     random.seed(seed)
 
 
+def dp_context(device):
+    """(rank, world, device) of this process.  Under `torch.distributed.run` (RANK / WORLD_SIZE / LOCAL_RANK in the
+    environment, or an initialised process group) the job is data parallel, one process per GPU, RCCL: the process group
+    is created here if the launcher has not done it, and the device becomes cuda:LOCAL_RANK."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), device
+    if world <= 1:
+        return 0, 1, device
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    if torch.device(device).type == "cuda":
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, world, device
+
+
 def mask_pretraining(data_cubes, save_path, model_name, img_size=9, bands=32, mask_ratio=0.50, lr=5e-3, wd=5e-2, bs=512,
                      epochs=100, depth=12, dim=64, s_depth=6, dec_dim=48, dec_depth=2, resume_path=None, device="cuda:0",
                      log=print):
+    """`bs` is the GLOBAL batch, as in the reference; under a data-parallel launch each rank takes bs / world cubes of every
+    batch (same permutation and python-random stream on every rank), gradients are averaged with the bucketed RCCL
+    all-reduce overlapped with the backward (hsimae_amd/parallel.py), and rank 0 writes the files."""
     device = torch.device(device)
+    rank, world, device = dp_context(device)
+    if bs % world:
+        raise ValueError(f"global batch {bs} is not divisible by the {world} ranks")
     train_dataset = HSIdataset4PT(data_cubes, train=True, device=device)
     del data_cubes
     log(f"dataset load finished: {len(train_dataset)} cubes; net {[dim, depth, dec_dim, dec_depth]}")
@@ -42,9 +70,12 @@ def mask_pretraining(data_cubes, save_path, model_name, img_size=9, bands=32, ma
                    embed_dim=dim, depth=depth, num_heads=dim // 16, s_depth=s_depth,
                    decoder_embed_dim=dec_dim, decoder_depth=dec_depth, decoder_num_heads=dec_dim // 8,
                    norm_pix_loss=True, trunc_init=True).to(device)
-    os.makedirs(save_path, exist_ok=True)
+    if world > 1:
+        model.enable_data_parallel()                    # broadcasts rank 0's initial weights
+    if rank == 0:
+        os.makedirs(save_path, exist_ok=True)
 
-    train_dataload = DeviceLoader(train_dataset, batch_size=bs, shuffle=True)
+    train_dataload = DeviceLoader(train_dataset, batch_size=bs // world, shuffle=True, rank=rank, world=world)
     optimizer = FusedAdamW(model, lr=lr, weight_decay=wd, betas=(0.9, 0.95))
     iters = epochs * len(train_dataload)
     scheduler = CosineLRScheduler(optimizer, t_initial=iters, lr_min=1e-6, warmup_t=int(np.ceil(iters * 0.05)))
@@ -67,8 +98,15 @@ def mask_pretraining(data_cubes, save_path, model_name, img_size=9, bands=32, ma
             scheduler.step(iter_num)
             iter_num += 1
             train_loss += loss.item()
-        epoch_loss_list.append(train_loss / len(train_dataload))
-        if resume_path is not None:
+        epoch_loss = train_loss / len(train_dataload)
+        if world > 1:                                   # logging only: mean of the ranks' epoch means
+            import torch.distributed as dist
+            t = torch.tensor([epoch_loss], dtype=torch.float64, device=device)
+            dist.all_reduce(t)
+            epoch_loss = float(t.item()) / world
+        epoch_loss_list.append(epoch_loss)
+        if resume_path is not None and rank == 0:
             save_resume(resume_path, model, optimizer, scheduler, epoch + 1, iter_num, epoch_loss_list, device)
-    save_final(model, save_path, model_name, epoch_loss_list, val_loss_list)
+    if rank == 0:
+        save_final(model, save_path, model_name, epoch_loss_list, val_loss_list)
     return model, epoch_loss_list

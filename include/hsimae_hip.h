@@ -8,8 +8,16 @@
  *
  * Contract
  *  - every pointer is device memory owned by the caller (PyTorch tensors); the library never
- *    allocates, frees or retains device memory and keeps no global mutable state;
- *  - all work is enqueued on the caller's `stream` (hipStream_t passed as void*), no implicit sync;
+ *    allocates, frees or retains device memory;
+ *  - process-wide state is limited to (a) per DEVICE, created on first use and kept for the life of the process:
+ *    one non-blocking side stream that runs the spectral axis stack next to the spatial one, plus a small pool of
+ *    timing-disabled events (fork / join, one per gradient range handed to the bucket callback) — the whole-pass
+ *    entry points look them up by the device that is current when they are called, so the caller must make the
+ *    device of its pointers current (HSIMAE_TWO_STREAMS=0 keeps everything on the caller's stream); (b) the cached
+ *    values of the HSIMAE_* environment switches (kernel-generation A/B switches for tests, read once);
+ *  - all work is enqueued on the caller's `stream` (hipStream_t passed as void*) or on the side stream, which is
+ *    forked from and joined back into it with events inside the same call: no implicit sync, nothing outlives the
+ *    caller's stream order;
  *  - return 0 on success; <0 argument errors (HSIMAE_E*); >0 a hipError_t from the launch.
  *    Nothing throws or exits across the boundary.  hsimae_strerror() names a code.
  *  - bf16 buffers are raw 16-bit words (`hs_bf16`); activation buffers that feed a GEMM as its
@@ -53,7 +61,14 @@ typedef struct {
     int32_t hidden;         /* SwiGLU hidden of the encoder blocks (Models.py:225) */
     int32_t dec_hidden;
     int32_t norm_pix_loss;
+    int32_t precision;      /* HSIMAE_PREC_BF16 (0) or HSIMAE_PREC_FP8: operand type of the encoder linears (see below) */
 } hsimae_config;
+/* precision: BF16 = bf16 MFMA operands everywhere.  FP8 = the encoder blocks' linears (q|k|v, proj, w1|w3, w2 and their
+ * data gradients) run on the MX block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4) with OCP e4m3 operands: weights are
+ * quantised at pack time, activations as they are staged, both with one e8m0 scale per 32 consecutive K elements (MX),
+ * fp32 accumulate; weight gradients, attention, LayerNorm, the decoder and the loss stay as in BF16.  fp32 masters and the
+ * state_dict are untouched. */
+enum { HSIMAE_PREC_BF16 = 0, HSIMAE_PREC_FP8 = 1 };
 
 /* Flat fp32 parameter buffer: parameters in `named_parameters()` registration order
  * (Models.py:342-424), each contiguous, no padding.  Returns the number of parameter tensors;
@@ -99,6 +114,11 @@ typedef struct {
        every encoder block, [n_enc_blocks][2][N*K] fp32 in execution order blocks_1[0..], blocks_2[0..], blocks[0..];
        x += scale * branch(x).  NULL = no DropPath.  Must be the same array in forward and backward. */
     const float* drop_scale;
+    /* optional (hsimae_backward / hsimae_encode_backward with a bucket callback): the stream the callback's consumer
+       launches its collectives from.  Before each callback the library makes this stream wait (event) for the kernels that
+       complete the reported range — including the ones on the side stream — so the ranges of the two axis stacks are
+       reported block by block instead of after the join.  NULL: ranges are reported once they are complete on `stream`. */
+    void* bucket_stream;
 } hsimae_io;
 
 int64_t hsimae_workspace_bytes(const hsimae_config* cfg, int32_t N, int32_t len_t, int32_t len_l);
@@ -275,6 +295,12 @@ int hsimae_agg_pool(const float* latent, float* pooled, int32_t N, int32_t T, in
  * (the output of `norm`) -> pred [N*T*9, 72] fp32.  io supplies N, len_t, len_l (K = len_t*len_l), ids_restore, params,
  * wpk and the workspace, as for hsimae_forward. */
 int hsimae_decode(const hsimae_config* cfg, const hsimae_io* io, const float* latent, float* pred, void* stream);
+/* Backward of hsimae_decode (autograd of Models.py:573-601 for callers that compose forward_encoder / forward_decoder /
+ * forward_loss themselves, e.g. Models.py:975-993): dpred [N*T*9, 72] fp32 is dL/d(pred); the activations hsimae_decode
+ * left in io->workspace are consumed.  Writes dlatent [N*K, D] fp32 (dL/d(latent), the input of hsimae_decode) and
+ * accumulates the decoder's parameter gradients into `grads` (flat layout; encoder entries are not touched). */
+int hsimae_decode_backward(const hsimae_config* cfg, const hsimae_io* io, const float* dpred, float* dlatent, float* grads,
+                           hsimae_bucket_cb cb, void* user, void* stream);
 
 /* ------------------------------------------------------------------ next row N2: input pipeline */
 /* One batch of training cubes assembled on the device from HBM-resident scenes (Model_Pretraining.py:40-51

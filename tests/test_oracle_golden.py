@@ -183,3 +183,58 @@ def test_trajectory_10_adamw_steps():
         loss, _, _ = O.forward(params, cfg, x, z[f"n1_{i}"], z[f"n2_{i}"], lt, ll)
         opt.zero_grad(); loss.backward(); opt.step()
         assert abs(loss.item() - ref) <= 1e-5 * abs(ref), (i, loss.item(), ref)
+
+
+def _construct_state(seed, bands=48):
+    """The reference's weights right after construction under `seed`: hsimae_amd.HSIMAE's constructor consumes the
+    init RNG exactly like the reference (pinned by init_checksums.json) and runs on CPU (parameter containers only)."""
+    import contextlib
+    import io
+    from hsimae_amd import HSIMAE
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=bands, b_patch_size=8, embed_dim=128, depth=12, num_heads=8,
+                   s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8, norm_pix_loss=True, trunc_init=True)
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def test_c1_config1_reference_scale_fixture_n64():
+    """BASELINE.json configs[0] exactly (Base, 48 bands, batch 64, reference weight scale): oracle vs the reference's record."""
+    s = json.load(open(os.path.join(G, "c1_refscale.json")))
+    z = np.load(os.path.join(G, "c1_refscale.npz"))
+    cfg = O.OracleConfig(bands=48)
+    assert (s["N"], s["len_t"], s["len_l"]) == (64, 2, 7) and len(s["grad_l2"]) == 532
+    P = _construct_state(s["model_seed"])
+    torch.manual_seed(s["x_seed"])
+    x = torch.rand(s["N"], 1, 48, 9, 9)
+    taps = {}
+    loss, pred, mimg, grads = O.forward_backward(P, cfg, x, z["noise_1"], z["noise_2"], 2, 7, taps)
+    assert abs(loss.item() - s["loss_fp32"]) <= 2e-6 * s["loss_fp32"]
+    keep, _, _ = O.mask_from_noise(z["noise_1"], z["noise_2"], 2, 7)
+    assert np.array_equal(keep, z["ids_keep"].astype(np.int64))
+    np.testing.assert_allclose(taps["latent"][:4].detach().numpy(), z["latent"], rtol=0, atol=2e-5)
+    for k, ref in s["grad_l2"].items():
+        assert abs(float(grads[k].double().norm()) - ref) <= 2e-4 * max(ref, 1e-6) + 1e-9, k
+    np.testing.assert_allclose(grads["blocks.0.mlp.w2.weight"].numpy(), z["g_blocks0_w2"], rtol=0, atol=2e-5 * np.abs(z["g_blocks0_w2"]).max())
+
+
+def test_c1_config1_trajectory_10_adamw_steps():
+    meta = json.load(open(os.path.join(G, "c1_trajectory.json")))
+    z = np.load(os.path.join(G, "c1_trajectory.npz"))
+    cfg = O.OracleConfig(bands=48)
+    P = _construct_state(meta["model_seed"])
+    torch.manual_seed(meta["x_seed"])
+    x = torch.rand(meta["N"], 1, 48, 9, 9)
+    nd = ["bias", "norm"]
+    names = list(P.keys())
+    params = {k: torch.nn.Parameter(P[k]) for k in names}
+    for k in ("pos_embed", "decoder_pos_embed"):
+        params[k].requires_grad_(False)
+    groups = [{"params": [params[n] for n in names if not any(k in n for k in nd)], "weight_decay": meta["wd"]},
+              {"params": [params[n] for n in names if any(k in n for k in nd)], "weight_decay": 0.0}]
+    opt = torch.optim.AdamW(groups, lr=meta["lr"], weight_decay=meta["wd"], betas=tuple(meta["betas"]))
+    for i, ref in enumerate(meta["losses"][:4]):          # 4 of the 10 steps keep the CPU suite short; the GPU test runs all 10
+        lt, ll = meta["grids"][i]
+        loss, _, _ = O.forward(params, cfg, x, z[f"n1_{i}"], z[f"n2_{i}"], lt, ll)
+        opt.zero_grad(); loss.backward(); opt.step()
+        assert abs(loss.item() - ref) <= 2e-5 * abs(ref), (i, loss.item(), ref)
