@@ -410,8 +410,7 @@ class HSIMAE(nn.Module):
         self._grad_views = [self._flat_grad[o: o + s].view(p.shape) for o, s, p in zip(self._offs, self._sizes, params)]
         self._trainable = [i for i, p in enumerate(params) if p.requires_grad and i != 1]   # 1 = mask_token (never used)
         # the encoder's / decoder's parameters are two contiguous ranges of the flat buffer (stand-alone backward passes)
-        names = [n_ for n_, _ in self.named_parameters() if not n_.startswith("cls_head.")]
-        dec0 = names.index("decoder_embed.weight")
+        dec0 = next(i for i, p in enumerate(params) if p is self.norm.bias) + 1       # decoder_embed.weight follows norm.bias
         self._enc_idx = [i for i in self._trainable if i < dec0]
         self._dec_idx = [i for i in self._trainable if i >= dec0]
         self._enc_range = (self._offs[self._enc_idx[0]], self._offs[dec0])

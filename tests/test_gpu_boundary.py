@@ -73,7 +73,7 @@ def _check_against_summary(s, z, m, x, loss_gate, norm_gate):
     for k, ref in s["grad_l2"].items():
         got = float(named[k].grad.double().norm())
         if k.endswith("attn.k.bias"):            # true gradient is exactly zero: the reference holds rounding noise only
-            assert got <= 50 * ref + 1e-6, k
+            assert got <= 5e-2 * s["grad_l2"][k.replace(".k.bias", ".q.bias")] + 1e-7, k
             continue
         e = abs(got - ref) / max(ref, 1e-12)
         if e > worst[1]:
