@@ -548,10 +548,13 @@ def main():
             out["input_pipeline"] = input_pipeline_ms(bands, N)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(bands)
+        C.CDLL(None).fflush(None)          # RCCL's banner sits in the C stdio buffer: flush it so the JSON is the LAST line
         print(json.dumps(out), flush=True)
     if use_ddp:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    C.CDLL(None).fflush(None)
 
 
 if __name__ == "__main__":

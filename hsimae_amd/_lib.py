@@ -116,6 +116,7 @@ SYMBOLS = {
     "hsimae_mask_from_noise": (C.c_int, [C.POINTER(MaskParams), vp]),
     "hsimae_patch_gather": (C.c_int, [C.POINTER(PatchParams), vp]),
     "hsimae_gemm": (C.c_int, [C.POINTER(GemmParams), i32, i32, vp]),
+    "hsimae_gemm_tiled": (C.c_int, [C.POINTER(GemmParams), i32, i32, i32, i32, vp]),
     "hsimae_pack_matrix": (C.c_int, [vp, i32, i32, vp]),
     "hsimae_enc_mlp_fwd": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(MlpWeights), vp, vp]),
     "hsimae_enc_mlp_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(MlpWeights), vp, vp, vp, vp, vp]),

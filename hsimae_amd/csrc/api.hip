@@ -856,6 +856,9 @@ int hsimae_patch_gather(const hsimae_patch_params* p, void* stream) { return p ?
 int hsimae_gemm(const hsimae_gemm_params* p, int32_t a_kind, int32_t epilogue, void* stream) {
     return p ? hs_gemm(*p, a_kind, epilogue, S(stream)) : HSIMAE_ENULL;
 }
+int hsimae_gemm_tiled(const hsimae_gemm_params* p, int32_t a_kind, int32_t epilogue, int32_t bm, int32_t kc, void* stream) {
+    return p ? hs_gemm_tiled(*p, a_kind, epilogue, bm, kc, S(stream)) : HSIMAE_ENULL;
+}
 int hsimae_pack_matrix(const hsimae_pack_desc* d, int32_t n, int32_t max_elems, void* stream) {
     return d ? hs_pack(d, n, max_elems, S(stream)) : HSIMAE_ENULL;
 }

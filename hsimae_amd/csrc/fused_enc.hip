@@ -36,12 +36,16 @@ extern "C" int hsimae_debug_phases_enc(unsigned long long* out, int reset) {
 
 namespace {
 
-constexpr int R = 48, MH = 2, NTH = 256;   // 48-row panels: three 4-wave workgroups per CU, 2304 = 3 x 768 workgroups at M = 110,592
+constexpr int MH = 2, NTH = 256;
 constexpr int LC = 64 + 8;         // 64-column chunk image row stride
 
-// Geometry for model width D and padded hidden width HP (multiples of 64 / 32).
-template <int D, int HP>
+// Geometry for model width D, padded hidden width HP (multiples of 64 / 32) and R_-row panels.
+//   D = 128: 48-row panels, three 4-wave workgroups per CU (2304 = 3 x 768 workgroups at M = 110,592)
+//   D = 256: 48-row panels, two workgroups per CU (the weight fragments of a 64-column hidden chunk are 64 / 96 registers)
+template <int D, int HP, int R_ = 48>
 struct MG {
+    static constexpr int R = R_;
+    static constexpr int WPC = D <= 128 ? 3 : 2;            // workgroups per CU the kernels are compiled for
     static constexpr int LU = D + 8;            // bf16 panel row stride (elements)
     static constexpr int LX = D + 4;            // fp32 staging row stride (floats)
     static constexpr int LG = HP + 8;           // gate image row stride
@@ -51,10 +55,15 @@ struct MG {
     static constexpr int KSH = HP / 32;         // k-steps over the hidden width
     static constexpr int LPR = D / 8;           // lanes per row in the wide layout
     static constexpr int KA = KSH > 6 ? 6 : KSH, KB = KSH - KA;
-    static constexpr int LDS_FWD = R * LU * 2 + 2 * R * LC * 2 + R * LX * 4;
+    // forward: the panel's fp32 copy (residual) is kept in LDS at D = 128 only; wider panels re-read x1 (L2-hot) instead
+    static constexpr bool KEEP_XR = D <= 128;
+    static constexpr int LDS_FWD_IMG = R * LU * 2 + 2 * R * LC * 2;
+    static constexpr int LDS_FWD = (LDS_FWD_IMG > R * LX * 4 ? LDS_FWD_IMG : R * LX * 4) + (KEEP_XR ? R * LX * 4 : 0);
     static constexpr int LDS_BWD = 2 * R * LU * 2 + 3 * R * LC * 2;
-    static_assert(R * LG * 2 >= R * LX * 4, "gate image region must hold the fp32 staging tile");
-    static_assert(R * LU * 2 + 3 * R * LC * 2 >= R * LX * 4, "dY panel + chunk images must hold the fp32 staging tile");
+    // backward: the fp32 tile of du2 goes over the dY panel + chunk images when they are large enough (D = 128), else
+    // over the whole arena (the U2 panel is dead by then)
+    static constexpr bool XS_AT_DY = R * LU * 2 + 3 * R * LC * 2 >= R * LX * 4;
+    static_assert(LDS_BWD >= R * LX * 4, "the arena must hold the fp32 staging tile");
     static_assert(2 * R * LU * 2 >= 2 * NTH * 8 * 4, "reduction scratch must fit in the two panels");
 };
 
@@ -141,8 +150,9 @@ struct EncMlpFwdArgs { const float* x1; const float* res2; float* x2; int M; Enc
 // 46-KB panel image) and the residual is added from an L2-hot re-read in the store loop, so a workgroup needs 36 KB of
 // LDS and ~150 registers: three workgroups per CU instead of two.
 template <int D, int HPE>
-__global__ __launch_bounds__(NTH, 3) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
+__global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     using G = MG<D, HPE>;
+    constexpr int R = G::R;
     constexpr int LU = G::LU, LX = G::LX, NCH = G::NCH, KSD = G::KSD, LPR = G::LPR;
     constexpr int MT4 = R / 16;                         // every wave covers all m-tiles of the panel
     constexpr int NJO = D / 64;                         // output n-tiles per wave (D / 16 over 4 waves)
@@ -150,9 +160,8 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Gc = U2 + R * LU;                           // two chunk images [64][LC]
     float* XS = reinterpret_cast<float*>(smem);         // fp32 store tile over U2 | Gc once the products are done
-    float* XR = reinterpret_cast<float*>(smem + R * LU * 2 + 2 * R * LC * 2);   // the panel's x1 in fp32: the residual (25 KB; a re-read from
-                                                                               // L2 missed: 57 MB of extra fetches per launch)
-    static_assert(R * LU * 2 + 2 * R * LC * 2 >= R * LX * 4, "store tile must fit over the panel + chunk images");
+    float* XR = reinterpret_cast<float*>(smem + (G::LDS_FWD_IMG > R * LX * 4 ? G::LDS_FWD_IMG : R * LX * 4));   // the panel's x1 in fp32: the
+                                                // residual (25 KB at D = 128; a re-read from L2 missed: 57 MB of extra fetches per launch)
     const G8 q = geo8();
     const int row0 = blockIdx.x * R;
     const EncMlpW& w = p.w;
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
         for (int i = 0; i < NI; ++i) {
             const int pc = threadIdx.x + NTH * i, row = pc / LPR;
             float (&f)[8] = fa[i];
-            st8(XR + row * LX + c8, f);
+            if constexpr (G::KEEP_XR) st8(XR + row * LX + c8, f);
             const float mean = redrow<LPR>(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
             float v = 0.f;
 #pragma unroll
@@ -274,7 +283,8 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
         if (row0 + row < p.M) {
             float f[8], t[8];
             ld8(XS + row * LX + c8, f);
-            ld8(XR + row * LX + c8, t);                                // residual from the panel's fp32 copy
+            if constexpr (G::KEEP_XR) ld8(XR + row * LX + c8, t);     // residual from the panel's fp32 copy
+            else ld8(p.x1 + (size_t)(row0 + row) * D + c8, t);         // ... or from an L2-hot re-read
             const float rs = p.rowscale ? p.rowscale[row0 + row] : 1.f;   // DropPath: x1 + scale * mlp(x1)
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], rs, t[e]);
@@ -300,8 +310,9 @@ struct EncMlpBwdArgs {
 };
 
 template <int D, int HPE>
-__global__ __launch_bounds__(NTH, 3) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
+__global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     using G = MG<D, HPE>;
+    constexpr int R = G::R;
     constexpr int LU = G::LU, LX = G::LX, NCH = G::NCH, KSD = G::KSD, KSH = G::KSH, LPR = G::LPR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     bf16_t* DH1 = DYb + R * LU;
     bf16_t* DH3 = DH1 + R * LC;
     bf16_t* Gc = DH3 + R * LC;
-    float* XS = reinterpret_cast<float*>(DYb);           // after the chunk loop: fp32 tile of du2
+    float* XS = reinterpret_cast<float*>(G::XS_AT_DY ? reinterpret_cast<char*>(DYb) : smem);   // after the chunk loop: fp32 tile of du2
     const G8 q = geo8();
     const int row0 = blockIdx.x * R;
     const EncMlpW& w = p.w;
@@ -539,7 +550,8 @@ __global__ __launch_bounds__(NTH, 3) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
 static int hp_of(int hidden) { return (hidden + 31) / 32 * 32; }
 
 bool hs_enc_mlp_fused_supported(int d, int hidden) {
-    return d == 128 && hp_of(hidden) == 352;      // the kernels are templates on <D, HP>; only Base is instantiated
+    // the kernels are templates on <D, HP>: Base (128, 344 -> 352) and Large (256, 684 -> 704) are instantiated
+    return (d == 128 && hp_of(hidden) == 352) || (d == 256 && hp_of(hidden) == 704);
 }
 
 static EncMlpW mkw(const EncMlpPtrs& b) {
@@ -563,8 +575,13 @@ int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, 
     if (M <= 0) return HS_OK;
     EncMlpFwdArgs a; a.x1 = x1; a.res2 = res2; a.x2 = x2; a.M = M; a.w = mkw(b); a.rowscale = rowscale;
     if (d == 128) {
+        constexpr int R = MG<128, 352>::R;
         set_attrs<128, 352>();
         hipLaunchKernelGGL((enc_mlp_fwd_kernel<128, 352>), dim3((M + R - 1) / R), dim3(NTH), (MG<128, 352>::LDS_FWD), s, a);
+    } else if (d == 256) {
+        constexpr int R = MG<256, 704>::R;
+        set_attrs<256, 704>();
+        hipLaunchKernelGGL((enc_mlp_fwd_kernel<256, 704>), dim3((M + R - 1) / R), dim3(NTH), (MG<256, 704>::LDS_FWD), s, a);
     } else {
         return HS_EUNSUPPORTED;
     }
@@ -578,8 +595,13 @@ int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs
     EncMlpBwdArgs a; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.u2 = u2; a.dh13 = dh13; a.g = g; a.M = M; a.w = mkw(b);
     a.g_n2w = g_n2w; a.g_n2b = g_n2b; a.dyb = dyb; a.dx1b = dx1b; a.rs_mlp = rs_mlp; a.rs_attn = rs_attn;
     if (d == 128) {
+        constexpr int R = MG<128, 352>::R;
         set_attrs<128, 352>();
         hipLaunchKernelGGL((enc_mlp_bwd_kernel<128, 352>), dim3((M + R - 1) / R), dim3(NTH), (MG<128, 352>::LDS_BWD), s, a);
+    } else if (d == 256) {
+        constexpr int R = MG<256, 704>::R;
+        set_attrs<256, 704>();
+        hipLaunchKernelGGL((enc_mlp_bwd_kernel<256, 704>), dim3((M + R - 1) / R), dim3(NTH), (MG<256, 704>::LDS_BWD), s, a);
     } else {
         return HS_EUNSUPPORTED;
     }

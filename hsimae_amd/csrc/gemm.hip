@@ -14,6 +14,7 @@
 // access; the first version's per-element 2-byte stores made every GEMM store-issue bound (profiles/).
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 // Per-phase cycle accounting for scripts/phase_timing.py (compiled only with -DHS_PHASE_TIMING; never in the shipped library)
 #ifdef HS_PHASE_TIMING
@@ -34,13 +35,15 @@ extern "C" int hsimae_debug_phases_gemm(unsigned long long* out, int reset) {
 
 namespace {
 
-constexpr int BM = 128;
 template <int KC> struct EpiRows { static constexpr int v = KC >= 512 ? 16 : 32; };   // rows per epilogue pass (LDS budget at K = 512)
 constexpr int TS = 132;            // fp32 LDS tile row stride (floats): conflict-free b32 writes
 
-template <int AK, int EPI, int KC>
-__global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(GemmParams p) {
+// BM: rows per workgroup.  128 (one workgroup per CU) for the narrow layers, where the weight stream per panel is small;
+// 64 (two to three workgroups per CU, so that one panel's staging / epilogue overlaps another's MFMA loop) for K >= 256.
+template <int AK, int EPI, int KC, int BM>
+__global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = BM / 16;
     constexpr int LDA = KC + 8;                       // LDS row stride (elements): 16-B pad => conflict-free b128 reads
     constexpr bool DUAL = (EPI == E_SWIGLU);
     constexpr int PR = EpiRows<KC>::v;
@@ -184,10 +187,10 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
     PH_DECL
 
     for (int nc = 0; nc < n_chunks; ++nc) {
-        f32x4 acc[8][2];
-        f32x4 acc2[DUAL ? 8 : 1][2];
+        f32x4 acc[MT][2];
+        f32x4 acc2[DUAL ? MT : 1][2];
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
                     const int ks = gb + i;
                     if (ks < nks) {
 #pragma unroll
-                        for (int mt = 0; mt < 8; ++mt) {
+                        for (int mt = 0; mt < MT; ++mt) {
                             const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (mt * 16 + arow) * LDA + ks * 32 + ag * 8);
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
@@ -442,39 +445,73 @@ __global__ __launch_bounds__(256, EPI == E_LN_BWD ? 2 : 1) void gemm_kernel(Gemm
     PH_FLUSH(((AK * 3 + (EPI == E_LN_BWD ? 2 : (EPI == E_BF16 ? 0 : 1))) * 4) % 64)
 }
 
-template <int AK, int EPI, int KC>
+template <int AK, int EPI, int KC, int BM>
 int launch(const GemmParams& p, hipStream_t s) {
     const int grid = (p.M + BM - 1) / BM;
     const size_t lds = (size_t)BM * (KC + 8) * 2 + BM * 2 * sizeof(float) + (EPI == E_SWIGLU ? 2 : 1) * EpiRows<KC>::v * TS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<AK, EPI, KC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<AK, EPI, KC, BM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<AK, EPI, KC>), dim3(grid), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_kernel<AK, EPI, KC, BM>), dim3(grid), dim3(256), lds, s, p);
     return (int)hipGetLastError();
+}
+
+// Tiling of the wide layers, from scripts/gemm_sweep.py at the Large / Huge shapes (profiles/r02_gemm_sweep.txt):
+// 64-row panels (two to three workgroups per CU: one panel's staging / epilogue overlaps another's MFMA loop) win
+// wherever the weight image is small enough that streaming it once per 64 rows instead of once per 128 costs less than
+// the overlap gains: q|k|v at d = 256 235 -> 175 us, gate backward 461 -> 216 us; they lose at d = 512 when K is deep
+// (w2 303 -> 355 us).  256-deep A chunks pay only together with 64-row panels (alone: 1.3-1.7x slower).
+// HSIMAE_GEMM_WIDE=0 keeps the 128-row / 128-deep form everywhere (A/B runs).
+static int wide_mode() {
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("HSIMAE_GEMM_WIDE"); m = e ? atoi(e) : 1; }
+    return m;
+}
+static thread_local int g_force_bm = 0, g_force_kc = 0;       // hsimae_gemm_tiled (tile sweeps): 0 = the shape rule below
+static bool small_weights(const GemmParams& p, bool dual) {
+    const int64_t nk = (int64_t)p.N * p.K;
+    if (p.K < 256) return false;
+    if (dual) return nk <= 400 * 1024;
+    return p.K <= 512 ? nk <= 800 * 1024 : nk <= 400 * 1024;
 }
 
 template <int AK, int EPI>
 int launch_kc(const GemmParams& p, hipStream_t s) {
+    bool bm64 = wide_mode() && small_weights(p, EPI == E_SWIGLU);
+    if (g_force_bm) bm64 = g_force_bm == 64;
     if constexpr (AK == A_F32_LN) {
-        if (p.K <= 128) return launch<AK, EPI, 128>(p, s);
-        if (p.K <= 256) return launch<AK, EPI, 256>(p, s);
-        if (p.K <= 512) return launch<AK, EPI, 512>(p, s);
+        if (p.K <= 128) return launch<AK, EPI, 128, 128>(p, s);
+        if (p.K <= 256) return bm64 ? launch<AK, EPI, 256, 64>(p, s) : launch<AK, EPI, 256, 128>(p, s);
+        if (p.K <= 512) return bm64 ? launch<AK, EPI, 512, 64>(p, s) : launch<AK, EPI, 512, 128>(p, s);
         return HS_EUNSUPPORTED;
+    } else if constexpr (EPI == E_LN_BWD) {
+        return launch<AK, EPI, 128, 128>(p, s);
     } else {
-        return launch<AK, EPI, 128>(p, s);
+        const bool kc256 = g_force_kc ? g_force_kc == 256 : (bm64 && p.K >= 256 && p.K <= 1024);
+        if (kc256) return bm64 ? launch<AK, EPI, 256, 64>(p, s) : launch<AK, EPI, 256, 128>(p, s);
+        return bm64 ? launch<AK, EPI, 128, 64>(p, s) : launch<AK, EPI, 128, 128>(p, s);
     }
 }
 
 }  // namespace
 
+int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s);
+int hs_gemm_tiled(const GemmParams& p, int akind, int epi, int bm, int kc, hipStream_t s) {
+    if ((bm != 0 && bm != 64 && bm != 128) || (kc != 0 && kc != 128 && kc != 256)) return HS_EDIMS;
+    g_force_bm = bm; g_force_kc = kc;
+    const int rc = hs_gemm(p, akind, epi, s);
+    g_force_bm = 0; g_force_kc = 0;
+    return rc;
+}
+
 int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s) {
     if (p.M <= 0) return HS_OK;
     if (p.K % 32 || p.N % 16 || p.lda % 8 || p.ldo % 8) return HS_EDIMS;
     if ((epi == E_F32 || epi == E_RES_F32 || epi == E_POS_F32) && p.n_valid % 8) return HS_EDIMS;
-    if (akind == A_F32_LN && epi == E_BF16 && hs_lnqkv_supported(p)) return hs_lnqkv(p, s);   // persistent LN1 + q|k|v (gemm_dma.hip)
+    if (akind == A_F32_LN && epi == E_BF16 && !g_force_bm && hs_lnqkv_supported(p)) return hs_lnqkv(p, s);   // persistent LN1 + q|k|v (gemm_dma.hip)
 #define CASE(AK, EP) \
     if (akind == AK && epi == EP) return launch_kc<AK, EP>(p, s);
     CASE(A_F32_LN, E_BF16)

@@ -22,6 +22,7 @@ typedef hsimae_loss_params LossParams;
 typedef hsimae_cube_params CubeParams;
 
 int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s);
+int hs_gemm_tiled(const GemmParams& p, int akind, int epi, int bm, int kc, hipStream_t s);   // tile sweep hook
 bool hs_lnbwd_dma_supported(const GemmParams& p);     // persistent LDS-DMA form of (A_BF16, E_LN_BWD) at N = 128, K = 384
 int hs_lnbwd_dma(const GemmParams& p, hipStream_t s);
 bool hs_lnqkv_supported(const GemmParams& p);          // persistent form of (A_F32_LN, E_BF16) at K = 128, N = 384

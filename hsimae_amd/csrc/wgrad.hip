@@ -85,21 +85,34 @@ __device__ __forceinline__ void store_rows(const RowRegs& rr, bool f32, bf16_t* 
     }
 }
 
+// Workgroup -> (tile w, row slice ms).  Workgroups go round-robin over the 8 XCDs (blockIdx % 8) and each XCD has its
+// own L2.  With whole groups of 8 row slices (narrow layers: 13 tiles x 16..40 slices) all tiles of one row slice sit on
+// one XCD, next to each other in launch order, so the operand slabs they share (x-hat under q|k|v, u2 under w1|w3, dy
+// under w2's k-slabs) are fetched from HBM once and hit in L2 for the rest (measured before: 1.8x the algorithmic bytes).
+// With fewer slices (wide layers: 196 tiles x 2 slices at d = 512) that map would leave XCDs idle (slice ms only ever
+// ran on XCD ms % 8: 1127 us per launch at d = 512): the tile list, which is ordered (task, n-slab, k-slab), is cut into 8
+// contiguous parts instead, one per XCD, so tiles that share a dO slab still share an L2 and every XCD has work.
+__device__ __forceinline__ bool decode_wg(const WgradParams& p, int tiles, int& w, int& ms) {
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    if ((p.msplit & 7) == 0) {
+        w = li % tiles; ms = xcd + 8 * (li / tiles);
+        return ms < p.msplit;
+    }
+    const int tpx = (tiles + 7) >> 3;
+    w = xcd * tpx + li % tpx; ms = li / tpx;
+    return w < tiles && ms < p.msplit;
+}
+
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t dOt[MC * TST];
     __shared__ __attribute__((aligned(16))) bf16_t At[MC * TST];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // decode (task, n-slab, k-slab, m-split).  Workgroups go round-robin over the 8 XCDs (blockIdx % 8) and each XCD
-    // has its own L2: all tiles of one row slice are placed on the same XCD, next to each other in launch order, so
-    // the operand slabs they share (x-hat under q|k|v, u2 under w1|w3, dy under w2's k-slabs) are fetched from HBM
-    // once and hit in L2 for the rest (measured before: 1.8x the algorithmic bytes).
+    // decode (task, n-slab, k-slab, m-split)
     int tiles = 0;
     for (int i = 0; i < p.ntasks; ++i) tiles += ((p.t[i].N + 127) / 128) * ((p.t[i].K + 127) / 128);
-    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-    int w = li % tiles;
-    const int ms = xcd + 8 * (li / tiles);
-    if (ms >= p.msplit) return;
+    int w, ms;
+    if (!decode_wg(p, tiles, w, ms)) return;
     int ti = 0, ns = 0, ks = 0;
     for (; ti < p.ntasks; ++ti) {
         const int nsl = (p.t[ti].N + 127) / 128, ksl = (p.t[ti].K + 127) / 128;
@@ -227,10 +240,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
 
     int tiles = 0;
     for (int i = 0; i < p.ntasks; ++i) tiles += ((p.t[i].N + 127) / 128) * ((p.t[i].K + 127) / 128);
-    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
-    int w = li % tiles;
-    const int ms = xcd + 8 * (li / tiles);
-    if (ms >= p.msplit) return;
+    int w, ms;
+    if (!decode_wg(p, tiles, w, ms)) return;
     int ti = 0, ns = 0, ks = 0;
     for (; ti < p.ntasks; ++ti) {
         const int nsl = (p.t[ti].N + 127) / 128, ksl = (p.t[ti].K + 127) / 128;
@@ -363,7 +374,7 @@ int hs_wgrad(const WgradParams& p, hipStream_t s) {
         if (t.dO_f32 || (int64_t)(p.M + DC) * t.ldo * 2 >= (1ll << 32) || (int64_t)(p.M + DC) * t.lda * 2 >= (1ll << 32)) dma = false;
         if ((reinterpret_cast<uintptr_t>(t.dO) | reinterpret_cast<uintptr_t>(t.A)) & 15) dma = false;
     }
-    const dim3 grid(8 * tiles * ((p.msplit + 7) / 8));
+    const dim3 grid((p.msplit & 7) == 0 ? 8 * tiles * (p.msplit / 8) : 8 * ((tiles + 7) / 8) * p.msplit);      // decode_wg
     if (dma) {
         // ring depth: a launch of at most one workgroup per CU has the LDS to itself (6 stages = 96 KB); larger
         // launches keep 3 stages so that three workgroups fit a CU.  HSIMAE_WGRAD_DS=3..6 forces one.

@@ -178,6 +178,10 @@ typedef struct {
     const float* a_rowscale; const float* out_rowscale;
 } hsimae_gemm_params;
 int hsimae_gemm(const hsimae_gemm_params* p, int32_t a_kind, int32_t epilogue, void* stream);
+/* The same kernel with the row-panel height (bm: 64 or 128) and the depth of an A chunk (kc: 128 or 256; ignored by the
+ * LayerNorm prologue, which stages all of K) forced instead of chosen by shape; 0 = the shape rule.  Measurement hook
+ * (scripts/gemm_sweep.py): results are identical for every tiling. */
+int hsimae_gemm_tiled(const hsimae_gemm_params* p, int32_t a_kind, int32_t epilogue, int32_t bm, int32_t kc, void* stream);
 
 /* One fp32 matrix -> packed image (placement n_off/k_off lets q|k|v or w1|w3 share an image). */
 typedef struct {
