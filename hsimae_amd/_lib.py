@@ -49,12 +49,13 @@ class GemmParams(C.Structure):
                 ("res", vp), ("res2", vp), ("ldr", i32), ("pos", vp), ("ids", vp), ("ldpos", i32),
                 ("h13", vp), ("ldh", i32), ("hoff", i32),
                 ("lnx", vp), ("dgamma", vp), ("dbeta", vp), ("accumulate", i32),
-                ("a_rowscale", vp), ("out_rowscale", vp)]
+                ("a_rowscale", vp), ("out_rowscale", vp),
+                ("prec", i32), ("W8", vp), ("S8", vp), ("W8b", vp), ("S8b", vp)]
 
 
 class PackDesc(C.Structure):
     _fields_ = [("src", vp), ("rows", i32), ("cols", i32), ("transpose", i32), ("n_off", i32), ("k_off", i32),
-                ("KS", i32), ("dst", vp)]
+                ("KS", i32), ("dst", vp), ("fp8", i32), ("scales", vp)]
 
 
 class AttnParams(C.Structure):

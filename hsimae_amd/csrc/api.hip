@@ -20,7 +20,7 @@ inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 struct BlkOff { int64_t n1w, n1b, qw, qb, kw, kb, vw, vb, pw, pb, n2w, n2b, w1w, w1b, w2w, w2b, w3w, w3b, end; };
 
 struct Geo {
-    int B, T, TL, D, H, hd, h, hp, Dd, Hd, hdd, hdec, hpd, depth, sdepth, nfus, ddepth, norm_pix;
+    int B, T, TL, D, H, hd, h, hp, Dd, Hd, hdd, hdec, hpd, depth, sdepth, nfus, ddepth, norm_pix, prec;
     bool has_axis, has_fus;
 };
 
@@ -37,6 +37,8 @@ int make_geo(const hsimae_config* c, Geo& g) {
     g.has_fus = g.sdepth < 12;                     // Models.py:385 (hard-coded 12)
     g.nfus = g.has_fus ? std::max(0, g.depth - g.sdepth) : 0;
     g.norm_pix = c->norm_pix_loss;
+    g.prec = c->precision;
+    if (g.prec != HSIMAE_PREC_BF16 && g.prec != HSIMAE_PREC_FP8) return HSIMAE_EUNSUPPORTED;
     if (g.D % 32 || g.Dd % 32 || g.D > 512 || g.Dd > 512) return HSIMAE_EUNSUPPORTED;
     if ((g.hd != 8 && g.hd != 16) || (g.hdd != 8 && g.hdd != 16)) return HSIMAE_EUNSUPPORTED;
     if (g.h <= 0 || g.hdec <= 0 || g.h % 4 || g.hdec % 4 || g.T > 64 || g.ddepth < 1) return HSIMAE_EUNSUPPORTED;
@@ -85,51 +87,76 @@ void make_playout(const Geo& g, PLayout& L) {
 }
 
 // ------------------------------------------------------------------ packed-weight layout (bf16 images + fp32 bias packs)
-struct BlkW { int64_t qkv, p, w1, w3, w2, qkvT, pT, w13T, w2T; int64_t bqkv; };   // element offsets (bf16) / float offsets
+struct Img8 { int64_t w, s; };            // byte offsets of an e4m3 image and of its e8m0 scale image (fp8 region)
+struct BlkW {
+    int64_t qkv, p, w1, w3, w2, qkvT, pT, w13T, w2T; int64_t bqkv;   // element offsets (bf16) / float offsets
+    Img8 qkv8, p8, w1_8, w3_8, w2_8, qkvT8, pT8, w13T8, w2T8;         // precision = FP8: encoder blocks only
+};
 struct WLayout {
     int64_t pe, de, deT, dp, dpT;
     std::vector<BlkW> b1, b2, bf, bd;
     int64_t bf16_elems;      // bf16 region size (elements), multiple of 8
     int64_t f32_elems;       // fp32 region (bias packs)
+    int64_t fp8_bytes;       // e4m3 images + scale images of the encoder blocks (precision = FP8), after the fp32 region
     int64_t total_elems;     // in bf16 units
 };
 
 void make_wlayout(const Geo& g, WLayout& W) {
-    int64_t cur = 0, fcur = 0;
+    int64_t cur = 0, fcur = 0, cur8 = 0;
     auto img = [&](int N, int K) { int64_t o = cur; cur += (int64_t)N * K; return o; };
-    auto blk = [&](int d, int hp) {
-        BlkW b;
+    auto img8 = [&](int N, int K) {       // [ceil(N/16)][ceil(K/128)][64 lanes][32 B] + one scale dword per (n-tile, 512-chunk, lane)
+        const int64_t nt = (N + 15) / 16, ks = (K + 127) / 128, kch = (ks + 3) / 4;
+        Img8 o; o.w = cur8; cur8 += nt * ks * 64 * 32; o.s = cur8; cur8 += nt * kch * 64 * 4;
+        return o;
+    };
+    auto blk = [&](int d, int hp, bool f8) {
+        BlkW b; std::memset(&b, 0, sizeof(b));
         b.qkv = img(3 * d, d); b.p = img(d, d); b.w1 = img(hp, d); b.w3 = img(hp, d); b.w2 = img(d, hp);
         b.qkvT = img(d, 3 * d); b.pT = img(d, d); b.w13T = img(d, 2 * hp); b.w2T = img(hp, d);
         b.bqkv = fcur; fcur += 3 * d;
+        if (f8) {
+            b.qkv8 = img8(3 * d, d); b.p8 = img8(d, d); b.w1_8 = img8(hp, d); b.w3_8 = img8(hp, d); b.w2_8 = img8(d, hp);
+            b.qkvT8 = img8(d, 3 * d); b.pT8 = img8(d, d); b.w13T8 = img8(d, 2 * hp); b.w2T8 = img8(hp, d);
+        }
         return b;
     };
+    const bool f8 = g.prec == HSIMAE_PREC_FP8;
     W.pe = img(g.D, 96);
     if (g.has_axis) {
-        for (int i = 0; i < g.sdepth; ++i) W.b1.push_back(blk(g.D, g.hp));
-        for (int i = 0; i < g.sdepth; ++i) W.b2.push_back(blk(g.D, g.hp));
+        for (int i = 0; i < g.sdepth; ++i) W.b1.push_back(blk(g.D, g.hp, f8));
+        for (int i = 0; i < g.sdepth; ++i) W.b2.push_back(blk(g.D, g.hp, f8));
     }
-    for (int i = 0; i < g.nfus; ++i) W.bf.push_back(blk(g.D, g.hp));
+    for (int i = 0; i < g.nfus; ++i) W.bf.push_back(blk(g.D, g.hp, f8));
     W.de = img(g.Dd, g.D); W.deT = img(g.D, g.Dd);
-    for (int i = 0; i < g.ddepth; ++i) W.bd.push_back(blk(g.Dd, g.hpd));
+    for (int i = 0; i < g.ddepth; ++i) W.bd.push_back(blk(g.Dd, g.hpd, false));
     W.dp = img(80, g.Dd); W.dpT = img(g.Dd, 96);
     W.bf16_elems = (cur + 7) & ~7ll;
-    W.f32_elems = fcur;
-    W.total_elems = W.bf16_elems + 2 * W.f32_elems;
+    W.f32_elems = (fcur + 3) & ~3ll;            // keeps the fp8 region 16-B aligned
+    W.fp8_bytes = cur8;
+    W.total_elems = W.bf16_elems + 2 * W.f32_elems + (cur8 + 1) / 2;
 }
 
 void pack_descs(const Geo& g, const PLayout& L, const WLayout& W, const float* P, hs_bf16* wpk,
                 std::vector<PackDesc>& out) {
     float* fbase = reinterpret_cast<float*>(wpk + W.bf16_elems);
+    unsigned char* base8 = reinterpret_cast<unsigned char*>(fbase + W.f32_elems);
     auto mat = [&](int64_t src, int rows, int cols, int tr, int n_off, int k_off, int K_img, int64_t dst) {
-        PackDesc d; d.src = P + src; d.rows = rows; d.cols = cols; d.transpose = tr; d.n_off = n_off; d.k_off = k_off;
+        PackDesc d; std::memset(&d, 0, sizeof(d));
+        d.src = P + src; d.rows = rows; d.cols = cols; d.transpose = tr; d.n_off = n_off; d.k_off = k_off;
         d.KS = K_img / 32; d.dst = wpk + dst; out.push_back(d);
     };
+    auto mat8 = [&](int64_t src, int rows, int cols, int tr, int n_off, int k_off, int K_img, const Img8& im) {
+        PackDesc d; std::memset(&d, 0, sizeof(d));
+        d.src = P + src; d.rows = rows; d.cols = cols; d.transpose = tr; d.n_off = n_off; d.k_off = k_off;
+        d.KS = (K_img + 127) / 128; d.dst = reinterpret_cast<hs_bf16*>(base8 + im.w); d.fp8 = 1; d.scales = base8 + im.s;
+        out.push_back(d);
+    };
     auto fcopy = [&](int64_t src, int n, int64_t dst_f, int off) {
-        PackDesc d; d.src = P + src; d.rows = 1; d.cols = n; d.transpose = 0; d.n_off = off; d.k_off = 0; d.KS = 0;
+        PackDesc d; std::memset(&d, 0, sizeof(d));
+        d.src = P + src; d.rows = 1; d.cols = n; d.transpose = 0; d.n_off = off; d.k_off = 0; d.KS = 0;
         d.dst = reinterpret_cast<hs_bf16*>(fbase + dst_f); out.push_back(d);
     };
-    auto blk = [&](const BlkOff& b, const BlkW& w, int d, int h, int hp) {
+    auto blk = [&](const BlkOff& b, const BlkW& w, int d, int h, int hp, bool f8) {
         mat(b.qw, d, d, 0, 0, 0, d, w.qkv); mat(b.kw, d, d, 0, d, 0, d, w.qkv); mat(b.vw, d, d, 0, 2 * d, 0, d, w.qkv);
         mat(b.pw, d, d, 0, 0, 0, d, w.p);
         mat(b.w1w, h, d, 0, 0, 0, d, w.w1); mat(b.w3w, h, d, 0, 0, 0, d, w.w3);
@@ -140,13 +167,24 @@ void pack_descs(const Geo& g, const PLayout& L, const WLayout& W, const float* P
         mat(b.w1w, h, d, 1, 0, 0, 2 * hp, w.w13T); mat(b.w3w, h, d, 1, 0, hp, 2 * hp, w.w13T);
         mat(b.w2w, d, h, 1, 0, 0, d, w.w2T);
         fcopy(b.qb, d, w.bqkv, 0); fcopy(b.kb, d, w.bqkv, d); fcopy(b.vb, d, w.bqkv, 2 * d);
+        if (f8) {                                     // the same images as MX e4m3 (encoder blocks, precision = FP8)
+            mat8(b.qw, d, d, 0, 0, 0, d, w.qkv8); mat8(b.kw, d, d, 0, d, 0, d, w.qkv8); mat8(b.vw, d, d, 0, 2 * d, 0, d, w.qkv8);
+            mat8(b.pw, d, d, 0, 0, 0, d, w.p8);
+            mat8(b.w1w, h, d, 0, 0, 0, d, w.w1_8); mat8(b.w3w, h, d, 0, 0, 0, d, w.w3_8);
+            mat8(b.w2w, d, h, 0, 0, 0, hp, w.w2_8);
+            mat8(b.qw, d, d, 1, 0, 0, 3 * d, w.qkvT8); mat8(b.kw, d, d, 1, 0, d, 3 * d, w.qkvT8); mat8(b.vw, d, d, 1, 0, 2 * d, 3 * d, w.qkvT8);
+            mat8(b.pw, d, d, 1, 0, 0, d, w.pT8);
+            mat8(b.w1w, h, d, 1, 0, 0, 2 * hp, w.w13T8); mat8(b.w3w, h, d, 1, 0, hp, 2 * hp, w.w13T8);
+            mat8(b.w2w, d, h, 1, 0, 0, d, w.w2T8);
+        }
     };
     mat(L.pew, g.D, 72, 0, 0, 0, 96, W.pe);
-    for (size_t i = 0; i < L.b1.size(); ++i) blk(L.b1[i], W.b1[i], g.D, g.h, g.hp);
-    for (size_t i = 0; i < L.b2.size(); ++i) blk(L.b2[i], W.b2[i], g.D, g.h, g.hp);
-    for (size_t i = 0; i < L.bf.size(); ++i) blk(L.bf[i], W.bf[i], g.D, g.h, g.hp);
+    const bool f8 = g.prec == HSIMAE_PREC_FP8;
+    for (size_t i = 0; i < L.b1.size(); ++i) blk(L.b1[i], W.b1[i], g.D, g.h, g.hp, f8);
+    for (size_t i = 0; i < L.b2.size(); ++i) blk(L.b2[i], W.b2[i], g.D, g.h, g.hp, f8);
+    for (size_t i = 0; i < L.bf.size(); ++i) blk(L.bf[i], W.bf[i], g.D, g.h, g.hp, f8);
     mat(L.dew, g.Dd, g.D, 0, 0, 0, g.D, W.de); mat(L.dew, g.Dd, g.D, 1, 0, 0, g.Dd, W.deT);
-    for (size_t i = 0; i < L.bd.size(); ++i) blk(L.bd[i], W.bd[i], g.Dd, g.hdec, g.hpd);
+    for (size_t i = 0; i < L.bd.size(); ++i) blk(L.bd[i], W.bd[i], g.Dd, g.hdec, g.hpd, false);
     mat(L.dpw, 72, g.Dd, 0, 0, 0, g.Dd, W.dp); mat(L.dpw, 72, g.Dd, 1, 0, 0, 96, W.dpT);
 }
 
@@ -210,6 +248,8 @@ struct BlkP {            // resolved pointers of one block
     const float *n1w, *n1b, *bqkv, *pb, *n2w, *n2b, *w1b, *w3b, *w2b;
     const hs_bf16 *qkv, *p, *w1, *w3, *w2, *qkvT, *pT, *w13T, *w2T;
     const float *qf, *kf, *vf, *pf, *w1f, *w3f;     // fp32 master weights (row-major), staged as bf16 by the fused decoder backward
+    int prec;                                       // HSIMAE_PREC_FP8: the block's linears run on the MX e4m3 images below
+    struct I8 { const uint8_t* w; const uint8_t* s; } qkv8, p8, w1_8, w3_8, w2_8, qkvT8, pT8, w13T8, w2T8;
 };
 
 BlkP resolve(const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk, const WLayout& WL) {
@@ -220,6 +260,17 @@ BlkP resolve(const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk,
     b.qkv = wpk + w.qkv; b.p = wpk + w.p; b.w1 = wpk + w.w1; b.w3 = wpk + w.w3; b.w2 = wpk + w.w2;
     b.qkvT = wpk + w.qkvT; b.pT = wpk + w.pT; b.w13T = wpk + w.w13T; b.w2T = wpk + w.w2T;
     b.qf = P + o.qw; b.kf = P + o.kw; b.vf = P + o.vw; b.pf = P + o.pw; b.w1f = P + o.w1w; b.w3f = P + o.w3w;
+    const uint8_t* base8 = reinterpret_cast<const uint8_t*>(fbase + WL.f32_elems);
+    auto i8 = [&](const Img8& im) { BlkP::I8 r; r.w = base8 + im.w; r.s = base8 + im.s; return r; };
+    b.prec = HSIMAE_PREC_BF16;
+    b.qkv8 = i8(w.qkv8); b.p8 = i8(w.p8); b.w1_8 = i8(w.w1_8); b.w3_8 = i8(w.w3_8); b.w2_8 = i8(w.w2_8);
+    b.qkvT8 = i8(w.qkvT8); b.pT8 = i8(w.pT8); b.w13T8 = i8(w.w13T8); b.w2T8 = i8(w.w2T8);
+    return b;
+}
+// encoder blocks under precision = FP8 (the decoder's blocks never are)
+BlkP resolve_enc(const Geo& g, const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk, const WLayout& WL) {
+    BlkP b = resolve(o, w, P, wpk, WL);
+    b.prec = g.prec;
     return b;
 }
 
@@ -321,7 +372,9 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
               int nsamples, int mode, int len_l, const float* res2, hipStream_t s, const float* rs_a = nullptr,
               const float* rs_m = nullptr) {
     GemmParams p = gp();
-    if (hs_attn_block_fusable(d, heads, Ts)) {
+    const bool f8 = P.prec == HSIMAE_PREC_FP8;        // the linears on MX e4m3 images, layer at a time (no fused kernels)
+    auto w8 = [&](GemmParams& q, const BlkP::I8& a) { if (f8) { q.prec = HSIMAE_PREC_FP8; q.W8 = a.w; q.S8 = a.s; } };
+    if (!f8 && hs_attn_block_fusable(d, heads, Ts)) {
         // LN1 + q|k|v + attention + projection + residual in one persistent kernel (attn.hip blk128_fwd_kernel)
         CK(hs_attn_block_fwd(x_in, P.n1w, P.n1b, P.qkv, P.bqkv, P.p, P.pb, b.u, b.qkv, b.o, b.lse, b.x1, rs_a, Ts, nsamples, mode,
                              len_l, s));
@@ -329,11 +382,12 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
     } else {
     p.A = x_in; p.lda = d; p.M = (int)M; p.N = 3 * d; p.K = d; p.n_valid = 3 * d; p.W = P.qkv; p.bias = P.bqkv;
     p.gamma = P.n1w; p.beta = P.n1b; p.u_out = b.u; p.ldu = d; p.out = b.qkv; p.ldo = 3 * d;
+    w8(p, P.qkv8);
     CK(hs_gemm(p, A_F32_LN, E_BF16, s));
     AttnParams a; std::memset(&a, 0, sizeof(a));
     a.qkv = b.qkv; a.ld = 3 * d; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
     a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = d; a.lse = b.lse;
-    if (hs_attn_proj_fusable(a)) {            // proj + residual inside the attention kernel (x1 = x + o Wp^T + b)
+    if (!f8 && hs_attn_proj_fusable(a)) {     // proj + residual inside the attention kernel (x1 = x + o Wp^T + b)
         a.proj_w = P.p; a.proj_b = P.pb; a.xres = x_in; a.x1 = b.x1; a.rowscale = rs_a;
         CK(hs_attn_fwd(a, s));
     } else {
@@ -341,18 +395,21 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
         p = gp();
         p.A = b.o; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d; p.W = P.p; p.bias = P.pb;
         p.res = x_in; p.ldr = d; p.out = b.x1; p.ldo = d; p.out_rowscale = rs_a;
+        w8(p, P.p8);
         CK(hs_gemm(p, A_BF16, E_RES_F32, s));
     }
     }
-    if (fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
+    if (!f8 && fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
     p = gp();
     p.A = b.x1; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = h; p.W = P.w1; p.W2 = P.w3; p.bias = P.w1b;
     p.bias2 = P.w3b; p.gamma = P.n2w; p.beta = P.n2b; p.u_out = b.u2; p.ldu = d; p.out = b.g; p.ldo = hp;
     p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp;
+    if (f8) { w8(p, P.w1_8); p.W8b = P.w3_8.w; p.S8b = P.w3_8.s; }
     CK(hs_gemm(p, A_F32_LN, E_SWIGLU, s));
     p = gp();
     p.A = b.g; p.lda = hp; p.M = (int)M; p.N = d; p.K = hp; p.n_valid = d; p.W = P.w2; p.bias = P.w2b;
     p.res = b.x1; p.res2 = res2; p.ldr = d; p.out = b.x2; p.ldo = d; p.out_rowscale = rs_m;
+    w8(p, P.w2_8);
     CK(hs_gemm(p, A_BF16, E_RES_F32, s));
     return HSIMAE_OK;
 }
@@ -381,7 +438,9 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     GemmParams p = gp();
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
     l.M = (int)M; l.d = d;
-    const bool fmlp = fused_mlp_enabled(d, h);
+    const bool f8 = P.prec == HSIMAE_PREC_FP8;
+    auto w8 = [&](GemmParams& q, const BlkP::I8& a) { if (f8) { q.prec = HSIMAE_PREC_FP8; q.W8 = a.w; q.S8 = a.s; } };
+    const bool fmlp = !f8 && fused_mlp_enabled(d, h);
     if (fmlp) {
         // recompute u2 / h1 / h3 / g inside the tile; emits dx1 and the wgrad operands u2, dh1|dh3, g, bf16 dY and dx1
         CK(hs_enc_mlp_bwd(b.x1, G0, G1, b.u2, w.dh13, b.g, w.g0b, w.g1b, (int)M, d, mlp_ptrs(P, h), grads + o.n2w,
@@ -389,9 +448,11 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     } else {
         p.A = G0; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = hp; p.W = P.w2T; p.out = w.dh13; p.ldo = 2 * hp;
         p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp; p.a_rowscale = rs_m;        // DropPath: the branch saw rs_m * dY
+        w8(p, P.w2T8);
         CK(hs_gemm(p, A_F32, E_SWIGLU_BWD, s));
         p = gp();
         p.A = w.dh13; p.lda = 2 * hp; p.M = (int)M; p.N = d; p.K = 2 * hp; p.n_valid = d; p.W = P.w13T; p.out = w.du; p.ldo = d;
+        w8(p, P.w13T8);
         CK(hs_gemm(p, A_BF16, E_F32, s));
         l.du = w.du; l.x = b.x1; l.gamma = P.n2w; l.dres = G0; l.dx = G1; l.accumulate = 0;
         l.dgamma = grads + o.n2w; l.dbeta = grads + o.n2b;
@@ -412,6 +473,7 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         p = gp();
         p.A = w.g1b; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d;      // (the bf16 copy carries the DropPath factor)
         p.W = P.pT; p.out = w.dob; p.ldo = d;
+        w8(p, P.pT8);
         CK(hs_gemm(p, A_BF16, E_BF16, s));
     }
     CK(hs_attn_bwd(a, s));
@@ -440,7 +502,7 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     // du never goes to HBM), two otherwise.  HSIMAE_FUSED_LNBWD=0 forces the two-kernel form.
     static int fuse_ln = -1;
     if (fuse_ln < 0) { const char* e = getenv("HSIMAE_FUSED_LNBWD"); fuse_ln = !(e && e[0] == '0'); }
-    const bool ln_fused = fuse_ln && d == 128;
+    const bool ln_fused = fuse_ln && d == 128 && !f8;
     p = gp();
     p.A = w.dqkv; p.lda = 3 * d; p.M = (int)M; p.N = d; p.K = 3 * d; p.n_valid = d; p.W = P.qkvT;
     if (ln_fused) {
@@ -449,6 +511,7 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         CK(hs_gemm(p, A_BF16, E_LN_BWD, s));       // K = 384: the persistent LDS-DMA kernel of gemm_dma.hip
     } else {
         p.out = w.du; p.ldo = d;
+        w8(p, P.qkvT8);
         CK(hs_gemm(p, A_BF16, E_F32, s));
     }
 
@@ -590,12 +653,12 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
         const float* xb = w.x0;
         for (int i = 0; i < g.sdepth; ++i) {
             // spatial stack: attend within one kept band group (Models.py:553,556)
-            BlkP b1 = resolve(c.L.b1[i], c.W.b1[i], P, io->wpk, c.W);
+            BlkP b1 = resolve_enc(g, c.L.b1[i], c.W.b1[i], P, io->wpk, c.W);
             const DropRs r1 = drop_rs(io, i, c.Me), r2d = drop_rs(io, g.sdepth + i, c.Me);
             CK(block_fwd(b1, xa, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, nullptr, s, r1.a, r1.m));
             xa = w.b1[i].x2;
             // spectral stack: attend within one kept position (Models.py:554,559)
-            BlkP b2 = resolve(c.L.b2[i], c.W.b2[i], P, io->wpk, c.W);
+            BlkP b2 = resolve_enc(g, c.L.b2[i], c.W.b2[i], P, io->wpk, c.W);
             const bool last = (i == g.sdepth - 1);
             const float* r2 = last ? xa : nullptr;                      // x1 + x2 fused into the last epilogue (Models.py:564)
             if (last && forked) {                                       // needs the spatial stack's result: rejoin first
@@ -609,7 +672,7 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
         x = xb;
     }
     for (int i = 0; i < g.nfus; ++i) {
-        BlkP bp = resolve(c.L.bf[i], c.W.bf[i], P, io->wpk, c.W);
+        BlkP bp = resolve_enc(g, c.L.bf[i], c.W.bf[i], P, io->wpk, c.W);
         const DropRs rf = drop_rs(io, (g.has_axis ? 2 * g.sdepth : 0) + i, c.Me);
         CK(block_fwd(bp, x, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, nullptr, s, rf.a, rf.m));
         x = w.bf[i].x2;
@@ -688,7 +751,7 @@ int hsimae_decode(const hsimae_config* cfg, const hsimae_io* io, const float* la
 static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hipStream_t s, Emitter& emit) {
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
     for (int i = g.nfus - 1; i >= 0; --i) {
-        BlkP bp = resolve(L.bf[i], c.W.bf[i], P, io->wpk, c.W);
+        BlkP bp = resolve_enc(g, L.bf[i], c.W.bf[i], P, io->wpk, c.W);
         const float* xin = (i > 0) ? w.bf[i - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
         const DropRs rf = drop_rs(io, (g.has_axis ? 2 * g.sdepth : 0) + i, c.Me);
         CK(block_bwd(bp, L.bf[i], grads, xin, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, w.G0, w.sc, w.G0, 0, s, 1,
@@ -710,7 +773,7 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
         // for the right stream through an event); without one the side stream's ranges wait for the join
         const bool per_block = emit.bucket != nullptr || !forked;
         for (int i = g.sdepth - 1; i >= 0; --i) {
-            BlkP b2 = resolve(L.b2[i], c.W.b2[i], P, io->wpk, c.W);
+            BlkP b2 = resolve_enc(g, L.b2[i], c.W.b2[i], P, io->wpk, c.W);
             const DropRs r1 = drop_rs(io, i, c.Me), r2d = drop_rs(io, g.sdepth + i, c.Me);
             const float* xin2 = (i > 0) ? w.b2[i - 1].x2 : w.x0;
             CK(block_bwd(b2, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, scr2, w.G0, 0, s2, forked ? 2 : 1,
@@ -720,7 +783,7 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
                 CK((int)hipEventRecord(sd.join, sd.s));
                 CK((int)hipStreamWaitEvent(s, sd.join, 0));
             }
-            BlkP b1 = resolve(L.b1[i], c.W.b1[i], P, io->wpk, c.W);
+            BlkP b1 = resolve_enc(g, L.b1[i], c.W.b1[i], P, io->wpk, c.W);
             const float* xin1 = (i > 0) ? w.b1[i - 1].x2 : w.x0;
             float* out = (i == 0) ? w.G0 : w.G2;
             CK(block_bwd(b1, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, out, i == 0, s, forked ? 2 : 1,

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 // Per-phase cycle accounting for scripts/phase_timing.py (compiled only with -DHS_PHASE_TIMING; never in the shipped library)
 #ifdef HS_PHASE_TIMING
@@ -35,29 +36,64 @@ extern "C" int hsimae_debug_phases_gemm(unsigned long long* out, int reset) {
 
 namespace {
 
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
 template <int KC> struct EpiRows { static constexpr int v = KC >= 512 ? 16 : 32; };   // rows per epilogue pass (LDS budget at K = 512)
 constexpr int TS = 132;            // fp32 LDS tile row stride (floats): conflict-free b32 writes
 
 // BM: rows per workgroup.  128 (one workgroup per CU) for the narrow layers, where the weight stream per panel is small;
 // 64 (two to three workgroups per CU, so that one panel's staging / epilogue overlaps another's MFMA loop) for K >= 256.
-template <int AK, int EPI, int KC, int BM>
+// F8: the MX block-scaled path (hsimae_config.precision = FP8): A is quantised to OCP e4m3 as it is staged, one e8m0
+// scale per 32 consecutive K elements of a row, the weights come pre-quantised the same way (pack8_kernel), and the
+// products run on v_mfma_scale_f32_16x16x128_f8f6f4 (K = 128 per instruction at twice the bf16 rate), fp32 accumulate.
+// Operand maps (pinned with exact data by scripts/micro/mx_layout.hip): lane (r = l & 15, g = l >> 4) holds, in bytes
+// 0..15 / 16..31 of its 8-dword operand, k = 16 g + j and k = 64 + 16 g + j of row r (A) / column r (B) of the 128-deep
+// step, and supplies in its scale register the e8m0 byte of 32-block g (k in [32 g, 32 g + 32)) of that row / column.
+template <int AK, int EPI, int KC, int BM, int F8>
 __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(!F8 || KC == 512, "the fp8 path stages 512-deep chunks (one scale dword per row and lane group)");
     constexpr int MT = BM / 16;
-    constexpr int LDA = KC + 8;                       // LDS row stride (elements): 16-B pad => conflict-free b128 reads
+    constexpr int LDA = F8 ? KC + 16 : KC + 8;        // LDS row stride (elements): 16-B pad => conflict-free b128 reads
+    constexpr int ABYTES = F8 ? BM * LDA : BM * LDA * 2;
+    constexpr int SCBYTES = F8 ? BM * 16 : 0;         // fp8: e8m0 scales [row][lane group g][k-step of the chunk]
     constexpr bool DUAL = (EPI == E_SWIGLU);
     constexpr int PR = EpiRows<KC>::v;
-    bf16_t* As = reinterpret_cast<bf16_t*>(smem);     // [128][KC+8]
-    float* rstat = reinterpret_cast<float*>(smem + BM * LDA * 2);   // [128][2] mean, rstd
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem);     // [BM][KC+8] bf16, or [BM][KC+16] e4m3 bytes
+    unsigned char* As8 = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* Sc = reinterpret_cast<unsigned char*>(smem + ABYTES);
+    float* rstat = reinterpret_cast<float*>(smem + ABYTES + SCBYTES);   // [BM][2] mean, rstd
     float* T1 = rstat + 2 * BM;                       // [PR][TS]
     float* T2 = T1 + PR * TS;                         // second tile (SwiGLU pair)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * BM;
-    const int KS_total = p.K / 32;
+    const int KS_total = F8 ? (p.K + 127) / 128 : p.K / 32;      // MFMA k-steps over K
     const int NT_total = p.N / 16;
     const int n_chunks = (NT_total + 7) / 8;
     const int k_chunks = (p.K + KC - 1) / KC;
+
+    // fp8: quantise 8 consecutive values of row r at chunk column c8 (the 4 adjacent lanes that share a 32-block agree
+    // on its scale through two shuffles) and store them with the block's e8m0 byte
+    auto put_a8 = [&](int r, int c8, const float (&f)[8]) {
+        float am = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(f[e]));
+        am = fmaxf(am, __shfl_xor(am, 1, 64));
+        am = fmaxf(am, __shfl_xor(am, 2, 64));
+        int eb = (int)((__float_as_uint(am) >> 23) & 0xffu) - 8;          // floor(log2(amax)) - emax(e4m3), biased by 127
+        eb = min(max(eb, 1), 254);
+        const float inv = __uint_as_float((unsigned)(254 - eb) << 23);    // 2^-(eb - 127)
+        float q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = fminf(fmaxf(f[e] * inv, -448.f), 448.f);   // v_cvt_pk_fp8_f32 does not saturate (> 464 -> NaN)
+        int lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], lo, true);
+        int hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], 0, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], hi, true);
+        *reinterpret_cast<int2*>(As8 + r * LDA + c8) = make_int2(lo, hi);
+        if ((c8 & 31) == 0) Sc[(r * 4 + ((c8 & 127) >> 5)) * 4 + (c8 >> 7)] = (unsigned char)eb;
+    };
 
     // LayerNorm prologue: each row is owned by TPR adjacent lanes (8 columns each).  All loads of a batch of
     // rows are issued before the first reduction, so one memory latency is exposed per batch instead of one per
@@ -105,7 +141,15 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
                 const bf16x8 val = cok ? cvt8(f[i]) : zero8();
                 if (cok && p.u_out && row0 + r < p.M)
                     HS_NT(true, reinterpret_cast<bf16x8*>(p.u_out + (size_t)(row0 + r) * p.ldu + c8), val);   // saved for the backward only
-                *reinterpret_cast<bf16x8*>(As + r * LDA + c8) = val;
+                if constexpr (F8) {
+                    if (!cok) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[i][e] = 0.f;
+                    }
+                    put_a8(r, c8, f[i]);
+                } else {
+                    *reinterpret_cast<bf16x8*>(As + r * LDA + c8) = val;
+                }
             }
         }
     };
@@ -119,15 +163,20 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
         for (int r = tid / TPR; r < BM; r += RPP) {
             const int row = min(row0 + r, p.M - 1);
             bf16x8 val = zero8();
+            float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (kcol < p.K) {
                 if constexpr (AK == A_BF16) {
                     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
                     val = *reinterpret_cast<const bf16x8*>(A + (size_t)row * p.lda + kcol);
+                    if constexpr (F8) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) f[i] = bf2f(val[i]);
+                    }
                 } else {
                     const float* A = reinterpret_cast<const float*>(p.A);
                     const float4 x0 = *reinterpret_cast<const float4*>(A + (size_t)row * p.lda + kcol);
                     const float4 x1 = *reinterpret_cast<const float4*>(A + (size_t)row * p.lda + kcol + 4);
-                    float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    f[0] = x0.x; f[1] = x0.y; f[2] = x0.z; f[3] = x0.w; f[4] = x1.x; f[5] = x1.y; f[6] = x1.z; f[7] = x1.w;
                     if constexpr (AK == A_F32) {
                         if (p.a_rowscale) {                       // DropPath: the branch gradient is scale * dY
                             const float rs = p.a_rowscale[row];
@@ -153,7 +202,8 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
                     }
                 }
             }
-            *reinterpret_cast<bf16x8*>(As + r * LDA + c8) = val;
+            if constexpr (F8) put_a8(r, c8, f);
+            else *reinterpret_cast<bf16x8*>(As + r * LDA + c8) = val;
         }
     };
 
@@ -162,25 +212,54 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
     // Weight fragments are fetched one group of G k-steps ahead of the MFMAs that use them, across k-chunk and
     // n-chunk boundaries: the group for the next n-chunk is in flight during this chunk's epilogue and the first
     // group overlaps the staging of A.  (Fetched at their use, every k-step exposed an L2 round trip.)
-    constexpr int G = (DUAL || AK == A_F32_LN) ? 2 : 4;       // the LN prologue holds 64 staging registers: stay at 2 waves/SIMD
-    struct Grp { bf16x8 b[G][2]; bf16x8 b2[DUAL ? G : 1][2]; };
+    constexpr int G = F8 ? 2 : ((DUAL || AK == A_F32_LN) ? 2 : 4);   // the LN prologue holds 64 staging registers: stay at 2 waves/SIMD
+    constexpr int KSTEP = F8 ? 128 : 32;                      // K per MFMA
+    using Frag = typename std::conditional<F8 != 0, i32x8, bf16x8>::type;
+    struct Grp { Frag b[G][2]; Frag b2[DUAL ? G : 1][2]; unsigned sb[2]; unsigned sb2[2]; };
     auto fetch = [&](int nc_, int kc_, int gb_, Grp& gr) {
-        const int ks0_ = kc_ * (KC / 32);
-        const int nks_ = min(KC / 32, KS_total - ks0_);
+        const int ks0_ = kc_ * (KC / KSTEP);
+        const int nks_ = min(KC / KSTEP, KS_total - ks0_);
 #pragma unroll
         for (int i = 0; i < G; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int nt = nc_ * 8 + wave * 2 + j, ks = gb_ + i;
-                if (nc_ < n_chunks && ks < nks_ && nt < NT_total) {
-                    const size_t off = (((size_t)nt * KS_total + ks0_ + ks) * 64 + lane) * 8;
-                    gr.b[i][j] = *reinterpret_cast<const bf16x8*>(p.W + off);
-                    if constexpr (DUAL) gr.b2[i][j] = *reinterpret_cast<const bf16x8*>(p.W2 + off);
+                const bool live = nc_ < n_chunks && ks < nks_ && nt < NT_total;
+                if constexpr (F8) {
+                    i32x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    gr.b[i][j] = z;
+                    if constexpr (DUAL) gr.b2[i][j] = z;
+                    if (live) {
+                        const size_t off = (((size_t)nt * KS_total + ks0_ + ks) * 64 + lane) * 32;
+                        const int4 lo = *reinterpret_cast<const int4*>(p.W8 + off), hi = *reinterpret_cast<const int4*>(p.W8 + off + 16);
+                        gr.b[i][j] = i32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        if constexpr (DUAL) {
+                            const int4 l2 = *reinterpret_cast<const int4*>(p.W8b + off), h2 = *reinterpret_cast<const int4*>(p.W8b + off + 16);
+                            gr.b2[i][j] = i32x8{l2.x, l2.y, l2.z, l2.w, h2.x, h2.y, h2.z, h2.w};
+                        }
+                    }
                 } else {
-                    gr.b[i][j] = zero8();
-                    if constexpr (DUAL) gr.b2[i][j] = zero8();
+                    if (live) {
+                        const size_t off = (((size_t)nt * KS_total + ks0_ + ks) * 64 + lane) * 8;
+                        gr.b[i][j] = *reinterpret_cast<const bf16x8*>(p.W + off);
+                        if constexpr (DUAL) gr.b2[i][j] = *reinterpret_cast<const bf16x8*>(p.W2 + off);
+                    } else {
+                        gr.b[i][j] = zero8();
+                        if constexpr (DUAL) gr.b2[i][j] = zero8();
+                    }
                 }
             }
+        if constexpr (F8) {       // the scale dword of this (n-tile, 512-deep chunk): byte s = k-step s of the chunk
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nt = nc_ * 8 + wave * 2 + j;
+                const bool live = nc_ < n_chunks && kc_ < k_chunks && nt < NT_total;
+                const size_t so = (((size_t)nt * k_chunks + kc_) * 64 + lane) * 4;
+                gr.sb[j] = live ? *reinterpret_cast<const unsigned*>(p.S8 + so) : 0u;
+                gr.sb2[j] = 0u;
+                if constexpr (DUAL) gr.sb2[j] = live ? *reinterpret_cast<const unsigned*>(p.S8b + so) : 0u;
+            }
+        }
     };
     Grp cur;
     fetch(0, 0, 0, cur);
@@ -204,8 +283,13 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
                 lds_barrier();
                 PH(0)
             }
-            const int ks0 = kc * (KC / 32);
-            const int nks = min(KC / 32, KS_total - ks0);
+            const int ks0 = kc * (KC / KSTEP);
+            const int nks = min(KC / KSTEP, KS_total - ks0);
+            unsigned sa[F8 ? MT : 1];
+            if constexpr (F8) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) sa[mt] = *reinterpret_cast<const unsigned*>(Sc + ((mt * 16 + arow) * 4 + ag) * 4);
+            }
             for (int gb = 0; gb < nks; gb += G) {
                 int nnc = nc, nkc = kc, ngb = gb + G;
                 if (ngb >= nks) { ngb = 0; if (++nkc >= k_chunks) { nkc = 0; ++nnc; } }
@@ -215,13 +299,32 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
                 for (int i = 0; i < G; ++i) {
                     const int ks = gb + i;
                     if (ks < nks) {
+                        if constexpr (F8) {
+                            const int sh = 8 * ks;                     // this k-step's byte of the scale dwords -> byte 0
+                            const int sb0 = (int)(cur.sb[0] >> sh), sb1 = (int)(cur.sb[1] >> sh);
+                            const int tb0 = (int)(cur.sb2[0] >> sh), tb1 = (int)(cur.sb2[1] >> sh);
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {
-                            const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (mt * 16 + arow) * LDA + ks * 32 + ag * 8);
+                            for (int mt = 0; mt < MT; ++mt) {
+                                const unsigned char* ap = As8 + (mt * 16 + arow) * LDA + ks * 128 + ag * 16;
+                                const int4 lo = *reinterpret_cast<const int4*>(ap), hi = *reinterpret_cast<const int4*>(ap + 64);
+                                const i32x8 a = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                                const int sam = (int)(sa[mt] >> sh);
+                                acc[mt][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, cur.b[i][0], acc[mt][0], 0, 0, 0, sam, 0, sb0);
+                                acc[mt][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, cur.b[i][1], acc[mt][1], 0, 0, 0, sam, 0, sb1);
+                                if constexpr (DUAL) {
+                                    acc2[mt][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, cur.b2[i][0], acc2[mt][0], 0, 0, 0, sam, 0, tb0);
+                                    acc2[mt][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, cur.b2[i][1], acc2[mt][1], 0, 0, 0, sam, 0, tb1);
+                                }
+                            }
+                        } else {
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) {
-                                acc[mt][j] = mfma16(a, cur.b[i][j], acc[mt][j]);
-                                if constexpr (DUAL) acc2[mt][j] = mfma16(a, cur.b2[i][j], acc2[mt][j]);
+                            for (int mt = 0; mt < MT; ++mt) {
+                                const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + (mt * 16 + arow) * LDA + ks * 32 + ag * 8);
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) {
+                                    acc[mt][j] = mfma16(a, cur.b[i][j], acc[mt][j]);
+                                    if constexpr (DUAL) acc2[mt][j] = mfma16(a, cur.b2[i][j], acc2[mt][j]);
+                                }
                             }
                         }
                     }
@@ -445,17 +548,18 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
     PH_FLUSH(((AK * 3 + (EPI == E_LN_BWD ? 2 : (EPI == E_BF16 ? 0 : 1))) * 4) % 64)
 }
 
-template <int AK, int EPI, int KC, int BM>
+template <int AK, int EPI, int KC, int BM, int F8 = 0>
 int launch(const GemmParams& p, hipStream_t s) {
     const int grid = (p.M + BM - 1) / BM;
-    const size_t lds = (size_t)BM * (KC + 8) * 2 + BM * 2 * sizeof(float) + (EPI == E_SWIGLU ? 2 : 1) * EpiRows<KC>::v * TS * sizeof(float);
+    const size_t abytes = F8 ? (size_t)BM * (KC + 16) + BM * 16 : (size_t)BM * (KC + 8) * 2;
+    const size_t lds = abytes + BM * 2 * sizeof(float) + (EPI == E_SWIGLU ? 2 : 1) * EpiRows<KC>::v * TS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<AK, EPI, KC, BM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<AK, EPI, KC, BM, F8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<AK, EPI, KC, BM>), dim3(grid), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_kernel<AK, EPI, KC, BM, F8>), dim3(grid), dim3(256), lds, s, p);
     return (int)hipGetLastError();
 }
 
@@ -478,8 +582,24 @@ static bool small_weights(const GemmParams& p, bool dual) {
     return p.K <= 512 ? nk <= 800 * 1024 : nk <= 400 * 1024;
 }
 
+// fp8 (MX) form: 512-deep e4m3 chunks; 64-row panels by the same weight-size rule (any K)
+template <int AK, int EPI>
+int launch_f8(const GemmParams& p, hipStream_t s) {
+    if constexpr (EPI == E_LN_BWD || EPI == E_POS_F32) {
+        return HS_EUNSUPPORTED;
+    } else {
+        if (!p.W8 || !p.S8 || (EPI == E_SWIGLU && (!p.W8b || !p.S8b))) return HSIMAE_ENULL;
+        if (AK == A_F32_LN && p.K > 512) return HS_EUNSUPPORTED;
+        const int64_t nk = (int64_t)p.N * p.K * (EPI == E_SWIGLU ? 2 : 1);
+        bool bm64 = nk <= 800 * 1024;
+        if (g_force_bm) bm64 = g_force_bm == 64;
+        return bm64 ? launch<AK, EPI, 512, 64, 1>(p, s) : launch<AK, EPI, 512, 128, 1>(p, s);
+    }
+}
+
 template <int AK, int EPI>
 int launch_kc(const GemmParams& p, hipStream_t s) {
+    if (p.prec == HSIMAE_PREC_FP8) return launch_f8<AK, EPI>(p, s);
     bool bm64 = wide_mode() && small_weights(p, EPI == E_SWIGLU);
     if (g_force_bm) bm64 = g_force_bm == 64;
     if constexpr (AK == A_F32_LN) {
@@ -511,7 +631,7 @@ int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s) {
     if (p.M <= 0) return HS_OK;
     if (p.K % 32 || p.N % 16 || p.lda % 8 || p.ldo % 8) return HS_EDIMS;
     if ((epi == E_F32 || epi == E_RES_F32 || epi == E_POS_F32) && p.n_valid % 8) return HS_EDIMS;
-    if (akind == A_F32_LN && epi == E_BF16 && !g_force_bm && hs_lnqkv_supported(p)) return hs_lnqkv(p, s);   // persistent LN1 + q|k|v (gemm_dma.hip)
+    if (akind == A_F32_LN && epi == E_BF16 && !g_force_bm && p.prec != HSIMAE_PREC_FP8 && hs_lnqkv_supported(p)) return hs_lnqkv(p, s);   // persistent LN1 + q|k|v (gemm_dma.hip)
 #define CASE(AK, EP) \
     if (akind == AK && epi == EP) return launch_kc<AK, EP>(p, s);
     CASE(A_F32_LN, E_BF16)
@@ -522,6 +642,7 @@ int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s) {
     CASE(A_BF16, E_F32)
     CASE(A_BF16, E_BF16)
     if (akind == A_BF16 && epi == E_LN_BWD) {
+        if (p.prec == HSIMAE_PREC_FP8) return HS_EUNSUPPORTED;
         if (p.N != 128 || p.n_valid != 128 || !p.lnx || !p.res || !p.gamma || !p.dgamma || !p.dbeta || p.ldr % 4 || p.ldo % 4)
             return HS_EUNSUPPORTED;
         if (hs_lnbwd_dma_supported(p)) return hs_lnbwd_dma(p, s);      // persistent, LDS-DMA fed (gemm_dma.hip)

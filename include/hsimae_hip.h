@@ -176,6 +176,12 @@ typedef struct {
     /* optional per-row factors [M] (DropPath): a_rowscale multiplies the rows of an A_F32 operand as it is staged;
        out_rowscale multiplies (product + bias) before the residual is added in E_RES_F32.  NULL = 1. */
     const float* a_rowscale; const float* out_rowscale;
+    /* prec = HSIMAE_PREC_FP8: the MX block-scaled e4m3 form of the same product (fp32 accumulate, same epilogues except
+       E_LN_BWD / E_POS_F32).  A is quantised on the fly; W8 / S8 (and W8b / S8b for the second matrix of E_SWIGLU) are the
+       e4m3 image and its e8m0 scale image of the weight as produced by hsimae_pack_matrix with desc.fp8 = 1
+       (K padded to a multiple of 128).  W / W2 are ignored.  prec = 0: bf16, the fields below are ignored. */
+    int32_t prec;
+    const uint8_t* W8; const uint8_t* S8; const uint8_t* W8b; const uint8_t* S8b;
 } hsimae_gemm_params;
 int hsimae_gemm(const hsimae_gemm_params* p, int32_t a_kind, int32_t epilogue, void* stream);
 /* The same kernel with the row-panel height (bm: 64 or 128) and the depth of an A chunk (kc: 128 or 256; ignored by the
@@ -190,6 +196,12 @@ typedef struct {
     int32_t n_off, k_off;
     int32_t KS;
     hs_bf16* dst;
+    /* fp8 = 1: quantise to the MX e4m3 image instead (hsimae_gemm_params.prec): KS = 128-deep k-steps of the image
+       (K padded to a multiple of 128), dst = the e4m3 image (bytes), scales = its e8m0 image, one dword per (n-tile,
+       512-deep chunk, lane).  k_off and the source's K extent must be multiples of 32 (a scale block never straddles
+       two sources).  Both images must be zero-filled once before the first pack. */
+    int32_t fp8;
+    uint8_t* scales;
 } hsimae_pack_desc;
 int hsimae_pack_matrix(const hsimae_pack_desc* desc_dev, int32_t ndesc, int32_t max_elems, void* stream);
 
