@@ -49,10 +49,13 @@ constexpr int TS = 132;            // fp32 LDS tile row stride (floats): conflic
 // Operand maps (pinned with exact data by scripts/micro/mx_layout.hip): lane (r = l & 15, g = l >> 4) holds, in bytes
 // 0..15 / 16..31 of its 8-dword operand, k = 16 g + j and k = 64 + 16 g + j of row r (A) / column r (B) of the 128-deep
 // step, and supplies in its scale register the e8m0 byte of 32-block g (k in [32 g, 32 g + 32)) of that row / column.
-template <int AK, int EPI, int KC, int BM, int F8>
+// NCH: 1 = n-chunk outer (the A panel is re-staged for every n-chunk when K spans several chunks); 2 / 4 = k outer with
+// that many accumulator sets (every A chunk staged once: the deep-K products, see the k-outer branch below).
+template <int AK, int EPI, int KC, int BM, int F8, int NCH>
 __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!F8 || KC == 512, "the fp8 path stages 512-deep chunks (one scale dword per row and lane group)");
+    static_assert(NCH == 1 || (AK != A_F32_LN && EPI != E_LN_BWD && EPI != E_SWIGLU), "k-outer: plain products only");
     constexpr int MT = BM / 16;
     constexpr int LDA = F8 ? KC + 16 : KC + 8;        // LDS row stride (elements): 16-B pad => conflict-free b128 reads
     constexpr int ABYTES = F8 ? BM * LDA : BM * LDA * 2;
@@ -265,36 +268,8 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
     fetch(0, 0, 0, cur);
     PH_DECL
 
-    for (int nc = 0; nc < n_chunks; ++nc) {
-        f32x4 acc[MT][2];
-        f32x4 acc2[DUAL ? MT : 1][2];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (DUAL) acc2[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-
-        for (int kc = 0; kc < k_chunks; ++kc) {
-            if (k_chunks > 1 || nc == 0) {
-                if (!(nc == 0 && kc == 0)) lds_barrier();
-                if constexpr (AK == A_F32_LN) stage_ln(); else stage(kc);
-                lds_barrier();
-                PH(0)
-            }
-            const int ks0 = kc * (KC / KSTEP);
-            const int nks = min(KC / KSTEP, KS_total - ks0);
-            unsigned sa[F8 ? MT : 1];
-            if constexpr (F8) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) sa[mt] = *reinterpret_cast<const unsigned*>(Sc + ((mt * 16 + arow) * 4 + ag) * 4);
-            }
-            for (int gb = 0; gb < nks; gb += G) {
-                int nnc = nc, nkc = kc, ngb = gb + G;
-                if (ngb >= nks) { ngb = 0; if (++nkc >= k_chunks) { nkc = 0; ++nnc; } }
-                Grp nxt;
-                fetch(nnc, nkc, ngb, nxt);
+    // one group of G k-steps of the current A chunk against the weight fragments in `cur`
+    auto mma = [&](f32x4 (&acc)[MT][2], f32x4 (&acc2)[DUAL ? MT : 1][2], const Grp& cur, int gb, int nks, const unsigned (&sa)[F8 ? MT : 1]) {
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
                     const int ks = gb + i;
@@ -329,11 +304,10 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
                         }
                     }
                 }
-                cur = nxt;
-            }
-        }
+    };
 
-        PH(1)
+    // epilogue of one 128-column chunk
+    auto epilogue = [&](int nc, f32x4 (&acc)[MT][2], f32x4 (&acc2)[DUAL ? MT : 1][2]) {
         // ---------------------------------------------------------------- epilogue for this 128-column chunk
         const int ccols = min(128, p.N - nc * 128);            // valid columns in this chunk (multiple of 16)
         if constexpr (EPI == E_LN_BWD) {
@@ -431,7 +405,7 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
                 atomicAdd((which ? p.dbeta : p.dgamma) + c, sacc);
             }
             PH(2)
-            continue;
+            return;
         }
 #pragma unroll
         for (int ps = 0; ps < BM / PR; ++ps) {
@@ -544,22 +518,103 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
             }
         }
         PH(2)
+    };
+
+    if constexpr (NCH == 1) {
+    for (int nc = 0; nc < n_chunks; ++nc) {
+        f32x4 acc[MT][2];
+        f32x4 acc2[DUAL ? MT : 1][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (DUAL) acc2[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        for (int kc = 0; kc < k_chunks; ++kc) {
+            if (k_chunks > 1 || nc == 0) {
+                if (!(nc == 0 && kc == 0)) lds_barrier();
+                if constexpr (AK == A_F32_LN) stage_ln(); else stage(kc);
+                lds_barrier();
+                PH(0)
+            }
+            const int ks0 = kc * (KC / KSTEP);
+            const int nks = min(KC / KSTEP, KS_total - ks0);
+            unsigned sa[F8 ? MT : 1];
+            if constexpr (F8) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) sa[mt] = *reinterpret_cast<const unsigned*>(Sc + ((mt * 16 + arow) * 4 + ag) * 4);
+            }
+            for (int gb = 0; gb < nks; gb += G) {
+                int nnc = nc, nkc = kc, ngb = gb + G;
+                if (ngb >= nks) { ngb = 0; if (++nkc >= k_chunks) { nkc = 0; ++nnc; } }
+                Grp nxt;
+                fetch(nnc, nkc, ngb, nxt);
+                mma(acc, acc2, cur, gb, nks, sa);
+                cur = nxt;
+            }
+        }
+        PH(1)
+        epilogue(nc, acc, acc2);
+    }
+    } else {
+        // k outer: every A chunk is staged (and, in fp8, quantised) ONCE and multiplied against all n-chunks, whose
+        // accumulators are all live (deep-K products with N <= 128 NCH: w2, the W1|W3 and q|k|v data gradients)
+        static_assert(NCH == 1 || !DUAL, "the gate pair keeps one accumulator set");
+        f32x4 accs[NCH][MT][2];
+        f32x4 acc2[1][2];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accs[c][mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < k_chunks; ++kc) {
+            if (kc) lds_barrier();
+            stage(kc);
+            lds_barrier();
+            PH(0)
+            const int ks0 = kc * (KC / KSTEP);
+            const int nks = min(KC / KSTEP, KS_total - ks0);
+            unsigned sa[F8 ? MT : 1];
+            if constexpr (F8) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) sa[mt] = *reinterpret_cast<const unsigned*>(Sc + ((mt * 16 + arow) * 4 + ag) * 4);
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c < n_chunks) {
+                    for (int gb = 0; gb < nks; gb += G) {
+                        int nnc = c, nkc = kc, ngb = gb + G;
+                        if (ngb >= nks) { ngb = 0; if (++nnc >= n_chunks) { nnc = 0; ++nkc; } }
+                        Grp nxt;
+                        fetch(nnc, nkc, ngb, nxt);
+                        mma(accs[c], acc2, cur, gb, nks, sa);
+                        cur = nxt;
+                    }
+                }
+            }
+        }
+        PH(1)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (c < n_chunks) epilogue(c, accs[c], acc2);
     }
     PH_FLUSH(((AK * 3 + (EPI == E_LN_BWD ? 2 : (EPI == E_BF16 ? 0 : 1))) * 4) % 64)
 }
 
-template <int AK, int EPI, int KC, int BM, int F8 = 0>
+template <int AK, int EPI, int KC, int BM, int F8 = 0, int NCH = 1>
 int launch(const GemmParams& p, hipStream_t s) {
     const int grid = (p.M + BM - 1) / BM;
     const size_t abytes = F8 ? (size_t)BM * (KC + 16) + BM * 16 : (size_t)BM * (KC + 8) * 2;
     const size_t lds = abytes + BM * 2 * sizeof(float) + (EPI == E_SWIGLU ? 2 : 1) * EpiRows<KC>::v * TS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<AK, EPI, KC, BM, F8>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<AK, EPI, KC, BM, F8, NCH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<AK, EPI, KC, BM, F8>), dim3(grid), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((gemm_kernel<AK, EPI, KC, BM, F8, NCH>), dim3(grid), dim3(256), lds, s, p);
     return (int)hipGetLastError();
 }
 
@@ -575,6 +630,12 @@ static int wide_mode() {
     return m;
 }
 static thread_local int g_force_bm = 0, g_force_kc = 0;       // hsimae_gemm_tiled (tile sweeps): 0 = the shape rule below
+// HSIMAE_GEMM_KOUTER=0: never the k-outer schedule (A/B runs)
+static bool k_outer() {
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("HSIMAE_GEMM_KOUTER"); m = !(e && e[0] == '0'); }
+    return m != 0;
+}
 static bool small_weights(const GemmParams& p, bool dual) {
     const int64_t nk = (int64_t)p.N * p.K;
     if (p.K < 256) return false;
@@ -593,6 +654,11 @@ int launch_f8(const GemmParams& p, hipStream_t s) {
         const int64_t nk = (int64_t)p.N * p.K * (EPI == E_SWIGLU ? 2 : 1);
         bool bm64 = nk <= 800 * 1024;
         if (g_force_bm) bm64 = g_force_bm == 64;
+        if constexpr (AK != A_F32_LN && EPI != E_SWIGLU) {
+            // deep K (several 512-chunks) and at most 4 n-chunks: k outer on 64-row panels, every chunk quantised once
+            if (k_outer() && p.K > 512 && p.N > 128 && p.N <= 512 && g_force_bm != 128)
+                return p.N <= 256 ? launch<AK, EPI, 512, 64, 1, 2>(p, s) : launch<AK, EPI, 512, 64, 1, 4>(p, s);
+        }
         return bm64 ? launch<AK, EPI, 512, 64, 1>(p, s) : launch<AK, EPI, 512, 128, 1>(p, s);
     }
 }
@@ -611,6 +677,10 @@ int launch_kc(const GemmParams& p, hipStream_t s) {
         return launch<AK, EPI, 128, 128>(p, s);
     } else {
         const bool kc256 = g_force_kc ? g_force_kc == 256 : (bm64 && p.K >= 256 && p.K <= 1024);
+        if constexpr (EPI != E_SWIGLU && EPI != E_SWIGLU_BWD) {
+            if (k_outer() && !g_force_bm && p.K > 256 && p.N > 128 && p.N <= 512)
+                return p.N <= 256 ? launch<AK, EPI, 256, 64, 0, 2>(p, s) : launch<AK, EPI, 256, 64, 0, 4>(p, s);
+        }
         if (kc256) return bm64 ? launch<AK, EPI, 256, 64>(p, s) : launch<AK, EPI, 256, 128>(p, s);
         return bm64 ? launch<AK, EPI, 128, 64>(p, s) : launch<AK, EPI, 128, 128>(p, s);
     }
