@@ -50,7 +50,7 @@ class GemmParams(C.Structure):
                 ("h13", vp), ("ldh", i32), ("hoff", i32),
                 ("lnx", vp), ("dgamma", vp), ("dbeta", vp), ("accumulate", i32),
                 ("a_rowscale", vp), ("out_rowscale", vp),
-                ("prec", i32), ("W8", vp), ("S8", vp), ("W8b", vp), ("S8b", vp)]
+                ("prec", i32), ("W8", vp), ("S8", vp), ("W8b", vp), ("S8b", vp), ("ln_width", i32)]
 
 
 class PackDesc(C.Structure):
@@ -61,7 +61,8 @@ class PackDesc(C.Structure):
 class AttnParams(C.Structure):
     _fields_ = [("qkv", vp), ("ld", i32), ("d", i32), ("heads", i32), ("hd", i32), ("Ts", i32), ("nsamples", i32),
                 ("mode", i32), ("len_l", i32), ("o", vp), ("ldo", i32), ("lse", vp), ("dout", vp), ("lddo", i32),
-                ("dqkv", vp), ("proj_w", vp), ("proj_b", vp), ("xres", vp), ("x1", vp), ("projT_w", vp), ("rowscale", vp)]
+                ("dqkv", vp), ("proj_w", vp), ("proj_b", vp), ("xres", vp), ("x1", vp), ("projT_w", vp), ("rowscale", vp),
+                ("kv_off", i32)]
 
 
 class MlpWeights(C.Structure):
@@ -80,12 +81,12 @@ class WgradParams(C.Structure):
 
 class LnBwdParams(C.Structure):
     _fields_ = [("du", vp), ("x", vp), ("stats", vp), ("gamma", vp), ("dres", vp), ("dx", vp), ("accumulate", i32),
-                ("dgamma", vp), ("dbeta", vp), ("M", i32), ("d", i32)]
+                ("dgamma", vp), ("dbeta", vp), ("M", i32), ("d", i32), ("ld", i32)]
 
 
 class AssembleParams(C.Structure):
     _fields_ = [("y", vp), ("N", i32), ("K", i32), ("TL", i32), ("Dd", i32), ("ids_restore", vp), ("pos", vp),
-                ("yfull", vp), ("dyfull", vp), ("dy", vp)]
+                ("yfull", vp), ("dyfull", vp), ("dy", vp), ("ld", i32)]
 
 
 class LossParams(C.Structure):

@@ -24,7 +24,7 @@ def _stale(target: str, deps: list[str]) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"),
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "plan.h"),
             os.path.join(HERE, "..", "include", "hsimae_hip.h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -50,5 +50,31 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+ASAN_LIB = os.path.join(HERE, "libhsimae_plan_asan.so")
+
+
+def build_asan(force: bool = False) -> str:
+    """Host-only sanitizer build of the planning code (csrc/plan.h: geometry, layouts, pack table, workspace carve) behind
+    the library's own C entry points: g++ -fsanitize=address,undefined.  CPU only; never loaded by the product."""
+    src = os.path.join(CSRC, "plan_host.cpp")
+    deps = [src, os.path.join(CSRC, "plan.h"), os.path.join(HERE, "..", "include", "hsimae_hip.h")]
+    if force or _stale(ASAN_LIB, deps):
+        cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+               "-fno-sanitize-recover=undefined", "-shared", "-fPIC", src, "-o", ASAN_LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(f"sanitizer build failed:\n{r.stderr[-4000:]}")
+    return ASAN_LIB
+
+
+def asan_runtime() -> str:
+    """Path of libasan for LD_PRELOAD (the interpreter itself is not instrumented)."""
+    r = subprocess.run([os.environ.get("CXX", "g++"), "-print-file-name=libasan.so"], capture_output=True, text=True)
+    return os.path.realpath(r.stdout.strip())
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--asan" in sys.argv:
+        print(build_asan(force="--force" in sys.argv))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -2,11 +2,14 @@
 // the whole-pass forward / backward schedules of the HSIMAE pretraining path.
 #include "common.h"
 #include "kernels.h"
+#include "plan.h"
 #include <vector>
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
+
+using namespace hsplan;
 
 namespace {
 
@@ -14,236 +17,6 @@ namespace {
 #define CK0(expr) do { int _e0 = (expr); if (_e0) return _e0; } while (0)
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
-inline int rup(int x, int m) { return (x + m - 1) / m * m; }
-
-// ------------------------------------------------------------------ parameter layout (flat fp32, registration order)
-struct BlkOff { int64_t n1w, n1b, qw, qb, kw, kb, vw, vb, pw, pb, n2w, n2b, w1w, w1b, w2w, w2b, w3w, w3b, end; };
-
-struct Geo {
-    int B, T, TL, D, H, hd, h, hp, Dd, Hd, hdd, hdec, hpd, depth, sdepth, nfus, ddepth, norm_pix, prec;
-    bool has_axis, has_fus;
-};
-
-int make_geo(const hsimae_config* c, Geo& g) {
-    if (!c) return HSIMAE_ENULL;
-    if (c->bands <= 0 || c->bands % 8) return HSIMAE_EDIMS;
-    g.B = c->bands; g.T = c->bands / 8; g.TL = g.T * 9;
-    g.D = c->embed_dim; g.H = c->num_heads; g.Dd = c->dec_dim; g.Hd = c->dec_heads;
-    if (g.D <= 0 || g.Dd <= 0 || g.H <= 0 || g.Hd <= 0 || g.D % g.H || g.Dd % g.Hd) return HSIMAE_EDIMS;
-    g.hd = g.D / g.H; g.hdd = g.Dd / g.Hd;
-    g.h = c->hidden; g.hdec = c->dec_hidden; g.hp = rup(g.h, 32); g.hpd = rup(g.hdec, 32);
-    g.depth = c->depth; g.sdepth = c->s_depth; g.ddepth = c->dec_depth;
-    g.has_axis = g.sdepth > 0;
-    g.has_fus = g.sdepth < 12;                     // Models.py:385 (hard-coded 12)
-    g.nfus = g.has_fus ? std::max(0, g.depth - g.sdepth) : 0;
-    g.norm_pix = c->norm_pix_loss;
-    g.prec = c->precision;
-    if (g.prec != HSIMAE_PREC_BF16 && g.prec != HSIMAE_PREC_FP8) return HSIMAE_EUNSUPPORTED;
-    if (g.D % 32 || g.Dd % 32 || g.D > 512 || g.Dd > 512) return HSIMAE_EUNSUPPORTED;
-    if ((g.hd != 8 && g.hd != 16) || (g.hdd != 8 && g.hdd != 16)) return HSIMAE_EUNSUPPORTED;
-    if (g.h <= 0 || g.hdec <= 0 || g.h % 4 || g.hdec % 4 || g.T > 64 || g.ddepth < 1) return HSIMAE_EUNSUPPORTED;
-    return HSIMAE_OK;
-}
-
-struct PLayout {
-    int64_t pos, mask_token, dpos, pew, peb, nw, nb, dew, deb, dnw, dnb, dpw, dpb, total;
-    std::vector<BlkOff> b1, b2, bf, bd;
-    std::vector<int64_t> offs, sizes;
-};
-
-void make_playout(const Geo& g, PLayout& L) {
-    int64_t cur = 0;
-    auto add = [&](int64_t n) { int64_t o = cur; L.offs.push_back(o); L.sizes.push_back(n); cur += n; return o; };
-    auto blk = [&](int d, int h) {
-        BlkOff b;
-        b.n1w = add(d); b.n1b = add(d);
-        b.qw = add((int64_t)d * d); b.qb = add(d);
-        b.kw = add((int64_t)d * d); b.kb = add(d);
-        b.vw = add((int64_t)d * d); b.vb = add(d);
-        b.pw = add((int64_t)d * d); b.pb = add(d);
-        b.n2w = add(d); b.n2b = add(d);
-        b.w1w = add((int64_t)h * d); b.w1b = add(h);
-        b.w2w = add((int64_t)d * h); b.w2b = add(d);
-        b.w3w = add((int64_t)h * d); b.w3b = add(h);
-        b.end = cur;
-        return b;
-    };
-    L.pos = add((int64_t)g.TL * g.D);
-    L.mask_token = add(g.Dd);
-    L.dpos = add((int64_t)g.TL * g.Dd);
-    L.pew = add((int64_t)g.D * 72);
-    L.peb = add(g.D);
-    if (g.has_axis) {
-        for (int i = 0; i < g.sdepth; ++i) L.b1.push_back(blk(g.D, g.h));
-        for (int i = 0; i < g.sdepth; ++i) L.b2.push_back(blk(g.D, g.h));
-    }
-    for (int i = 0; i < g.nfus; ++i) L.bf.push_back(blk(g.D, g.h));
-    L.nw = add(g.D); L.nb = add(g.D);
-    L.dew = add((int64_t)g.Dd * g.D); L.deb = add(g.Dd);
-    for (int i = 0; i < g.ddepth; ++i) L.bd.push_back(blk(g.Dd, g.hdec));
-    L.dnw = add(g.Dd); L.dnb = add(g.Dd);
-    L.dpw = add((int64_t)72 * g.Dd); L.dpb = add(72);
-    L.total = cur;
-}
-
-// ------------------------------------------------------------------ packed-weight layout (bf16 images + fp32 bias packs)
-struct Img8 { int64_t w, s; };            // byte offsets of an e4m3 image and of its e8m0 scale image (fp8 region)
-struct BlkW {
-    int64_t qkv, p, w1, w3, w2, qkvT, pT, w13T, w2T; int64_t bqkv;   // element offsets (bf16) / float offsets
-    Img8 qkv8, p8, w1_8, w3_8, w2_8, qkvT8, pT8, w13T8, w2T8;         // precision = FP8: encoder blocks only
-};
-struct WLayout {
-    int64_t pe, de, deT, dp, dpT;
-    std::vector<BlkW> b1, b2, bf, bd;
-    int64_t bf16_elems;      // bf16 region size (elements), multiple of 8
-    int64_t f32_elems;       // fp32 region (bias packs)
-    int64_t fp8_bytes;       // e4m3 images + scale images of the encoder blocks (precision = FP8), after the fp32 region
-    int64_t total_elems;     // in bf16 units
-};
-
-void make_wlayout(const Geo& g, WLayout& W) {
-    int64_t cur = 0, fcur = 0, cur8 = 0;
-    auto img = [&](int N, int K) { int64_t o = cur; cur += (int64_t)N * K; return o; };
-    auto img8 = [&](int N, int K) {       // [ceil(N/16)][ceil(K/128)][64 lanes][32 B] + one scale dword per (n-tile, 512-chunk, lane)
-        const int64_t nt = (N + 15) / 16, ks = (K + 127) / 128, kch = (ks + 3) / 4;
-        Img8 o; o.w = cur8; cur8 += nt * ks * 64 * 32; o.s = cur8; cur8 += nt * kch * 64 * 4;
-        return o;
-    };
-    auto blk = [&](int d, int hp, bool f8) {
-        BlkW b; std::memset(&b, 0, sizeof(b));
-        b.qkv = img(3 * d, d); b.p = img(d, d); b.w1 = img(hp, d); b.w3 = img(hp, d); b.w2 = img(d, hp);
-        b.qkvT = img(d, 3 * d); b.pT = img(d, d); b.w13T = img(d, 2 * hp); b.w2T = img(hp, d);
-        b.bqkv = fcur; fcur += 3 * d;
-        if (f8) {
-            b.qkv8 = img8(3 * d, d); b.p8 = img8(d, d); b.w1_8 = img8(hp, d); b.w3_8 = img8(hp, d); b.w2_8 = img8(d, hp);
-            b.qkvT8 = img8(d, 3 * d); b.pT8 = img8(d, d); b.w13T8 = img8(d, 2 * hp); b.w2T8 = img8(hp, d);
-        }
-        return b;
-    };
-    const bool f8 = g.prec == HSIMAE_PREC_FP8;
-    W.pe = img(g.D, 96);
-    if (g.has_axis) {
-        for (int i = 0; i < g.sdepth; ++i) W.b1.push_back(blk(g.D, g.hp, f8));
-        for (int i = 0; i < g.sdepth; ++i) W.b2.push_back(blk(g.D, g.hp, f8));
-    }
-    for (int i = 0; i < g.nfus; ++i) W.bf.push_back(blk(g.D, g.hp, f8));
-    W.de = img(g.Dd, g.D); W.deT = img(g.D, g.Dd);
-    for (int i = 0; i < g.ddepth; ++i) W.bd.push_back(blk(g.Dd, g.hpd, false));
-    W.dp = img(80, g.Dd); W.dpT = img(g.Dd, 96);
-    W.bf16_elems = (cur + 7) & ~7ll;
-    W.f32_elems = (fcur + 3) & ~3ll;            // keeps the fp8 region 16-B aligned
-    W.fp8_bytes = cur8;
-    W.total_elems = W.bf16_elems + 2 * W.f32_elems + (cur8 + 1) / 2;
-}
-
-void pack_descs(const Geo& g, const PLayout& L, const WLayout& W, const float* P, hs_bf16* wpk,
-                std::vector<PackDesc>& out) {
-    float* fbase = reinterpret_cast<float*>(wpk + W.bf16_elems);
-    unsigned char* base8 = reinterpret_cast<unsigned char*>(fbase + W.f32_elems);
-    auto mat = [&](int64_t src, int rows, int cols, int tr, int n_off, int k_off, int K_img, int64_t dst) {
-        PackDesc d; std::memset(&d, 0, sizeof(d));
-        d.src = P + src; d.rows = rows; d.cols = cols; d.transpose = tr; d.n_off = n_off; d.k_off = k_off;
-        d.KS = K_img / 32; d.dst = wpk + dst; out.push_back(d);
-    };
-    auto mat8 = [&](int64_t src, int rows, int cols, int tr, int n_off, int k_off, int K_img, const Img8& im) {
-        PackDesc d; std::memset(&d, 0, sizeof(d));
-        d.src = P + src; d.rows = rows; d.cols = cols; d.transpose = tr; d.n_off = n_off; d.k_off = k_off;
-        d.KS = (K_img + 127) / 128; d.dst = reinterpret_cast<hs_bf16*>(base8 + im.w); d.fp8 = 1; d.scales = base8 + im.s;
-        out.push_back(d);
-    };
-    auto fcopy = [&](int64_t src, int n, int64_t dst_f, int off) {
-        PackDesc d; std::memset(&d, 0, sizeof(d));
-        d.src = P + src; d.rows = 1; d.cols = n; d.transpose = 0; d.n_off = off; d.k_off = 0; d.KS = 0;
-        d.dst = reinterpret_cast<hs_bf16*>(fbase + dst_f); out.push_back(d);
-    };
-    auto blk = [&](const BlkOff& b, const BlkW& w, int d, int h, int hp, bool f8) {
-        mat(b.qw, d, d, 0, 0, 0, d, w.qkv); mat(b.kw, d, d, 0, d, 0, d, w.qkv); mat(b.vw, d, d, 0, 2 * d, 0, d, w.qkv);
-        mat(b.pw, d, d, 0, 0, 0, d, w.p);
-        mat(b.w1w, h, d, 0, 0, 0, d, w.w1); mat(b.w3w, h, d, 0, 0, 0, d, w.w3);
-        mat(b.w2w, d, h, 0, 0, 0, hp, w.w2);
-        // transposed images for the data gradients
-        mat(b.qw, d, d, 1, 0, 0, 3 * d, w.qkvT); mat(b.kw, d, d, 1, 0, d, 3 * d, w.qkvT); mat(b.vw, d, d, 1, 0, 2 * d, 3 * d, w.qkvT);
-        mat(b.pw, d, d, 1, 0, 0, d, w.pT);
-        mat(b.w1w, h, d, 1, 0, 0, 2 * hp, w.w13T); mat(b.w3w, h, d, 1, 0, hp, 2 * hp, w.w13T);
-        mat(b.w2w, d, h, 1, 0, 0, d, w.w2T);
-        fcopy(b.qb, d, w.bqkv, 0); fcopy(b.kb, d, w.bqkv, d); fcopy(b.vb, d, w.bqkv, 2 * d);
-        if (f8) {                                     // the same images as MX e4m3 (encoder blocks, precision = FP8)
-            mat8(b.qw, d, d, 0, 0, 0, d, w.qkv8); mat8(b.kw, d, d, 0, d, 0, d, w.qkv8); mat8(b.vw, d, d, 0, 2 * d, 0, d, w.qkv8);
-            mat8(b.pw, d, d, 0, 0, 0, d, w.p8);
-            mat8(b.w1w, h, d, 0, 0, 0, d, w.w1_8); mat8(b.w3w, h, d, 0, 0, 0, d, w.w3_8);
-            mat8(b.w2w, d, h, 0, 0, 0, hp, w.w2_8);
-            mat8(b.qw, d, d, 1, 0, 0, 3 * d, w.qkvT8); mat8(b.kw, d, d, 1, 0, d, 3 * d, w.qkvT8); mat8(b.vw, d, d, 1, 0, 2 * d, 3 * d, w.qkvT8);
-            mat8(b.pw, d, d, 1, 0, 0, d, w.pT8);
-            mat8(b.w1w, h, d, 1, 0, 0, 2 * hp, w.w13T8); mat8(b.w3w, h, d, 1, 0, hp, 2 * hp, w.w13T8);
-            mat8(b.w2w, d, h, 1, 0, 0, d, w.w2T8);
-        }
-    };
-    mat(L.pew, g.D, 72, 0, 0, 0, 96, W.pe);
-    const bool f8 = g.prec == HSIMAE_PREC_FP8;
-    for (size_t i = 0; i < L.b1.size(); ++i) blk(L.b1[i], W.b1[i], g.D, g.h, g.hp, f8);
-    for (size_t i = 0; i < L.b2.size(); ++i) blk(L.b2[i], W.b2[i], g.D, g.h, g.hp, f8);
-    for (size_t i = 0; i < L.bf.size(); ++i) blk(L.bf[i], W.bf[i], g.D, g.h, g.hp, f8);
-    mat(L.dew, g.Dd, g.D, 0, 0, 0, g.D, W.de); mat(L.dew, g.Dd, g.D, 1, 0, 0, g.Dd, W.deT);
-    for (size_t i = 0; i < L.bd.size(); ++i) blk(L.bd[i], W.bd[i], g.Dd, g.hdec, g.hpd, false);
-    mat(L.dpw, 72, g.Dd, 0, 0, 0, g.Dd, W.dp); mat(L.dpw, 72, g.Dd, 1, 0, 0, 96, W.dpT);
-}
-
-// ------------------------------------------------------------------ workspace
-struct BlkBuf { hs_bf16* u; hs_bf16* qkv; float* lse; hs_bf16* o; float* x1; hs_bf16* u2; hs_bf16* h13; hs_bf16* g; float* x2; };
-
-struct Scr { float* G1; float* du; hs_bf16* dh13; hs_bf16* dob; hs_bf16* dqkv; hs_bf16* g0b; hs_bf16* g1b; };   // per-stream backward scratch (g0b/g1b: bf16 dY / dx1)
-
-struct Ws {
-    Scr sc, sc2;                      // sc2: encoder-sized second set for the side stream (spectral stack)
-    hs_bf16* a_pe; float* x0;
-    std::vector<BlkBuf> b1, b2, bf, bd;
-    hs_bf16* lat; float* y; float* yfull; hs_bf16* zn; float* pred; hs_bf16* dpred; float* partial;
-    float *G0, *G1, *G2, *du; hs_bf16 *dh13, *dob, *dqkv, *dyb;
-    int64_t bytes;
-};
-
-void carve(const Geo& g, int N, int K, char* base, Ws& w) {
-    int64_t cur = 0;
-    auto take = [&](int64_t bytes) { char* p = base ? base + cur : nullptr; cur += (bytes + 255) & ~255ll; return p; };
-    const int64_t Me = (int64_t)N * K, Md = (int64_t)N * g.TL;
-    auto blk = [&](int64_t M, int d, int heads, int hp) {
-        BlkBuf b;
-        b.u = (hs_bf16*)take(M * d * 2); b.qkv = (hs_bf16*)take(M * 3 * d * 2); b.lse = (float*)take(M * heads * 4);
-        b.o = (hs_bf16*)take(M * d * 2); b.x1 = (float*)take(M * d * 4); b.u2 = (hs_bf16*)take(M * d * 2);
-        b.h13 = (hs_bf16*)take(M * 2 * hp * 2); b.g = (hs_bf16*)take(M * hp * 2); b.x2 = (float*)take(M * d * 4);
-        return b;
-    };
-    w.a_pe = (hs_bf16*)take(Me * 96 * 2);
-    w.x0 = (float*)take(Me * g.D * 4);
-    w.b1.clear(); w.b2.clear(); w.bf.clear(); w.bd.clear();
-    if (g.has_axis) {
-        for (int i = 0; i < g.sdepth; ++i) w.b1.push_back(blk(Me, g.D, g.H, g.hp));
-        for (int i = 0; i < g.sdepth; ++i) w.b2.push_back(blk(Me, g.D, g.H, g.hp));
-    }
-    for (int i = 0; i < g.nfus; ++i) w.bf.push_back(blk(Me, g.D, g.H, g.hp));
-    w.lat = (hs_bf16*)take(Me * g.D * 2);
-    w.y = (float*)take(Me * g.Dd * 4);
-    w.yfull = (float*)take(Md * g.Dd * 4);
-    for (int i = 0; i < g.ddepth; ++i) w.bd.push_back(blk(Md, g.Dd, g.Hd, g.hpd));
-    w.zn = (hs_bf16*)take(Md * g.Dd * 2);
-    w.pred = (float*)take(Md * 72 * 4);
-    w.dpred = (hs_bf16*)take(Md * 96 * 2);
-    w.partial = (float*)take((int64_t)hs_loss_partials(N, g.T) * 4);
-    const int64_t gmax = std::max(Me * g.D, Md * g.Dd);
-    w.G0 = (float*)take(gmax * 4); w.G1 = (float*)take(gmax * 4); w.G2 = (float*)take(gmax * 4); w.du = (float*)take(gmax * 4);
-    w.dh13 = (hs_bf16*)take(std::max(Me * 2 * g.hp, Md * 2 * g.hpd) * 2);
-    w.dob = (hs_bf16*)take(gmax * 2);
-    w.dqkv = (hs_bf16*)take(gmax * 3 * 2);
-    w.dyb = (hs_bf16*)take(Me * g.Dd * 2);
-    w.sc.G1 = w.G1; w.sc.du = w.du; w.sc.dh13 = w.dh13; w.sc.dob = w.dob; w.sc.dqkv = w.dqkv;
-    w.sc2.G1 = (float*)take(Me * g.D * 4); w.sc2.du = (float*)take(Me * g.D * 4);
-    w.sc2.dh13 = (hs_bf16*)take(Me * 2 * g.hp * 2); w.sc2.dob = (hs_bf16*)take(Me * g.D * 2);
-    w.sc2.dqkv = (hs_bf16*)take(Me * g.D * 3 * 2);
-    w.sc.g0b = (hs_bf16*)take(gmax * 2); w.sc.g1b = (hs_bf16*)take(gmax * 2);     // (also decoder rows on the layer-at-a-time path)
-    w.sc2.g0b = (hs_bf16*)take(Me * g.D * 2); w.sc2.g1b = (hs_bf16*)take(Me * g.D * 2);
-    w.bytes = cur;
-}
-
 struct BlkP {            // resolved pointers of one block
     const float *n1w, *n1b, *bqkv, *pb, *n2w, *n2b, *w1b, *w3b, *w2b;
     const hs_bf16 *qkv, *p, *w1, *w3, *w2, *qkvT, *pT, *w13T, *w2T;
@@ -372,6 +145,7 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
               int nsamples, int mode, int len_l, const float* res2, hipStream_t s, const float* rs_a = nullptr,
               const float* rs_m = nullptr) {
     GemmParams p = gp();
+    const int dp = rup(d, 32);                        // storage width of the rows (plan.h Geo::Dp); the fused kernels need dp == d
     const bool f8 = P.prec == HSIMAE_PREC_FP8;        // the linears on MX e4m3 images, layer at a time (no fused kernels)
     auto w8 = [&](GemmParams& q, const BlkP::I8& a) { if (f8) { q.prec = HSIMAE_PREC_FP8; q.W8 = a.w; q.S8 = a.s; } };
     if (!f8 && hs_attn_block_fusable(d, heads, Ts)) {
@@ -380,54 +154,40 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
                              len_l, s));
         if (fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
     } else {
-    p.A = x_in; p.lda = d; p.M = (int)M; p.N = 3 * d; p.K = d; p.n_valid = 3 * d; p.W = P.qkv; p.bias = P.bqkv;
-    p.gamma = P.n1w; p.beta = P.n1b; p.u_out = b.u; p.ldu = d; p.out = b.qkv; p.ldo = 3 * d;
+    p.A = x_in; p.lda = dp; p.M = (int)M; p.N = 3 * dp; p.K = dp; p.n_valid = 3 * dp; p.W = P.qkv; p.bias = P.bqkv;
+    p.gamma = P.n1w; p.beta = P.n1b; p.u_out = b.u; p.ldu = dp; p.out = b.qkv; p.ldo = 3 * dp; p.ln_width = d;
     w8(p, P.qkv8);
     CK(hs_gemm(p, A_F32_LN, E_BF16, s));
     AttnParams a; std::memset(&a, 0, sizeof(a));
-    a.qkv = b.qkv; a.ld = 3 * d; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
-    a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = d; a.lse = b.lse;
+    a.qkv = b.qkv; a.ld = 3 * dp; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
+    a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = dp; a.lse = b.lse; a.kv_off = dp;
     if (!f8 && hs_attn_proj_fusable(a)) {     // proj + residual inside the attention kernel (x1 = x + o Wp^T + b)
         a.proj_w = P.p; a.proj_b = P.pb; a.xres = x_in; a.x1 = b.x1; a.rowscale = rs_a;
         CK(hs_attn_fwd(a, s));
     } else {
         CK(hs_attn_fwd(a, s));
         p = gp();
-        p.A = b.o; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d; p.W = P.p; p.bias = P.pb;
-        p.res = x_in; p.ldr = d; p.out = b.x1; p.ldo = d; p.out_rowscale = rs_a;
+        p.A = b.o; p.lda = dp; p.M = (int)M; p.N = dp; p.K = dp; p.n_valid = d; p.W = P.p; p.bias = P.pb;
+        p.res = x_in; p.ldr = dp; p.out = b.x1; p.ldo = dp; p.out_rowscale = rs_a;
         w8(p, P.p8);
         CK(hs_gemm(p, A_BF16, E_RES_F32, s));
     }
     }
     if (!f8 && fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
     p = gp();
-    p.A = b.x1; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = h; p.W = P.w1; p.W2 = P.w3; p.bias = P.w1b;
-    p.bias2 = P.w3b; p.gamma = P.n2w; p.beta = P.n2b; p.u_out = b.u2; p.ldu = d; p.out = b.g; p.ldo = hp;
-    p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp;
+    p.A = b.x1; p.lda = dp; p.M = (int)M; p.N = hp; p.K = dp; p.n_valid = h; p.W = P.w1; p.W2 = P.w3; p.bias = P.w1b;
+    p.bias2 = P.w3b; p.gamma = P.n2w; p.beta = P.n2b; p.u_out = b.u2; p.ldu = dp; p.out = b.g; p.ldo = hp;
+    p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp; p.ln_width = d;
     if (f8) { w8(p, P.w1_8); p.W8b = P.w3_8.w; p.S8b = P.w3_8.s; }
     CK(hs_gemm(p, A_F32_LN, E_SWIGLU, s));
     p = gp();
-    p.A = b.g; p.lda = hp; p.M = (int)M; p.N = d; p.K = hp; p.n_valid = d; p.W = P.w2; p.bias = P.w2b;
-    p.res = b.x1; p.res2 = res2; p.ldr = d; p.out = b.x2; p.ldo = d; p.out_rowscale = rs_m;
+    p.A = b.g; p.lda = hp; p.M = (int)M; p.N = dp; p.K = hp; p.n_valid = d; p.W = P.w2; p.bias = P.w2b;
+    p.res = b.x1; p.res2 = res2; p.ldr = dp; p.out = b.x2; p.ldo = dp; p.out_rowscale = rs_m;
     w8(p, P.w2_8);
     CK(hs_gemm(p, A_BF16, E_RES_F32, s));
     return HSIMAE_OK;
 }
 
-int wgrad_msplit(int tiles, int64_t M, int concurrent = 1) {
-    const int chunks = (int)((M + 63) / 64);
-    // the kernel holds 2 workgroups per CU (196 registers: 64 accumulators + the prefetched next chunk): keep the
-    // launch to one resident wave of workgroups (HSIMAE_WGRAD_WGS overrides the 512 for experiments)
-    static int budget = 0;
-    if (!budget) { const char* e = getenv("HSIMAE_WGRAD_WGS"); budget = e ? std::max(8, atoi(e)) : 512; }
-    // `concurrent` launches resident at once (the forked axis stacks) share the budget as long as each still gets whole
-    // groups of 8 row slices: slice ms runs on XCD ms % 8, so fewer than 8 slices leave XCDs idle (D = 256: 52 tiles,
-    // sharing made the step 13 % slower; D = 128: 13 tiles, 2 % faster).
-    int ms = std::max(1, budget / std::max(1, concurrent) / std::max(1, tiles));
-    if (ms < 8) ms = std::max(1, budget / std::max(1, tiles));
-    if (ms >= 8) ms &= ~7;              // whole XCD groups (wgrad.hip places row slice ms on XCD ms % 8)
-    return std::min(ms, chunks);
-}
 
 // One Block backward: data grads (7 launches) + all weight/bias grads of the block (1 launch).
 int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, const BlkBuf& b, int64_t M, int d,
@@ -436,8 +196,9 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
               const float* rs_m = nullptr) {
     float* G1 = w.G1;
     GemmParams p = gp();
+    const int dp = rup(d, 32);                        // storage width (see block_fwd)
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
-    l.M = (int)M; l.d = d;
+    l.M = (int)M; l.d = d; l.ld = dp;
     const bool f8 = P.prec == HSIMAE_PREC_FP8;
     auto w8 = [&](GemmParams& q, const BlkP::I8& a) { if (f8) { q.prec = HSIMAE_PREC_FP8; q.W8 = a.w; q.S8 = a.s; } };
     const bool fmlp = !f8 && fused_mlp_enabled(d, h);
@@ -446,12 +207,12 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         CK(hs_enc_mlp_bwd(b.x1, G0, G1, b.u2, w.dh13, b.g, w.g0b, w.g1b, (int)M, d, mlp_ptrs(P, h), grads + o.n2w,
                           grads + o.n2b, s, rs_m, rs_a));
     } else {
-        p.A = G0; p.lda = d; p.M = (int)M; p.N = hp; p.K = d; p.n_valid = hp; p.W = P.w2T; p.out = w.dh13; p.ldo = 2 * hp;
+        p.A = G0; p.lda = dp; p.M = (int)M; p.N = hp; p.K = dp; p.n_valid = hp; p.W = P.w2T; p.out = w.dh13; p.ldo = 2 * hp;
         p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp; p.a_rowscale = rs_m;        // DropPath: the branch saw rs_m * dY
         w8(p, P.w2T8);
         CK(hs_gemm(p, A_F32, E_SWIGLU_BWD, s));
         p = gp();
-        p.A = w.dh13; p.lda = 2 * hp; p.M = (int)M; p.N = d; p.K = 2 * hp; p.n_valid = d; p.W = P.w13T; p.out = w.du; p.ldo = d;
+        p.A = w.dh13; p.lda = 2 * hp; p.M = (int)M; p.N = dp; p.K = 2 * hp; p.n_valid = d; p.W = P.w13T; p.out = w.du; p.ldo = dp;
         w8(p, P.w13T8);
         CK(hs_gemm(p, A_BF16, E_F32, s));
         l.du = w.du; l.x = b.x1; l.gamma = P.n2w; l.dres = G0; l.dx = G1; l.accumulate = 0;
@@ -459,20 +220,20 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         CK(hs_ln_bwd(l, s));
         // bf16 copies of dY / dx1 (with the DropPath factors folded in) so that the weight gradients below take the
         // LDS-DMA kernel: 666 -> ~300 us per block at D = 256
-        CK(hs_rows_to_bf16(G0, w.g0b, M, d, rs_m, s));
-        CK(hs_rows_to_bf16(G1, w.g1b, M, d, rs_a, s));
+        CK(hs_rows_to_bf16(G0, w.g0b, M, dp, rs_m, s));
+        CK(hs_rows_to_bf16(G1, w.g1b, M, dp, rs_a, s));
     }
     AttnParams a; std::memset(&a, 0, sizeof(a));
-    a.qkv = b.qkv; a.ld = 3 * d; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
-    a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = d; a.lse = b.lse; a.dout = w.dob; a.lddo = d; a.dqkv = w.dqkv;
+    a.qkv = b.qkv; a.ld = 3 * dp; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
+    a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = dp; a.lse = b.lse; a.dout = w.dob; a.lddo = dp; a.dqkv = w.dqkv; a.kv_off = dp;
     static int fuse_pb = -1;                  // HSIMAE_FUSED_PROJ_BWD=0: keep the projection's data gradient a separate GEMM
     if (fuse_pb < 0) { const char* e = getenv("HSIMAE_FUSED_PROJ_BWD"); fuse_pb = !(e && e[0] == '0'); }
     if (fuse_pb && fmlp && hs_attn_proj_fusable(a)) {    // dO = dx1 Wp inside the attention backward (dx1 = the bf16 copy from enc_mlp_bwd)
         a.dout = w.g1b; a.projT_w = P.pT;
     } else {
         p = gp();
-        p.A = w.g1b; p.lda = d; p.M = (int)M; p.N = d; p.K = d; p.n_valid = d;      // (the bf16 copy carries the DropPath factor)
-        p.W = P.pT; p.out = w.dob; p.ldo = d;
+        p.A = w.g1b; p.lda = dp; p.M = (int)M; p.N = dp; p.K = dp; p.n_valid = dp;  // (the bf16 copy carries the DropPath factor)
+        p.W = P.pT; p.out = w.dob; p.ldo = dp;
         w8(p, P.pT8);
         CK(hs_gemm(p, A_BF16, E_BF16, s));
     }
@@ -485,13 +246,13 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         t.dO = dO; t.dO_f32 = f32; t.ldo = ldo; t.A = A; t.lda = lda; t.N = N; t.K = K; t.dW = grads + dW; t.ldw = K;
         t.db = grads + db; t.dO_rowscale = f32 ? rs : nullptr;
     };
-    task(w.dqkv, 0, 3 * d, b.u, d, d, d, o.qw, o.qb);
-    task(w.dqkv + d, 0, 3 * d, b.u, d, d, d, o.kw, o.kb);
-    task(w.dqkv + 2 * d, 0, 3 * d, b.u, d, d, d, o.vw, o.vb);
-    task(w.g1b, 0, d, b.o, d, d, d, o.pw, o.pb);                // all-bf16 operands: wgrad takes its LDS-DMA path
-    task(w.dh13, 0, 2 * hp, b.u2, d, h, d, o.w1w, o.w1b);
-    task(w.dh13 + hp, 0, 2 * hp, b.u2, d, h, d, o.w3w, o.w3b);
-    task(w.g0b, 0, d, b.g, hp, d, h, o.w2w, o.w2b);
+    task(w.dqkv, 0, 3 * dp, b.u, dp, d, d, o.qw, o.qb);
+    task(w.dqkv + dp, 0, 3 * dp, b.u, dp, d, d, o.kw, o.kb);
+    task(w.dqkv + 2 * dp, 0, 3 * dp, b.u, dp, d, d, o.vw, o.vb);
+    task(w.g1b, 0, dp, b.o, dp, d, d, o.pw, o.pb);              // all-bf16 operands: wgrad takes its LDS-DMA path
+    task(w.dh13, 0, 2 * hp, b.u2, dp, h, d, o.w1w, o.w1b);
+    task(w.dh13 + hp, 0, 2 * hp, b.u2, dp, h, d, o.w3w, o.w3b);
+    task(w.g0b, 0, dp, b.g, hp, d, h, o.w2w, o.w2b);
     g.M = (int)M;
     int tiles = 0;
     for (int i = 0; i < g.ntasks; ++i) tiles += ((g.t[i].N + 127) / 128) * ((g.t[i].K + 127) / 128);
@@ -504,13 +265,13 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     if (fuse_ln < 0) { const char* e = getenv("HSIMAE_FUSED_LNBWD"); fuse_ln = !(e && e[0] == '0'); }
     const bool ln_fused = fuse_ln && d == 128 && !f8;
     p = gp();
-    p.A = w.dqkv; p.lda = 3 * d; p.M = (int)M; p.N = d; p.K = 3 * d; p.n_valid = d; p.W = P.qkvT;
+    p.A = w.dqkv; p.lda = 3 * dp; p.M = (int)M; p.N = dp; p.K = 3 * dp; p.n_valid = d; p.W = P.qkvT;
     if (ln_fused) {
         p.out = dx_out; p.ldo = d; p.res = G1; p.ldr = d; p.lnx = x_in; p.gamma = P.n1w; p.accumulate = accumulate;
         p.dgamma = grads + o.n1w; p.dbeta = grads + o.n1b;
         CK(hs_gemm(p, A_BF16, E_LN_BWD, s));       // K = 384: the persistent LDS-DMA kernel of gemm_dma.hip
     } else {
-        p.out = w.du; p.ldo = d;
+        p.out = w.du; p.ldo = dp;
         w8(p, P.qkvT8);
         CK(hs_gemm(p, A_BF16, E_F32, s));
     }
@@ -536,7 +297,7 @@ int make_ctx(const hsimae_config* cfg, const hsimae_io* io, Ctx& c, bool need_ws
     if (c.N <= 0 || c.len_t < 1 || c.len_t > c.g.T || c.len_l < 1 || c.len_l > 9) return HSIMAE_EDIMS;
     c.K = c.len_t * c.len_l;
     c.Me = (int64_t)c.N * c.K; c.Md = (int64_t)c.N * c.g.TL;
-    if (c.Md * 96 >= (1ll << 31) || c.Me * 3 * c.g.D >= (1ll << 31)) return HSIMAE_EUNSUPPORTED;   // 32-bit row math in kernels
+    if (c.Md * 96 >= (1ll << 31) || c.Me * 3 * c.g.Dp >= (1ll << 31)) return HSIMAE_EUNSUPPORTED;   // 32-bit row math in kernels
     make_playout(c.g, c.L);
     make_wlayout(c.g, c.W);
     if (need_ws) {
@@ -567,36 +328,15 @@ const char* hsimae_strerror(int code) {
 }
 
 int hsimae_param_layout(const hsimae_config* cfg, int64_t* offsets, int64_t* sizes, int max_entries) {
-    Geo g; int e = make_geo(cfg, g); if (e) return e;
-    PLayout L; make_playout(g, L);
-    const int n = (int)L.offs.size();
-    for (int i = 0; i < n && i < max_entries; ++i) {
-        if (offsets) offsets[i] = L.offs[i];
-        if (sizes) sizes[i] = L.sizes[i];
-    }
-    return n;
+    return param_layout(cfg, offsets, sizes, max_entries);
 }
 
-int64_t hsimae_wpk_elems(const hsimae_config* cfg) {
-    Geo g; if (make_geo(cfg, g)) return -1;
-    WLayout W; make_wlayout(g, W);
-    return W.total_elems;
-}
+int64_t hsimae_wpk_elems(const hsimae_config* cfg) { return wpk_elems(cfg); }
 
-int64_t hsimae_pack_table_bytes(const hsimae_config* cfg) {
-    Geo g; if (make_geo(cfg, g)) return -1;
-    PLayout L; make_playout(g, L); WLayout W; make_wlayout(g, W);
-    std::vector<PackDesc> d; pack_descs(g, L, W, nullptr, nullptr, d);
-    return (int64_t)d.size() * sizeof(PackDesc);
-}
+int64_t hsimae_pack_table_bytes(const hsimae_config* cfg) { return pack_table_bytes(cfg); }
 
 int hsimae_build_pack_table(const hsimae_config* cfg, const float* params_dev, hs_bf16* wpk_dev, void* table_host) {
-    Geo g; CK(make_geo(cfg, g));
-    if (!params_dev || !wpk_dev || !table_host) return HSIMAE_ENULL;
-    PLayout L; make_playout(g, L); WLayout W; make_wlayout(g, W);
-    std::vector<PackDesc> d; pack_descs(g, L, W, params_dev, wpk_dev, d);
-    std::memcpy(table_host, d.data(), d.size() * sizeof(PackDesc));
-    return HSIMAE_OK;
+    return build_pack_table(cfg, params_dev, wpk_dev, table_host);
 }
 
 int hsimae_pack_params(const hsimae_config* cfg, const void* table_dev, void* stream) {
@@ -608,10 +348,7 @@ int hsimae_pack_params(const hsimae_config* cfg, const void* table_dev, void* st
 }
 
 int64_t hsimae_workspace_bytes(const hsimae_config* cfg, int32_t N, int32_t len_t, int32_t len_l) {
-    Geo g; if (make_geo(cfg, g)) return -1;
-    if (N <= 0 || len_t < 1 || len_l < 1) return -1;
-    Ws w; carve(g, N, len_t * len_l, nullptr, w);
-    return w.bytes;
+    return workspace_bytes(cfg, N, len_t, len_l);
 }
 
 // DropPath factors of encoder block `e` (execution order blocks_1, blocks_2, blocks): {attention, MLP} row vectors
@@ -637,8 +374,8 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
     pp.K = c.K; pp.ids_keep = io->ids_keep; pp.out = w.a_pe; pp.pos_ids = nullptr;
     CK(hs_patch_gather(pp, s));
     GemmParams p = gp();
-    p.A = w.a_pe; p.lda = 96; p.M = (int)c.Me; p.N = g.D; p.K = 96; p.n_valid = g.D; p.W = io->wpk + c.W.pe; p.bias = P + c.L.peb;
-    p.pos = P + c.L.pos; p.ids = io->ids_keep; p.ldpos = g.D; p.out = w.x0; p.ldo = g.D;
+    p.A = w.a_pe; p.lda = 96; p.M = (int)c.Me; p.N = g.Dp; p.K = 96; p.n_valid = g.D; p.W = io->wpk + c.W.pe; p.bias = P + c.L.peb;
+    p.pos = P + c.L.pos; p.ids = io->ids_keep; p.ldpos = g.D; p.out = w.x0; p.ldo = g.Dp;
     CK(hs_gemm(p, A_BF16, E_POS_F32, s));
 
     const float* x = w.x0;
@@ -678,16 +415,16 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
         x = w.bf[i].x2;
     }
     if (encoder_only) {                       // `norm` only (Models.py:570 / 892): the latent the fine-tuning head reads
-        CK(hs_ln_fwd(x, P + c.L.nw, P + c.L.nb, io->latent, (int)c.Me, g.D, s));
+        CK(hs_ln_fwd(x, P + c.L.nw, P + c.L.nb, io->latent, (int)c.Me, g.D, s, g.Dp, g.D));
         return HSIMAE_OK;
     }
     // norm + decoder_embed (Models.py:570, 579)
     p = gp();
-    p.A = x; p.lda = g.D; p.M = (int)c.Me; p.N = g.Dd; p.K = g.D; p.n_valid = g.Dd; p.W = io->wpk + c.W.de; p.bias = P + c.L.deb;
-    p.gamma = P + c.L.nw; p.beta = P + c.L.nb; p.u_out = w.lat; p.ldu = g.D; p.out = w.y; p.ldo = g.Dd;
+    p.A = x; p.lda = g.Dp; p.M = (int)c.Me; p.N = g.Ddp; p.K = g.Dp; p.n_valid = g.Dd; p.W = io->wpk + c.W.de; p.bias = P + c.L.deb;
+    p.gamma = P + c.L.nw; p.beta = P + c.L.nb; p.u_out = w.lat; p.ldu = g.Dp; p.out = w.y; p.ldo = g.Ddp; p.ln_width = g.D;
     CK(hs_gemm(p, A_F32_LN, E_F32, s));
     AssembleParams as; std::memset(&as, 0, sizeof(as));
-    as.y = w.y; as.N = c.N; as.K = c.K; as.TL = g.TL; as.Dd = g.Dd; as.ids_restore = io->ids_restore; as.pos = P + c.L.dpos;
+    as.y = w.y; as.N = c.N; as.K = c.K; as.TL = g.TL; as.Dd = g.Dd; as.ld = g.Ddp; as.ids_restore = io->ids_restore; as.pos = P + c.L.dpos;
     as.yfull = w.yfull;
     CK(hs_assemble_fwd(as, s));
     const float* z = w.yfull;
@@ -700,8 +437,8 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
     }
     // decoder_norm + decoder_pred (Models.py:597-600)
     p = gp();
-    p.A = z; p.lda = g.Dd; p.M = (int)c.Md; p.N = 80; p.K = g.Dd; p.n_valid = 72; p.W = io->wpk + c.W.dp; p.bias = P + c.L.dpb;
-    p.gamma = P + c.L.dnw; p.beta = P + c.L.dnb; p.u_out = w.zn; p.ldu = g.Dd; p.out = w.pred; p.ldo = 72;
+    p.A = z; p.lda = g.Ddp; p.M = (int)c.Md; p.N = 80; p.K = g.Ddp; p.n_valid = 72; p.W = io->wpk + c.W.dp; p.bias = P + c.L.dpb;
+    p.gamma = P + c.L.dnw; p.beta = P + c.L.dnb; p.u_out = w.zn; p.ldu = g.Ddp; p.out = w.pred; p.ldo = 72; p.ln_width = g.Dd;
     CK(hs_gemm(p, A_F32_LN, E_F32, s));
     LossParams lp; std::memset(&lp, 0, sizeof(lp));
     const float sum_mask = (float)((int64_t)c.N * (g.TL - c.K));
@@ -711,7 +448,7 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
     lp.pred_img = io->want_recons ? io->pred_img : nullptr; lp.mask_img = io->want_recons ? io->mask_img : nullptr;
     CK(hs_loss(lp, s));
     if (io->pred) CK((int)hipMemcpyAsync(io->pred, w.pred, c.Md * 72 * 4, hipMemcpyDeviceToDevice, s));
-    if (io->latent) CK(hs_ln_fwd(x, P + c.L.nw, P + c.L.nb, io->latent, (int)c.Me, g.D, s));
+    if (io->latent) CK(hs_ln_fwd(x, P + c.L.nw, P + c.L.nb, io->latent, (int)c.Me, g.D, s, g.Dp, g.D));
     return HSIMAE_OK;
 }
 
@@ -724,12 +461,17 @@ int hsimae_decode(const hsimae_config* cfg, const hsimae_io* io, const float* la
     hipStream_t s = S(stream);
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w;
     GemmParams p = gp();                      // decoder_embed (Models.py:579)
-    p.A = latent; p.lda = g.D; p.M = (int)c.Me; p.N = g.Dd; p.K = g.D; p.n_valid = g.Dd; p.W = io->wpk + c.W.de; p.bias = P + c.L.deb;
-    p.out = w.y; p.ldo = g.Dd;
+    const float* lat_in = latent;
+    if (g.Dp != g.D) {      // rows stored wider than the model: stage the caller's [Me][D] latent into a padded buffer (pad columns are zeros)
+        CK((int)hipMemcpy2DAsync(w.G2, (size_t)g.Dp * 4, latent, (size_t)g.D * 4, (size_t)g.D * 4, (size_t)c.Me, hipMemcpyDeviceToDevice, s));
+        lat_in = w.G2;
+    }
+    p.A = lat_in; p.lda = g.Dp; p.M = (int)c.Me; p.N = g.Ddp; p.K = g.Dp; p.n_valid = g.Dd; p.W = io->wpk + c.W.de; p.bias = P + c.L.deb;
+    p.out = w.y; p.ldo = g.Ddp;
     CK(hs_gemm(p, A_F32, E_F32, s));
-    CK(hs_rows_to_bf16(latent, w.lat, c.Me, g.D, nullptr, s));      // decoder_embed's wgrad operand (hsimae_decode_backward)
+    CK(hs_rows_to_bf16(lat_in, w.lat, c.Me, g.Dp, nullptr, s));     // decoder_embed's wgrad operand (hsimae_decode_backward)
     AssembleParams as; std::memset(&as, 0, sizeof(as));
-    as.y = w.y; as.N = c.N; as.K = c.K; as.TL = g.TL; as.Dd = g.Dd; as.ids_restore = io->ids_restore; as.pos = P + c.L.dpos;
+    as.y = w.y; as.N = c.N; as.K = c.K; as.TL = g.TL; as.Dd = g.Dd; as.ld = g.Ddp; as.ids_restore = io->ids_restore; as.pos = P + c.L.dpos;
     as.yfull = w.yfull;
     CK(hs_assemble_fwd(as, s));
     const float* z = w.yfull;
@@ -741,8 +483,8 @@ int hsimae_decode(const hsimae_config* cfg, const hsimae_io* io, const float* la
         z = w.bd[i].x2;
     }
     p = gp();                                 // decoder_norm + decoder_pred (Models.py:597-600)
-    p.A = z; p.lda = g.Dd; p.M = (int)c.Md; p.N = 80; p.K = g.Dd; p.n_valid = 72; p.W = io->wpk + c.W.dp; p.bias = P + c.L.dpb;
-    p.gamma = P + c.L.dnw; p.beta = P + c.L.dnb; p.u_out = w.zn; p.ldu = g.Dd; p.out = pred; p.ldo = 72;
+    p.A = z; p.lda = g.Ddp; p.M = (int)c.Md; p.N = 80; p.K = g.Ddp; p.n_valid = 72; p.W = io->wpk + c.W.dp; p.bias = P + c.L.dpb;
+    p.gamma = P + c.L.dnw; p.beta = P + c.L.dnb; p.u_out = w.zn; p.ldu = g.Ddp; p.out = pred; p.ldo = 72; p.ln_width = g.Dd;
     return hs_gemm(p, A_F32_LN, E_F32, s);
 }
 
@@ -762,7 +504,7 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
         // d(x1 + x2) feeds both stacks (Models.py:564); the spectral stack's backward runs on the side stream
         Side& sd = side();
         const bool forked = sd.ok && g.sdepth > 1;
-        CK((int)hipMemcpyAsync(w.G2, w.G0, c.Me * g.D * 4, hipMemcpyDeviceToDevice, s));
+        CK((int)hipMemcpyAsync(w.G2, w.G0, c.Me * g.Dp * 4, hipMemcpyDeviceToDevice, s));
         if (forked) {
             CK((int)hipEventRecord(sd.fork, s));
             CK((int)hipStreamWaitEvent(sd.s, sd.fork, 0));
@@ -797,7 +539,7 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
     }
     {   // patch_embed.proj: only the kept tokens carry gradient (Models.py:528); no input gradient
         WgradParams wg; std::memset(&wg, 0, sizeof(wg));
-        WgradTask& t = wg.t[0]; t.dO = w.G0; t.dO_f32 = 1; t.ldo = g.D; t.A = w.a_pe; t.lda = 96; t.N = g.D; t.K = 72;
+        WgradTask& t = wg.t[0]; t.dO = w.G0; t.dO_f32 = 1; t.ldo = g.Dp; t.A = w.a_pe; t.lda = 96; t.N = g.D; t.K = 72;
         t.dW = grads + L.pew; t.ldw = 72; t.db = grads + L.peb;
         wg.ntasks = 1; wg.M = (int)c.Me; wg.msplit = wgrad_msplit((g.D + 127) / 128, c.Me);
         CK(hs_wgrad(wg, s));
@@ -813,18 +555,18 @@ static int decoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
     const float* zlast = w.bd[g.ddepth - 1].x2;
     GemmParams p = gp();
-    p.A = w.dpred; p.lda = 96; p.M = (int)c.Md; p.N = g.Dd; p.K = 96; p.n_valid = g.Dd; p.W = io->wpk + c.W.dpT; p.out = w.du; p.ldo = g.Dd;
+    p.A = w.dpred; p.lda = 96; p.M = (int)c.Md; p.N = g.Ddp; p.K = 96; p.n_valid = g.Dd; p.W = io->wpk + c.W.dpT; p.out = w.du; p.ldo = g.Ddp;
     CK(hs_gemm(p, A_BF16, E_F32, s));
     {
         WgradParams wg; std::memset(&wg, 0, sizeof(wg));
-        WgradTask& t = wg.t[0]; t.dO = w.dpred; t.dO_f32 = 0; t.ldo = 96; t.A = w.zn; t.lda = g.Dd; t.N = 72; t.K = g.Dd;
+        WgradTask& t = wg.t[0]; t.dO = w.dpred; t.dO_f32 = 0; t.ldo = 96; t.A = w.zn; t.lda = g.Ddp; t.N = 72; t.K = g.Dd;
         t.dW = grads + L.dpw; t.ldw = g.Dd; t.db = grads + L.dpb;
         wg.ntasks = 1; wg.M = (int)c.Md; wg.msplit = wgrad_msplit(1, c.Md);
         CK(hs_wgrad(wg, s));
     }
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
     l.du = w.du; l.x = zlast; l.gamma = P + L.dnw; l.dres = nullptr; l.dx = w.G0; l.dgamma = grads + L.dnw; l.dbeta = grads + L.dnb;
-    l.M = (int)c.Md; l.d = g.Dd;
+    l.M = (int)c.Md; l.d = g.Dd; l.ld = g.Ddp;
     CK(hs_ln_bwd(l, s));
     CK(emit(L.dnw, L.total, s));
 
@@ -850,14 +592,14 @@ static int decoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
     }
     // sequence assembly + decoder_embed
     AssembleParams as; std::memset(&as, 0, sizeof(as));
-    as.N = c.N; as.K = c.K; as.TL = g.TL; as.Dd = g.Dd; as.ids_restore = io->ids_restore; as.dyfull = w.G0; as.dy = w.dyb;
+    as.N = c.N; as.K = c.K; as.TL = g.TL; as.Dd = g.Dd; as.ld = g.Ddp; as.ids_restore = io->ids_restore; as.dyfull = w.G0; as.dy = w.dyb;
     CK(hs_assemble_bwd(as, s));
     p = gp();
-    p.A = w.dyb; p.lda = g.Dd; p.M = (int)c.Me; p.N = g.D; p.K = g.Dd; p.n_valid = g.D; p.W = io->wpk + c.W.deT; p.out = w.du; p.ldo = g.D;
+    p.A = w.dyb; p.lda = g.Ddp; p.M = (int)c.Me; p.N = g.Dp; p.K = g.Ddp; p.n_valid = g.D; p.W = io->wpk + c.W.deT; p.out = w.du; p.ldo = g.Dp;
     CK(hs_gemm(p, A_BF16, E_F32, s));
     {
         WgradParams wg; std::memset(&wg, 0, sizeof(wg));
-        WgradTask& t = wg.t[0]; t.dO = w.dyb; t.dO_f32 = 0; t.ldo = g.Dd; t.A = w.lat; t.lda = g.D; t.N = g.Dd; t.K = g.D;
+        WgradTask& t = wg.t[0]; t.dO = w.dyb; t.dO_f32 = 0; t.ldo = g.Ddp; t.A = w.lat; t.lda = g.Dp; t.N = g.Dd; t.K = g.D;
         t.dW = grads + L.dew; t.ldw = g.D; t.db = grads + L.deb;
         wg.ntasks = 1; wg.M = (int)c.Me; wg.msplit = wgrad_msplit(((g.Dd + 127) / 128) * ((g.D + 127) / 128), c.Me);
         CK(hs_wgrad(wg, s));
@@ -877,7 +619,7 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
     const float* xf = g.nfus ? w.bf[g.nfus - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
     l.du = w.du; l.x = xf; l.gamma = P + L.nw; l.dres = nullptr; l.dx = w.G0; l.dgamma = grads + L.nw; l.dbeta = grads + L.nb;
-    l.M = (int)c.Me; l.d = g.D;
+    l.M = (int)c.Me; l.d = g.D; l.ld = g.Dp;
     CK(hs_ln_bwd(l, s));
     CK(emit(L.nw, L.deb + g.Dd, s));
     return encoder_backward(c, io, grads, s, emit);
@@ -893,7 +635,7 @@ int hsimae_decode_backward(const hsimae_config* cfg, const hsimae_io* io, const 
     Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0};
     CK(decoder_backward(c, io, grads, s, emit));
     CK(emit(L.dew, L.deb + g.Dd, s));
-    return (int)hipMemcpyAsync(dlatent, w.du, c.Me * g.D * 4, hipMemcpyDeviceToDevice, s);
+    return (int)hipMemcpy2DAsync(dlatent, (size_t)g.D * 4, w.du, (size_t)g.Dp * 4, (size_t)g.D * 4, (size_t)c.Me, hipMemcpyDeviceToDevice, s);
 }
 
 int hsimae_encode_backward(const hsimae_config* cfg, const hsimae_io* io, const float* dlatent, float* grads,
@@ -905,8 +647,13 @@ int hsimae_encode_backward(const hsimae_config* cfg, const hsimae_io* io, const 
     // `norm` (Models.py:892): dlatent -> d(x of the last encoder block) in G0
     const float* xf = g.nfus ? w.bf[g.nfus - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
-    l.du = dlatent; l.x = xf; l.gamma = P + L.nw; l.dres = nullptr; l.dx = w.G0; l.dgamma = grads + L.nw; l.dbeta = grads + L.nb;
-    l.M = (int)c.Me; l.d = g.D;
+    const float* dlat = dlatent;
+    if (g.Dp != g.D) {          // rows stored wider than the model: the caller's [Me][D] gradient into a padded buffer
+        CK((int)hipMemcpy2DAsync(w.du, (size_t)g.Dp * 4, dlatent, (size_t)g.D * 4, (size_t)g.D * 4, (size_t)c.Me, hipMemcpyDeviceToDevice, s));
+        dlat = w.du;
+    }
+    l.du = dlat; l.x = xf; l.gamma = P + L.nw; l.dres = nullptr; l.dx = w.G0; l.dgamma = grads + L.nw; l.dbeta = grads + L.nb;
+    l.M = (int)c.Me; l.d = g.D; l.ld = g.Dp;
     CK(hs_ln_bwd(l, s));
     Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0};
     CK(emit(L.nw, L.nb + g.D, s));

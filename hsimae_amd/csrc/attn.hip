@@ -13,6 +13,9 @@
 // recomputes the scores in both orientations instead of transposing dS through LDS.
 #include "common.h"
 #include "kernels.h"
+
+// column offset of k inside a q|k|v row (v: twice that): the storage width when rows are stored wider than d
+#define KVO(p) ((p).kv_off ? (p).kv_off : (p).d)
 #include <cstdlib>
 
 #ifndef HS_NT_C
@@ -119,8 +122,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     if (active) {
         const bf16_t* base = p.qkv + row_base * p.ld + head * HD;
         load_slice<HD>(base, p.ld, p.Ts, lane, Qr, nullptr, 0);
-        load_slice<HD>(base + p.d, p.ld, p.Ts, lane, Kr, nullptr, 0);
-        load_slice<HD>(base + 2 * p.d, p.ld, p.Ts, lane, nullptr, Vt, L::VST);
+        load_slice<HD>(base + KVO(p), p.ld, p.Ts, lane, Kr, nullptr, 0);
+        load_slice<HD>(base + 2 * KVO(p), p.ld, p.Ts, lane, nullptr, Vt, L::VST);
     }
     lds_barrier();
     if (!active) return;
@@ -211,8 +214,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     if (active) {
         const bf16_t* base = p.qkv + row_base * p.ld + head * HD;
         load_slice<HD>(base, p.ld, p.Ts, lane, Qr, Qt, L::VST);
-        load_slice<HD>(base + p.d, p.ld, p.Ts, lane, Kr, Kt, L::VST);
-        load_slice<HD>(base + 2 * p.d, p.ld, p.Ts, lane, Vr, nullptr, 0);
+        load_slice<HD>(base + KVO(p), p.ld, p.Ts, lane, Kr, Kt, L::VST);
+        load_slice<HD>(base + 2 * KVO(p), p.ld, p.Ts, lane, Vr, nullptr, 0);
         load_slice<HD>(p.dout + row_base * p.lddo + head * HD, p.lddo, p.Ts, lane, dOr, dOt, L::VST);
         for (int tok = lane; tok < p.Ts; tok += 64) {
             const bf16_t* orow = p.o + (row_base + tok) * p.ldo + head * HD;
@@ -319,8 +322,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
             bf16x4 vk, vv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { vk[r] = (bf16_t)dk[r]; vv[r] = (bf16_t)dv[r]; }
-            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + p.d + g * 4) = vk;
-            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + 2 * p.d + g * 4) = vv;
+            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + KVO(p) + g * 4) = vk;
+            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + 2 * KVO(p) + g * 4) = vv;
         }
     }
 }
@@ -389,8 +392,8 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(AttnParams p) {
     if (active) {
         const bf16_t* base = p.qkv + row_base * p.ld + head * 16;
         load16<NT>(base, p.ld, p.Ts, lane, Qi);
-        load16<NT>(base + p.d, p.ld, p.Ts, lane, Ki);
-        load16<NT>(base + 2 * p.d, p.ld, p.Ts, lane, Vi);
+        load16<NT>(base + KVO(p), p.ld, p.Ts, lane, Ki);
+        load16<NT>(base + 2 * KVO(p), p.ld, p.Ts, lane, Vi);
     }
     lds_barrier();
     if (!active) return;
@@ -473,8 +476,8 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(AttnParams p) {
     if (active) {
         const bf16_t* base = p.qkv + row_base * p.ld + head * 16;
         load16<NT>(base, p.ld, p.Ts, lane, Qi);
-        load16<NT>(base + p.d, p.ld, p.Ts, lane, Ki);
-        load16<NT>(base + 2 * p.d, p.ld, p.Ts, lane, Vi);
+        load16<NT>(base + KVO(p), p.ld, p.Ts, lane, Ki);
+        load16<NT>(base + 2 * KVO(p), p.ld, p.Ts, lane, Vi);
         load16<NT>(p.dout + row_base * p.lddo + head * 16, p.lddo, p.Ts, lane, Di);
         for (int tok = lane; tok < L::ROWS; tok += 64) {
             float acc = 0.f, l = 1e30f;                          // rows past Ts: exp2(s - 1e30) = 0
@@ -554,8 +557,8 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(AttnParams p) {
             bf16x4 vk, vv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { vk[r] = (bf16_t)(dkT[kt][r] * scale); vv[r] = (bf16_t)dvT[kt][r]; }
-            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + p.d + g * 4) = vk;
-            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + 2 * p.d + g * 4) = vv;
+            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + KVO(p) + g * 4) = vk;
+            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + 2 * KVO(p) + g * 4) = vv;
         }
     }
 }

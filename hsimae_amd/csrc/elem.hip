@@ -2,6 +2,7 @@
 // LayerNorm backward, decoder sequence assembly (fwd/bwd), normalised-pixel MSE loss + recons.
 #include "common.h"
 #include "kernels.h"
+#include "plan.h"
 #include <algorithm>
 #include <cmath>
 
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { x[u][e] = 0.f; du[u][e] = 0.f; rs[u][e] = 0.f; }
             if (ok) {
-                const size_t o = (size_t)r * p.d + c8;
+                const size_t o = (size_t)r * (p.ld ? p.ld : p.d) + c8;
                 ld8(p.x + o, x[u]);
                 ld8(p.du + o, du[u]);
                 if (p.dres) ld8(p.dres + o, rs[u]);
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
                     dg[e] += du[u][e] * x[u][e];
                     db[e] += du[u][e];
                 }
-                float* op = p.dx + (size_t)r * p.d + c8;
+                float* op = p.dx + (size_t)r * (p.ld ? p.ld : p.d) + c8;
                 *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
 }
 
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float* gamma, const float* beta, float* out,
-                                                      int M, int d) {
+                                                      int M, int d, int ldx, int ldo) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wave;
     if (r >= M) return;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = lane + 64 * i;
-        v[i] = c < d ? x[(size_t)r * d + c] : 0.f;
+        v[i] = c < d ? x[(size_t)r * ldx + c] : 0.f;
         s += v[i];
     }
     const float mean = wave_sum(s) / (float)d;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = lane + 64 * i;
-        if (c < d) out[(size_t)r * d + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        if (c < d) out[(size_t)r * ldo + c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
     }
 }
 
@@ -270,12 +271,13 @@ __global__ __launch_bounds__(256) void assemble_bwd_fast_kernel(AssembleParams p
 }
 
 __global__ __launch_bounds__(256) void assemble_fwd_kernel(AssembleParams p) {
+    const int LD = p.ld ? p.ld : p.Dd;           // row stride of y / yfull (storage width)
     __shared__ float meanv[512];
     const int n = blockIdx.x;
-    const float* y = p.y + (size_t)n * p.K * p.Dd;
+    const float* y = p.y + (size_t)n * p.K * LD;
     for (int c = threadIdx.x; c < p.Dd; c += 256) {
         float s = 0.f;
-        for (int k = 0; k < p.K; ++k) s += y[(size_t)k * p.Dd + c];
+        for (int k = 0; k < p.K; ++k) s += y[(size_t)k * LD + c];
         meanv[c] = s / (float)p.K;
     }
     __syncthreads();
@@ -283,21 +285,22 @@ __global__ __launch_bounds__(256) void assemble_fwd_kernel(AssembleParams p) {
     for (int e = threadIdx.x; e < total; e += 256) {
         const int i = e / p.Dd, c = e - i * p.Dd;
         const int r = p.ids_restore[(size_t)n * p.TL + i];
-        const float v = (r < p.K) ? y[(size_t)r * p.Dd + c] : meanv[c];
-        p.yfull[((size_t)n * p.TL + i) * p.Dd + c] = v + p.pos[(size_t)i * p.Dd + c];
+        const float v = (r < p.K) ? y[(size_t)r * LD + c] : meanv[c];
+        p.yfull[((size_t)n * p.TL + i) * LD + c] = v + p.pos[(size_t)i * p.Dd + c];
     }
 }
 
 // dy[n,k,:] = dyfull[n, slot(k), :] + (1/K) * sum_{masked i} dyfull[n,i,:]      (bf16 out: GEMM / wgrad operand)
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(AssembleParams p) {
+    const int LD = p.ld ? p.ld : p.Dd;
     __shared__ float msum[512];
     const int n = blockIdx.x;
-    const float* dyf = p.dyfull + (size_t)n * p.TL * p.Dd;
+    const float* dyf = p.dyfull + (size_t)n * p.TL * LD;
     const int32_t* rest = p.ids_restore + (size_t)n * p.TL;
     for (int c = threadIdx.x; c < p.Dd; c += 256) {
         float s = 0.f;
         for (int i = 0; i < p.TL; ++i)
-            if (rest[i] >= p.K) s += dyf[(size_t)i * p.Dd + c];
+            if (rest[i] >= p.K) s += dyf[(size_t)i * LD + c];
         msum[c] = s / (float)p.K;
     }
     __syncthreads();
@@ -305,13 +308,13 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(AssembleParams p) {
     for (int e = threadIdx.x; e < total; e += 256) {
         const int i = e / p.Dd, c = e - i * p.Dd;
         const int r = rest[i];
-        if (r < p.K) p.dy[((size_t)n * p.K + r) * p.Dd + c] = (bf16_t)(dyf[(size_t)i * p.Dd + c] + msum[c]);
+        if (r < p.K) p.dy[((size_t)n * p.K + r) * LD + c] = (bf16_t)(dyf[(size_t)i * LD + c] + msum[c]);
     }
 }
 
 // ------------------------------------------------------------------ loss + recons (Models.py:603-625)
 // One wave per token row; lanes own features f = lane and lane + 64 (< 72).
-constexpr int LOSS_ROWS_PER_WG = 32;
+using hsplan::LOSS_ROWS_PER_WG;       // plan.h (the workspace carve sizes the partial-sum buffer with it)
 
 __global__ __launch_bounds__(256) void loss_kernel(LossParams p) {
     __shared__ float wsum[4];
@@ -560,18 +563,18 @@ int hs_ln_bwd(const LnBwdParams& p, hipStream_t s) {
     return launch_ln_bwd<64>(p, s);
 }
 
-int hs_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int M, int d, hipStream_t s) {
+int hs_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int M, int d, hipStream_t s, int ldx, int ldo) {
     if (M <= 0) return HS_OK;
     if (d > 512) return HS_EUNSUPPORTED;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, out, M, d);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, out, M, d, ldx ? ldx : d, ldo ? ldo : d);
     return (int)hipGetLastError();
 }
 
 int hs_assemble_fwd(const AssembleParams& p, hipStream_t s) {
     if (p.N <= 0) return HS_OK;
     if (p.Dd > 512) return HS_EUNSUPPORTED;
-    if (p.TL <= 512 && p.Dd == 64) hipLaunchKernelGGL(assemble_fwd_fast_kernel<16>, dim3(p.N), dim3(256), 0, s, p);
-    else if (p.TL <= 512 && p.Dd == 32) hipLaunchKernelGGL(assemble_fwd_fast_kernel<8>, dim3(p.N), dim3(256), 0, s, p);
+    if (p.TL <= 512 && p.Dd == 64 && (!p.ld || p.ld == 64)) hipLaunchKernelGGL(assemble_fwd_fast_kernel<16>, dim3(p.N), dim3(256), 0, s, p);
+    else if (p.TL <= 512 && p.Dd == 32 && (!p.ld || p.ld == 32)) hipLaunchKernelGGL(assemble_fwd_fast_kernel<8>, dim3(p.N), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(assemble_fwd_kernel, dim3(p.N), dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
@@ -579,8 +582,8 @@ int hs_assemble_fwd(const AssembleParams& p, hipStream_t s) {
 int hs_assemble_bwd(const AssembleParams& p, hipStream_t s) {
     if (p.N <= 0) return HS_OK;
     if (p.Dd > 512) return HS_EUNSUPPORTED;
-    if (p.TL <= 512 && p.Dd == 64) hipLaunchKernelGGL(assemble_bwd_fast_kernel<16>, dim3(p.N), dim3(256), 0, s, p);
-    else if (p.TL <= 512 && p.Dd == 32) hipLaunchKernelGGL(assemble_bwd_fast_kernel<8>, dim3(p.N), dim3(256), 0, s, p);
+    if (p.TL <= 512 && p.Dd == 64 && (!p.ld || p.ld == 64)) hipLaunchKernelGGL(assemble_bwd_fast_kernel<16>, dim3(p.N), dim3(256), 0, s, p);
+    else if (p.TL <= 512 && p.Dd == 32 && (!p.ld || p.ld == 32)) hipLaunchKernelGGL(assemble_bwd_fast_kernel<8>, dim3(p.N), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(assemble_bwd_kernel, dim3(p.N), dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
@@ -669,10 +672,7 @@ int hs_rows_pad_bf16(const float* src, hs_bf16* dst, int64_t rows, int cols, int
     return (int)hipGetLastError();
 }
 
-int hs_loss_partials(int N, int T) {
-    const int64_t M = (int64_t)N * T * 9;
-    return (int)std::max<int64_t>((M + LOSS_ROWS_PER_WG - 1) / LOSS_ROWS_PER_WG, N);     // either kernel form of hs_loss
-}
+int hs_loss_partials(int N, int T) { return hsplan::loss_partials(N, T); }
 
 int hs_add2(const float* a, const float* b, float* out, int64_t n, hipStream_t s) {
     if (n <= 0) return HS_OK;

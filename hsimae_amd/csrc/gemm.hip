@@ -105,11 +105,12 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
         constexpr int TPR = KC / 8, RPP = 256 / TPR, NPASS = BM / RPP, NB = NPASS < 8 ? NPASS : 8;
         const float* A = reinterpret_cast<const float*>(p.A);
         const int c8 = (tid % TPR) * 8;
-        const bool cok = c8 < p.K;
+        const int lnw = p.ln_width ? p.ln_width : p.K;      // the LayerNorm's width (< K when rows are stored padded)
+        const bool cok = c8 < p.K, cv = c8 < lnw;
         float g[8], bt[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { g[e] = cok ? p.gamma[c8 + e] : 0.f; bt[e] = cok ? p.beta[c8 + e] : 0.f; }
-        const float invk = 1.f / (float)p.K;
+        for (int e = 0; e < 8; ++e) { g[e] = cv ? p.gamma[c8 + e] : 0.f; bt[e] = cv ? p.beta[c8 + e] : 0.f; }
+        const float invk = 1.f / (float)lnw;
         for (int pb = 0; pb < NPASS; pb += NB) {
             float f[NB][8];
 #pragma unroll
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
                 const int r = tid / TPR + (pb + i) * RPP;
                 const int row = min(row0 + r, p.M - 1);
                 float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-                if (cok) {
+                if (cv) {
                     x0 = *reinterpret_cast<const float4*>(A + (size_t)row * p.lda + c8);
                     x1 = *reinterpret_cast<const float4*>(A + (size_t)row * p.lda + c8 + 4);
                 }
@@ -135,17 +136,17 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
                 const float mean = sm * invk;
                 float q = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float dl = cok ? f[i][e] - mean : 0.f; q += dl * dl; }
+                for (int e = 0; e < 8; ++e) { const float dl = cv ? f[i][e] - mean : 0.f; q += dl * dl; }
 #pragma unroll
                 for (int o = TPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
                 const float rstd = rsqrtf(q * invk + 1e-5f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[i][e] = (f[i][e] - mean) * rstd * g[e] + bt[e];
-                const bf16x8 val = cok ? cvt8(f[i]) : zero8();
+                const bf16x8 val = cv ? cvt8(f[i]) : zero8();
                 if (cok && p.u_out && row0 + r < p.M)
                     HS_NT(true, reinterpret_cast<bf16x8*>(p.u_out + (size_t)(row0 + r) * p.ldu + c8), val);   // saved for the backward only
                 if constexpr (F8) {
-                    if (!cok) {
+                    if (!cv) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) f[i][e] = 0.f;
                     }

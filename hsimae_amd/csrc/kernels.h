@@ -33,7 +33,7 @@ int hs_attn_bwd(const AttnParams& p, hipStream_t s);
 bool hs_attn_proj_fusable(const AttnParams& p);      // proj_w / projT_w fusion available for this shape (d=128, 8 heads, Ts<=32)
 int hs_wgrad(const WgradParams& p, hipStream_t s);
 int hs_ln_bwd(const LnBwdParams& p, hipStream_t s);
-int hs_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int M, int d, hipStream_t s);
+int hs_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int M, int d, hipStream_t s, int ldx = 0, int ldo = 0);
 int hs_mask(const MaskParams& p, hipStream_t s);
 int hs_patch_gather(const PatchParams& p, hipStream_t s);
 int hs_assemble_fwd(const AssembleParams& p, hipStream_t s);

@@ -477,7 +477,7 @@ class HSIMAE(nn.Module):
         nbytes = lib.hsimae_workspace_bytes(C.byref(cfg), N, self.len_t, self.len_l)
         if nbytes < 0:
             raise RuntimeError("hsimae_workspace_bytes: unsupported configuration")
-        ws = self._pool.lease(nbytes + 256, dev)
+        ws = self._lease_workspace(nbytes, dev, N, K)
         ws_ptr = (ws.data_ptr() + 255) // 256 * 256
         loss = torch.empty((), dtype=torch.float32, device=dev)
         mask = torch.empty(N, TL, dtype=torch.float32, device=dev)
@@ -508,6 +508,18 @@ class HSIMAE(nn.Module):
             pred_img = torch.empty(0, device=dev)
             mask_img = torch.empty(0, device=dev)
         return loss, pred_img, mask_img, state
+
+    def _lease_workspace(self, nbytes, dev, N, K):
+        """Arena for one pass.  Widths that are not multiples of 32 are stored zero-padded (include/hsimae_hip.h,
+        hsimae_io.workspace): the arena is zero-filled whenever its carve (a function of N and K) changes; the kernels
+        keep the pad columns zero from then on."""
+        ws = self._pool.lease(nbytes + 256, dev)
+        if self.dim % 32 or self.dec_dim % 32:
+            key = (N, K, self._precision)
+            if getattr(ws, "_hs_carve", None) != key:
+                ws.zero_()
+                ws._hs_carve = key
+        return ws
 
     def _apply_grads(self, scratch, scale, idxs=None, rng=None):
         """`.grad` semantics for the parameters `idxs` (flat range `rng`): scratch * scale is ASSIGNED where the gradient
@@ -586,7 +598,7 @@ class HSIMAE(nn.Module):
             stream = torch.cuda.current_stream(dev).cuda_stream
             self._ensure_packed(stream)
             nbytes = lib.hsimae_workspace_bytes(C.byref(cfg), N, self.len_t, self.len_l)
-            ws = self._pool.lease(nbytes + 256, dev)
+            ws = self._lease_workspace(nbytes, dev, N, K)
             lat = x.detach().to(torch.float32).contiguous()
             ids = ids_restore.to(device=dev, dtype=torch.int32).contiguous()
             pred = torch.empty(N, T * L, 72, dtype=torch.float32, device=dev)

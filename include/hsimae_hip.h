@@ -48,7 +48,8 @@ const char* hsimae_strerror(int code);
 
 /* ------------------------------------------------------------------ model geometry */
 /* Mirrors the HSIMAE constructor arguments that shape the tensors (Models.py:312-332) for the
- * supported family: img_size 9, patch_size 3, b_patch_size 8, in_chans 1, qkv bias on. */
+ * supported family: img_size 9, patch_size 3, b_patch_size 8, in_chans 1, qkv bias on; embed_dim / dec_dim multiples
+ * of 8 up to 512 with head dim 8 or 16 (widths that are not multiples of 32 run zero-padded to the next one). */
 typedef struct {
     int32_t bands;          /* B, multiple of 8; T = B/8 */
     int32_t embed_dim;      /* D */
@@ -96,7 +97,10 @@ typedef struct {
     const float* noise2;          /* [N,9]  (Models.py:513) */
     const float* params;          /* flat fp32 parameters */
     const hs_bf16* wpk;           /* packed images */
-    void* workspace;              /* hsimae_workspace_bytes() bytes, 256-B aligned */
+    void* workspace;              /* hsimae_workspace_bytes() bytes, 256-B aligned.  When embed_dim or dec_dim is not a multiple
+                                     of 32, rows are stored at the width rounded up to 32 and the columns past the true
+                                     width must be zeros: zero-fill the workspace once before its first use with a given
+                                     (N, len_t * len_l) — the kernels never write anything but zeros there. */
     int64_t workspace_bytes;
     float grad_scale;             /* folded into dLoss/dpred (1/world_size for data parallel) */
     int32_t want_recons;          /* write pred_img / mask_img */
@@ -182,6 +186,9 @@ typedef struct {
        (K padded to a multiple of 128).  W / W2 are ignored.  prec = 0: bf16, the fields below are ignored. */
     int32_t prec;
     const uint8_t* W8; const uint8_t* S8; const uint8_t* W8b; const uint8_t* S8b;
+    /* A_F32_LN: number of leading columns the LayerNorm runs over when the rows are stored wider than the model width
+       (K = storage width, a multiple of 32; the columns past ln_width are read as zeros and stay zeros); 0 = K. */
+    int32_t ln_width;
 } hsimae_gemm_params;
 int hsimae_gemm(const hsimae_gemm_params* p, int32_t a_kind, int32_t epilogue, void* stream);
 /* The same kernel with the row-panel height (bm: 64 or 128) and the depth of an A chunk (kc: 128 or 256; ignored by the
@@ -241,6 +248,8 @@ typedef struct {
     const hs_bf16* projT_w;
     /* optional per-row factor [rows] on the fused projection branch (DropPath): x1 = xres + rowscale * (o Wp^T + bp) */
     const float* rowscale;
+    /* column offset of k (and 2x: of v) inside a qkv / dqkv row when rows are stored wider than d (storage width); 0 = d */
+    int32_t kv_off;
 } hsimae_attn_params;
 int hsimae_attn_fwd(const hsimae_attn_params* p, void* stream);
 int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream);
@@ -264,6 +273,7 @@ int32_t hsimae_wgrad_msplit(int32_t tiles, int64_t M);
 typedef struct {
     const float* du; const float* x; const float* stats; const float* gamma; const float* dres;
     float* dx; int32_t accumulate; float* dgamma; float* dbeta; int32_t M, d;
+    int32_t ld;                   /* row stride of du / x / dres / dx in floats (storage width); 0 = d */
 } hsimae_lnbwd_params;
 int hsimae_ln_bwd(const hsimae_lnbwd_params* p, void* stream);
 /* Plain LayerNorm forward, fp32 in/out (Models.py:570 when a caller wants the fp32 latent). */
@@ -273,6 +283,7 @@ int hsimae_ln_fwd(const float* x, const float* gamma, const float* beta, float* 
 typedef struct {
     const float* y; int32_t N, K, TL, Dd; const int32_t* ids_restore; const float* pos;
     float* yfull; const float* dyfull; hs_bf16* dy;
+    int32_t ld;                   /* row stride of y / yfull / dyfull / dy (storage width); 0 = Dd */
 } hsimae_assemble_params;
 int hsimae_assemble_fwd(const hsimae_assemble_params* p, void* stream);
 int hsimae_assemble_bwd(const hsimae_assemble_params* p, void* stream);

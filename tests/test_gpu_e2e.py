@@ -447,6 +447,57 @@ def test_large_and_huge_widths_against_oracle(name, bands, dim, grid, N):
     print(f"[{name}] worst grad rms-rel {worst}")
 
 
+def test_large_n64_both_grids_against_oracle():
+    """C3's model (HSIMAE-Large, the reference's default `enc_paras = [12, 256, 9]`, Model_Pretraining.py:130) at batch 64
+    on both candidate grids: fused MLP-half kernels at D = 256, 64-row GEMM panels, k-outer data-gradient GEMMs."""
+    cfg = O.OracleConfig(bands=96, embed_dim=256, num_heads=16)
+    state = O.init_state(cfg, seed=11, std=0.02)
+    N = 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(N, 1, 96, 9, 9, generator=g)
+    n1, n2 = torch.rand(N, 12, generator=g), torch.rand(N, 9, generator=g)
+    for grid in ((3, 9), (9, 3)):
+        ref_loss, ref_pred, ref_mask, ref_grads = O.forward_backward(state, cfg, x, n1.numpy(), n2.numpy(), *grid)
+        m = build(cfg, state)
+        loss, pred, mask = m(x.to(DEV), 0.75, noise=(n1, n2), grid=grid)
+        loss.backward()
+        assert torch.equal(mask.cpu(), ref_mask)
+        rel = abs(loss.item() - ref_loss.item()) / ref_loss.item()
+        assert rel <= 1e-4, rel
+        named = dict(m.named_parameters())
+        worst = max((grad_err(named, ref_grads, k), k) for k in ref_grads)
+        assert worst[0] < 3e-2, worst
+        print(f"[Large N=64 {grid}] loss rel {rel:.2e}, worst grad rms-rel {worst}")
+
+
+@pytest.mark.parametrize("name,bands,dim,N,prec", [("Large", 96, 256, 4096, "bf16"), ("Huge fp8", 192, 512, 1024, "fp8")])
+def test_large_and_huge_full_size_properties(name, bands, dim, N, prec):
+    """BASELINE.json configs[2] / configs[4] at their per-GPU batch (4096 / 1024): size-independent properties — finite loss
+    and gradients, masks bit-exact against the oracle's closed form, the kept-token count, and batch-size independence of
+    the per-sample predictions (the first 32 cubes alone give the same prediction images)."""
+    cfg = O.OracleConfig(bands=bands, embed_dim=dim, num_heads=dim // 16)
+    m = build(cfg, O.init_state(cfg, seed=5, std=0.02)).set_precision(prec)
+    T = bands // 8
+    torch.manual_seed(7)
+    x = torch.rand(N, 1, bands, 9, 9, device=DEV)
+    n1, n2 = torch.rand(N, T), torch.rand(N, 9)
+    grid = HSIMAE.grid_candidates(T, 9, 0.75)[0]
+    K = grid[0] * grid[1]
+    loss, pred, mask = m(x, 0.75, noise=(n1, n2), grid=grid)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and torch.isfinite(pred).all() and 0.5 < loss.item() < 2.0
+    assert float(mask.sum()) == N * (T * 9 - K) * 72
+    k2, r2, m2 = O.mask_from_noise(n1.numpy(), n2.numpy(), *grid)
+    assert torch.equal(mask.cpu(), O.unpatchify(torch.from_numpy(m2).unsqueeze(2).repeat(1, 1, 72), cfg))
+    for pname, p in m.named_parameters():
+        if p.requires_grad and pname != "mask_token":
+            assert p.grad is not None and torch.isfinite(p.grad).all(), pname
+    with torch.no_grad():
+        small = m(x[:32], 0.75, noise=(n1[:32], n2[:32]), grid=grid)[1]
+    assert rms_rel(small, pred[:32]) < (1e-6 if prec == "bf16" else 1e-6)
+
+
 def test_fused_adamw_matches_torch_adamw_and_training_step():
     """hsimae_adamw_step (one launch over the flat buffer) against torch.optim.AdamW with the reference's two
     name-filtered groups (Model_Pretraining.py:80-86), 6 steps on the same gradients; then a real training loop."""
