@@ -81,10 +81,11 @@ class DualViT(HSIMAE):
         if self._head_pack is None or self._head_pack[0] != key:
             nc, k = w.shape
             npad = (nc + 15) // 16 * 16
-            img = torch.zeros(npad * k, dtype=torch.bfloat16, device=dev)
+            kp = (k + 31) // 32 * 32                          # K extent of the image: whole MFMA k-steps (T * D need not be one)
+            img = torch.zeros(npad * kp, dtype=torch.bfloat16, device=dev)
             src = w.detach().to(device=dev, dtype=torch.float32).contiguous()
             desc = (_lib.PackDesc * 1)(_lib.PackDesc(src=src.data_ptr(), rows=nc, cols=k, transpose=0, n_off=0, k_off=0,
-                                                     KS=k // 32, dst=img.data_ptr()))
+                                                     KS=kp // 32, dst=img.data_ptr()))
             table = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).clone().to(dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(_lib.load().hsimae_pack_matrix(table.data_ptr(), 1, src.numel(), stream), "hsimae_pack_matrix")
@@ -107,7 +108,12 @@ class DualViT(HSIMAE):
         _lib.check(lib.hsimae_agg_pool(x.data_ptr(), pooled.data_ptr(), N, T, L, D, stream), "hsimae_agg_pool")
         img, bias, npad = self._packed_head(dev)
         out = torch.empty(N, npad, dtype=torch.float32, device=dev)
-        p = _lib.GemmParams(A=pooled.data_ptr(), lda=T * D, M=N, N=npad, K=T * D, n_valid=npad, W=img.data_ptr(),
+        k, kp = T * D, (T * D + 31) // 32 * 32
+        a = pooled
+        if kp != k:                                           # zero-padded operand rows (whole k-steps)
+            a = torch.zeros(N, kp, dtype=torch.float32, device=dev)
+            a[:, :k] = pooled
+        p = _lib.GemmParams(A=a.data_ptr(), lda=kp, M=N, N=npad, K=kp, n_valid=npad, W=img.data_ptr(),
                             bias=bias.data_ptr(), out=out.data_ptr(), ldo=npad)
         _lib.check(lib.hsimae_gemm(C.byref(p), _lib.A_F32, _lib.E_F32, stream), "hsimae_gemm")
         return out[:, :self.num_class], pooled

@@ -8,8 +8,8 @@ parts: same signature, same order of operations, hyper-parameters and RNG consum
   optimizer  : hsimae_amd.FusedAdamW (default betas), CosineLRScheduler stepped per EPOCH with
                t_initial=epochs, lr_min=lr/100, warmup_t=ceil(0.1 epochs), warmup_lr_init=lr/100  (:103-106, 236)
   metrics    : OA / AA / kappa on the labeled pixels (gt != 0, classes shifted by one)             (:171-178, 206-215)
-Not carried over: the matplotlib figure (:131-137, 222-233, 240-241).  Widths must be multiples of 32 (the kernels'
-k-step); the reference's defaults dim=144 / dec_dim=72 raise `configuration not supported`.
+Not carried over: the matplotlib figure (:131-137, 222-233, 240-241).  The reference's defaults dim=144 / dec_dim=72 (widths that
+are not multiples of the kernels' 32-deep k-step) run zero-padded to 160 / 96 inside the library.
 """
 from __future__ import annotations
 

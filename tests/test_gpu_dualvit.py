@@ -177,6 +177,44 @@ def test_base_width_finetune_step_against_oracle():
         assert torch.equal(m(x.cuda()), m(x.cuda()))
 
 
+def test_finetune_step_at_the_reference_scripts_default_widths_144_72():
+    """Model_Finetuning.py:66-67 defaults (dim 144 = 9 heads of 16, dec_dim 72 = 9 heads of 8, GWPCA's 32 bands): widths that
+    are not multiples of 32 run zero-padded to 160 / 96; one training step against the oracle."""
+    from hsimae_amd import DualViT
+    cfg = O.OracleConfig(bands=32, embed_dim=144, num_heads=9, depth=12, s_depth=6, decoder_embed_dim=72, decoder_depth=2,
+                         decoder_num_heads=9, norm_pix_loss=True)
+    state = O.init_state(cfg, seed=2, std=0.05)
+    g = torch.Generator().manual_seed(18)
+    state["cls_head.weight"] = torch.randn(16, 144 * 4, generator=g) * 0.02
+    state["cls_head.bias"] = torch.randn(16, generator=g) * 0.05
+    m = quiet(DualViT, img_size=9, patch_size=3, in_chans=1, bands=32, b_patch_size=8, num_class=16, embed_dim=144, depth=12,
+              num_heads=9, s_depth=6, decoder_embed_dim=72, decoder_depth=2, decoder_num_heads=9, norm_pix_loss=True,
+              trunc_init=True, drop_path=0.2)
+    m.load_state_dict(state)
+    m = m.cuda().train()
+    N, Nu = 5, 7
+    x = torch.rand(N, 1, 32, 9, 9, generator=g)
+    xu = torch.rand(Nu, 1, 32, 9, 9, generator=g)
+    y = torch.tensor([1, 0, 5, 15, 3])
+    n1 = torch.rand(N + Nu, cfg.T, generator=g)
+    n2 = torch.rand(N + Nu, cfg.L, generator=g)
+    len_t, len_l = 2, 4                                   # mask ratio 0.8 at T = 4: (2, 4) or (4, 2)
+    torch.manual_seed(3)
+    d_cls = O.draw_drop_factors(cfg, 0.2, N, cfg.T, cfg.L)
+    d_rec = O.draw_drop_factors(cfg, 0.2, N + Nu, len_t, len_l)
+    lam = 1.0
+    o_rec, o_pred, o_loss, o_grads = O.dualvit_train_step(state, cfg, x, xu, y, lam, n1.numpy(), n2.numpy(), len_t, len_l,
+                                                           d_cls, d_rec)
+    loss_rec, _, _, pred = m(x.cuda(), xu.cuda(), mask_ratio=0.8, noise=(n1, n2), grid=(len_t, len_l), drop_factors=(d_cls, d_rec))
+    loss = lam * loss_rec + torch.nn.functional.cross_entropy(pred, y.cuda(), reduction="mean", ignore_index=0)
+    loss.backward()
+    assert abs(float(loss_rec) - float(o_rec)) < 1e-4 * float(o_rec), (float(loss_rec), float(o_rec))
+    assert rms_rel(pred.detach().cpu(), o_pred) < 1e-2
+    worst, wname = grad_report(m, o_grads)
+    print(f"[finetune 144/72] loss_rec {float(loss_rec):.6f} oracle {float(o_rec):.6f}  worst grad rms-rel {worst:.2e} ({wname})")
+    assert worst < 3e-2, (worst, wname)
+
+
 def test_dual_branch_finetuning_loop_learns_separable_classes(tmp_path):
     """The reference's fine-tuning entry point (Model_Finetuning.py:66-240) end to end on synthetic cubes whose class
     is a spectral offset: train loss falls, validation OA ends far above chance, the checkpoint has DualViT's keys."""
