@@ -29,7 +29,7 @@ class IO(C.Structure):
                 ("grad_scale", f32), ("want_recons", i32),
                 ("loss", vp), ("pred_img", vp), ("mask_img", vp), ("mask", vp),
                 ("ids_keep", vp), ("ids_restore", vp), ("latent", vp), ("pred", vp), ("drop_scale", vp),
-                ("bucket_stream", vp)]
+                ("bucket_stream", vp), ("det_acc", vp)]
 
 
 class MaskParams(C.Structure):
@@ -50,7 +50,8 @@ class GemmParams(C.Structure):
                 ("h13", vp), ("ldh", i32), ("hoff", i32),
                 ("lnx", vp), ("dgamma", vp), ("dbeta", vp), ("accumulate", i32),
                 ("a_rowscale", vp), ("out_rowscale", vp),
-                ("prec", i32), ("W8", vp), ("S8", vp), ("W8b", vp), ("S8b", vp), ("ln_width", i32)]
+                ("prec", i32), ("W8", vp), ("S8", vp), ("W8b", vp), ("S8b", vp), ("ln_width", i32),
+                ("det_base", vp), ("det_acc", vp)]
 
 
 class PackDesc(C.Structure):
@@ -76,12 +77,13 @@ class WgradTask(C.Structure):
 
 
 class WgradParams(C.Structure):
-    _fields_ = [("t", WgradTask * 8), ("ntasks", i32), ("M", i32), ("msplit", i32)]
+    _fields_ = [("t", WgradTask * 8), ("ntasks", i32), ("M", i32), ("msplit", i32), ("det_base", vp), ("det_acc", vp)]
 
 
 class LnBwdParams(C.Structure):
     _fields_ = [("du", vp), ("x", vp), ("stats", vp), ("gamma", vp), ("dres", vp), ("dx", vp), ("accumulate", i32),
-                ("dgamma", vp), ("dbeta", vp), ("M", i32), ("d", i32), ("ld", i32)]
+                ("dgamma", vp), ("dbeta", vp), ("M", i32), ("d", i32), ("ld", i32),
+                ("det_base", vp), ("det_acc", vp)]
 
 
 class AssembleParams(C.Structure):

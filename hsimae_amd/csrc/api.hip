@@ -91,7 +91,9 @@ hipEvent_t pool_event(Side& sd) {
 // without it a range may only be reported once it is complete on the caller's stream.
 struct Emitter {
     hsimae_bucket_cb cb; void* user; hipStream_t bucket; int stage;
+    float* grads; const int64_t* det_acc;              // deterministic mode: the range's fixed-point sums become fp32 first
     int operator()(int64_t off, int64_t end, hipStream_t done_on) {
+        if (det_acc) CK0(hs_det_convert(det_acc + off, grads + off, end - off, done_on));
         if (cb) {
             if (bucket) {
                 hipEvent_t e = pool_event(side());
@@ -193,19 +195,19 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
 int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, const BlkBuf& b, int64_t M, int d,
               int heads, int h, int hp, int Ts, int nsamples, int mode, int len_l, float* G0, const Scr& w,
               float* dx_out, int accumulate, hipStream_t s, int concurrent = 1, const float* rs_a = nullptr,
-              const float* rs_m = nullptr) {
+              const float* rs_m = nullptr, int64_t* det_acc = nullptr) {
     float* G1 = w.G1;
     GemmParams p = gp();
     const int dp = rup(d, 32);                        // storage width (see block_fwd)
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
-    l.M = (int)M; l.d = d; l.ld = dp;
+    l.M = (int)M; l.d = d; l.ld = dp; l.det_base = grads; l.det_acc = det_acc;
     const bool f8 = P.prec == HSIMAE_PREC_FP8;
     auto w8 = [&](GemmParams& q, const BlkP::I8& a) { if (f8) { q.prec = HSIMAE_PREC_FP8; q.W8 = a.w; q.S8 = a.s; } };
     const bool fmlp = !f8 && fused_mlp_enabled(d, h);
     if (fmlp) {
         // recompute u2 / h1 / h3 / g inside the tile; emits dx1 and the wgrad operands u2, dh1|dh3, g, bf16 dY and dx1
         CK(hs_enc_mlp_bwd(b.x1, G0, G1, b.u2, w.dh13, b.g, w.g0b, w.g1b, (int)M, d, mlp_ptrs(P, h), grads + o.n2w,
-                          grads + o.n2b, s, rs_m, rs_a));
+                          grads + o.n2b, s, rs_m, rs_a, HsDet{grads, reinterpret_cast<long long*>(det_acc)}));
     } else {
         p.A = G0; p.lda = dp; p.M = (int)M; p.N = hp; p.K = dp; p.n_valid = hp; p.W = P.w2T; p.out = w.dh13; p.ldo = 2 * hp;
         p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp; p.a_rowscale = rs_m;        // DropPath: the branch saw rs_m * dY
@@ -253,7 +255,7 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     task(w.dh13, 0, 2 * hp, b.u2, dp, h, d, o.w1w, o.w1b);
     task(w.dh13 + hp, 0, 2 * hp, b.u2, dp, h, d, o.w3w, o.w3b);
     task(w.g0b, 0, dp, b.g, hp, d, h, o.w2w, o.w2b);
-    g.M = (int)M;
+    g.M = (int)M; g.det_base = grads; g.det_acc = det_acc;
     int tiles = 0;
     for (int i = 0; i < g.ntasks; ++i) tiles += ((g.t[i].N + 127) / 128) * ((g.t[i].K + 127) / 128);
     g.msplit = wgrad_msplit(tiles, M, concurrent);
@@ -268,7 +270,7 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     p.A = w.dqkv; p.lda = 3 * dp; p.M = (int)M; p.N = dp; p.K = 3 * dp; p.n_valid = d; p.W = P.qkvT;
     if (ln_fused) {
         p.out = dx_out; p.ldo = d; p.res = G1; p.ldr = d; p.lnx = x_in; p.gamma = P.n1w; p.accumulate = accumulate;
-        p.dgamma = grads + o.n1w; p.dbeta = grads + o.n1b;
+        p.dgamma = grads + o.n1w; p.dbeta = grads + o.n1b; p.det_base = grads; p.det_acc = det_acc;
         CK(hs_gemm(p, A_BF16, E_LN_BWD, s));       // K = 384: the persistent LDS-DMA kernel of gemm_dma.hip
     } else {
         p.out = w.du; p.ldo = dp;
@@ -497,7 +499,7 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
         const float* xin = (i > 0) ? w.bf[i - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
         const DropRs rf = drop_rs(io, (g.has_axis ? 2 * g.sdepth : 0) + i, c.Me);
         CK(block_bwd(bp, L.bf[i], grads, xin, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, w.G0, w.sc, w.G0, 0, s, 1,
-                     rf.a, rf.m));
+                     rf.a, rf.m, io->det_acc));
         CK(emit(L.bf[i].n1w, L.bf[i].end, s));
     }
     if (g.has_axis) {
@@ -519,7 +521,7 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
             const DropRs r1 = drop_rs(io, i, c.Me), r2d = drop_rs(io, g.sdepth + i, c.Me);
             const float* xin2 = (i > 0) ? w.b2[i - 1].x2 : w.x0;
             CK(block_bwd(b2, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, scr2, w.G0, 0, s2, forked ? 2 : 1,
-                         r2d.a, r2d.m));
+                         r2d.a, r2d.m, io->det_acc));
             if (per_block) CK(emit(L.b2[i].n1w, L.b2[i].end, s2));
             if (i == 0 && forked) {                 // the spatial stack's last step accumulates onto the spectral dX
                 CK((int)hipEventRecord(sd.join, sd.s));
@@ -529,7 +531,7 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
             const float* xin1 = (i > 0) ? w.b1[i - 1].x2 : w.x0;
             float* out = (i == 0) ? w.G0 : w.G2;
             CK(block_bwd(b1, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, out, i == 0, s, forked ? 2 : 1,
-                         r1.a, r1.m));
+                         r1.a, r1.m, io->det_acc));
             if (per_block) CK(emit(L.b1[i].n1w, L.b1[i].end, s));
         }
         if (!per_block) {     // back-to-front, all complete on the caller's stream by now
@@ -541,6 +543,7 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
         WgradParams wg; std::memset(&wg, 0, sizeof(wg));
         WgradTask& t = wg.t[0]; t.dO = w.G0; t.dO_f32 = 1; t.ldo = g.Dp; t.A = w.a_pe; t.lda = 96; t.N = g.D; t.K = 72;
         t.dW = grads + L.pew; t.ldw = 72; t.db = grads + L.peb;
+        wg.det_base = grads; wg.det_acc = io->det_acc;
         wg.ntasks = 1; wg.M = (int)c.Me; wg.msplit = wgrad_msplit((g.D + 127) / 128, c.Me);
         CK(hs_wgrad(wg, s));
     }
@@ -561,12 +564,13 @@ static int decoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
         WgradParams wg; std::memset(&wg, 0, sizeof(wg));
         WgradTask& t = wg.t[0]; t.dO = w.dpred; t.dO_f32 = 0; t.ldo = 96; t.A = w.zn; t.lda = g.Ddp; t.N = 72; t.K = g.Dd;
         t.dW = grads + L.dpw; t.ldw = g.Dd; t.db = grads + L.dpb;
+        wg.det_base = grads; wg.det_acc = io->det_acc;
         wg.ntasks = 1; wg.M = (int)c.Md; wg.msplit = wgrad_msplit(1, c.Md);
         CK(hs_wgrad(wg, s));
     }
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
     l.du = w.du; l.x = zlast; l.gamma = P + L.dnw; l.dres = nullptr; l.dx = w.G0; l.dgamma = grads + L.dnw; l.dbeta = grads + L.dnb;
-    l.M = (int)c.Md; l.d = g.Dd; l.ld = g.Ddp;
+    l.M = (int)c.Md; l.d = g.Dd; l.ld = g.Ddp; l.det_base = grads; l.det_acc = io->det_acc;
     CK(hs_ln_bwd(l, s));
     CK(emit(L.dnw, L.total, s));
 
@@ -582,11 +586,13 @@ static int decoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
             dg.pw = grads + o.pw; dg.pb = grads + o.pb; dg.n2w = grads + o.n2w; dg.n2b = grads + o.n2b;
             dg.w1w = grads + o.w1w; dg.w1b = grads + o.w1b; dg.w2w = grads + o.w2w; dg.w2b = grads + o.w2b;
             dg.w3w = grads + o.w3w; dg.w3b = grads + o.w3b;
+            dg.det = HsDet{grads, reinterpret_cast<long long*>(io->det_acc)};
             // MLP half then attention half, both persistent with the block's weight gradients held in registers
             // (measured equal to "row-tile kernel + wgrad operands through HBM" at d = 64, with 0.7 GB less traffic)
             CK(hs_dec_block_bwd(xin, w.bd[i].x1, w.G0, w.G1, w.G0, w.bd[i].o, w.bd[i].lse, c.N, g.TL, dec_ptrs(bp, g.hdec), dg, s));
         } else {
-            CK(block_bwd(bp, L.bd[i], grads, xin, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, w.G0, w.sc, w.G0, 0, s));
+            CK(block_bwd(bp, L.bd[i], grads, xin, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, w.G0, w.sc, w.G0, 0, s, 1, nullptr, nullptr,
+                         io->det_acc));
         }
         CK(emit(L.bd[i].n1w, L.bd[i].end, s));
     }
@@ -601,6 +607,7 @@ static int decoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
         WgradParams wg; std::memset(&wg, 0, sizeof(wg));
         WgradTask& t = wg.t[0]; t.dO = w.dyb; t.dO_f32 = 0; t.ldo = g.Ddp; t.A = w.lat; t.lda = g.Dp; t.N = g.Dd; t.K = g.D;
         t.dW = grads + L.dew; t.ldw = g.D; t.db = grads + L.deb;
+        wg.det_base = grads; wg.det_acc = io->det_acc;
         wg.ntasks = 1; wg.M = (int)c.Me; wg.msplit = wgrad_msplit(((g.Dd + 127) / 128) * ((g.D + 127) / 128), c.Me);
         CK(hs_wgrad(wg, s));
     }
@@ -612,14 +619,15 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
     Ctx c; CK(make_ctx(cfg, io, c, true));
     if (!grads || !io->ids_restore) return HSIMAE_ENULL;
     hipStream_t s = S(stream);
+    if (io->det_acc) CK((int)hipMemsetAsync(io->det_acc, 0, (size_t)c.L.total * 8, s));     // deterministic mode: fixed-point shadow sums
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
-    Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0};
+    Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0, grads, io->det_acc};
     CK(decoder_backward(c, io, grads, s, emit));
     // norm (Models.py:570)
     const float* xf = g.nfus ? w.bf[g.nfus - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
     l.du = w.du; l.x = xf; l.gamma = P + L.nw; l.dres = nullptr; l.dx = w.G0; l.dgamma = grads + L.nw; l.dbeta = grads + L.nb;
-    l.M = (int)c.Me; l.d = g.D; l.ld = g.Dp;
+    l.M = (int)c.Me; l.d = g.D; l.ld = g.Dp; l.det_base = grads; l.det_acc = io->det_acc;
     CK(hs_ln_bwd(l, s));
     CK(emit(L.nw, L.deb + g.Dd, s));
     return encoder_backward(c, io, grads, s, emit);
@@ -630,9 +638,10 @@ int hsimae_decode_backward(const hsimae_config* cfg, const hsimae_io* io, const 
     Ctx c; CK(make_ctx(cfg, io, c, true));
     if (!grads || !dpred || !dlatent || !io->ids_restore) return HSIMAE_ENULL;
     hipStream_t s = S(stream);
+    if (io->det_acc) CK((int)hipMemsetAsync(io->det_acc, 0, (size_t)c.L.total * 8, s));     // deterministic mode: fixed-point shadow sums
     const Geo& g = c.g; const Ws& w = c.w; const PLayout& L = c.L;
     CK(hs_rows_pad_bf16(dpred, w.dpred, c.Md, 72, 96, s));
-    Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0};
+    Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0, grads, io->det_acc};
     CK(decoder_backward(c, io, grads, s, emit));
     CK(emit(L.dew, L.deb + g.Dd, s));
     return (int)hipMemcpy2DAsync(dlatent, (size_t)g.D * 4, w.du, (size_t)g.Dp * 4, (size_t)g.D * 4, (size_t)c.Me, hipMemcpyDeviceToDevice, s);
@@ -643,6 +652,7 @@ int hsimae_encode_backward(const hsimae_config* cfg, const hsimae_io* io, const 
     Ctx c; CK(make_ctx(cfg, io, c, true));
     if (!grads || !dlatent) return HSIMAE_ENULL;
     hipStream_t s = S(stream);
+    if (io->det_acc) CK((int)hipMemsetAsync(io->det_acc, 0, (size_t)c.L.total * 8, s));     // deterministic mode: fixed-point shadow sums
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
     // `norm` (Models.py:892): dlatent -> d(x of the last encoder block) in G0
     const float* xf = g.nfus ? w.bf[g.nfus - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
@@ -653,9 +663,9 @@ int hsimae_encode_backward(const hsimae_config* cfg, const hsimae_io* io, const 
         dlat = w.du;
     }
     l.du = dlat; l.x = xf; l.gamma = P + L.nw; l.dres = nullptr; l.dx = w.G0; l.dgamma = grads + L.nw; l.dbeta = grads + L.nb;
-    l.M = (int)c.Me; l.d = g.D; l.ld = g.Dp;
+    l.M = (int)c.Me; l.d = g.D; l.ld = g.Dp; l.det_base = grads; l.det_acc = io->det_acc;
     CK(hs_ln_bwd(l, s));
-    Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0};
+    Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0, grads, io->det_acc};
     CK(emit(L.nw, L.nb + g.D, s));
     return encoder_backward(c, io, grads, s, emit);
 }

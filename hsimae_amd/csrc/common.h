@@ -70,6 +70,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Gradient commits.  Default: fp32 global atomics (summation order varies from run to run in the last bits).  Deterministic
+// mode (hsimae_io.det_acc): every addend is converted to 64-bit fixed point (scale 2^44: 5.7e-14 resolution, +-5.2e5 range)
+// and added with an INTEGER atomic into a shadow buffer indexed like the gradient buffer — integer addition is
+// associative, so the sum does not depend on the order in which the workgroups arrive; the shadow is converted back to
+// fp32 once per reported range (det_convert_kernel).  `base` = the flat gradient buffer the pointers point into.
+struct HsDet { const float* base; long long* acc; };
+#define HS_DET_SCALE 17592186044416.0f         /* 2^44 */
+__device__ __forceinline__ void hs_gadd(const HsDet& d, float* ptr, float v) {
+    if (d.acc) {
+        const long long q = __float2ll_rn(v * HS_DET_SCALE);
+        atomicAdd(reinterpret_cast<unsigned long long*>(d.acc + (ptr - d.base)), static_cast<unsigned long long>(q));
+    } else {
+        atomicAdd(ptr, v);
+    }
+}
+
 // Packed weight image ("wpk"): W[N][K] (row-major, K contiguous) zero-padded to NT=ceil(N/16)
 // n-tiles and KS=ceil(K/32) k-steps, stored in MFMA B-fragment order:
 //   element index ((nt*KS + ks)*64 + lane)*8 + j  holds  W[nt*16 + (lane&15)][ks*32 + 8*(lane>>4) + j]

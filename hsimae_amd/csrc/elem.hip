@@ -168,8 +168,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
         float g = 0.f, b = 0.f;
 #pragma unroll 4
         for (int k = 0; k < G; ++k) { g += red[0][k][c]; b += red[1][k][c]; }
-        if (p.dgamma) atomicAdd(p.dgamma + c, g);
-        if (p.dbeta) atomicAdd(p.dbeta + c, b);
+        const HsDet det{p.det_base, reinterpret_cast<long long*>(p.det_acc)};
+        if (p.dgamma) hs_gadd(det, p.dgamma + c, g);
+        if (p.dbeta) hs_gadd(det, p.dbeta + c, b);
     }
 }
 
@@ -669,6 +670,18 @@ int hs_rows_pad_bf16(const float* src, hs_bf16* dst, int64_t rows, int cols, int
     if (cols > ldd) return HS_EDIMS;
     const int grid = (int)std::min<int64_t>((rows * ldd + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(rows_pad_bf16_kernel, dim3(grid), dim3(256), 0, s, src, dst, rows, cols, ldd);
+    return (int)hipGetLastError();
+}
+
+// deterministic mode: fixed-point shadow sums of grads[off, off + n) -> fp32 (added onto what the plain stores left there)
+__global__ __launch_bounds__(256) void det_convert_kernel(const long long* __restrict__ acc, float* __restrict__ g, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        g[i] += (float)((double)acc[i] * (1.0 / (double)HS_DET_SCALE));
+}
+int hs_det_convert(const int64_t* acc, float* g, int64_t n, hipStream_t s) {
+    if (n <= 0) return HS_OK;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(det_convert_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const long long*>(acc), g, n);
     return (int)hipGetLastError();
 }
 

@@ -646,7 +646,7 @@ __device__ __forceinline__ float red8(float v) {
 }
 
 // Commit per-thread column partials (wide layout: thread owns columns 8*(tid&7)..+7) with one atomic per column.
-__device__ __forceinline__ void flush_wide(float* red /* [NT_][8] LDS */, const float* part, float* dst) {
+__device__ __forceinline__ void flush_wide(float* red /* [NT_][8] LDS */, const float* part, float* dst, const HsDet& det) {
     lds_barrier();
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = part[e];
@@ -655,13 +655,14 @@ __device__ __forceinline__ void flush_wide(float* red /* [NT_][8] LDS */, const 
         const int c = threadIdx.x, c8 = c >> 3, e = c & 7;
         float s = 0.f;
         for (int t = c8; t < NT_; t += 8) s += red[t * 8 + e];
-        atomicAdd(dst + c, s);
+        hs_gadd(det, dst + c, s);
     }
 }
 
 struct DecBwdMlpArgs {
     const float* x1; const float* dy; float* dx1; int nsamples, Ts; DecW w; const bf16_t *w2T, *w13T; const float *w1f, *w3f;
     float *g_n2w, *g_n2b, *g_w1w, *g_w1b, *g_w3w, *g_w3b, *g_w2w, *g_w2b;
+    HsDet det;
 };
 
 template <int MT>
@@ -900,9 +901,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
     PH_FLUSH(8)
     // ---- commit
     float* red = XS;
-    flush_wide(red, dgam, p.g_n2w);
-    flush_wide(red, dbet, p.g_n2b);
-    flush_wide(red, db2, p.g_w2b);
+    flush_wide(red, dgam, p.g_n2w, p.det);
+    flush_wide(red, dbet, p.g_n2b, p.det);
+    flush_wide(red, db2, p.g_w2b, p.det);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
             b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
             const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
-            if (q.g == 0 && col < p.w.h) { atomicAdd(p.g_w1b + col, a); atomicAdd(p.g_w3b + col, b); }
+            if (q.g == 0 && col < p.w.h) { hs_gadd(p.det, p.g_w1b + col, a); hs_gadd(p.det, p.g_w3b + col, b); }
         }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -925,10 +926,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                     const int n = nt * 16 + q.g * 4 + r, k = ((q.wave & 1) * 2 + k2) * 16 + q.c16;
                     const float v = accW[c][t][k2][r];
                     if (mat == 0) {                       // dW2[d][h]: row n (model dim), column c*64 + k (hidden)
-                        if (c * 64 + k < p.w.h) atomicAdd(p.g_w2w + (size_t)n * p.w.h + c * 64 + k, v);
+                        if (c * 64 + k < p.w.h) hs_gadd(p.det, p.g_w2w + (size_t)n * p.w.h + c * 64 + k, v);
                     } else {                              // dW1 / dW3 [h][d]: row c*64 + n (hidden), column k
                         float* dst = mat == 1 ? p.g_w1w : p.g_w3w;
-                        if (c * 64 + n < p.w.h) atomicAdd(dst + (size_t)(c * 64 + n) * D + k, v);
+                        if (c * 64 + n < p.w.h) hs_gadd(p.det, dst + (size_t)(c * 64 + n) * D + k, v);
                     }
                 }
         }
@@ -1056,6 +1057,7 @@ struct DecBwdAttnArgs {
     const float* x; const float* dx1; float* dx; const bf16_t* o; const float* lse_g; int nsamples, Ts; DecW w; const bf16_t *qkvT, *pT;
     const float *qf, *kf, *vf, *pf;
     float *g_n1w, *g_n1b, *g_qw, *g_qb, *g_kw, *g_kb, *g_vw, *g_vb, *g_pw, *g_pb;
+    HsDet det;
 };
 
 template <int MT>
@@ -1328,9 +1330,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     PH_FLUSH(0)
     // ---- commit
     float* red = XS;
-    flush_wide(red, dgam, p.g_n1w);
-    flush_wide(red, dbet, p.g_n1b);
-    flush_wide(red, dbp, p.g_pb);
+    flush_wide(red, dgam, p.g_n1w, p.det);
+    flush_wide(red, dbet, p.g_n1b, p.det);
+    flush_wide(red, dbp, p.g_pb, p.det);
     {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1338,14 +1340,14 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
             const int col = q.wave * HD + q.g * 4 + r;
-            if (q.c16 == 0 && q.g < 2) { atomicAdd(p.g_qb + col, a); atomicAdd(p.g_kb + col, b); atomicAdd(p.g_vb + col, c); }
+            if (q.c16 == 0 && q.g < 2) { hs_gadd(p.det, p.g_qb + col, a); hs_gadd(p.det, p.g_kb + col, b); hs_gadd(p.det, p.g_vb + col, c); }
         }
     }
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            atomicAdd(p.g_pw + (size_t)((q.wave >> 1) * 16 + q.g * 4 + r) * D + ((q.wave & 1) * 2 + k2) * 16 + q.c16, accP[k2][r]);
+            hs_gadd(p.det, p.g_pw + (size_t)((q.wave >> 1) * 16 + q.g * 4 + r) * D + ((q.wave & 1) * 2 + k2) * 16 + q.c16, accP[k2][r]);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
@@ -1354,7 +1356,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                atomicAdd(dst + (size_t)(nt * 16 + q.g * 4 + r) * D + ((q.wave & 1) * 2 + k2) * 16 + q.c16, accQ[t][k2][r]);
+                hs_gadd(p.det, dst + (size_t)(nt * 16 + q.g * 4 + r) * D + ((q.wave & 1) * 2 + k2) * 16 + q.c16, accQ[t][k2][r]);
     }
 }
 
@@ -1411,12 +1413,12 @@ int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx
     a.x1 = x1; a.dy = dy; a.dx1 = dx1_tmp; a.nsamples = nsamples; a.Ts = Ts; a.w = w; a.w2T = bp.w2T; a.w13T = bp.w13T;
     a.w1f = bp.w1f; a.w3f = bp.w3f;
     a.g_n2w = g.n2w; a.g_n2b = g.n2b; a.g_w1w = g.w1w; a.g_w1b = g.w1b; a.g_w3w = g.w3w; a.g_w3b = g.w3b;
-    a.g_w2w = g.w2w; a.g_w2b = g.w2b;
+    a.g_w2w = g.w2w; a.g_w2b = g.w2b; a.det = g.det;
     DecBwdAttnArgs b;
     b.x = x; b.dx1 = dx1_tmp; b.dx = dx; b.o = o; b.lse_g = lse; b.nsamples = nsamples; b.Ts = Ts; b.w = w; b.qkvT = bp.qkvT; b.pT = bp.pT;
     b.qf = bp.qf; b.kf = bp.kf; b.vf = bp.vf; b.pf = bp.pf;
     b.g_n1w = g.n1w; b.g_n1b = g.n1b; b.g_qw = g.qw; b.g_qb = g.qb; b.g_kw = g.kw; b.g_kb = g.kb; b.g_vw = g.vw;
-    b.g_vb = g.vb; b.g_pw = g.pw; b.g_pb = g.pb;
+    b.g_vb = g.vb; b.g_pw = g.pw; b.g_pb = g.pb; b.det = g.det;
     const int mt = (Ts + 15) / 16;
     if (mt <= 4) return launch_bwd<4>(a, b, s);
     if (mt <= 7) return launch_bwd<7>(a, b, s);

@@ -307,6 +307,7 @@ struct EncMlpBwdArgs {
     // DropPath (NULL = none): the MLP branch saw rs_mlp * dY, so dyb and everything derived from it carry the factor;
     // dx1b is what the attention branch sees, rs_attn * dx1.  dx1 itself (the residual path) is unscaled.
     const float* rs_mlp; const float* rs_attn;
+    HsDet det;
 };
 
 template <int D, int HPE>
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
         const int which = t2 / D, c = t2 % D, o8 = c >> 3, e = c & 7;
         float s = 0.f;
         for (int t = o8; t < NTH; t += LPR) s += red[which * NTH * 8 + t * 8 + e];
-        atomicAdd((which ? p.g_n2b : p.g_n2w) + c, s);
+        hs_gadd(p.det, (which ? p.g_n2b : p.g_n2w) + c, s);
     }
     PH(5)
     PH_FLUSH(0)
@@ -590,10 +591,10 @@ int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, 
 
 int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
                    hs_bf16* dx1b, int M, int d, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s,
-                   const float* rs_mlp, const float* rs_attn) {
+                   const float* rs_mlp, const float* rs_attn, HsDet det) {
     if (M <= 0) return HS_OK;
     EncMlpBwdArgs a; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.u2 = u2; a.dh13 = dh13; a.g = g; a.M = M; a.w = mkw(b);
-    a.g_n2w = g_n2w; a.g_n2b = g_n2b; a.dyb = dyb; a.dx1b = dx1b; a.rs_mlp = rs_mlp; a.rs_attn = rs_attn;
+    a.g_n2w = g_n2w; a.g_n2b = g_n2b; a.dyb = dyb; a.dx1b = dx1b; a.rs_mlp = rs_mlp; a.rs_attn = rs_attn; a.det = det;
     if (d == 128) {
         constexpr int R = MG<128, 352>::R;
         set_attrs<128, 352>();

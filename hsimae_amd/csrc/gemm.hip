@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
                 const int which = tid >> 7, c = tid & 127, o8 = c >> 3, e = c & 7;
                 float sacc = 0.f;
                 for (int t2 = o8; t2 < 256; t2 += 16) sacc += red[which * 2048 + t2 * 8 + e];
-                atomicAdd((which ? p.dbeta : p.dgamma) + c, sacc);
+                hs_gadd(HsDet{p.det_base, reinterpret_cast<long long*>(p.det_acc)}, (which ? p.dbeta : p.dgamma) + c, sacc);
             }
             PH(2)
             return;

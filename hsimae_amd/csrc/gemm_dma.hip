@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void lnbwd_dma_kernel(GemmParams p) {
         const int which = tid >> 7, c = tid & 127, o8 = c >> 3, e = c & 7;
         float sacc = 0.f;
         for (int t2 = o8; t2 < 256; t2 += 16) sacc += red[which * 2048 + t2 * 8 + e];
-        atomicAdd((which ? p.dbeta : p.dgamma) + c, sacc);
+        hs_gadd(HsDet{p.det_base, reinterpret_cast<long long*>(p.det_acc)}, (which ? p.dbeta : p.dgamma) + c, sacc);
     }
 }
 

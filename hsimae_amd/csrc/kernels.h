@@ -44,6 +44,7 @@ int hs_cube_gather(const CubeParams& p, hipStream_t s);
 int hs_agg_pool(const float* latent, float* pooled, int N, int T, int L, int D, hipStream_t s);
 int hs_rows_to_bf16(const float* src, hs_bf16* dst, int64_t rows, int d, const float* rowscale, hipStream_t s);
 int hs_rows_pad_bf16(const float* src, hs_bf16* dst, int64_t rows, int cols, int ldd, hipStream_t s);
+int hs_det_convert(const int64_t* acc, float* g, int64_t n, hipStream_t s);
 int hs_add2(const float* a, const float* b, float* out, int64_t n, hipStream_t s);
 
 // ------------------------------------------------------------------ fused_dec.hip (decoder Block, one workgroup per sample)
@@ -53,7 +54,10 @@ struct DecBlockPtrs {
     const float *qf, *kf, *vf, *pf, *w1f, *w3f;    // fp32 row-major weights [out][in] (the backward stages them in LDS as bf16)
     int h;
 };
-struct DecBlockGrads { float *n1w, *n1b, *qw, *qb, *kw, *kb, *vw, *vb, *pw, *pb, *n2w, *n2b, *w1w, *w1b, *w2w, *w2b, *w3w, *w3b; };
+struct DecBlockGrads {
+    float *n1w, *n1b, *qw, *qb, *kw, *kb, *vw, *vb, *pw, *pb, *n2w, *n2b, *w1w, *w1b, *w2w, *w2b, *w3w, *w3b;
+    HsDet det;                    // deterministic commits (common.h); {nullptr, nullptr} = fp32 atomics
+};
 bool hs_dec_fused_supported(int d, int heads, int hidden, int Ts);
 int hs_dec_block_fwd(const float* x, float* x1, float* x2, hs_bf16* o, float* lse, int nsamples, int Ts,
                      const DecBlockPtrs& bp, hipStream_t s);
@@ -75,7 +79,7 @@ int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, 
                    const float* rowscale = nullptr);
 int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
                    hs_bf16* dx1b, int M, int d, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s,
-                   const float* rs_mlp = nullptr, const float* rs_attn = nullptr);
+                   const float* rs_mlp = nullptr, const float* rs_attn = nullptr, HsDet det = HsDet{nullptr, nullptr});
 
 int hs_adamw(float* p, const float* g, float* m, float* v, const unsigned char* group, int64_t n, float lr, float b1, float b2,
              float eps, float wd, int step, hipStream_t s);

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     for (int i = 0; i < p.ntasks; ++i) tiles += ((p.t[i].N + 127) / 128) * ((p.t[i].K + 127) / 128);
     int w, ms;
     if (!decode_wg(p, tiles, w, ms)) return;
+    const HsDet det{p.det_base, reinterpret_cast<long long*>(p.det_acc)};
     int ti = 0, ns = 0, ks = 0;
     for (; ti < p.ntasks; ++ti) {
         const int nsl = (p.t[ti].N + 127) / 128, ksl = (p.t[ti].K + 127) / 128;
@@ -178,9 +179,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + (wave * 2 + i) * 16 + g * 4 + r;
                 const int k = k0 + j * 16 + c16;
-                if (n < t.N && k < t.K) atomicAdd(t.dW + (size_t)n * t.ldw + k, acc[i][j][r]);
+                if (n < t.N && k < t.K) hs_gadd(det, t.dW + (size_t)n * t.ldw + k, acc[i][j][r]);
             }
-    if (want_bias && n0 + bcol < t.N) atomicAdd(t.db + n0 + bcol, bsum);
+    if (want_bias && n0 + bcol < t.N) hs_gadd(det, t.db + n0 + bcol, bsum);
 }
 
 
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
     for (int i = 0; i < p.ntasks; ++i) tiles += ((p.t[i].N + 127) / 128) * ((p.t[i].K + 127) / 128);
     int w, ms;
     if (!decode_wg(p, tiles, w, ms)) return;
+    const HsDet det{p.det_base, reinterpret_cast<long long*>(p.det_acc)};
     int ti = 0, ns = 0, ks = 0;
     for (; ti < p.ntasks; ++ti) {
         const int nsl = (p.t[ti].N + 127) / 128, ksl = (p.t[ti].K + 127) / 128;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + (wave * 2 + i) * 16 + g * 4 + r;
                 const int k = k0 + j * 16 + c16;
-                if (n < t.N && k < t.K) atomicAdd(t.dW + (size_t)n * t.ldw + k, acc[i][j][r]);
+                if (n < t.N && k < t.K) hs_gadd(det, t.dW + (size_t)n * t.ldw + k, acc[i][j][r]);
             }
     if (want_bias && c16 == 0) {
 #pragma unroll
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + (wave * 2 + i) * 16 + g * 4 + r;
-                if (n < t.N) atomicAdd(t.db + n, accb[i][r]);
+                if (n < t.N) hs_gadd(det, t.db + n, accb[i][r]);
             }
     }
 }

@@ -212,6 +212,10 @@ class DualViT(HSIMAE):
             scratch = self._flat_scratch
             scratch.zero_()                                   # weight grads are accumulated with atomics
             nocb = _lib.BUCKET_CB(0)
+            det = self._det_buffer(dev)
+            for st in (saved["rec"], saved["cls"]):
+                if st is not None:
+                    st["io"].det_acc = det
             if saved["rec"] is not None and g_loss is not None:
                 saved["rec"].check_alive()
                 saved["rec"]["_done"] = True

@@ -123,6 +123,11 @@ typedef struct {
        complete the reported range — including the ones on the side stream — so the ranges of the two axis stacks are
        reported block by block instead of after the join.  NULL: ranges are reported once they are complete on `stream`. */
     void* bucket_stream;
+    /* optional deterministic gradient reduction (hsimae_backward / _encode_backward / _decode_backward): an int64 buffer
+       with one element per element of `grads` (contents irrelevant on entry).  Weight-gradient partial sums are then
+       accumulated in 64-bit fixed point with integer atomics (order-independent) and converted to fp32 at the end, so two
+       runs on the same inputs produce bit-identical gradients.  NULL: fp32 atomics (faster; last-bit run-to-run noise). */
+    int64_t* det_acc;
 } hsimae_io;
 
 int64_t hsimae_workspace_bytes(const hsimae_config* cfg, int32_t N, int32_t len_t, int32_t len_l);
@@ -189,6 +194,7 @@ typedef struct {
     /* A_F32_LN: number of leading columns the LayerNorm runs over when the rows are stored wider than the model width
        (K = storage width, a multiple of 32; the columns past ln_width are read as zeros and stay zeros); 0 = K. */
     int32_t ln_width;
+    const float* det_base; int64_t* det_acc;      /* E_LN_BWD: deterministic dgamma / dbeta commits, as in hsimae_lnbwd_params */
 } hsimae_gemm_params;
 int hsimae_gemm(const hsimae_gemm_params* p, int32_t a_kind, int32_t epilogue, void* stream);
 /* The same kernel with the row-panel height (bm: 64 or 128) and the depth of an A chunk (kc: 128 or 256; ignored by the
@@ -263,7 +269,10 @@ typedef struct {
     float* db;
     const float* dO_rowscale;     /* optional per-row factor [M] on an fp32 dO (DropPath); NULL = 1 */
 } hsimae_wgrad_task;
-typedef struct { hsimae_wgrad_task t[8]; int32_t ntasks; int32_t M; int32_t msplit; } hsimae_wgrad_params;
+typedef struct {
+    hsimae_wgrad_task t[8]; int32_t ntasks; int32_t M; int32_t msplit;
+    const float* det_base; int64_t* det_acc;      /* deterministic dW / db commits, as in hsimae_lnbwd_params; NULL = fp32 atomics */
+} hsimae_wgrad_params;
 int hsimae_wgrad(const hsimae_wgrad_params* p, void* stream);
 /* The row split (msplit) hsimae_backward uses for a launch of `tiles` 128x128 dW tiles over M rows: one resident
    wave of workgroups, whole groups of 8 (row slice ms runs on XCD ms % 8). */
@@ -274,6 +283,9 @@ typedef struct {
     const float* du; const float* x; const float* stats; const float* gamma; const float* dres;
     float* dx; int32_t accumulate; float* dgamma; float* dbeta; int32_t M, d;
     int32_t ld;                   /* row stride of du / x / dres / dx in floats (storage width); 0 = d */
+    /* deterministic commits (hsimae_io.det_acc): dgamma / dbeta point into the flat gradient buffer starting at det_base and
+       the sums go to det_acc[ptr - det_base] in 64-bit fixed point instead; both NULL = fp32 atomics */
+    const float* det_base; int64_t* det_acc;
 } hsimae_lnbwd_params;
 int hsimae_ln_bwd(const hsimae_lnbwd_params* p, void* stream);
 /* Plain LayerNorm forward, fp32 in/out (Models.py:570 when a caller wants the fp32 latent). */

@@ -267,6 +267,41 @@ def test_reference_default_widths_construct_and_match_oracle(dim, dec_dim, bands
     assert worst[0] <= 3e-2, worst
 
 
+@pytest.mark.parametrize("dim,bands,N,prec", [(128, 48, 64, "bf16"), (256, 96, 16, "bf16"), (512, 192, 4, "fp8")])
+def test_deterministic_mode_is_bit_reproducible(dim, bands, N, prec):
+    """SURVEY 5 (determinism): with `deterministic` on, two runs on the same inputs give bit-identical gradients for all 532
+    tensors (fused and layer-at-a-time schedules, two streams); the result agrees with the fp32-atomics path to rounding."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        torch.manual_seed(1)
+        m = HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=bands, b_patch_size=8, embed_dim=dim, depth=12, num_heads=dim // 16,
+                   s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8, norm_pix_loss=True, trunc_init=True)
+    m = m.to(DEV).set_precision(prec)
+    perturb_like_fixture(m, 3, std=0.05)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(N, 1, bands, 9, 9, generator=g).to(DEV)
+    T = bands // 8
+    nz = (torch.rand(N, T, generator=g), torch.rand(N, 9, generator=g))
+    grid = HSIMAE.grid_candidates(T, 9, 0.75)[0]
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        loss = m(x, 0.75, noise=nz, grid=grid)[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), _grads(m)
+
+    m.deterministic = True
+    l1, g1 = run()
+    l2, g2 = run()
+    assert l1 == l2 and len(g1) == 532
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    m.deterministic = False
+    _, g3 = run()
+    worst = max((float((g1[k] - g3[k]).abs().max() / g3[k].abs().max().clamp_min(1e-20)), k) for k in g1 if not k.endswith("attn.k.bias"))
+    assert worst[0] < 2e-4, worst
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 def test_model_on_a_non_default_device():
     torch.cuda.set_device(0)
