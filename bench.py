@@ -343,7 +343,7 @@ def cpu_baseline(bands):
         t0 = time.perf_counter()
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-probe", str(cores), "--probe-bands", str(bands)],
-                               capture_output=True, text=True, timeout=40)
+                               capture_output=True, text=True, timeout=25)
             probe = float(r.stdout.strip().splitlines()[-1])
         except (subprocess.TimeoutExpired, ValueError, IndexError):
             probe = 0.0
@@ -358,7 +358,7 @@ def cpu_baseline(bands):
     c1_rate, c1_steps = _oracle_rate(48, 64, 2, 7, best, 4.0)
     return {"value": round(tried[best][0], 2), "unit": "patches/s", "cores": best, "kind": "port",
             "sample": f"oracle fwd+bwd fp32, HSIMAE-Base 9x9x{bands}, batch 256, median of {tried[best][1]} steps after 1 warm-up",
-            "threads_tried": {str(c): (round(r, 2) if r > 0 else "probe timed out (>40 s at batch 32)") for c, (r, _) in tried.items()},
+            "threads_tried": {str(c): (round(r, 2) if r > 0 else "probe timed out (>25 s at batch 32)") for c, (r, _) in tried.items()},
             "host_cores": allc,
             "config1": {"value": round(c1_rate, 2), "unit": "patches/s", "cores": best,
                         "sample": f"oracle fwd+bwd fp32, HSIMAE-Base 9x9x48, batch 64, median of {c1_steps} steps after 1 warm-up"}}
