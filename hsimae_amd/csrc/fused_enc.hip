@@ -42,7 +42,9 @@ constexpr int LC = 64 + 8;         // 64-column chunk image row stride
 // Geometry for model width D, padded hidden width HP (multiples of 64 / 32) and R_-row panels.
 //   D = 128: 48-row panels, three 4-wave workgroups per CU (2304 = 3 x 768 workgroups at M = 110,592)
 //   D = 256: 48-row panels, two workgroups per CU (the weight fragments of a 64-column hidden chunk are 64 / 96 registers)
-template <int D, int HP, int R_ = 48>
+//   D =  64: 64-row panels (8 lanes per row: the panel must be a multiple of 32 rows), three workgroups per CU — the MLP half
+//            of a decoder block when the decoder runs layer at a time (216-token sequences, Huge)
+template <int D, int HP, int R_ = (D == 64 ? 64 : 48)>
 struct MG {
     static constexpr int R = R_;
     static constexpr int WPC = D <= 128 ? 3 : 2;            // workgroups per CU the kernels are compiled for
@@ -551,8 +553,9 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
 static int hp_of(int hidden) { return (hidden + 31) / 32 * 32; }
 
 bool hs_enc_mlp_fused_supported(int d, int hidden) {
-    // the kernels are templates on <D, HP>: Base (128, 344 -> 352) and Large (256, 684 -> 704) are instantiated
-    return (d == 128 && hp_of(hidden) == 352) || (d == 256 && hp_of(hidden) == 704);
+    // the kernels are templates on <D, HP>: Base (128, 344 -> 352), Large (256, 684 -> 704) and the decoder width
+    // (64, 172 -> 192) are instantiated
+    return (d == 128 && hp_of(hidden) == 352) || (d == 256 && hp_of(hidden) == 704) || (d == 64 && hp_of(hidden) == 192);
 }
 
 static EncMlpW mkw(const EncMlpPtrs& b) {
@@ -583,6 +586,10 @@ int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, 
         constexpr int R = MG<256, 704>::R;
         set_attrs<256, 704>();
         hipLaunchKernelGGL((enc_mlp_fwd_kernel<256, 704>), dim3((M + R - 1) / R), dim3(NTH), (MG<256, 704>::LDS_FWD), s, a);
+    } else if (d == 64) {
+        constexpr int R = MG<64, 192>::R;
+        set_attrs<64, 192>();
+        hipLaunchKernelGGL((enc_mlp_fwd_kernel<64, 192>), dim3((M + R - 1) / R), dim3(NTH), (MG<64, 192>::LDS_FWD), s, a);
     } else {
         return HS_EUNSUPPORTED;
     }
@@ -603,6 +610,10 @@ int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs
         constexpr int R = MG<256, 704>::R;
         set_attrs<256, 704>();
         hipLaunchKernelGGL((enc_mlp_bwd_kernel<256, 704>), dim3((M + R - 1) / R), dim3(NTH), (MG<256, 704>::LDS_BWD), s, a);
+    } else if (d == 64) {
+        constexpr int R = MG<64, 192>::R;
+        set_attrs<64, 192>();
+        hipLaunchKernelGGL((enc_mlp_bwd_kernel<64, 192>), dim3((M + R - 1) / R), dim3(NTH), (MG<64, 192>::LDS_BWD), s, a);
     } else {
         return HS_EUNSUPPORTED;
     }
