@@ -1,0 +1,108 @@
+"""Data-parallel gradient equality on a real MI355X (tier 4): two ranks, each with half of a global batch, must end
+with the gradients a single process computes on the whole batch.
+
+The GPU box has ONE GPU and RCCL refuses two ranks on one device, so the two ranks share cuda:0 and talk over **gloo**
+(device tensors, staged through the host).  Everything else is the production path: `enable_data_parallel()` (broadcast of
+rank 0's weights), the bucket callback fired from inside `hsimae_backward`, the reducer's launch stream made to wait on the
+library's events (side-stream ranges included), bucket merging of the interleaved axis-stack ranges, 1/world folded into
+dLoss/dpred.  The RCCL transport itself runs in `bench.py --force-ddp` (one rank) and in the driver's multi-GPU runs.
+"""
+import contextlib
+import io
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model(seed):
+    from hsimae_amd import HSIMAE
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        return HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=48, b_patch_size=8, embed_dim=128, depth=12, num_heads=8,
+                      s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8, norm_pix_loss=True, trunc_init=True)
+
+
+def _inputs(N):
+    g = torch.Generator().manual_seed(123)
+    return torch.rand(N, 1, 48, 9, 9, generator=g), torch.rand(N, 6, generator=g), torch.rand(N, 9, generator=g)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        m = _model(seed=100 + rank).cuda()               # different weights per rank: the broadcast must fix that
+        m.enable_data_parallel(bucket_bytes=1 << 20)
+        m.deterministic = True                            # fixed-point reduction: the comparison is not blurred by atomics
+        N = 32
+        x, n1, n2 = _inputs(N)
+        per = N // world
+        sl = slice(rank * per, (rank + 1) * per)
+        losses = []
+        for step in range(2):                             # two steps: the second reuses arena, events and launch stream
+            m.zero_grad(set_to_none=True)
+            loss, _, _ = m(x[sl].cuda(), 0.75, noise=(n1[sl], n2[sl]), grid=(2, 7))
+            loss.backward()
+            torch.cuda.synchronize()
+            losses.append(loss.item())
+        # numpy (pickled by value): torch tensors travel through the queue as shared-memory handles that die with the worker
+        grads = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters() if p.grad is not None}
+        launched = list(m._reducer.launched)
+        sd0 = m.state_dict()["blocks.0.mlp.w1.weight"].cpu().numpy()
+        q.put((rank, "ok", losses, grads if rank == 0 else None, launched, sd0))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc() + repr(e), None, None, None, None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process_on_the_global_batch():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+    assert [r[1] for r in res] == ["ok", "ok"], [r[1] for r in res]
+    # rank 0's weights reached rank 1
+    assert (res[0][5] == res[1][5]).all()
+    # the collectives cover the trainable part of the flat buffer in a few buckets, identically on both ranks
+    assert res[0][4] == res[1][4] and 3 <= len(res[0][4]) <= 40
+    # single process, whole batch, rank 0's weights
+    m = _model(seed=100).cuda()
+    m.deterministic = True
+    x, n1, n2 = _inputs(32)
+    loss, _, _ = m(x.cuda(), 0.75, noise=(n1, n2), grid=(2, 7))
+    loss.backward()
+    torch.cuda.synchronize()
+    # equal sum(mask) per rank => mean of the rank losses == the global masked mean
+    mean_rank_loss = 0.5 * (res[0][2][1] + res[1][2][1])
+    assert abs(mean_rank_loss - loss.item()) <= 2e-6 * abs(loss.item())
+    named = dict(m.named_parameters())
+    worst = ("", 0.0)
+    for k, g in res[0][3].items():
+        ref = named[k].grad.detach().cpu()
+        e = float((torch.from_numpy(g) - ref).abs().max() / ref.abs().max().clamp_min(1e-20))
+        if not k.endswith("attn.k.bias") and e > worst[1]:
+            worst = (k, e)
+    # same arithmetic per sample, different partition of the row sums (fp32 partials inside each rank's kernels)
+    assert worst[1] < 2e-3, worst
