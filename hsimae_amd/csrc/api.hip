@@ -191,6 +191,14 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
 }
 
 
+// d = 256 (rows of exactly two 128-column chunks): LayerNorm backward as the epilogue of the k-outer GEMM
+// (gemm.hip epilogue_ln_ko).  HSIMAE_FUSED_LNBWD=0 keeps the separate du store + ln_bwd pass.
+static bool wide_ln_fused(int d, int dp) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("HSIMAE_FUSED_LNBWD"); on = !(e && e[0] == '0'); }
+    return on && dp == d && d == 256;
+}
+
 // One Block backward: data grads (7 launches) + all weight/bias grads of the block (1 launch).
 int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, const BlkBuf& b, int64_t M, int d,
               int heads, int h, int hp, int Ts, int nsamples, int mode, int len_l, float* G0, const Scr& w,
@@ -214,12 +222,19 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         w8(p, P.w2T8);
         CK(hs_gemm(p, A_F32, E_SWIGLU_BWD, s));
         p = gp();
-        p.A = w.dh13; p.lda = 2 * hp; p.M = (int)M; p.N = dp; p.K = 2 * hp; p.n_valid = d; p.W = P.w13T; p.out = w.du; p.ldo = dp;
+        p.A = w.dh13; p.lda = 2 * hp; p.M = (int)M; p.N = dp; p.K = 2 * hp; p.n_valid = d; p.W = P.w13T;
         w8(p, P.w13T8);
-        CK(hs_gemm(p, A_BF16, E_F32, s));
-        l.du = w.du; l.x = b.x1; l.gamma = P.n2w; l.dres = G0; l.dx = G1; l.accumulate = 0;
-        l.dgamma = grads + o.n2w; l.dbeta = grads + o.n2b;
-        CK(hs_ln_bwd(l, s));
+        if (wide_ln_fused(d, dp)) {           // LayerNorm-2 backward as the epilogue of the k-outer GEMM (the whole row is on chip)
+            p.out = G1; p.ldo = dp; p.res = G0; p.ldr = dp; p.lnx = b.x1; p.gamma = P.n2w; p.accumulate = 0;
+            p.dgamma = grads + o.n2w; p.dbeta = grads + o.n2b; p.det_base = grads; p.det_acc = det_acc;
+            CK(hs_gemm(p, A_BF16, E_LN_BWD, s));
+        } else {
+            p.out = w.du; p.ldo = dp;
+            CK(hs_gemm(p, A_BF16, E_F32, s));
+            l.du = w.du; l.x = b.x1; l.gamma = P.n2w; l.dres = G0; l.dx = G1; l.accumulate = 0;
+            l.dgamma = grads + o.n2w; l.dbeta = grads + o.n2b;
+            CK(hs_ln_bwd(l, s));
+        }
         // bf16 copies of dY / dx1 (with the DropPath factors folded in) so that the weight gradients below take the
         // LDS-DMA kernel: 666 -> ~300 us per block at D = 256
         CK(hs_rows_to_bf16(G0, w.g0b, M, dp, rs_m, s));
@@ -265,13 +280,14 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     // du never goes to HBM), two otherwise.  HSIMAE_FUSED_LNBWD=0 forces the two-kernel form.
     static int fuse_ln = -1;
     if (fuse_ln < 0) { const char* e = getenv("HSIMAE_FUSED_LNBWD"); fuse_ln = !(e && e[0] == '0'); }
-    const bool ln_fused = fuse_ln && d == 128 && !f8;
+    const bool ln_fused = fuse_ln && ((d == 128 && !f8) || wide_ln_fused(d, dp));
     p = gp();
     p.A = w.dqkv; p.lda = 3 * dp; p.M = (int)M; p.N = dp; p.K = 3 * dp; p.n_valid = d; p.W = P.qkvT;
     if (ln_fused) {
         p.out = dx_out; p.ldo = d; p.res = G1; p.ldr = d; p.lnx = x_in; p.gamma = P.n1w; p.accumulate = accumulate;
         p.dgamma = grads + o.n1w; p.dbeta = grads + o.n1b; p.det_base = grads; p.det_acc = det_acc;
-        CK(hs_gemm(p, A_BF16, E_LN_BWD, s));       // K = 384: the persistent LDS-DMA kernel of gemm_dma.hip
+        if (d != 128) w8(p, P.qkvT8);
+        CK(hs_gemm(p, A_BF16, E_LN_BWD, s));       // d = 128, K = 384: the persistent LDS-DMA kernel of gemm_dma.hip; d = 256 / 512: k-outer
     } else {
         p.out = w.du; p.ldo = dp;
         w8(p, P.qkvT8);

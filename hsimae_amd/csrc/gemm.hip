@@ -14,6 +14,7 @@
 // access; the first version's per-element 2-byte stores made every GEMM store-issue bound (profiles/).
 #include "common.h"
 #include "kernels.h"
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -55,7 +56,7 @@ template <int AK, int EPI, int KC, int BM, int F8, int NCH>
 __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!F8 || KC == 512, "the fp8 path stages 512-deep chunks (one scale dword per row and lane group)");
-    static_assert(NCH == 1 || (AK != A_F32_LN && EPI != E_LN_BWD && EPI != E_SWIGLU), "k-outer: plain products only");
+    static_assert(NCH == 1 || (AK != A_F32_LN && EPI != E_SWIGLU), "k-outer: no LayerNorm prologue, no gate pair");
     constexpr int MT = BM / 16;
     constexpr int LDA = F8 ? KC + 16 : KC + 8;        // LDS row stride (elements): 16-B pad => conflict-free b128 reads
     constexpr int ABYTES = F8 ? BM * LDA : BM * LDA * 2;
@@ -521,6 +522,124 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
         PH(2)
     };
 
+    // LayerNorm backward over rows wider than one 128-column chunk (k-outer only: all NCH chunks' accumulators are live, so
+    // the whole row of du is on chip): out = res (+ out) + LNbwd(du; lnx, gamma), dgamma / dbeta through an LDS table
+    // (ds_add per pass) and one commit per column and workgroup.  Replaces a separate du store + ln_bwd pass at d = 256 / 512.
+    auto epilogue_ln_ko = [&](f32x4 (&accs)[NCH][MT][2]) {
+        if constexpr (EPI == E_LN_BWD && NCH > 1) {
+            constexpr int PRL = 16;                               // rows per pass: NCH tiles of [16][TS] floats
+            constexpr int NW = 128 * NCH;                         // row width = N
+            float* TT = T1;                                       // NCH tiles
+            float dgam[NCH][8], dbet[NCH][8];                     // this thread's column octets, summed over its rows
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { dgam[c][e] = 0.f; dbet[c][e] = 0.f; }
+            const int c8 = (tid & 15) * 8, rl = tid >> 4;         // 16 rows x 16 octets per pass and chunk
+            float gm[NCH][8];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gm[c][e] = p.gamma[c * 128 + c8 + e];
+            const float invn = 1.f / (float)NW;
+#pragma unroll
+            for (int ps = 0; ps < BM / PRL; ++ps) {
+                __builtin_amdgcn_sched_barrier(0);
+                const int row = row0 + ps * PRL + rl;
+                const bool rok = row < p.M;
+                float xr[NCH][8];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xr[c][e] = 0.f;
+                    if (rok) {
+                        const float* xp = p.lnx + (size_t)row * p.ldr + c * 128 + c8;
+                        const float4 a0 = *reinterpret_cast<const float4*>(xp), a1 = *reinterpret_cast<const float4*>(xp + 4);
+                        xr[c][0] = a0.x; xr[c][1] = a0.y; xr[c][2] = a0.z; xr[c][3] = a0.w;
+                        xr[c][4] = a1.x; xr[c][5] = a1.y; xr[c][6] = a1.z; xr[c][7] = a1.w;
+                    }
+                }
+                lds_barrier();                                    // previous pass's tiles consumed (and GB zeroed)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            TT[(c * PRL + ag * 4 + r) * TS + wave * 32 + j * 16 + arow] = accs[c][ps][j][r];
+                lds_barrier();
+                // row statistics of x over all NCH chunks (16 lanes x NCH octets)
+                float sm = 0.f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sm += xr[c][e];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+                const float mean = sm * invn;
+                float q = 0.f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { xr[c][e] -= mean; q += xr[c][e] * xr[c][e]; }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+                const float rstd = rsqrtf(q * invn + 1e-5f);
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const float4 t0 = *reinterpret_cast<const float4*>(TT + (c * PRL + rl) * TS + c8);
+                    const float4 t1 = *reinterpret_cast<const float4*>(TT + (c * PRL + rl) * TS + c8 + 4);
+                    const float du[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        xr[c][e] *= rstd;                         // x-hat
+                        const float t = du[e] * gm[c][e];
+                        a += t; b += t * xr[c][e];
+                        if (rok) { dgam[c][e] += du[e] * xr[c][e]; dbet[c][e] += du[e]; }
+                    }
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                a *= invn; b *= invn;
+                if (rok) {
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const float4 t0 = *reinterpret_cast<const float4*>(TT + (c * PRL + rl) * TS + c8);
+                        const float4 t1 = *reinterpret_cast<const float4*>(TT + (c * PRL + rl) * TS + c8 + 4);
+                        const float du[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                        const float* rp = p.res + (size_t)row * p.ldr + c * 128 + c8;
+                        const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+                        float v[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+                        float* op = reinterpret_cast<float*>(p.out) + (size_t)row * p.ldo + c * 128 + c8;
+                        if (p.accumulate) {
+                            const float4 o0 = *reinterpret_cast<const float4*>(op), o1 = *reinterpret_cast<const float4*>(op + 4);
+                            v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w; v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += rstd * (du[e] * gm[c][e] - a - xr[c][e] * b);
+                        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                }
+            }
+            // dgamma / dbeta: the 16 threads that share an octet -> LDS, fixed-order sum, one commit per column and workgroup
+            const HsDet det{p.det_base, reinterpret_cast<long long*>(p.det_acc)};
+            float* red = T1;                                      // [2][256][8] floats = 16 KB <= NCH * PRL * TS * 4
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                lds_barrier();
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { red[tid * 8 + e] = dgam[c][e]; red[2048 + tid * 8 + e] = dbet[c][e]; }
+                lds_barrier();
+                const int which = tid >> 7, col = tid & 127, o8 = col >> 3, e = col & 7;
+                float sacc = 0.f;
+                for (int t2 = o8; t2 < 256; t2 += 16) sacc += red[which * 2048 + t2 * 8 + e];
+                hs_gadd(det, (which ? p.dbeta : p.dgamma) + c * 128 + col, sacc);
+            }
+        }
+    };
+
     if constexpr (NCH == 1) {
     for (int nc = 0; nc < n_chunks; ++nc) {
         f32x4 acc[MT][2];
@@ -597,9 +716,13 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
             }
         }
         PH(1)
+        if constexpr (EPI == E_LN_BWD) {
+            epilogue_ln_ko(accs);
+        } else {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
-            if (c < n_chunks) epilogue(c, accs[c], acc2);
+            for (int c = 0; c < NCH; ++c)
+                if (c < n_chunks) epilogue(c, accs[c], acc2);
+        }
     }
     PH_FLUSH(((AK * 3 + (EPI == E_LN_BWD ? 2 : (EPI == E_BF16 ? 0 : 1))) * 4) % 64)
 }
@@ -608,7 +731,9 @@ template <int AK, int EPI, int KC, int BM, int F8 = 0, int NCH = 1>
 int launch(const GemmParams& p, hipStream_t s) {
     const int grid = (p.M + BM - 1) / BM;
     const size_t abytes = F8 ? (size_t)BM * (KC + 16) + BM * 16 : (size_t)BM * (KC + 8) * 2;
-    const size_t lds = abytes + BM * 2 * sizeof(float) + (EPI == E_SWIGLU ? 2 : 1) * EpiRows<KC>::v * TS * sizeof(float);
+    size_t tiles = (EPI == E_SWIGLU ? 2 : 1) * EpiRows<KC>::v * TS * sizeof(float);
+    if (EPI == E_LN_BWD && NCH > 1) tiles = std::max(tiles, (size_t)NCH * 16 * TS * sizeof(float));
+    const size_t lds = abytes + BM * 2 * sizeof(float) + tiles;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<AK, EPI, KC, BM, F8, NCH>),
@@ -712,6 +837,17 @@ int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s) {
     CASE(A_BF16, E_POS_F32)
     CASE(A_BF16, E_F32)
     CASE(A_BF16, E_BF16)
+    if (akind == A_BF16 && epi == E_LN_BWD && p.N == 256) {
+        // 256-wide rows: the k-outer form (both chunks' accumulators live), bf16 or MX fp8 operands.  (At N = 512 the four
+        // accumulator sets + the per-thread dgamma / dbeta sums spill 100 registers; an LDS table for those sums with
+        // ds_add was 9 ms slower per Huge step than the separate ln_bwd pass.)
+        if (p.n_valid != p.N || !p.lnx || !p.res || !p.gamma || !p.dgamma || !p.dbeta || p.ldr % 4 || p.ldo % 4) return HS_EUNSUPPORTED;
+        if (p.prec == HSIMAE_PREC_FP8) {
+            if (!p.W8 || !p.S8) return HSIMAE_ENULL;
+            return launch<A_BF16, E_LN_BWD, 512, 64, 1, 2>(p, s);
+        }
+        return launch<A_BF16, E_LN_BWD, 256, 64, 0, 2>(p, s);
+    }
     if (akind == A_BF16 && epi == E_LN_BWD) {
         if (p.prec == HSIMAE_PREC_FP8) return HS_EUNSUPPORTED;
         if (p.N != 128 || p.n_valid != 128 || !p.lnx || !p.res || !p.gamma || !p.dgamma || !p.dbeta || p.ldr % 4 || p.ldo % 4)
