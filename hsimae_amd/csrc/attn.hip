@@ -349,57 +349,64 @@ __device__ __forceinline__ bf16x4 cvt4(f32x4 v) {
     return r;
 }
 
-constexpr int RS16 = 24;          // image row stride (elements): 16 + 8 pad => conflict-free 8-byte row reads
+constexpr int RS16 = 24;          // image row stride (elements) at head dim 16: 16 + 8 pad => conflict-free 8-byte row reads
 
-template <int NT>
+// HD = 8 (the decoder's heads, layer-at-a-time decoder: 216-token sequences): the same kernels with the head dim
+// zero-extended to the K = 16 MFMA — an image row is the head's 8 columns + 8 zeros (stride 16 elements: the pad IS the
+// zero half, rows r and r + 8 share banks), lane groups 2, 3 contribute and receive nothing.  HPW = heads (waves) per
+// workgroup: 4, or 2 for sequences of more than 7 tiles (LDS: 4 images of 224 rows per head).
+template <int NT, int HD = 16, int HPW = 4>
 struct Lay16 {
+    static constexpr int RS = HD == 16 ? RS16 : 16;
     static constexpr int ROWS = NT * 16;
-    static constexpr int IMG = ROWS * RS16;                               // elements per image
+    static constexpr int IMG = ROWS * RS;                                 // elements per image
     static constexpr int CLS = ROWS * 4;
     static constexpr int FWD_WAVE = 3 * IMG * 2;                          // Q K V
-    static constexpr int BWD_WAVE = 4 * IMG * 2 + 2 * ROWS * 4 + 2 * 16 * RS16 * 2;   // Q K V dO | lse delta | T(P, dS)
+    static constexpr int BWD_WAVE = 4 * IMG * 2 + 2 * ROWS * 4 + 2 * 16 * RS * 2;     // Q K V dO | lse delta | T(P, dS)
 };
 
 // rows [0, Ts) of one head's slice -> row-major image; rows [Ts, ROWS) zero (finite: P = 0 there, but 0 * NaN = NaN)
-template <int NT>
+template <int NT, int HD = 16>
 __device__ __forceinline__ void load16(const bf16_t* src, int ld, int Ts, int lane, bf16_t* img) {
+    constexpr int RS = HD == 16 ? RS16 : 16;
     for (int idx = lane; idx < NT * 16 * 2; idx += 64) {
         const int tok = idx >> 1, pc = idx & 1;
         bf16x8 v = zero8();
-        if (tok < Ts) v = *reinterpret_cast<const bf16x8*>(src + (size_t)tok * ld + pc * 8);
-        *reinterpret_cast<bf16x8*>(img + tok * RS16 + pc * 8) = v;
+        if (tok < Ts && pc * 8 < HD) v = *reinterpret_cast<const bf16x8*>(src + (size_t)tok * ld + pc * 8);
+        *reinterpret_cast<bf16x8*>(img + tok * RS + pc * 8) = v;          // HD = 8: the second piece is the zero half
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void attn16_fwd_kernel(AttnParams p) {
-    using L = Lay16<NT>;
+template <int NT, int HD = 16, int HPW = 4>
+__global__ __launch_bounds__(64 * HPW) void attn16_fwd_kernel(AttnParams p) {
+    using L = Lay16<NT, HD, HPW>;
+    constexpr int RS16 = L::RS;                 // (shadows the head-dim-16 constant: every image access below uses the layout's stride)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int hgroups = (p.heads + 3) / 4;
-    const int sample = blockIdx.x / hgroups, head = (blockIdx.x % hgroups) * 4 + wave;
+    const int hgroups = (p.heads + HPW - 1) / HPW;
+    const int sample = blockIdx.x / hgroups, head = (blockIdx.x % hgroups) * HPW + wave;
     const bool active = head < p.heads;
     int* cls = reinterpret_cast<int*>(smem);
     bf16_t* Qi = reinterpret_cast<bf16_t*>(smem + L::CLS + wave * L::FWD_WAVE);
     bf16_t* Ki = Qi + L::IMG;
     bf16_t* Vi = Ki + L::IMG;
-    for (int i = threadIdx.x; i < L::ROWS; i += 256) {
+    for (int i = threadIdx.x; i < L::ROWS; i += 64 * HPW) {
         int c = -1;
         if (i < p.Ts) c = (p.mode == 1) ? i / p.len_l : (p.mode == 2) ? i % p.len_l : 0;
         cls[i] = c;
     }
     const size_t row_base = (size_t)sample * p.Ts;
     if (active) {
-        const bf16_t* base = p.qkv + row_base * p.ld + head * 16;
-        load16<NT>(base, p.ld, p.Ts, lane, Qi);
-        load16<NT>(base + KVO(p), p.ld, p.Ts, lane, Ki);
-        load16<NT>(base + 2 * KVO(p), p.ld, p.Ts, lane, Vi);
+        const bf16_t* base = p.qkv + row_base * p.ld + head * HD;
+        load16<NT, HD>(base, p.ld, p.Ts, lane, Qi);
+        load16<NT, HD>(base + KVO(p), p.ld, p.Ts, lane, Ki);
+        load16<NT, HD>(base + 2 * KVO(p), p.ld, p.Ts, lane, Vi);
     }
     lds_barrier();
     if (!active) return;
 
     const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3;
-    const float sc = 0.25f * 1.4426950408889634f;               // 16^-0.5 * log2(e)
+    const float sc = (HD == 16 ? 0.25f : 0.35355339059327373f) * 1.4426950408889634f;      // hd^-0.5 * log2(e)
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     for (int qt = 0; qt < NT; ++qt) {
         if (qt * 16 >= p.Ts) break;
@@ -444,19 +451,20 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(AttnParams p) {
             bf16x4 ov;
 #pragma unroll
             for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
-            *reinterpret_cast<bf16x4*>(p.o + (row_base + query) * p.ldo + head * 16 + g * 4) = ov;
+            if (g * 4 < HD) *reinterpret_cast<bf16x4*>(p.o + (row_base + query) * p.ldo + head * HD + g * 4) = ov;
             if (g == 0 && p.lse) p.lse[(row_base + query) * p.heads + head] = m + __builtin_amdgcn_logf(fmaxf(lsum, 1e-30f));
         }
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void attn16_bwd_kernel(AttnParams p) {
-    using L = Lay16<NT>;
+template <int NT, int HD = 16, int HPW = 4>
+__global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
+    using L = Lay16<NT, HD, HPW>;
+    constexpr int RS16 = L::RS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int hgroups = (p.heads + 3) / 4;
-    const int sample = blockIdx.x / hgroups, head = (blockIdx.x % hgroups) * 4 + wave;
+    const int hgroups = (p.heads + HPW - 1) / HPW;
+    const int sample = blockIdx.x / hgroups, head = (blockIdx.x % hgroups) * HPW + wave;
     const bool active = head < p.heads;
     int* cls = reinterpret_cast<int*>(smem);
     bf16_t* Qi = reinterpret_cast<bf16_t*>(smem + L::CLS + wave * L::BWD_WAVE);
@@ -467,25 +475,25 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(AttnParams p) {
     float* delta = lse + L::ROWS;
     bf16_t* Tp = reinterpret_cast<bf16_t*>(delta + L::ROWS);
     bf16_t* Td = Tp + 16 * RS16;
-    for (int i = threadIdx.x; i < L::ROWS; i += 256) {
+    for (int i = threadIdx.x; i < L::ROWS; i += 64 * HPW) {
         int c = -1;
         if (i < p.Ts) c = (p.mode == 1) ? i / p.len_l : (p.mode == 2) ? i % p.len_l : 0;
         cls[i] = c;
     }
     const size_t row_base = (size_t)sample * p.Ts;
     if (active) {
-        const bf16_t* base = p.qkv + row_base * p.ld + head * 16;
-        load16<NT>(base, p.ld, p.Ts, lane, Qi);
-        load16<NT>(base + KVO(p), p.ld, p.Ts, lane, Ki);
-        load16<NT>(base + 2 * KVO(p), p.ld, p.Ts, lane, Vi);
-        load16<NT>(p.dout + row_base * p.lddo + head * 16, p.lddo, p.Ts, lane, Di);
+        const bf16_t* base = p.qkv + row_base * p.ld + head * HD;
+        load16<NT, HD>(base, p.ld, p.Ts, lane, Qi);
+        load16<NT, HD>(base + KVO(p), p.ld, p.Ts, lane, Ki);
+        load16<NT, HD>(base + 2 * KVO(p), p.ld, p.Ts, lane, Vi);
+        load16<NT, HD>(p.dout + row_base * p.lddo + head * HD, p.lddo, p.Ts, lane, Di);
         for (int tok = lane; tok < L::ROWS; tok += 64) {
             float acc = 0.f, l = 1e30f;                          // rows past Ts: exp2(s - 1e30) = 0
             if (tok < p.Ts) {
-                const bf16_t* orow = p.o + (row_base + tok) * p.ldo + head * 16;
-                const bf16_t* drow = p.dout + (row_base + tok) * p.lddo + head * 16;
+                const bf16_t* orow = p.o + (row_base + tok) * p.ldo + head * HD;
+                const bf16_t* drow = p.dout + (row_base + tok) * p.lddo + head * HD;
 #pragma unroll
-                for (int e = 0; e < 16; e += 8) {
+                for (int e = 0; e < HD; e += 8) {
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(orow + e);
                     const bf16x8 b = *reinterpret_cast<const bf16x8*>(drow + e);
 #pragma unroll
@@ -501,10 +509,10 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(AttnParams p) {
     if (!active) return;
 
     const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3;
-    const float scale = 0.25f, sc = 0.25f * 1.4426950408889634f;
+    const float scale = HD == 16 ? 0.25f : 0.35355339059327373f, sc = scale * 1.4426950408889634f;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const int troff = (4 * g + q4) * RS16 + 4 * p4;
-    bf16_t* dq_base = p.dqkv + row_base * p.ld + head * 16;
+    bf16_t* dq_base = p.dqkv + row_base * p.ld + head * HD;
     f32x4 dkT[NT], dvT[NT];                       // [d = 4g + r][key c16], accumulated over the query tiles
     bf16x4 KT[NT];                                // K^T[d = c16][key 4g + j]
 #pragma unroll
@@ -547,13 +555,13 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(AttnParams p) {
             bf16x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dqT[r] * scale);
-            *reinterpret_cast<bf16x4*>(dq_base + (size_t)query * p.ld + g * 4) = v;
+            if (g * 4 < HD) *reinterpret_cast<bf16x4*>(dq_base + (size_t)query * p.ld + g * 4) = v;
         }
     }
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
         const int key = kt * 16 + c16;
-        if (key < p.Ts) {
+        if (key < p.Ts && g * 4 < HD) {
             bf16x4 vk, vv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { vk[r] = (bf16_t)(dkT[kt][r] * scale); vv[r] = (bf16_t)dvT[kt][r]; }
@@ -1101,20 +1109,21 @@ int launch_attn128(const AttnParams& p, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <int NT, bool BWD>
+template <int NT, bool BWD, int HD = 16, int HPW = 4>
 int launch_attn16(const AttnParams& p, hipStream_t s) {
-    using L = Lay16<NT>;
-    const int hgroups = (p.heads + 3) / 4;
-    const size_t lds = L::CLS + 4 * (size_t)(BWD ? L::BWD_WAVE : L::FWD_WAVE);
+    using L = Lay16<NT, HD, HPW>;
+    const int hgroups = (p.heads + HPW - 1) / HPW;
+    const size_t lds = L::CLS + HPW * (size_t)(BWD ? L::BWD_WAVE : L::FWD_WAVE);
+    if (lds > 160 * 1024) return HS_EUNSUPPORTED;
     static bool attr_set = false;
     if constexpr (BWD) {
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<NT>),
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<NT, HD, HPW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-        hipLaunchKernelGGL((attn16_bwd_kernel<NT>), dim3(p.nsamples * hgroups), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((attn16_bwd_kernel<NT, HD, HPW>), dim3(p.nsamples * hgroups), dim3(64 * HPW), lds, s, p);
     } else {
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_fwd_kernel<NT>),
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_fwd_kernel<NT, HD, HPW>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-        hipLaunchKernelGGL((attn16_fwd_kernel<NT>), dim3(p.nsamples * hgroups), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((attn16_fwd_kernel<NT, HD, HPW>), dim3(p.nsamples * hgroups), dim3(64 * HPW), lds, s, p);
     }
     return (int)hipGetLastError();
 }
@@ -1159,6 +1168,13 @@ int dispatch(const AttnParams& p, hipStream_t s) {
         if (nt <= 3) return launch_attn16<3, BWD>(p, s);
         if (nt <= 4) return launch_attn16<4, BWD>(p, s);
         if (nt <= 7) return launch_attn16<7, BWD>(p, s);
+    }
+    static int v8 = -1;                      // HSIMAE_ATTN8_V2=0: first-generation kernels at head dim 8
+    if (v8 < 0) { const char* e = getenv("HSIMAE_ATTN8_V2"); v8 = !(e && e[0] == '0'); }
+    if (p.hd == 8 && v2 && v8 && p.lse) {    // the second-generation kernels with the head dim zero-extended to 16
+        if (nt <= 4) return launch_attn16<4, BWD, 8, 4>(p, s);
+        if (nt <= 7) return launch_attn16<7, BWD, 8, 4>(p, s);
+        if (nt <= 14) return launch_attn16<14, BWD, 8, 2>(p, s);
     }
     if (p.hd == 16) {
         if (nt <= 1) return launch_attn<16, 1, BWD>(p, s);
