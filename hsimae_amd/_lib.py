@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhsimae_hip.so")
+# HSIMAE_LIB: another build of the same library (A/B runs of compile-time variants: hsimae_amd/variants/*.so)
+LIB_PATH = os.environ.get("HSIMAE_LIB") or os.path.join(HERE, "libhsimae_hip.so")
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

@@ -39,7 +39,16 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
-template <int KC> struct EpiRows { static constexpr int v = KC >= 512 ? 16 : 32; };   // rows per epilogue pass (LDS budget at K = 512)
+// Rows per epilogue pass (the fp32 exchange tile(s) [PR][TS]).  bf16: 32, or 16 where the 512-deep A panel leaves no room.
+// fp8: the e4m3 panel is half the bytes, so the tile could be taller — fewer passes, each with two workgroup barriers (the
+// gate epilogue of LN2 + w1|w3 at d = 512 ran 88 passes per workgroup at PR = 16).  HS_EPI_ROWS_F8 (-D) for A/B builds.
+#ifndef HS_EPI_ROWS_F8
+#define HS_EPI_ROWS_F8 16     /* 32: +0.3 ms, 64: +0.8 ms per Huge step (measured): the taller tiles cost the 64-row kernels an occupancy step */
+#endif
+template <int KC, int F8 = 0, int BM = 128> struct EpiRows {
+    static constexpr int f8rows = HS_EPI_ROWS_F8 > BM ? BM : HS_EPI_ROWS_F8;
+    static constexpr int v = F8 ? f8rows : (KC >= 512 ? 16 : 32);
+};
 constexpr int TS = 132;            // fp32 LDS tile row stride (floats): conflict-free b32 writes
 
 // BM: rows per workgroup.  128 (one workgroup per CU) for the narrow layers, where the weight stream per panel is small;
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
     constexpr int ABYTES = F8 ? BM * LDA : BM * LDA * 2;
     constexpr int SCBYTES = F8 ? BM * 16 : 0;         // fp8: e8m0 scales [row][lane group g][k-step of the chunk]
     constexpr bool DUAL = (EPI == E_SWIGLU);
-    constexpr int PR = EpiRows<KC>::v;
+    constexpr int PR = EpiRows<KC, F8, BM>::v;
     bf16_t* As = reinterpret_cast<bf16_t*>(smem);     // [BM][KC+8] bf16, or [BM][KC+16] e4m3 bytes
     unsigned char* As8 = reinterpret_cast<unsigned char*>(smem);
     unsigned char* Sc = reinterpret_cast<unsigned char*>(smem + ABYTES);
@@ -731,7 +740,7 @@ template <int AK, int EPI, int KC, int BM, int F8 = 0, int NCH = 1>
 int launch(const GemmParams& p, hipStream_t s) {
     const int grid = (p.M + BM - 1) / BM;
     const size_t abytes = F8 ? (size_t)BM * (KC + 16) + BM * 16 : (size_t)BM * (KC + 8) * 2;
-    size_t tiles = (EPI == E_SWIGLU ? 2 : 1) * EpiRows<KC>::v * TS * sizeof(float);
+    size_t tiles = (EPI == E_SWIGLU ? 2 : 1) * EpiRows<KC, F8, BM>::v * TS * sizeof(float);
     if (EPI == E_LN_BWD && NCH > 1) tiles = std::max(tiles, (size_t)NCH * 16 * TS * sizeof(float));
     const size_t lds = abytes + BM * 2 * sizeof(float) + tiles;
     static bool attr_set = false;
