@@ -139,7 +139,10 @@ class DeviceLoader:
 
     def __len__(self):
         n, gb = len(self.dataset), self.batch_size * self.world
-        return n // gb if self.drop_last else (n + gb - 1) // gb
+        if self.drop_last:
+            return n // gb
+        # the ragged last global batch is kept only if every rank gets at least one cube (see _LoaderIter)
+        return n // gb + (1 if n % gb >= self.world else 0)
 
     def __iter__(self):
         return _LoaderIter(self)

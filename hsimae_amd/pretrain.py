@@ -43,12 +43,16 @@ def dp_context(device):
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
+    backend = os.environ.get("HSIMAE_DP_BACKEND")       # tests: "gloo" lets two ranks share one GPU (RCCL refuses that)
     if torch.device(device).type == "cuda":
-        device = torch.device("cuda", local)
+        device = torch.device("cuda", local if torch.cuda.device_count() > local else 0)
         torch.cuda.set_device(device)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if (backend or "nccl") == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group(backend or "gloo", rank=rank, world_size=world)
     return rank, world, device
 
 
@@ -90,8 +94,17 @@ def mask_pretraining(data_cubes, save_path, model_name, img_size=9, bands=32, ma
         train_loss = 0.0
         model.train()
         seed_everything(42 + epoch)                     # `for x in stable(train_dataload, 42 + epoch)`
+        T = bands // 8
         for x in train_dataload:
-            loss, _, _ = model(x, mask_ratio=mask_ratio)
+            noise = None
+            if world > 1:
+                # the masking noise of the GLOBAL batch, drawn identically on every rank (same device-generator seed), each
+                # rank keeping its rows: the ranks' samples get different noise, as the samples of one big batch would
+                per = x.shape[0]
+                n1 = torch.rand(per * world, T, device=device)
+                n2 = torch.rand(per * world, 9, device=device)
+                noise = (n1[rank * per:(rank + 1) * per], n2[rank * per:(rank + 1) * per])
+            loss, _, _ = model(x, mask_ratio=mask_ratio, noise=noise)
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()

@@ -127,7 +127,7 @@ def _shard_worker(rank, world, port, q):
         seed_everything(42)
         full = [b for b in DeviceLoader(FakeCubes(n), batch_size=gbs, shuffle=True)]
         assert py_pos == random.random(), "python-random stream differs from the single-process run"
-        assert len(mine) == len(ld) == len(full)
+        assert len(mine) == len(ld) and len(ld) in (len(full), len(full) - 1)      # a ragged tail of < world cubes is dropped
         gathered = [None] * w
         dist.all_gather_object(gathered, mine)
         for step, (fi, ff) in enumerate(full):

@@ -106,3 +106,72 @@ def test_two_ranks_equal_one_process_on_the_global_batch():
             worst = (k, e)
     # same arithmetic per sample, different partition of the row sums (fp32 partials inside each rank's kernels)
     assert worst[1] < 2e-3, worst
+
+
+def _cubes():
+    import numpy as np
+    from oracle import loader_oracle as LO
+    rng = np.random.default_rng(5)
+    scenes = [rng.random((16, 17, 32)).astype(np.float32), rng.random((13, 15, 32)).astype(np.float32)]
+    cut = []
+    for num, sc in enumerate(scenes):
+        cut += LO.split_info(sc.shape, (9, 9, 32), (3, 3, 1), num, 1, 0)
+    return [scenes, np.array(cut[:24], dtype=np.int16)]      # 24 cubes = 3 global batches of 8: nothing ragged to drop
+
+
+_KW = dict(img_size=9, bands=32, mask_ratio=0.5, lr=5e-3, wd=5e-2, bs=8, depth=3, dim=32, s_depth=2, dec_dim=32, dec_depth=2,
+           log=lambda *_: None)
+
+
+def _train_worker(rank, world, port, out_dir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSIMAE_DP_BACKEND="gloo", HSIMAE_DETERMINISTIC="1")
+    try:
+        import hsimae_amd
+        from hsimae_amd.pretrain import seed_everything
+        seed_everything(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model, losses = hsimae_amd.mask_pretraining(_cubes(), out_dir, "m.pkl", epochs=2, device="cuda:0", **_KW)
+        w = model.state_dict()["blocks.0.mlp.w2.weight"].cpu().numpy()
+        q.put((rank, "ok", losses, w, os.path.exists(os.path.join(out_dir, "m.pkl"))))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc() + repr(e), None, None, None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_mask_pretraining_two_ranks_tracks_the_single_process_run(tmp_path):
+    """The training entry point under a 2-rank launch (global batch 8 = 2 x 4): same permutation, flips, grid and masking
+    noise as the single-process run at batch 8, gradients averaged by the reducer -> the same loss trajectory and weights."""
+    import numpy as np
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    out = str(tmp_path / "dp")
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, out, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+    assert [r[1] for r in res] == ["ok", "ok"], [r[1] for r in res]
+    assert res[0][4] and np.array_equal(res[0][3], res[1][3])          # rank 0 wrote the files; the ranks hold the same weights
+    assert np.allclose(res[0][2], res[1][2])                            # the logged epoch loss is the all-reduced mean
+    # single process, same global batch
+    import hsimae_amd
+    from hsimae_amd.pretrain import seed_everything
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    os.environ["HSIMAE_DETERMINISTIC"] = "1"
+    try:
+        seed_everything(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model, losses = hsimae_amd.mask_pretraining(_cubes(), str(tmp_path / "sp"), "m.pkl", epochs=2, device="cuda:0", **_KW)
+    finally:
+        os.environ.pop("HSIMAE_DETERMINISTIC", None)
+    assert np.allclose(res[0][2], losses, rtol=2e-3), (res[0][2], losses)
+    w = model.state_dict()["blocks.0.mlp.w2.weight"].cpu().numpy()
+    assert np.abs(res[0][3] - w).max() <= 2e-2 * np.abs(w).max()
