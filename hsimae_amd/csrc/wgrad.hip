@@ -6,6 +6,7 @@
 // One workgroup owns a 128x128 tile of dW for a slice of the rows (split-M), accumulates it in registers
 // (16 accumulators per wave) and commits it with fp32 atomics; bias gradients (column sums of dO) ride
 // along.  Up to 8 linears are batched per launch (one transformer block's q, k, v, proj, w1, w3, w2).
+// Launches whose matrices are all at least 256 wide (d = 256 / 512) use 256x256 tiles instead (WT<true> below).
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
@@ -195,33 +196,61 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
 // wave instruction, lane i -> bytes [16 i, 16 i + 16)).  Bank conflicts of the transpose reads are avoided by
 // permuting which 16-byte column chunk each lane FETCHES: slot s of row r holds column chunk s ^ swz(r).
 constexpr int DC = 32;                     // rows per stage (one MFMA k-step)
-constexpr int STAGE_ELEMS = 2 * DC * 128;  // bf16 elements per stage (16 KB)
 
 typedef __attribute__((address_space(3))) void* lds_vptr;
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
 
+// Tile geometry of the DMA kernel.
+//   BIG = false: 128 x 128 dW tile, 4 waves (wave = 32 n x 128 k), stage = 2 x 32 rows x 256 B = 16 KB, up to 3 workgroups per CU.
+//   BIG = true : 256 x 256 dW tile, 8 waves as 4 (n) x 2 (k) (wave = 64 n x 128 k, 128 accumulator registers), stage = 32 KB,
+//                one workgroup per CU.  Every workgroup streams (TN + TK) operand columns per row: at d >= 256 the 128-tiles
+//                fetched 2.8 GB (Large) / 5.5 GB (Huge) per launch through L2 / Infinity Cache at ~10 TB/s — that, not the MFMA
+//                (26 % busy) or the LDS, was the bound — and the 256-tiles fetch half of it.
+template <bool BIG>
+struct WT {
+    static constexpr int T = BIG ? 256 : 128;          // tile edge (columns of dO and of A per workgroup)
+    static constexpr int NTHR = BIG ? 512 : 256;
+    static constexpr int NF = BIG ? 4 : 2;             // n-fragments (16 dW rows each) per wave
+    static constexpr int ROWB = T * 2;                 // bytes per LDS row
+    static constexpr int STAGE_ELEMS = 2 * DC * T;     // bf16 elements per stage: dO[32][T] | A[32][T]
+    static constexpr int RPI = 1024 / ROWB;            // rows per DMA wave-instruction (1 KB)
+};
+
 // The transpose reads of the DMA kernel are issued as inline asm: for a ds_read the compiler can see, it inserts
 // `s_waitcnt vmcnt(0)` first (the LDS-DMA loads might alias it), which would drain the whole prefetch ring every
 // chunk.  Arrival of a stage is tracked by hand instead (wait_vm + s_barrier), and so is lgkmcnt (wait_lds).
+template <bool BIG>
 __device__ __forceinline__ uint32_t frag_sw_addr(uint32_t tile_bytes, int col0, int lane) {
-    // element j of lane l = tile[8 (l>>4) + j][col0 + (l&15)] of a swizzled [32][128] stage tile (see frag_tr_rows)
+    // element j of lane l = tile[8 (l>>4) + j][col0 + (l&15)] of a swizzled [32][T] stage tile (see frag_tr_rows)
     const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
     const int row = 8 * g + q;
-    const int chunk = ((col0 >> 3) + (pq >> 1)) ^ swz(row);
-    return tile_bytes + (uint32_t)(row * 256 + chunk * 16 + (pq & 1) * 8);       // rows +4: +1024 B, same swizzle
+    const int chunk = ((col0 >> 3) + (pq >> 1)) ^ swz(row);       // the swizzle permutes 16-B chunks inside a 256-B group
+    return tile_bytes + (uint32_t)(row * WT<BIG>::ROWB + chunk * 16 + (pq & 1) * 8);       // rows +4: same swizzle
 }
 struct Frag2 { bf16x4 lo, hi; };
+template <bool BIG>
 __device__ __forceinline__ void tr_read2(uint32_t addr, Frag2& f) {
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"
-                 : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr) : "memory");
+    if constexpr (BIG)
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048"
+                     : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr) : "memory");
+    else
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024"
+                     : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr) : "memory");
 }
 __device__ __forceinline__ bf16x8 join(const Frag2& f) { return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 // lgkmcnt(0), tied to the fragments so that nothing that uses them is scheduled above it
-__device__ __forceinline__ void wait_lds(Frag2 (&x)[2], Frag2 (&y)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(x[0].lo), "+v"(x[0].hi), "+v"(x[1].lo), "+v"(x[1].hi), "+v"(y[0].lo), "+v"(y[0].hi), "+v"(y[1].lo),
-                   "+v"(y[1].hi), "+v"(y[2].lo), "+v"(y[2].hi), "+v"(y[3].lo), "+v"(y[3].hi) :: "memory");
+template <int NA>
+__device__ __forceinline__ void wait_lds(Frag2 (&x)[NA], Frag2 (&y)[4]) {
+    if constexpr (NA == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(x[0].lo), "+v"(x[0].hi), "+v"(x[1].lo), "+v"(x[1].hi), "+v"(y[0].lo), "+v"(y[0].hi), "+v"(y[1].lo),
+                       "+v"(y[1].hi), "+v"(y[2].lo), "+v"(y[2].hi), "+v"(y[3].lo), "+v"(y[3].hi) :: "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(x[0].lo), "+v"(x[0].hi), "+v"(x[1].lo), "+v"(x[1].hi), "+v"(x[2].lo), "+v"(x[2].hi), "+v"(x[3].lo),
+                       "+v"(x[3].hi), "+v"(y[0].lo), "+v"(y[0].hi), "+v"(y[1].lo),
+                       "+v"(y[1].hi), "+v"(y[2].lo), "+v"(y[2].hi), "+v"(y[3].lo), "+v"(y[3].hi) :: "memory");
 }
 __device__ __forceinline__ void wait_lds(Frag2 (&y)[4]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -232,32 +261,50 @@ __device__ __forceinline__ void wait_lds(Frag2 (&y)[4]) {
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int DS>                        // ring stages
-__global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
+__host__ __device__ inline int wg_tiles(const WgradParams& p, int T) {
+    int tiles = 0;
+    for (int i = 0; i < p.ntasks; ++i) tiles += ((p.t[i].N + T - 1) / T) * ((p.t[i].K + T - 1) / T);
+    return tiles;
+}
+
+template <int DS, bool BIG>                        // ring stages, tile geometry
+__global__ __launch_bounds__(WT<BIG>::NTHR) void wgrad_dma_kernel(WgradParams p) {
+    using G = WT<BIG>;
+    constexpr int T = G::T, NF = G::NF, STAGE_ELEMS = G::STAGE_ELEMS;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = BIG ? wave >> 1 : wave, wk = BIG ? wave & 1 : 0;      // this wave's n-group (NF fragments) and 128-wide k half
 
-    int tiles = 0;
-    for (int i = 0; i < p.ntasks; ++i) tiles += ((p.t[i].N + 127) / 128) * ((p.t[i].K + 127) / 128);
+    const int tiles = wg_tiles(p, T);
     int w, ms;
-    if (!decode_wg(p, tiles, w, ms)) return;
+    if constexpr (BIG) {
+        // one workgroup per CU: the launch is cut into 8 equal contiguous parts of the (row slice, tile) list, one per XCD,
+        // so the tiles of a row slice (which share its operand slabs) sit on one L2 and every XCD has the same load
+        const int total = tiles * p.msplit, per = (total + 7) >> 3;
+        const int li = blockIdx.x >> 3;
+        const int f = (blockIdx.x & 7) * per + li;
+        if (li >= per || f >= total) return;
+        ms = f / tiles; w = f - ms * tiles;
+    } else {
+        if (!decode_wg(p, tiles, w, ms)) return;
+    }
     const HsDet det{p.det_base, reinterpret_cast<long long*>(p.det_acc)};
     int ti = 0, ns = 0, ks = 0;
     for (; ti < p.ntasks; ++ti) {
-        const int nsl = (p.t[ti].N + 127) / 128, ksl = (p.t[ti].K + 127) / 128;
+        const int nsl = (p.t[ti].N + T - 1) / T, ksl = (p.t[ti].K + T - 1) / T;
         if (w < nsl * ksl) { ns = w / ksl; ks = w % ksl; break; }
         w -= nsl * ksl;
     }
     if (ti >= p.ntasks) return;
     const WgradTask t = p.t[ti];
-    const int n0 = ns * 128, k0 = ks * 128;
+    const int n0 = ns * T, k0 = ks * T;
     const int nchunks = (p.M + DC - 1) / DC;
     const int cpw = (nchunks + p.msplit - 1) / p.msplit;
     const int cbeg = ms * cpw, cend = min(nchunks, cbeg + cpw);
     const int nch = cend - cbeg;
-    const bool want_bias = (t.db != nullptr) && (ks == 0);
+    const bool want_bias = (t.db != nullptr) && (ks == 0) && (wk == 0);
 
     // Out-of-range rows (last chunk) come back as zeros from the buffer bounds check.  Columns past N / K of a slab
     // are whatever follows in the row: they only reach dW rows / columns that are never committed.
@@ -265,12 +312,14 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
     const uint32_t bytes_a = (uint32_t)min((int64_t)p.M * t.lda * 2, (int64_t)0xffffffffu);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(t.dO), 0, bytes_d, 0x00020000);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)t.A, 0, bytes_a, 0x00020000);
-    // this wave's two DMA instructions per operand and chunk: rows 4 (2 wave + i) + (lane >> 4), slot lane & 15
+    // this wave's two DMA instructions per operand and chunk (1 KB = RPI rows each): rows RPI (2 wave + i) + lane / (64 / RPI),
+    // 16-byte slot lane % (64 / RPI)
     uint32_t vd[2], va[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int row = 4 * (2 * wave + i) + (lane >> 4);
-        const int chunk = (lane & 15) ^ swz(row);
+        constexpr int LPR = 64 / G::RPI;                     // lanes per row
+        const int row = G::RPI * (2 * wave + i) + lane / LPR;
+        const int chunk = (lane % LPR) ^ swz(row);
         vd[i] = (uint32_t)(row * t.ldo + n0 + 8 * chunk) * 2u;
         va[i] = (uint32_t)(row * t.lda + k0 + 8 * chunk) * 2u;
     }
@@ -282,12 +331,12 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_vptr)(st + (2 * wave + i) * 512), 16, vd[i], od, 0, HS_NT_W);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)(st + DC * 128 + (2 * wave + i) * 512), 16, va[i], oa, 0, HS_NT_W);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)(st + DC * T + (2 * wave + i) * 512), 16, va[i], oa, 0, HS_NT_W);
     };
 
-    f32x4 acc[2][8], accb[2];
+    f32x4 acc[NF][8], accb[NF];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NF; ++i) {
         accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -305,53 +354,55 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
         if (i + DS - 2 < nch) wait_vm<(DS - 2) * 4>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();          // every wave's part of chunk i is in LDS; everyone is done with stage i-1
         if (i + DS - 1 < nch) issue(cbeg + i + DS - 1, stage == 0 ? DS - 1 : stage - 1);
-        const uint32_t dOt = lds_base + (uint32_t)stage * (STAGE_ELEMS * 2), At = dOt + DC * 256;
-        Frag2 fa[2], fb0[4], fb1[4];
+        const uint32_t dOt = lds_base + (uint32_t)stage * (STAGE_ELEMS * 2), At = dOt + DC * G::ROWB;
+        Frag2 fa[NF], fb0[4], fb1[4];
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) tr_read2(frag_sw_addr(dOt, (wave * 2 + ii) * 16, lane), fa[ii]);
+        for (int ii = 0; ii < NF; ++ii) tr_read2<BIG>(frag_sw_addr<BIG>(dOt, (wn * NF + ii) * 16, lane), fa[ii]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tr_read2(frag_sw_addr(At, j * 16, lane), fb0[j]);
-        wait_lds(fa, fb0);
+        for (int j = 0; j < 4; ++j) tr_read2<BIG>(frag_sw_addr<BIG>(At, wk * 128 + j * 16, lane), fb0[j]);
+        wait_lds<NF>(fa, fb0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tr_read2(frag_sw_addr(At, (4 + j) * 16, lane), fb1[j]);
-        const bf16x8 a[2] = {join(fa[0]), join(fa[1])};
+        for (int j = 0; j < 4; ++j) tr_read2<BIG>(frag_sw_addr<BIG>(At, wk * 128 + (4 + j) * 16, lane), fb1[j]);
+        bf16x8 a[NF];
+#pragma unroll
+        for (int ii = 0; ii < NF; ++ii) a[ii] = join(fa[ii]);
         if (want_bias) {                       // column sums of dO as one more MFMA against ones: no extra LDS traffic
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) accb[ii] = mfma16(a[ii], ones, accb[ii]);
+            for (int ii = 0; ii < NF; ++ii) accb[ii] = mfma16(a[ii], ones, accb[ii]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bf16x8 b = join(fb0[j]);
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) acc[ii][j] = mfma16(a[ii], b, acc[ii][j]);
+            for (int ii = 0; ii < NF; ++ii) acc[ii][j] = mfma16(a[ii], b, acc[ii][j]);
         }
         wait_lds(fb1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bf16x8 b = join(fb1[j]);
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) acc[ii][4 + j] = mfma16(a[ii], b, acc[ii][4 + j]);
+            for (int ii = 0; ii < NF; ++ii) acc[ii][4 + j] = mfma16(a[ii], b, acc[ii][4 + j]);
         }
         stage = stage == DS - 1 ? 0 : stage + 1;
     }
 
     const int c16 = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NF; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + (wave * 2 + i) * 16 + g * 4 + r;
-                const int k = k0 + j * 16 + c16;
+                const int n = n0 + (wn * NF + i) * 16 + g * 4 + r;
+                const int k = k0 + wk * 128 + j * 16 + c16;
                 if (n < t.N && k < t.K) hs_gadd(det, t.dW + (size_t)n * t.ldw + k, acc[i][j][r]);
             }
     if (want_bias && c16 == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NF; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + (wave * 2 + i) * 16 + g * 4 + r;
+                const int n = n0 + (wn * NF + i) * 16 + g * 4 + r;
                 if (n < t.N) hs_gadd(det, t.db + n, accb[i][r]);
             }
     }
@@ -362,38 +413,53 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(WgradParams p) {
 int hs_wgrad(const WgradParams& p, hipStream_t s) {
     if (p.ntasks <= 0 || p.M <= 0) return HS_OK;
     if (p.ntasks > 8 || p.msplit < 1) return HS_EDIMS;
-    int tiles = 0;
-    for (int i = 0; i < p.ntasks; ++i) {
+    for (int i = 0; i < p.ntasks; ++i)
         if (p.t[i].ldo % 8 || p.t[i].lda % 8) return HS_EDIMS;
-        tiles += ((p.t[i].N + 127) / 128) * ((p.t[i].K + 127) / 128);
-    }
+    const int tiles = wg_tiles(p, 128);
     // all operands bf16 and addressable with 32-bit buffer offsets -> LDS-DMA kernel (HSIMAE_WGRAD_DMA=0 disables it)
-    static int dma_ok = -1;
-    if (dma_ok < 0) { const char* e = getenv("HSIMAE_WGRAD_DMA"); dma_ok = !(e && e[0] == '0'); }
-    bool dma = dma_ok != 0;
+    static int dma_ok = -1, big_ok = -1, ds_env = -1;
+    if (dma_ok < 0) {
+        const char* e = getenv("HSIMAE_WGRAD_DMA"); dma_ok = !(e && e[0] == '0');
+        e = getenv("HSIMAE_WGRAD_BIG"); big_ok = !(e && e[0] == '0');
+        e = getenv("HSIMAE_WGRAD_DS");
+        ds_env = e ? atoi(e) : 0;
+        if (ds_env < 3 || ds_env > 6) ds_env = 0;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WT<false>::STAGE_ELEMS * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * WT<false>::STAGE_ELEMS * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * WT<false>::STAGE_ELEMS * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WT<true>::STAGE_ELEMS * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WT<true>::STAGE_ELEMS * 2);
+    }
+    bool dma = dma_ok != 0, big = big_ok != 0;
     for (int i = 0; i < p.ntasks; ++i) {
         const WgradTask& t = p.t[i];
         if (t.dO_f32 || (int64_t)(p.M + DC) * t.ldo * 2 >= (1ll << 32) || (int64_t)(p.M + DC) * t.lda * 2 >= (1ll << 32)) dma = false;
         if ((reinterpret_cast<uintptr_t>(t.dO) | reinterpret_cast<uintptr_t>(t.A)) & 15) dma = false;
+        if (t.N < 256 || t.K < 256) big = false;            // wide layers only: a 256-tile of a 128-wide matrix is half padding
+    }
+    if (dma && big) {
+        // 256 x 256 tiles, one workgroup per CU: the row split that fills the chip once (p.msplit is sized for 128-tiles)
+        WgradParams q = p;
+        const int t256 = wg_tiles(p, 256), nchunks = (p.M + DC - 1) / DC;
+        static int wgs = 0;
+        if (!wgs) { const char* e = getenv("HSIMAE_WGRAD_BIG_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 8) wgs = 256; }
+        q.msplit = std::max(1, std::min(wgs / std::max(1, t256), nchunks));
+        const int total = t256 * q.msplit;
+        const dim3 grid(8 * ((total + 7) / 8));
+        if (ds_env == 3) hipLaunchKernelGGL((wgrad_dma_kernel<3, true>), grid, dim3(512), 3 * WT<true>::STAGE_ELEMS * 2, s, q);
+        else hipLaunchKernelGGL((wgrad_dma_kernel<4, true>), grid, dim3(512), 4 * WT<true>::STAGE_ELEMS * 2, s, q);
+        return (int)hipGetLastError();
     }
     const dim3 grid((p.msplit & 7) == 0 ? 8 * tiles * (p.msplit / 8) : 8 * ((tiles + 7) / 8) * p.msplit);      // decode_wg
     if (dma) {
         // ring depth: a launch of at most one workgroup per CU has the LDS to itself (6 stages = 96 KB); larger
         // launches keep 3 stages so that three workgroups fit a CU.  HSIMAE_WGRAD_DS=3..6 forces one.
-        static int ds_env = -1;
-        if (ds_env < 0) {
-            const char* e = getenv("HSIMAE_WGRAD_DS");
-            ds_env = e ? atoi(e) : 0;
-            if (ds_env < 3 || ds_env > 6) ds_env = 0;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE_ELEMS * 2);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * STAGE_ELEMS * 2);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * STAGE_ELEMS * 2);
-        }
+        constexpr int SB = WT<false>::STAGE_ELEMS * 2;
         const int ds = ds_env ? ds_env : (grid.x <= 256 ? 6 : 3);
-        if (ds == 3) hipLaunchKernelGGL(wgrad_dma_kernel<3>, grid, dim3(256), 3 * STAGE_ELEMS * 2, s, p);
-        else if (ds == 4) hipLaunchKernelGGL(wgrad_dma_kernel<4>, grid, dim3(256), 4 * STAGE_ELEMS * 2, s, p);
-        else if (ds == 5) hipLaunchKernelGGL(wgrad_dma_kernel<5>, grid, dim3(256), 5 * STAGE_ELEMS * 2, s, p);
-        else hipLaunchKernelGGL(wgrad_dma_kernel<6>, grid, dim3(256), 6 * STAGE_ELEMS * 2, s, p);
+        if (ds == 3) hipLaunchKernelGGL((wgrad_dma_kernel<3, false>), grid, dim3(256), 3 * SB, s, p);
+        else if (ds == 4) hipLaunchKernelGGL((wgrad_dma_kernel<4, false>), grid, dim3(256), 4 * SB, s, p);
+        else if (ds == 5) hipLaunchKernelGGL((wgrad_dma_kernel<5, false>), grid, dim3(256), 5 * SB, s, p);
+        else hipLaunchKernelGGL((wgrad_dma_kernel<6, false>), grid, dim3(256), 6 * SB, s, p);
     } else {
         hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, p);
     }

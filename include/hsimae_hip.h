@@ -260,7 +260,10 @@ typedef struct {
 int hsimae_attn_fwd(const hsimae_attn_params* p, void* stream);
 int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream);
 
-/* Weight / bias gradients of up to 8 linears in one launch (autograd of F.linear). */
+/* Weight / bias gradients of up to 8 linears in one launch (autograd of F.linear).  msplit = number of row slices the
+   128 x 128 dW tiles are split into (partial sums meet in dW through atomics).  When every task of a launch has N >= 256 and
+   K >= 256 and bf16 operands, the launch runs on 256 x 256 tiles, one workgroup per CU, and sizes its own row split (msplit is
+   then only validated); the result is the same sum. */
 typedef struct {
     const void* dO; int32_t dO_f32; int32_t ldo;
     const hs_bf16* A; int32_t lda;

@@ -334,7 +334,10 @@ def test_attention_forward_backward(d, heads, Ts, mode, len_l):
 
 
 # ----------------------------------------------------------------------------------------------- wgrad
-@pytest.mark.parametrize("M,N,K,f32", [(1000, 128, 128, 0), (777, 344, 128, 0), (500, 128, 344, 1), (300, 72, 64, 0), (640, 128, 72, 1)])
+@pytest.mark.parametrize("M,N,K,f32", [(1000, 128, 128, 0), (777, 344, 128, 0), (500, 128, 344, 1), (300, 72, 64, 0), (640, 128, 72, 1),
+                                       # N, K >= 256: the 256 x 256 tiles (8 waves, one workgroup per CU), whole and ragged tiles
+                                       (2000, 256, 256, 0), (5003, 704, 256, 0), (1500, 256, 696, 0), (9000, 1376, 512, 0),
+                                       (700, 512, 1376, 0), (1500, 256, 256, 1)])
 def test_wgrad_and_bias_grad(M, N, K, f32):
     torch.manual_seed(6)
     lib = _lib.load()
@@ -356,6 +359,43 @@ def test_wgrad_and_bias_grad(M, N, K, f32):
     ref = dOr.t() @ A[:, :K].float()
     assert rel_err(dW, ref) < 5e-5
     assert rel_err(db, dOr.sum(0)) < 5e-5
+
+
+def test_wgrad_wide_block_batch():
+    """One wide transformer block's seven linears in one launch, laid out as hsimae_backward passes them at d = 256: q | k | v as
+    column ranges of one dqkv slab, w1 | w3 of one dh13 slab; gradients accumulate onto what the buffers hold."""
+    torch.manual_seed(16)
+    lib = _lib.load()
+    M, d, h = 3100, 256, 680
+    hp = rup(h, 32)
+    dqkv = torch.randn(M, 3 * d, device=DEV).to(torch.bfloat16)
+    u = torch.randn(M, d, device=DEV).to(torch.bfloat16)
+    g1b = torch.randn(M, d, device=DEV).to(torch.bfloat16)
+    o = torch.randn(M, d, device=DEV).to(torch.bfloat16)
+    dh13 = torch.zeros(M, 2 * hp, device=DEV, dtype=torch.bfloat16)
+    dh13[:, :h] = torch.randn(M, h, device=DEV).to(torch.bfloat16)
+    dh13[:, hp:hp + h] = torch.randn(M, h, device=DEV).to(torch.bfloat16)
+    u2 = torch.randn(M, d, device=DEV).to(torch.bfloat16)
+    g0b = torch.randn(M, d, device=DEV).to(torch.bfloat16)
+    gt = torch.zeros(M, hp, device=DEV, dtype=torch.bfloat16)
+    gt[:, :h] = torch.randn(M, h, device=DEV).to(torch.bfloat16)
+    specs = [(dqkv, 0, 3 * d, u, d, d, d), (dqkv, d, 3 * d, u, d, d, d), (dqkv, 2 * d, 3 * d, u, d, d, d), (g1b, 0, d, o, d, d, d),
+             (dh13, 0, 2 * hp, u2, d, h, d), (dh13, hp, 2 * hp, u2, d, h, d), (g0b, 0, d, gt, hp, d, h)]
+    wp = _lib.WgradParams()
+    outs = []
+    for i, (dO, off, ldo, A, lda, N, K) in enumerate(specs):
+        dW = torch.full((N, K), 0.5, device=DEV)
+        db = torch.full((N,), -1.0, device=DEV)
+        outs.append((dW, db))
+        wp.t[i] = _lib.WgradTask(dO=dO.data_ptr() + 2 * off, dO_f32=0, ldo=ldo, A=A.data_ptr(), lda=lda, N=N, K=K,
+                                 dW=dW.data_ptr(), ldw=K, db=db.data_ptr())
+    wp.ntasks, wp.M, wp.msplit = len(specs), M, 8
+    _lib.check(lib.hsimae_wgrad(C.byref(wp), stream()), "wgrad")
+    torch.cuda.synchronize()
+    for (dO, off, ldo, A, lda, N, K), (dW, db) in zip(specs, outs):
+        dOr = dO[:, off:off + N].float()
+        assert rel_err(dW - 0.5, dOr.t() @ A[:, :K].float()) < 5e-5
+        assert rel_err(db + 1.0, dOr.sum(0)) < 5e-5
 
 
 # ----------------------------------------------------------------------------------------------- LayerNorm bwd / fwd
