@@ -117,6 +117,50 @@ def test_c1_config1_reference_scale_n64():
     print(f"config 1: loss rel {rel:.2e}; worst grad norm {worst}")
 
 
+@pytest.mark.parametrize("tag,precision,loss_gate,norm_gate,rms_gate",
+                         [("c3", "bf16", 1e-4, 2e-2, 2e-2), ("c5", "bf16", 1e-4, 2e-2, 2e-2), ("c5", "fp8", 1e-3, 6e-2, 1.5e-1)])
+def test_wide_configs_match_the_reference_record(tag, precision, loss_gate, norm_gate, rms_gate):
+    """HSIMAE-Large (D = 256, 16 heads) and the D = 512 / 32-head / 192-band model against the reference's own record
+    (tests/golden/make_golden_wide.py; reference weights after construction).  bf16: the north-star gates (loss 1e-4 relative,
+    gradient norms 2e-2).  fp8 (MX e4m3 encoder linears): loss 1e-3, gradient norms 6 %, gradient elements 15 % RMS — the fp8 tolerance of DESIGN.md 4
+    (measured: loss 2.4e-5, worst norm 2.8 %)."""
+    s = json.load(open(os.path.join(G, f"{tag}_refscale.json")))
+    z = np.load(os.path.join(G, f"{tag}_refscale.npz"))
+    torch.manual_seed(s["model_seed"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=s["bands"], b_patch_size=8, embed_dim=s["dim"], depth=12,
+                   num_heads=s["heads"], s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8,
+                   norm_pix_loss=True, trunc_init=True).to(DEV)
+    m.set_precision(precision)
+    torch.manual_seed(s["x_seed"])
+    x = torch.rand(s["N"], 1, s["bands"], 9, 9)
+    n1, n2 = torch.from_numpy(z["noise_1"]), torch.from_numpy(z["noise_2"])
+    loss, pred, mask = m(x.to(DEV), 0.75, noise=(n1, n2), grid=(s["len_t"], s["len_l"]))
+    loss.backward()
+    rel = abs(loss.item() - s["loss_fp32"]) / s["loss_fp32"]
+    assert rel <= loss_gate, f"loss {loss.item()} vs reference {s['loss_fp32']} (rel {rel:.2e})"
+    assert float(mask.sum().item()) == s["mask_img_sum"]                      # the masking is index work: exact in every precision
+    _, _, _, ids_k = m.forward_encoder(x.to(DEV), 0.75, noise=(n1, n2), grid=(s["len_t"], s["len_l"]))
+    assert torch.equal(ids_k.cpu(), torch.from_numpy(z["ids_keep"].astype(np.int64)))
+    named = dict(m.named_parameters())
+    worst = ("", 0.0)
+    for k, ref in s["grad_l2"].items():
+        got = float(named[k].grad.double().norm())
+        if k.endswith("attn.k.bias"):            # true gradient is exactly zero
+            assert got <= 5e-2 * s["grad_l2"][k.replace(".k.bias", ".q.bias")] + 1e-7, k
+            continue
+        e = abs(got - ref) / max(ref, 1e-12)
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] <= norm_gate, f"gradient L2 norm of {worst[0]} off by {worst[1]:.2e}"
+    for key, name in (("g_blocks0_w2", "blocks.0.mlp.w2.weight"), ("g_b1_0_q", "blocks_1.0.attn.q.weight"),
+                      ("g_dec7_w1", "decoder_blocks.7.mlp.w1.weight"), ("g_pe", "patch_embed.proj.weight")):
+        ref = torch.from_numpy(z[key])
+        e = rms_rel(named[name].grad[:ref.shape[0]], ref)
+        assert e <= rms_gate, (name, e)
+    print(f"{tag} {precision}: loss rel {rel:.2e}; worst grad norm {worst}")
+
+
 def test_c1_config1_trajectory_matches_reference():
     """F6 at config 1: 10 AdamW steps (stock torch.optim.AdamW on the same Parameters), each loss <= 1e-3 relative."""
     meta = json.load(open(os.path.join(G, "c1_trajectory.json")))

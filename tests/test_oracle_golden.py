@@ -185,7 +185,7 @@ def test_trajectory_10_adamw_steps():
         assert abs(loss.item() - ref) <= 1e-5 * abs(ref), (i, loss.item(), ref)
 
 
-def _construct_state(seed, bands=48):
+def _construct_state(seed, bands=48, dim=128, heads=8):
     """The reference's weights right after construction under `seed`: hsimae_amd.HSIMAE's constructor consumes the
     init RNG exactly like the reference (pinned by init_checksums.json) and runs on CPU (parameter containers only)."""
     import contextlib
@@ -193,7 +193,7 @@ def _construct_state(seed, bands=48):
     from hsimae_amd import HSIMAE
     torch.manual_seed(seed)
     with contextlib.redirect_stdout(io.StringIO()):
-        m = HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=bands, b_patch_size=8, embed_dim=128, depth=12, num_heads=8,
+        m = HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=bands, b_patch_size=8, embed_dim=dim, depth=12, num_heads=heads,
                    s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8, norm_pix_loss=True, trunc_init=True)
     return {k: v.detach().clone() for k, v in m.state_dict().items()}
 
@@ -216,6 +216,32 @@ def test_c1_config1_reference_scale_fixture_n64():
     for k, ref in s["grad_l2"].items():
         assert abs(float(grads[k].double().norm()) - ref) <= 2e-4 * max(ref, 1e-6) + 1e-9, k
     np.testing.assert_allclose(grads["blocks.0.mlp.w2.weight"].numpy(), z["g_blocks0_w2"], rtol=0, atol=2e-5 * np.abs(z["g_blocks0_w2"]).max())
+
+
+@pytest.mark.parametrize("tag", ["c3", "c5"])
+def test_wide_configs_reference_scale_fixture(tag):
+    """The oracle at the WIDE shapes against the reference's record (tests/golden/make_golden_wide.py): HSIMAE-Large
+    (D = 256, 16 heads, 96 bands, N = 16) and the D = 512 / 32-head / 192-band model (N = 4) — the 16- and 32-head paths of
+    BASELINE.json configs[2] / configs[4] are pinned to the reference, not only to the Base shapes."""
+    s = json.load(open(os.path.join(G, f"{tag}_refscale.json")))
+    z = np.load(os.path.join(G, f"{tag}_refscale.npz"))
+    cfg = O.OracleConfig(bands=s["bands"], embed_dim=s["dim"], num_heads=s["heads"])
+    assert len(s["grad_l2"]) == 532
+    P = _construct_state(s["model_seed"], s["bands"], s["dim"], s["heads"])
+    torch.manual_seed(s["x_seed"])
+    x = torch.rand(s["N"], 1, s["bands"], 9, 9)
+    taps = {}
+    loss, pred, mimg, grads = O.forward_backward(P, cfg, x, z["noise_1"], z["noise_2"], s["len_t"], s["len_l"], taps)
+    assert abs(loss.item() - s["loss_fp32"]) <= 2e-6 * s["loss_fp32"]
+    keep, _, _ = O.mask_from_noise(z["noise_1"], z["noise_2"], s["len_t"], s["len_l"])
+    assert np.array_equal(keep, z["ids_keep"].astype(np.int64))
+    np.testing.assert_allclose(taps["latent"][:2].detach().numpy(), z["latent"], rtol=0, atol=2e-5)
+    for k, ref in s["grad_l2"].items():
+        assert abs(float(grads[k].double().norm()) - ref) <= 2e-4 * max(ref, 1e-6) + 1e-9, k
+    for key, name in (("g_blocks0_w2", "blocks.0.mlp.w2.weight"), ("g_b1_0_q", "blocks_1.0.attn.q.weight"),
+                      ("g_dec7_w1", "decoder_blocks.7.mlp.w1.weight"), ("g_pe", "patch_embed.proj.weight")):
+        ref = z[key]
+        np.testing.assert_allclose(grads[name].numpy()[:ref.shape[0]], ref, rtol=0, atol=2e-5 * np.abs(ref).max())
 
 
 def test_c1_config1_trajectory_10_adamw_steps():
