@@ -226,7 +226,17 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
     // Weight fragments are fetched one group of G k-steps ahead of the MFMAs that use them, across k-chunk and
     // n-chunk boundaries: the group for the next n-chunk is in flight during this chunk's epilogue and the first
     // group overlaps the staging of A.  (Fetched at their use, every k-step exposed an L2 round trip.)
-    constexpr int G = F8 ? 2 : ((DUAL || AK == A_F32_LN) ? 2 : 4);   // the LN prologue holds 64 staging registers: stay at 2 waves/SIMD
+#ifndef HS_G_F8_128
+#define HS_G_F8_128 2
+#endif
+#ifndef HS_G_BF_128
+#define HS_G_BF_128 4
+#endif
+#ifndef HS_G_F8_64
+#define HS_G_F8_64 2
+#endif
+    constexpr int G = F8 ? (BM == 128 ? HS_G_F8_128 : HS_G_F8_64)
+                         : ((DUAL || AK == A_F32_LN) ? 2 : (BM == 128 ? HS_G_BF_128 : 4));   // the LN prologue holds 64 staging registers: stay at 2 waves/SIMD
     constexpr int KSTEP = F8 ? 128 : 32;                      // K per MFMA
     using Frag = typename std::conditional<F8 != 0, i32x8, bf16x8>::type;
     struct Grp { Frag b[G][2]; Frag b2[DUAL ? G : 1][2]; unsigned sb[2]; unsigned sb2[2]; };
@@ -787,11 +797,18 @@ int launch_f8(const GemmParams& p, hipStream_t s) {
         if (!p.W8 || !p.S8 || (EPI == E_SWIGLU && (!p.W8b || !p.S8b))) return HSIMAE_ENULL;
         if (AK == A_F32_LN && p.K > 512) return HS_EUNSUPPORTED;
         const int64_t nk = (int64_t)p.N * p.K * (EPI == E_SWIGLU ? 2 : 1);
-        bool bm64 = nk <= 800 * 1024;
+        // 64-row panels for every fp8 product: the e4m3 weight stream per panel is half the bf16 one, and two to three resident
+        // workgroups hide the fragment fetches that one 128-row workgroup exposes (Huge step 57.7 -> 55.6 ms; 128 rows everywhere:
+        // 76.8 ms, and a deeper fragment prefetch there does not help: 87.8 ms)
+        bool bm64 = true;
+        (void)nk;
+        static int env_bm = -1;                   // HSIMAE_GEMM_F8_BM=64|128: force the panel height of the fp8 GEMMs (A/B runs)
+        if (env_bm < 0) { const char* e = getenv("HSIMAE_GEMM_F8_BM"); env_bm = e ? atoi(e) : 0; }
+        if (env_bm) bm64 = env_bm == 64;
         if (g_force_bm) bm64 = g_force_bm == 64;
         if constexpr (AK != A_F32_LN && EPI != E_SWIGLU) {
             // deep K (several 512-chunks) and at most 4 n-chunks: k outer on 64-row panels, every chunk quantised once
-            if (k_outer() && p.K > 512 && p.N > 128 && p.N <= 512 && g_force_bm != 128)
+            if (k_outer() && p.K > 512 && p.N > 128 && p.N <= 512 && g_force_bm != 128 && env_bm != 128)
                 return p.N <= 256 ? launch<AK, EPI, 512, 64, 1, 2>(p, s) : launch<AK, EPI, 512, 64, 1, 4>(p, s);
         }
         return bm64 ? launch<AK, EPI, 512, 64, 1>(p, s) : launch<AK, EPI, 512, 128, 1>(p, s);
