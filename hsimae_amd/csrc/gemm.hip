@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
     // rows are issued before the first reduction, so one memory latency is exposed per batch instead of one per
     // row (the first version walked rows one wave at a time and was latency bound, profiles/).
     auto stage_ln = [&]() {
-        constexpr int TPR = KC / 8, RPP = 256 / TPR, NPASS = BM / RPP, NB = NPASS < 8 ? NPASS : 8;
+#ifndef HS_LN_NB
+#define HS_LN_NB 4      /* rows staged per batch and thread: 8 held 64 registers and cost the 64-row kernels a wave of occupancy (LN1 + q|k|v at d = 256: 202 -> 137 VGPRs; Large -1.1 %, Huge -1.7 % per step) */
+#endif
+        constexpr int TPR = KC / 8, RPP = 256 / TPR, NPASS = BM / RPP, NB = NPASS < HS_LN_NB ? NPASS : HS_LN_NB;
         const float* A = reinterpret_cast<const float*>(p.A);
         const int c8 = (tid % TPR) * 8;
         const int lnw = p.ln_width ? p.ln_width : p.K;      // the LayerNorm's width (< K when rows are stored padded)
