@@ -62,7 +62,7 @@ constexpr int TS = 132;            // fp32 LDS tile row stride (floats): conflic
 // NCH: 1 = n-chunk outer (the A panel is re-staged for every n-chunk when K spans several chunks); 2 / 4 = k outer with
 // that many accumulator sets (every A chunk staged once: the deep-K products, see the k-outer branch below).
 template <int AK, int EPI, int KC, int BM, int F8, int NCH>
-__global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM <= 64) ? 2 : 1) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(!F8 || KC == 512, "the fp8 path stages 512-deep chunks (one scale dword per row and lane group)");
     static_assert(NCH == 1 || (AK != A_F32_LN && EPI != E_SWIGLU), "k-outer: no LayerNorm prologue, no gate pair");
@@ -221,6 +221,38 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
             }
             if constexpr (F8) put_a8(r, c8, f);
             else *reinterpret_cast<bf16x8*>(As + r * LDA + c8) = val;
+        }
+    };
+
+    // k-outer, bf16 A: the next chunk's rows are loaded into registers BEFORE this chunk's MFMA loop and stored (fp8: quantised)
+    // after it, so their HBM latency is covered by the loop instead of exposed between two barriers (the staging phase was
+    // 69 % of the d = 512 du / du2 / w2 products and 87 % of the d = 256 LN-backward GEMM: scripts/phase_timing.py)
+    constexpr int NPF = (NCH > 1 && AK == A_BF16) ? BM * KC / 8 / 256 : 1;        // 16-byte pieces per thread and chunk
+    auto stage_load = [&](int kc, bf16x8 (&pre)[NPF]) {
+        constexpr int TPR = KC / 8, RPP = 256 / TPR;
+        const int kcol = kc * KC + (tid % TPR) * 8;
+        const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int row = min(row0 + tid / TPR + i * RPP, p.M - 1);
+            pre[i] = zero8();
+            if (kcol < p.K) pre[i] = *reinterpret_cast<const bf16x8*>(A + (size_t)row * p.lda + kcol);
+        }
+    };
+    auto stage_store = [&](const bf16x8 (&pre)[NPF]) {
+        constexpr int TPR = KC / 8, RPP = 256 / TPR;
+        const int c8 = (tid % TPR) * 8;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int r = tid / TPR + i * RPP;
+            if constexpr (F8) {
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = bf2f(pre[i][e]);
+                put_a8(r, c8, f);
+            } else {
+                *reinterpret_cast<bf16x8*>(As + r * LDA + c8) = pre[i];
+            }
         }
     };
 
@@ -711,10 +743,15 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM == 64) ? 2 : 1) void ge
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) accs[c][mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 pre[NPF];
+        if constexpr (AK == A_BF16) stage_load(0, pre);
         for (int kc = 0; kc < k_chunks; ++kc) {
             if (kc) lds_barrier();
-            stage(kc);
+            if constexpr (AK == A_BF16) stage_store(pre); else stage(kc);
             lds_barrier();
+            if constexpr (AK == A_BF16) {
+                if (kc + 1 < k_chunks) stage_load(kc + 1, pre);
+            }
             PH(0)
             const int ks0 = kc * (KC / KSTEP);
             const int nks = min(KC / KSTEP, KS_total - ks0);
@@ -778,6 +815,12 @@ static int wide_mode() {
     return m;
 }
 static thread_local int g_force_bm = 0, g_force_kc = 0;       // hsimae_gemm_tiled (tile sweeps): 0 = the shape rule below
+// HSIMAE_GEMM_KO_BM=32|64: panel height of the k-outer products (A/B runs; default below)
+static int ko_bm() {
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("HSIMAE_GEMM_KO_BM"); m = e ? atoi(e) : 0; }
+    return m;
+}
 // HSIMAE_GEMM_KOUTER=0: never the k-outer schedule (A/B runs)
 static bool k_outer() {
     static int m = -1;
@@ -811,8 +854,12 @@ int launch_f8(const GemmParams& p, hipStream_t s) {
         if (g_force_bm) bm64 = g_force_bm == 64;
         if constexpr (AK != A_F32_LN && EPI != E_SWIGLU) {
             // deep K (several 512-chunks) and at most 4 n-chunks: k outer on 64-row panels, every chunk quantised once
-            if (k_outer() && p.K > 512 && p.N > 128 && p.N <= 512 && g_force_bm != 128 && env_bm != 128)
+            if (k_outer() && p.K > 512 && p.N > 128 && p.N <= 512 && g_force_bm != 128 && env_bm != 128) {
+                if constexpr (AK == A_BF16) {         // register-prefetched A chunks: 32-row panels keep them at 32 registers
+                    if (ko_bm() != 64) return p.N <= 256 ? launch<AK, EPI, 512, 32, 1, 2>(p, s) : launch<AK, EPI, 512, 32, 1, 4>(p, s);
+                }
                 return p.N <= 256 ? launch<AK, EPI, 512, 64, 1, 2>(p, s) : launch<AK, EPI, 512, 64, 1, 4>(p, s);
+            }
         }
         return bm64 ? launch<AK, EPI, 512, 64, 1>(p, s) : launch<AK, EPI, 512, 128, 1>(p, s);
     }
@@ -833,8 +880,12 @@ int launch_kc(const GemmParams& p, hipStream_t s) {
     } else {
         const bool kc256 = g_force_kc ? g_force_kc == 256 : (bm64 && p.K >= 256 && p.K <= 1024);
         if constexpr (EPI != E_SWIGLU && EPI != E_SWIGLU_BWD) {
-            if (k_outer() && !g_force_bm && p.K > 256 && p.N > 128 && p.N <= 512)
+            if (k_outer() && !g_force_bm && p.K > 256 && p.N > 128 && p.N <= 512) {
+                if constexpr (AK == A_BF16) {
+                    if (ko_bm() == 32) return p.N <= 256 ? launch<AK, EPI, 256, 32, 0, 2>(p, s) : launch<AK, EPI, 256, 32, 0, 4>(p, s);
+                }
                 return p.N <= 256 ? launch<AK, EPI, 256, 64, 0, 2>(p, s) : launch<AK, EPI, 256, 64, 0, 4>(p, s);
+            }
         }
         if (kc256) return bm64 ? launch<AK, EPI, 256, 64>(p, s) : launch<AK, EPI, 256, 128>(p, s);
         return bm64 ? launch<AK, EPI, 128, 64>(p, s) : launch<AK, EPI, 128, 128>(p, s);
@@ -873,9 +924,9 @@ int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s) {
         if (p.n_valid != p.N || !p.lnx || !p.res || !p.gamma || !p.dgamma || !p.dbeta || p.ldr % 4 || p.ldo % 4) return HS_EUNSUPPORTED;
         if (p.prec == HSIMAE_PREC_FP8) {
             if (!p.W8 || !p.S8) return HSIMAE_ENULL;
-            return launch<A_BF16, E_LN_BWD, 512, 64, 1, 2>(p, s);
+            return ko_bm() != 64 ? launch<A_BF16, E_LN_BWD, 512, 32, 1, 2>(p, s) : launch<A_BF16, E_LN_BWD, 512, 64, 1, 2>(p, s);
         }
-        return launch<A_BF16, E_LN_BWD, 256, 64, 0, 2>(p, s);
+        return ko_bm() == 32 ? launch<A_BF16, E_LN_BWD, 256, 32, 0, 2>(p, s) : launch<A_BF16, E_LN_BWD, 256, 64, 0, 2>(p, s);
     }
     if (akind == A_BF16 && epi == E_LN_BWD) {
         if (p.prec == HSIMAE_PREC_FP8) return HS_EUNSUPPORTED;

@@ -40,12 +40,16 @@ def main():
     L.LIB_PATH = lib_path
     import torch
     from hsimae_amd import HSIMAE
-    batch = int(os.environ.get("BATCH", "4096"))
+    # MODEL=base|large|huge (huge runs the fp8 encoder linears), BATCH overrides the per-model default
+    bands, dim, heads, dbatch = {"base": (96, 128, 8, 4096), "large": (96, 256, 16, 4096), "huge": (192, 512, 32, 1024)}[os.environ.get("MODEL", "base")]
+    batch = int(os.environ.get("BATCH", str(dbatch)))
     torch.manual_seed(0)
-    m = HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=96, b_patch_size=8, embed_dim=128, depth=12, num_heads=8,
+    m = HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=bands, b_patch_size=8, embed_dim=dim, depth=12, num_heads=heads,
                s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8, norm_pix_loss=True,
                trunc_init=True).cuda()
-    x = torch.rand(batch, 1, 96, 9, 9, device="cuda")
+    if dim == 512:
+        m.set_precision("fp8")
+    x = torch.rand(batch, 1, bands, 9, 9, device="cuda")
     lib = L.load()
     lib.hsimae_debug_phases.restype = ctypes.c_int
     lib.hsimae_debug_phases.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
@@ -65,8 +69,9 @@ def main():
     lib.hsimae_debug_phases_gemm(buf3, 1)          # accumulated over the 3 iterations
     v = list(buf) + list(buf2)
     g = list(buf3)
-    for name, base in (("gemm A_BF16 -> bf16 (dO / misc)", 0), ("gemm A_BF16 -> f32 family (proj+res, pos)", 4), ("gemm A_BF16 E_LN_BWD (du + LN1 bwd)", 8),
-                       ("gemm A_F32_LN -> bf16 (LN1 + qkv)", 24), ("gemm A_F32_LN -> f32 family", 28)):
+    for name, base in (("gemm A_BF16 -> bf16 (dO / misc)", 0), ("gemm A_BF16 -> f32 family (proj+res, w2+res, du, du2, pos)", 4),
+                       ("gemm A_BF16 E_LN_BWD (du + LN1 bwd)", 8), ("gemm A_F32 -> bf16", 12), ("gemm A_F32 -> other (gate backward)", 16),
+                       ("gemm A_F32_LN -> bf16 (LN1 + qkv)", 24), ("gemm A_F32_LN -> other (LN2 + w1|w3 + gate)", 28)):
         tot = sum(g[base:base + 3]) or 1
         print(f"{name}: wave-0 cycles {tot}: stage {100.0 * g[base] / tot:.1f} %  k-loop {100.0 * g[base + 1] / tot:.1f} %  epilogue {100.0 * g[base + 2] / tot:.1f} %")
     names = {
