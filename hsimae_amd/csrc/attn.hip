@@ -377,6 +377,31 @@ __device__ __forceinline__ void load16(const bf16_t* src, int ld, int Ts, int la
     }
 }
 
+// The same for all HPW heads of the workgroup at once, by all its threads: consecutive lanes take consecutive 16-byte pieces of
+// a token's HPW * HD contiguous columns (128 B at head dim 16), instead of every wave fetching / writing 32-byte pieces of its
+// own head at the row stride.  `img0` = wave 0's image of this matrix, `wstride` = elements between two waves' images.
+template <int NT, int HD, int HPW>
+__device__ __forceinline__ void load16_wg(const bf16_t* src, int ld, int Ts, int nheads, bf16_t* img0, int wstride) {
+    constexpr int RS = HD == 16 ? RS16 : 16, PCS = HD / 8, PPR = HPW * PCS;
+    for (int idx = threadIdx.x; idx < NT * 16 * PPR; idx += 64 * HPW) {
+        const int tok = idx / PPR, pc = idx - tok * PPR, w = pc / PCS, sub = pc - w * PCS;
+        bf16x8 v = zero8();
+        if (tok < Ts && w < nheads) v = *reinterpret_cast<const bf16x8*>(src + (size_t)tok * ld + w * HD + sub * 8);
+        bf16_t* dst = img0 + w * wstride + tok * RS + sub * 8;
+        *reinterpret_cast<bf16x8*>(dst) = v;
+        if constexpr (HD == 8) *reinterpret_cast<bf16x8*>(dst + 8) = zero8();      // the zero half of the K = 16 operand
+    }
+}
+template <int NT, int HD, int HPW>
+__device__ __forceinline__ void store16_wg(bf16_t* dst, int ld, int Ts, int nheads, const bf16_t* img0, int wstride) {
+    constexpr int RS = HD == 16 ? RS16 : 16, PCS = HD / 8, PPR = HPW * PCS;
+    for (int idx = threadIdx.x; idx < NT * 16 * PPR; idx += 64 * HPW) {
+        const int tok = idx / PPR, pc = idx - tok * PPR, w = pc / PCS, sub = pc - w * PCS;
+        if (tok < Ts && w < nheads)
+            *reinterpret_cast<bf16x8*>(dst + (size_t)tok * ld + w * HD + sub * 8) = *reinterpret_cast<const bf16x8*>(img0 + w * wstride + tok * RS + sub * 8);
+    }
+}
+
 template <int NT, int HD = 16, int HPW = 4>
 __global__ __launch_bounds__(64 * HPW) void attn16_fwd_kernel(AttnParams p) {
     using L = Lay16<NT, HD, HPW>;
@@ -396,19 +421,21 @@ __global__ __launch_bounds__(64 * HPW) void attn16_fwd_kernel(AttnParams p) {
         cls[i] = c;
     }
     const size_t row_base = (size_t)sample * p.Ts;
-    if (active) {
-        const bf16_t* base = p.qkv + row_base * p.ld + head * HD;
-        load16<NT, HD>(base, p.ld, p.Ts, lane, Qi);
-        load16<NT, HD>(base + KVO(p), p.ld, p.Ts, lane, Ki);
-        load16<NT, HD>(base + 2 * KVO(p), p.ld, p.Ts, lane, Vi);
+    const int head0 = (blockIdx.x % hgroups) * HPW, nheads = min(HPW, p.heads - head0);
+    bf16_t* img0 = reinterpret_cast<bf16_t*>(smem + L::CLS);
+    constexpr int WSTR = L::FWD_WAVE / 2;
+    {
+        const bf16_t* base = p.qkv + row_base * p.ld + head0 * HD;
+        load16_wg<NT, HD, HPW>(base, p.ld, p.Ts, nheads, img0, WSTR);
+        load16_wg<NT, HD, HPW>(base + KVO(p), p.ld, p.Ts, nheads, img0 + L::IMG, WSTR);
+        load16_wg<NT, HD, HPW>(base + 2 * KVO(p), p.ld, p.Ts, nheads, img0 + 2 * L::IMG, WSTR);
     }
     lds_barrier();
-    if (!active) return;
 
     const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3;
     const float sc = (HD == 16 ? 0.25f : 0.35355339059327373f) * 1.4426950408889634f;      // hd^-0.5 * log2(e)
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int qt = 0; qt < NT && active; ++qt) {
         if (qt * 16 >= p.Ts) break;
         const int query = qt * 16 + c16;
         const int qcls = cls[query];
@@ -451,10 +478,13 @@ __global__ __launch_bounds__(64 * HPW) void attn16_fwd_kernel(AttnParams p) {
             bf16x4 ov;
 #pragma unroll
             for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
-            if (g * 4 < HD) *reinterpret_cast<bf16x4*>(p.o + (row_base + query) * p.ldo + head * HD + g * 4) = ov;
+            // in place over this head's q rows of the finished query tile (only this wave reads them); leaves as whole row segments below
+            if (g * 4 < HD) *reinterpret_cast<bf16x4*>(Qi + query * RS16 + g * 4) = ov;
             if (g == 0 && p.lse) p.lse[(row_base + query) * p.heads + head] = m + __builtin_amdgcn_logf(fmaxf(lsum, 1e-30f));
         }
     }
+    lds_barrier();
+    store16_wg<NT, HD, HPW>(p.o + row_base * p.ldo + head0 * HD, p.ldo, p.Ts, nheads, img0, WSTR);
 }
 
 template <int NT, int HD = 16, int HPW = 4>
@@ -481,12 +511,17 @@ __global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
         cls[i] = c;
     }
     const size_t row_base = (size_t)sample * p.Ts;
+    const int head0 = (blockIdx.x % hgroups) * HPW, nheads = min(HPW, p.heads - head0);
+    bf16_t* img0 = reinterpret_cast<bf16_t*>(smem + L::CLS);
+    constexpr int WSTR = L::BWD_WAVE / 2;
+    {
+        const bf16_t* base = p.qkv + row_base * p.ld + head0 * HD;
+        load16_wg<NT, HD, HPW>(base, p.ld, p.Ts, nheads, img0, WSTR);
+        load16_wg<NT, HD, HPW>(base + KVO(p), p.ld, p.Ts, nheads, img0 + L::IMG, WSTR);
+        load16_wg<NT, HD, HPW>(base + 2 * KVO(p), p.ld, p.Ts, nheads, img0 + 2 * L::IMG, WSTR);
+        load16_wg<NT, HD, HPW>(p.dout + row_base * p.lddo + head0 * HD, p.lddo, p.Ts, nheads, img0 + 3 * L::IMG, WSTR);
+    }
     if (active) {
-        const bf16_t* base = p.qkv + row_base * p.ld + head * HD;
-        load16<NT, HD>(base, p.ld, p.Ts, lane, Qi);
-        load16<NT, HD>(base + KVO(p), p.ld, p.Ts, lane, Ki);
-        load16<NT, HD>(base + 2 * KVO(p), p.ld, p.Ts, lane, Vi);
-        load16<NT, HD>(p.dout + row_base * p.lddo + head * HD, p.lddo, p.Ts, lane, Di);
         for (int tok = lane; tok < L::ROWS; tok += 64) {
             float acc = 0.f, l = 1e30f;                          // rows past Ts: exp2(s - 1e30) = 0
             if (tok < p.Ts) {
@@ -506,18 +541,16 @@ __global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
         }
     }
     lds_barrier();
-    if (!active) return;
 
     const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3;
     const float scale = HD == 16 ? 0.25f : 0.35355339059327373f, sc = scale * 1.4426950408889634f;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const int troff = (4 * g + q4) * RS16 + 4 * p4;
-    bf16_t* dq_base = p.dqkv + row_base * p.ld + head * HD;
     f32x4 dkT[NT], dvT[NT];                       // [d = 4g + r][key c16], accumulated over the query tiles
     bf16x4 KT[NT];                                // K^T[d = c16][key 4g + j]
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) { dkT[kt] = z4; dvT[kt] = z4; KT[kt] = tr4(Ki + kt * 16 * RS16 + troff); }
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int qt = 0; qt < NT && active; ++qt) {
         if (qt * 16 >= p.Ts) break;
         const int query = qt * 16 + c16;
         const int qcls = cls[query];
@@ -551,24 +584,32 @@ __global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
             dkT[kt] = mfma_k16(QT, Bds, dkT[kt]);
             dvT[kt] = mfma_k16(DT, Bp, dvT[kt]);
         }
-        if (query < p.Ts) {
+        {   // dq in place over this head's q rows of the finished query tile; dk / dv below, once every read of K / V is done.
+            // The gradients leave as whole row segments (store16_wg) instead of 8-byte pieces at the row stride.
             bf16x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dqT[r] * scale);
-            if (g * 4 < HD) *reinterpret_cast<bf16x4*>(dq_base + (size_t)query * p.ld + g * 4) = v;
+            if (g * 4 < HD) *reinterpret_cast<bf16x4*>(Qi + query * RS16 + g * 4) = v;
         }
     }
+    if (active) {
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-        const int key = kt * 16 + c16;
-        if (key < p.Ts && g * 4 < HD) {
-            bf16x4 vk, vv;
+        for (int kt = 0; kt < NT; ++kt) {
+            const int key = kt * 16 + c16;
+            if (g * 4 < HD) {
+                bf16x4 vk, vv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { vk[r] = (bf16_t)(dkT[kt][r] * scale); vv[r] = (bf16_t)dvT[kt][r]; }
-            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + KVO(p) + g * 4) = vk;
-            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + 2 * KVO(p) + g * 4) = vv;
+                for (int r = 0; r < 4; ++r) { vk[r] = (bf16_t)(dkT[kt][r] * scale); vv[r] = (bf16_t)dvT[kt][r]; }
+                *reinterpret_cast<bf16x4*>(Ki + key * RS16 + g * 4) = vk;
+                *reinterpret_cast<bf16x4*>(Vi + key * RS16 + g * 4) = vv;
+            }
         }
     }
+    lds_barrier();
+    bf16_t* dq_base = p.dqkv + row_base * p.ld + head0 * HD;
+    store16_wg<NT, HD, HPW>(dq_base, p.ld, p.Ts, nheads, img0, WSTR);
+    store16_wg<NT, HD, HPW>(dq_base + KVO(p), p.ld, p.Ts, nheads, img0 + L::IMG, WSTR);
+    store16_wg<NT, HD, HPW>(dq_base + 2 * KVO(p), p.ld, p.Ts, nheads, img0 + 2 * L::IMG, WSTR);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
