@@ -349,52 +349,44 @@ __device__ __forceinline__ bf16x4 cvt4(f32x4 v) {
     return r;
 }
 
+__device__ __forceinline__ bf16x4 zero4_() { bf16x4 z; z[0] = z[1] = z[2] = z[3] = (bf16_t)0.f; return z; }
+
 constexpr int RS16 = 24;          // image row stride (elements) at head dim 16: 16 + 8 pad => conflict-free 8-byte row reads
 
 // HD = 8 (the decoder's heads, layer-at-a-time decoder: 216-token sequences): the same kernels with the head dim
-// zero-extended to the K = 16 MFMA — an image row is the head's 8 columns + 8 zeros (stride 16 elements: the pad IS the
-// zero half, rows r and r + 8 share banks), lane groups 2, 3 contribute and receive nothing.  HPW = heads (waves) per
-// workgroup: 4, or 2 for sequences of more than 7 tiles (LDS: 4 images of 224 rows per head).
+// zero-extended to the K = 16 MFMA.  The images hold the head's 8 columns only (16-byte rows); the zero half of every operand
+// whose CONTRACTION runs over the head dim (the row fragments of q, k, v, dO) is supplied in registers (lane groups 2, 3 = 0),
+// and the transposed fragments' columns 8..15 (the next row's data) only reach output rows d >= 8, which nobody stores.
+// (With the zeros stored in the images a 224-row backward needed 29 KB per head: two heads per workgroup, 4 waves per CU;
+// compact images: four heads per workgroup, two workgroups per CU.)
 template <int NT, int HD = 16, int HPW = 4>
 struct Lay16 {
-    static constexpr int RS = HD == 16 ? RS16 : 16;
+    static constexpr int RS = HD == 16 ? RS16 : 8;                        // HD = 8: compact 16-byte rows (see below)
+    static constexpr int TRS = HD == 16 ? RS16 : 16;                      // row stride of the 16 x 16 P / dS transposition tiles
     static constexpr int ROWS = NT * 16;
     static constexpr int IMG = ROWS * RS;                                 // elements per image
     static constexpr int CLS = ROWS * 4;
     static constexpr int FWD_WAVE = 3 * IMG * 2;                          // Q K V
-    static constexpr int BWD_WAVE = 4 * IMG * 2 + 2 * ROWS * 4 + 2 * 16 * RS * 2;     // Q K V dO | lse delta | T(P, dS)
+    static constexpr int BWD_WAVE = 4 * IMG * 2 + 2 * ROWS * 4 + 2 * 16 * TRS * 2;    // Q K V dO | lse delta | T(P, dS)
 };
 
-// rows [0, Ts) of one head's slice -> row-major image; rows [Ts, ROWS) zero (finite: P = 0 there, but 0 * NaN = NaN)
-template <int NT, int HD = 16>
-__device__ __forceinline__ void load16(const bf16_t* src, int ld, int Ts, int lane, bf16_t* img) {
-    constexpr int RS = HD == 16 ? RS16 : 16;
-    for (int idx = lane; idx < NT * 16 * 2; idx += 64) {
-        const int tok = idx >> 1, pc = idx & 1;
-        bf16x8 v = zero8();
-        if (tok < Ts && pc * 8 < HD) v = *reinterpret_cast<const bf16x8*>(src + (size_t)tok * ld + pc * 8);
-        *reinterpret_cast<bf16x8*>(img + tok * RS + pc * 8) = v;          // HD = 8: the second piece is the zero half
-    }
-}
-
-// The same for all HPW heads of the workgroup at once, by all its threads: consecutive lanes take consecutive 16-byte pieces of
+// Rows [0, Ts) of the workgroup's HPW heads -> row-major per-wave images (rows [Ts, ROWS) zero: P = 0 there, but 0 * NaN = NaN),
+// by all its threads: consecutive lanes take consecutive 16-byte pieces of
 // a token's HPW * HD contiguous columns (128 B at head dim 16), instead of every wave fetching / writing 32-byte pieces of its
 // own head at the row stride.  `img0` = wave 0's image of this matrix, `wstride` = elements between two waves' images.
 template <int NT, int HD, int HPW>
 __device__ __forceinline__ void load16_wg(const bf16_t* src, int ld, int Ts, int nheads, bf16_t* img0, int wstride) {
-    constexpr int RS = HD == 16 ? RS16 : 16, PCS = HD / 8, PPR = HPW * PCS;
+    constexpr int RS = HD == 16 ? RS16 : 8, PCS = HD / 8, PPR = HPW * PCS;
     for (int idx = threadIdx.x; idx < NT * 16 * PPR; idx += 64 * HPW) {
         const int tok = idx / PPR, pc = idx - tok * PPR, w = pc / PCS, sub = pc - w * PCS;
         bf16x8 v = zero8();
         if (tok < Ts && w < nheads) v = *reinterpret_cast<const bf16x8*>(src + (size_t)tok * ld + w * HD + sub * 8);
-        bf16_t* dst = img0 + w * wstride + tok * RS + sub * 8;
-        *reinterpret_cast<bf16x8*>(dst) = v;
-        if constexpr (HD == 8) *reinterpret_cast<bf16x8*>(dst + 8) = zero8();      // the zero half of the K = 16 operand
+        *reinterpret_cast<bf16x8*>(img0 + w * wstride + tok * RS + sub * 8) = v;
     }
 }
 template <int NT, int HD, int HPW>
 __device__ __forceinline__ void store16_wg(bf16_t* dst, int ld, int Ts, int nheads, const bf16_t* img0, int wstride) {
-    constexpr int RS = HD == 16 ? RS16 : 16, PCS = HD / 8, PPR = HPW * PCS;
+    constexpr int RS = HD == 16 ? RS16 : 8, PCS = HD / 8, PPR = HPW * PCS;
     for (int idx = threadIdx.x; idx < NT * 16 * PPR; idx += 64 * HPW) {
         const int tok = idx / PPR, pc = idx - tok * PPR, w = pc / PCS, sub = pc - w * PCS;
         if (tok < Ts && w < nheads)
@@ -439,12 +431,12 @@ __global__ __launch_bounds__(64 * HPW) void attn16_fwd_kernel(AttnParams p) {
         if (qt * 16 >= p.Ts) break;
         const int query = qt * 16 + c16;
         const int qcls = cls[query];
-        const bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qi + query * RS16 + 4 * g);
+        const bf16x4 bq = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Qi + query * RS16 + 4 * g) : zero4_();
         f32x4 s[NT];
         float m = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-            const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Ki + (kt * 16 + c16) * RS16 + 4 * g);
+            const bf16x4 ak = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Ki + (kt * 16 + c16) * RS16 + 4 * g) : zero4_();
             s[kt] = mfma_k16(ak, bq, z4);
             const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
             const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
@@ -504,7 +496,8 @@ __global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
     float* lse = reinterpret_cast<float*>(Di + L::IMG);
     float* delta = lse + L::ROWS;
     bf16_t* Tp = reinterpret_cast<bf16_t*>(delta + L::ROWS);
-    bf16_t* Td = Tp + 16 * RS16;
+    constexpr int TRS = L::TRS;
+    bf16_t* Td = Tp + 16 * TRS;
     for (int i = threadIdx.x; i < L::ROWS; i += 64 * HPW) {
         int c = -1;
         if (i < p.Ts) c = (p.mode == 1) ? i / p.len_l : (p.mode == 2) ? i % p.len_l : 0;
@@ -545,7 +538,7 @@ __global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
     const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3;
     const float scale = HD == 16 ? 0.25f : 0.35355339059327373f, sc = scale * 1.4426950408889634f;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const int troff = (4 * g + q4) * RS16 + 4 * p4;
+    const int troff = (4 * g + q4) * RS16 + 4 * p4, ttoff = (4 * g + q4) * TRS + 4 * p4;
     f32x4 dkT[NT], dvT[NT];                       // [d = 4g + r][key c16], accumulated over the query tiles
     bf16x4 KT[NT];                                // K^T[d = c16][key 4g + j]
 #pragma unroll
@@ -554,16 +547,16 @@ __global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
         if (qt * 16 >= p.Ts) break;
         const int query = qt * 16 + c16;
         const int qcls = cls[query];
-        const bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qi + query * RS16 + 4 * g);
-        const bf16x4 bdo = *reinterpret_cast<const bf16x4*>(Di + query * RS16 + 4 * g);
+        const bf16x4 bq = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Qi + query * RS16 + 4 * g) : zero4_();
+        const bf16x4 bdo = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Di + query * RS16 + 4 * g) : zero4_();
         const float lqn = -lse[query], dl = delta[query];
         const bf16x4 QT = tr4(Qi + qt * 16 * RS16 + troff);      // Q^T[d = c16][query 4g + j]
         const bf16x4 DT = tr4(Di + qt * 16 * RS16 + troff);
         f32x4 dqT = z4;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
-            const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Ki + (kt * 16 + c16) * RS16 + 4 * g);
-            const bf16x4 av = *reinterpret_cast<const bf16x4*>(Vi + (kt * 16 + c16) * RS16 + 4 * g);
+            const bf16x4 ak = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Ki + (kt * 16 + c16) * RS16 + 4 * g) : zero4_();
+            const bf16x4 av = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Vi + (kt * 16 + c16) * RS16 + 4 * g) : zero4_();
             const f32x4 s = mfma_k16(ak, bq, z4);                // S^T[key 4g + r][query c16]
             const f32x4 dp = mfma_k16(av, bdo, z4);
             const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
@@ -577,10 +570,10 @@ __global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
             }
             const bf16x4 pb = cvt4(pv), dsb = cvt4(ds);
             dqT = mfma_k16(KT[kt], dsb, dqT);
-            *reinterpret_cast<bf16x4*>(Tp + c16 * RS16 + 4 * g) = pb;
-            *reinterpret_cast<bf16x4*>(Td + c16 * RS16 + 4 * g) = dsb;
+            *reinterpret_cast<bf16x4*>(Tp + c16 * TRS + 4 * g) = pb;
+            *reinterpret_cast<bf16x4*>(Td + c16 * TRS + 4 * g) = dsb;
             asm volatile("" ::: "memory");
-            const bf16x4 Bp = tr4(Tp + troff), Bds = tr4(Td + troff);       // [k = query 4g + j][col key c16]
+            const bf16x4 Bp = tr4(Tp + ttoff), Bds = tr4(Td + ttoff);       // [k = query 4g + j][col key c16]
             dkT[kt] = mfma_k16(QT, Bds, dkT[kt]);
             dvT[kt] = mfma_k16(DT, Bp, dvT[kt]);
         }
@@ -1154,7 +1147,7 @@ template <int NT, bool BWD, int HD = 16, int HPW = 4>
 int launch_attn16(const AttnParams& p, hipStream_t s) {
     using L = Lay16<NT, HD, HPW>;
     const int hgroups = (p.heads + HPW - 1) / HPW;
-    const size_t lds = L::CLS + HPW * (size_t)(BWD ? L::BWD_WAVE : L::FWD_WAVE);
+    const size_t lds = L::CLS + HPW * (size_t)(BWD ? L::BWD_WAVE : L::FWD_WAVE) + 32;      // + the last transposed read's overhang at HD = 8
     if (lds > 160 * 1024) return HS_EUNSUPPORTED;
     static bool attr_set = false;
     if constexpr (BWD) {
@@ -1215,7 +1208,7 @@ int dispatch(const AttnParams& p, hipStream_t s) {
     if (p.hd == 8 && v2 && v8 && p.lse) {    // the second-generation kernels with the head dim zero-extended to 16
         if (nt <= 4) return launch_attn16<4, BWD, 8, 4>(p, s);
         if (nt <= 7) return launch_attn16<7, BWD, 8, 4>(p, s);
-        if (nt <= 14) return launch_attn16<14, BWD, 8, 2>(p, s);
+        if (nt <= 14) return launch_attn16<14, BWD, 8, 4>(p, s);
     }
     if (p.hd == 16) {
         if (nt <= 1) return launch_attn<16, 1, BWD>(p, s);
