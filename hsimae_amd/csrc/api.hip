@@ -191,12 +191,16 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
 }
 
 
-// d = 256 (rows of exactly two 128-column chunks): LayerNorm backward as the epilogue of the k-outer GEMM
-// (gemm.hip epilogue_ln_ko).  HSIMAE_FUSED_LNBWD=0 keeps the separate du store + ln_bwd pass.
-static bool wide_ln_fused(int d, int dp) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("HSIMAE_FUSED_LNBWD"); on = !(e && e[0] == '0'); }
-    return on && dp == d && d == 256;
+// d = 256 / 512 (rows of exactly two / four 128-column chunks): LayerNorm backward as the epilogue of the k-outer GEMM
+// (gemm.hip epilogue_ln_ko; d = 512 on 32-row panels, fp8 only: Huge fp8 49.9 -> 48.9 ms per step, but bf16 60.2 -> 61.5).
+// HSIMAE_FUSED_LNBWD=0 keeps the separate du store + ln_bwd pass, HSIMAE_FUSED_LNBWD_512=0 keeps it at d = 512 only.
+static bool wide_ln_fused(int d, int dp, bool f8) {
+    static int on = -1, on512 = -1;
+    if (on < 0) {
+        const char* e = getenv("HSIMAE_FUSED_LNBWD"); on = !(e && e[0] == '0');
+        e = getenv("HSIMAE_FUSED_LNBWD_512"); on512 = !(e && e[0] == '0');
+    }
+    return on && dp == d && (d == 256 || (d == 512 && f8 && on512));
 }
 
 // One Block backward: data grads (7 launches) + all weight/bias grads of the block (1 launch).
@@ -224,7 +228,7 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         p = gp();
         p.A = w.dh13; p.lda = 2 * hp; p.M = (int)M; p.N = dp; p.K = 2 * hp; p.n_valid = d; p.W = P.w13T;
         w8(p, P.w13T8);
-        if (wide_ln_fused(d, dp)) {           // LayerNorm-2 backward as the epilogue of the k-outer GEMM (the whole row is on chip)
+        if (wide_ln_fused(d, dp, f8)) {       // LayerNorm-2 backward as the epilogue of the k-outer GEMM (the whole row is on chip)
             p.out = G1; p.ldo = dp; p.res = G0; p.ldr = dp; p.lnx = b.x1; p.gamma = P.n2w; p.accumulate = 0;
             p.dgamma = grads + o.n2w; p.dbeta = grads + o.n2b; p.det_base = grads; p.det_acc = det_acc;
             CK(hs_gemm(p, A_BF16, E_LN_BWD, s));
@@ -280,7 +284,7 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     // du never goes to HBM), two otherwise.  HSIMAE_FUSED_LNBWD=0 forces the two-kernel form.
     static int fuse_ln = -1;
     if (fuse_ln < 0) { const char* e = getenv("HSIMAE_FUSED_LNBWD"); fuse_ln = !(e && e[0] == '0'); }
-    const bool ln_fused = fuse_ln && ((d == 128 && !f8) || wide_ln_fused(d, dp));
+    const bool ln_fused = fuse_ln && ((d == 128 && !f8) || wide_ln_fused(d, dp, f8));
     p = gp();
     p.A = w.dqkv; p.lda = 3 * dp; p.M = (int)M; p.N = dp; p.K = 3 * dp; p.n_valid = d; p.W = P.qkvT;
     if (ln_fused) {

@@ -917,6 +917,15 @@ int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s) {
     CASE(A_BF16, E_POS_F32)
     CASE(A_BF16, E_F32)
     CASE(A_BF16, E_BF16)
+    if (akind == A_BF16 && epi == E_LN_BWD && p.N == 512) {
+        // 512-wide rows: four accumulator sets on 32-row panels (on 64-row panels they spilled 100 registers)
+        if (p.n_valid != p.N || !p.lnx || !p.res || !p.gamma || !p.dgamma || !p.dbeta || p.ldr % 4 || p.ldo % 4) return HS_EUNSUPPORTED;
+        if (p.prec == HSIMAE_PREC_FP8) {
+            if (!p.W8 || !p.S8) return HSIMAE_ENULL;
+            return launch<A_BF16, E_LN_BWD, 512, 32, 1, 4>(p, s);
+        }
+        return launch<A_BF16, E_LN_BWD, 256, 32, 0, 4>(p, s);
+    }
     if (akind == A_BF16 && epi == E_LN_BWD && p.N == 256) {
         // 256-wide rows: the k-outer form (both chunks' accumulators live), bf16 or MX fp8 operands.  (At N = 512 the four
         // accumulator sets + the per-thread dgamma / dbeta sums spill 100 registers; an LDS table for those sums with
