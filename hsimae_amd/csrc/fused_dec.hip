@@ -1090,6 +1090,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         *reinterpret_cast<bf16x8*>(WQ + (m * D + row) * LU + k8) = cvt8(f);
     }
     for (int i = threadIdx.x; i < 5 * D; i += NT_) CB[i] = i < 3 * D ? p.w.bqkv[i] : (i < 4 * D ? p.w.n1w[i - 3 * D] : p.w.n1b[i - 4 * D]);
+    // The first sample's LayerNorm reads gamma / beta from CB before the loop's first barrier: without this one a fast wave
+    // could read what a slower wave had not staged yet (stale LDS of the previous kernel) — seen as a 1e-3-level deviation of
+    // one decoder block's q / k / v gradients in ~3 % of the runs at batch 64, where every sample is a workgroup's first.
+    lds_barrier();
 
     f32x4 accP[2], accQ[3][2];         // dWp: n-tile = wave>>1; dWq|dWk|dWv: 12 n-tiles x 4 k-tiles, 3 x 2 per wave
 #pragma unroll
