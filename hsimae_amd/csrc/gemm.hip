@@ -271,7 +271,10 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM <= 64) ? 2 : 1) void ge
 #define HS_G_F8_64 2
 #endif
     constexpr int G = F8 ? (BM == 128 ? HS_G_F8_128 : HS_G_F8_64)
-                         : ((DUAL || AK == A_F32_LN) ? 2 : (BM == 128 ? HS_G_BF_128 : 4));   // the LN prologue holds 64 staging registers: stay at 2 waves/SIMD
+#ifndef HS_G_BF_LN
+#define HS_G_BF_LN 4      /* k-steps of weight fragments in flight in the bf16 LayerNorm-prologue GEMMs: 2 -> 4 once the staging batch went to 4 rows (153 VGPRs, still 3 waves per SIMD): Large 37.41 -> 37.16 ms */
+#endif
+                         : (DUAL ? 2 : (AK == A_F32_LN ? HS_G_BF_LN : (BM == 128 ? HS_G_BF_128 : 4)));
     constexpr int KSTEP = F8 ? 128 : 32;                      // K per MFMA
     using Frag = typename std::conditional<F8 != 0, i32x8, bf16x8>::type;
     struct Grp { Frag b[G][2]; Frag b2[DUAL ? G : 1][2]; unsigned sb[2]; unsigned sb2[2]; };
