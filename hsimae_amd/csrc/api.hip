@@ -115,6 +115,14 @@ bool fused_dec_enabled(const Geo& g) {
     return hs_dec_fused_supported(g.Dd, g.Hd, g.hdec, g.TL);
 }
 
+// Forward of one fused decoder block.  Default (round 3): the attention half with q / k / v in registers
+// (dec_attn_fwd_kernel, 16 waves per CU) + the MLP half as the row-panel kernel enc_mlp_fwd_kernel<64, 192>;
+// HSIMAE_DEC_SPLIT=0 selects the one-kernel form (dec_block_fwd_kernel) for A/B tests.
+bool dec_split_enabled() {
+    const char* e = getenv("HSIMAE_DEC_SPLIT");
+    return !(e && e[0] == '0');
+}
+
 // HSIMAE_FUSED_MLP=0 forces the layer-at-a-time MLP half of the encoder blocks
 bool fused_mlp_enabled(int d, int h) {
     const char* e = getenv("HSIMAE_FUSED_MLP");
@@ -140,6 +148,14 @@ DecBlockPtrs dec_ptrs(const BlkP& b, int h) {
 }
 
 GemmParams gp() { GemmParams p; std::memset(&p, 0, sizeof(p)); return p; }
+
+int dec_block_fwd_fused(const BlkP& bp, const float* z, const BlkBuf& b, int N, int64_t Md, int TL, int Dd, int hdec, hipStream_t s) {
+    if (dec_split_enabled() && hs_enc_mlp_fused_supported(Dd, hdec)) {
+        CK(hs_dec_attn_fwd(z, b.x1, b.o, b.lse, N, TL, dec_ptrs(bp, hdec), s));
+        return hs_enc_mlp_fwd(b.x1, nullptr, b.x2, (int)Md, Dd, mlp_ptrs(bp, hdec), s);
+    }
+    return hs_dec_block_fwd(z, b.x1, b.x2, b.o, b.lse, N, TL, dec_ptrs(bp, hdec), s);
+}
 
 // One transformer Block forward (Models.py:303-306): 5 launches.
 // rs_a / rs_m: optional per-row DropPath factors of the attention / MLP branch (Models.py:304-305), NULL = none.
@@ -336,7 +352,9 @@ int make_ctx(const hsimae_config* cfg, const hsimae_io* io, Ctx& c, bool need_ws
 // ====================================================================== C ABI
 extern "C" {
 
-int hsimae_version(void) { return 100; }
+int hsimae_version(void) { return 101; }
+
+int hsimae_two_streams_active(void) { return side().ok ? 1 : 0; }
 
 const char* hsimae_strerror(int code) {
     switch (code) {
@@ -453,7 +471,7 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
     const bool fdec = fused_dec_enabled(g);
     for (int i = 0; i < g.ddepth; ++i) {
         BlkP bp = resolve(c.L.bd[i], c.W.bd[i], P, io->wpk, c.W);
-        if (fdec) CK(hs_dec_block_fwd(z, w.bd[i].x1, w.bd[i].x2, w.bd[i].o, w.bd[i].lse, c.N, g.TL, dec_ptrs(bp, g.hdec), s));
+        if (fdec) CK(dec_block_fwd_fused(bp, z, w.bd[i], c.N, c.Md, g.TL, g.Dd, g.hdec, s));
         else CK(block_fwd(bp, z, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, nullptr, s));
         z = w.bd[i].x2;
     }
@@ -500,7 +518,7 @@ int hsimae_decode(const hsimae_config* cfg, const hsimae_io* io, const float* la
     const bool fdec = fused_dec_enabled(g);
     for (int i = 0; i < g.ddepth; ++i) {
         BlkP bp = resolve(c.L.bd[i], c.W.bd[i], P, io->wpk, c.W);
-        if (fdec) CK(hs_dec_block_fwd(z, w.bd[i].x1, w.bd[i].x2, w.bd[i].o, w.bd[i].lse, c.N, g.TL, dec_ptrs(bp, g.hdec), s));
+        if (fdec) CK(dec_block_fwd_fused(bp, z, w.bd[i], c.N, c.Md, g.TL, g.Dd, g.hdec, s));
         else CK(block_fwd(bp, z, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, nullptr, s));
         z = w.bd[i].x2;
     }

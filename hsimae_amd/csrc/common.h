@@ -79,6 +79,10 @@ struct HsDet { const float* base; long long* acc; };
 #define HS_DET_SCALE 17592186044416.0f         /* 2^44 */
 __device__ __forceinline__ void hs_gadd(const HsDet& d, float* ptr, float v) {
     if (d.acc) {
+        // NaN / Inf / out-of-range addends must not vanish in the integer sum (__float2ll_rn(NaN) = 0, large values
+        // saturate): poison the fp32 slot instead — it was zero-filled before the backward and det_convert_kernel ADDS the
+        // converted sum onto it, so the gradient comes out NaN as it does on the fp32-atomics path
+        if (!(fabsf(v) < 2.6e5f)) { *ptr = __builtin_nanf(""); return; }
         const long long q = __float2ll_rn(v * HS_DET_SCALE);
         atomicAdd(reinterpret_cast<unsigned long long*>(d.acc + (ptr - d.base)), static_cast<unsigned long long>(q));
     } else {

@@ -601,6 +601,171 @@ __global__ __launch_bounds__(256, 2) void dec_block_fwd_kernel(DecFwdArgs p) {
     PH_FLUSH(16)
 }
 
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ f32x4 mfma16k16(bf16x4 a, bf16x4 b, f32x4 c) {
+    // D[16x16] += A[16x16] * B[16x16].  lane l: A[row l&15][k 4(l>>4)+j], B[k 4(l>>4)+j][col l&15]; D as mfma16.
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4 zero4() {
+    u32x2 z = {0u, 0u};
+    return __builtin_bit_cast(bf16x4, z);
+}
+
+// ====================================================================== forward, second generation: attention half
+// x1 = x + proj(attention(LN1 x)) with the sample's q / k / v and the softmax tiles held in REGISTERS (round 3).
+// dec_block_fwd_kernel above keeps q | k | v in three LDS images (64 KB per sample with the LayerNorm image => two
+// 4-wave workgroups per CU at 256 registers) and reads every score operand back from LDS.  Here wave w owns heads 2w and
+// 2w + 1 end to end:
+//   * q^T, k^T come out of operand-swapped MFMAs (D[row = dim 4g+r][col = token c16]): a lane holds 4 head dims of one
+//     token — exactly the A / B fragment of the K = 16 MFMA whose contraction runs over the head dims, so
+//     S^T[key][query] = mfma(k, q) needs no LDS at all; v comes out in the plain orientation (lane = dim, registers =
+//     4 tokens), which is the operand of O^T[dim][query] = sum_key v^T[dim][key] P^T[key][query] next to the S^T
+//     accumulators themselves (two key tiles packed into one K = 32 MFMA).
+//   * LDS holds only the LayerNorm image (A operand of q | k | v) and the attention output image (A operand of the
+//     projection): 32 KB per workgroup, <= 128 registers => four workgroups = 16 waves per CU.
+//   * the projection accumulates in the swapped orientation too, so a lane owns 4 consecutive output columns of a row:
+//     residual load and x1 store are 16-byte accesses straight from / to HBM, no fp32 staging tile.
+// The MLP half of the block then runs as the row-panel kernel of fused_enc.hip (enc_mlp_fwd_kernel<64, 192>); x1 is
+// written for the backward anyway, so the split costs one L2-hot re-read of x1.
+struct DecAttnFwdArgs { const float* x; float* x1; bf16_t* o; float* lse; int nsamples, Ts; DecW w; };
+
+template <int MT>
+__global__ __launch_bounds__(256, 4) void dec_attn_fwd_kernel(DecAttnFwdArgs p) {
+    constexpr int R = MT * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* U = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Oi = U + R * LU;
+    const Geo4 q = geo();
+    const float sc = 0.35355339059327373f * 1.4426950408889634f;     // 8^-0.5 * log2(e)
+    constexpr int NPAIR = (MT + 1) / 2;
+
+    {   // one sample per workgroup (not persistent: nothing of a sample's working set is worth keeping, and a sample loop
+        // makes hipcc hoist ~50 registers of loop-invariant addresses and masks over the whole body)
+        const int sample = blockIdx.x;
+        const size_t rb = (size_t)sample * p.Ts;
+        const DecW& w = p.w;
+        // this wave's 16 columns of Wq | Wk | Wv (packed [3 * 4 n-tiles][2 k-steps]); in flight under the LayerNorm
+        bf16x8 fw[3][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                fw[c][ks] = *reinterpret_cast<const bf16x8*>(w.qkv + (((size_t)(c * 4 + q.wave) * 2 + ks) * 64 + q.lane) * 8);
+        const f32x4 bq4 = *reinterpret_cast<const f32x4*>(w.bqkv + q.wave * 16 + q.g * 4);
+        const f32x4 bk4 = *reinterpret_cast<const f32x4*>(w.bqkv + D + q.wave * 16 + q.g * 4);
+        const float bv1 = w.bqkv[2 * D + q.wave * 16 + q.c16];
+        ln_rows<MT, false, 256>(p.x + rb * D, p.Ts, w.n1w, w.n1b, U, nullptr, nullptr);
+        lds_barrier();
+
+        // q^T, k^T (lane = token, registers = 4 dims of this wave's 16) and v (lane = dim, registers = 4 tokens)
+        // k and v stay in registers for the whole sample; q^T (needed one tile at a time) is parked in this wave's own 16
+        // columns of the O image — the slot that head's output later overwrites (head A's output only touches head A's
+        // 8 columns, so head B's q survives it) — no other wave reads those columns before the barrier below
+        bf16x4 kT[MT], vN[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(U + (mt * 16 + q.c16) * LU + q.g * 8);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(U + (mt * 16 + q.c16) * LU + 32 + q.g * 8);
+            f32x4 aq = bq4, ak = bk4, av = f32x4{bv1, bv1, bv1, bv1};
+            aq = mfma16(fw[0][0], a0, aq); aq = mfma16(fw[0][1], a1, aq);
+            ak = mfma16(fw[1][0], a0, ak); ak = mfma16(fw[1][1], a1, ak);
+            av = mfma16(a0, fw[2][0], av); av = mfma16(a1, fw[2][1], av);
+            *reinterpret_cast<bf16x4*>(Oi + (mt * 16 + q.c16) * LU + q.wave * 16 + q.g * 4) = cvt4(aq);
+            kT[mt] = cvt4(ak); vN[mt] = cvt4(av);
+        }
+
+        // padding keys (rows >= Ts) are masked through the MFMA's C operand; with MT = 7 (65..112 tokens) tiles 0..3 are full
+        constexpr int KMIN = (MT > 4) ? 4 : 0;
+        f32x4 cinit[MT - KMIN];
+#pragma unroll
+        for (int kt = KMIN; kt < MT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cinit[kt - KMIN][r] = (kt * 16 + q.g * 4 + r >= p.Ts) ? -INFINITY : 0.f;
+
+#pragma unroll 1
+        for (int hh = 0; hh < 2; ++hh) {
+            const bool mine = (q.g >> 1) == hh;            // this lane group carries head hh's dims
+            const int head = q.wave * 2 + hh;
+#pragma unroll
+            for (int qt = 0; qt < MT; ++qt) {
+                if (qt * 16 >= p.Ts) continue;             // (uniform)
+                const int query = qt * 16 + q.c16;
+                bf16x4 bq = *reinterpret_cast<const bf16x4*>(Oi + query * LU + q.wave * 16 + q.g * 4);
+                if (!mine) bq = zero4();
+                f32x4 s[MT];
+#pragma unroll
+                for (int kt = 0; kt < MT; ++kt)
+                    s[kt] = mfma16k16(kT[kt], bq, kt < KMIN ? f32x4{0.f, 0.f, 0.f, 0.f} : cinit[kt < KMIN ? 0 : kt - KMIN]);
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                const float nm = -m * sc;
+                float lsum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc, nm));
+                        s[kt][r] = e; lsum += e;
+                    }
+                lsum += __shfl_xor(lsum, 16, 64);
+                lsum += __shfl_xor(lsum, 32, 64);
+                const float inv = __builtin_amdgcn_rcpf(lsum);
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pp = 0; pp < NPAIR; ++pp) {
+                    const int ta = 2 * pp, tb = (2 * pp + 1 < MT) ? 2 * pp + 1 : 2 * pp;
+                    const bf16x8 pc = pack2(s[ta], (2 * pp + 1 < MT) ? s[tb] : f32x4{0.f, 0.f, 0.f, 0.f});
+                    const bf16x8 vc = __builtin_shufflevector(vN[ta], vN[tb], 0, 1, 2, 3, 4, 5, 6, 7);
+                    o = mfma16(vc, pc, o);                  // O^T[dim 4g+r][query c16]
+                }
+                if (mine) {
+                    bf16x4 ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
+                    *reinterpret_cast<bf16x4*>(Oi + query * LU + q.wave * 16 + q.g * 4) = ov;
+                    if ((q.g & 1) == 0 && query < p.Ts)
+                        p.lse[(rb + query) * 8 + head] = m * sc + __builtin_amdgcn_logf(lsum);   // log2-domain, [row][head]
+                }
+            }
+        }
+        // projection fragments of this wave's 16 output columns
+        bf16x8 fp[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            fp[ks] = *reinterpret_cast<const bf16x8*>(w.p + (((size_t)q.wave * 2 + ks) * 64 + q.lane) * 8);
+        const f32x4 pb4 = *reinterpret_cast<const f32x4*>(w.pb + q.wave * 16 + q.g * 4);
+        lds_barrier();
+        // residual rows of this wave's 16 output columns, all in flight before the projection's MFMAs
+        f32x4 xr[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = mt * 16 + q.c16;
+            xr[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < p.Ts) xr[mt] = *reinterpret_cast<const f32x4*>(p.x + (rb + row) * D + q.wave * 16 + q.g * 4);
+        }
+        // attention output kept for the backward (dWp operand), 16-byte row pieces
+        for (int pc = threadIdx.x; pc < R * 8; pc += 256) {
+            const int row = pc >> 3, k8 = (pc & 7) * 8;
+            if (row < p.Ts) HS_NT(HS_NT_D, reinterpret_cast<bf16x8*>(p.o + (rb + row) * D + k8), *reinterpret_cast<const bf16x8*>(Oi + row * LU + k8));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = mt * 16 + q.c16;
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Oi + row * LU + q.g * 8);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Oi + row * LU + 32 + q.g * 8);
+            f32x4 acc = pb4;
+            acc = mfma16(fp[0], b0, acc); acc = mfma16(fp[1], b1, acc);     // D[row = out column 4g+r][col = token c16]
+            acc += xr[mt];
+            if (row < p.Ts) *reinterpret_cast<f32x4*>(p.x1 + (rb + row) * D + q.wave * 16 + q.g * 4) = acc;
+        }
+    }
+}
+
 // ====================================================================== backward
 // The decoder block's backward is two persistent kernels per block (weight gradients stay in registers across
 // all the samples a workgroup walks and are committed once with atomics — 198 KB of dW per block fit on chip):
@@ -936,15 +1101,6 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
 }
 
 
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-__device__ __forceinline__ f32x4 mfma16k16(bf16x4 a, bf16x4 b, f32x4 c) {
-    // D[16x16] += A[16x16] * B[16x16].  lane l: A[row l&15][k 4(l>>4)+j], B[k 4(l>>4)+j][col l&15]; D as mfma16.
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ bf16x4 zero4() {
-    u32x2 z = {0u, 0u};
-    return __builtin_bit_cast(bf16x4, z);
-}
 // 4 consecutive image rows of one column per lane: element j of lane (c16, g) = img[row0(g) + j][col0 + c16];
 // `a` is the lane's own 8-byte piece img[row0(g) + (c16 >> 2)][col0 + 4 (c16 & 3) ..].
 __device__ __forceinline__ bf16x4 tr4(const bf16_t* a) {
@@ -1379,6 +1535,18 @@ int launch_fwd(const DecFwdArgs& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+template <int MT>
+int launch_attn_fwd(const DecAttnFwdArgs& a, hipStream_t s) {
+    constexpr int LDS = 2 * MT * 16 * LU * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_attn_fwd_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dec_attn_fwd_kernel<MT>), dim3(a.nsamples), dim3(256), LDS, s, a);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 template <int MT>
@@ -1426,6 +1594,19 @@ int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx
     const int mt = (Ts + 15) / 16;
     if (mt <= 4) return launch_bwd<4>(a, b, s);
     if (mt <= 7) return launch_bwd<7>(a, b, s);
+    return HS_EUNSUPPORTED;
+}
+
+// attention half of the block only (x1 = x + proj(attention(LN1 x)); O and logsumexp kept for the backward)
+int hs_dec_attn_fwd(const float* x, float* x1, hs_bf16* o, float* lse, int nsamples, int Ts, const DecBlockPtrs& bp, hipStream_t s) {
+    DecAttnFwdArgs a;
+    a.x = x; a.x1 = x1; a.o = o; a.lse = lse; a.nsamples = nsamples; a.Ts = Ts;
+    a.w.n1w = bp.n1w; a.w.n1b = bp.n1b; a.w.bqkv = bp.bqkv; a.w.pb = bp.pb; a.w.n2w = bp.n2w; a.w.n2b = bp.n2b;
+    a.w.w1b = bp.w1b; a.w.w3b = bp.w3b; a.w.w2b = bp.w2b;
+    a.w.qkv = bp.qkv; a.w.p = bp.p; a.w.w1 = bp.w1; a.w.w3 = bp.w3; a.w.w2 = bp.w2; a.w.h = bp.h;
+    const int mt = (Ts + 15) / 16;
+    if (mt <= 4) return launch_attn_fwd<4>(a, s);
+    if (mt <= 7) return launch_attn_fwd<7>(a, s);
     return HS_EUNSUPPORTED;
 }
 

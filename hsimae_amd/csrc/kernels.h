@@ -61,6 +61,7 @@ struct DecBlockGrads {
 bool hs_dec_fused_supported(int d, int heads, int hidden, int Ts);
 int hs_dec_block_fwd(const float* x, float* x1, float* x2, hs_bf16* o, float* lse, int nsamples, int Ts,
                      const DecBlockPtrs& bp, hipStream_t s);
+int hs_dec_attn_fwd(const float* x, float* x1, hs_bf16* o, float* lse, int nsamples, int Ts, const DecBlockPtrs& bp, hipStream_t s);
 int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o,
                      const float* lse, int nsamples, int Ts, const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s);
 

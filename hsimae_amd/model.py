@@ -661,9 +661,12 @@ class HSIMAE(nn.Module):
             partial = torch.empty(lib.hsimae_loss_partials(N, T), dtype=torch.float32, device=dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
             dpred = torch.empty(N * TL, 96, dtype=torch.bfloat16, device=dev) if want_grad else None
+            # data parallel: the reducer SUMs the ranks' gradients, so dLoss/dpred carries the 1/world of the mean
+            # (hsimae_forward folds the same factor in through hsimae_io.grad_scale)
+            world = self._reducer.world_size if self._reducer is not None else 1
             p = _lib.LossParams(x=imgs.data_ptr(), sn=imgs.stride(0), sb=imgs.stride(2), sh=imgs.stride(3), sw=imgs.stride(4),
                                 N=N, T=T, pred=pr.data_ptr(), mask=mk.data_ptr(), norm_pix=int(bool(self.norm_pix_loss)),
-                                inv_scale=(1.0 / (72.0 * sum_mask)) if want_grad else 0.0, partial=partial.data_ptr(),
+                                inv_scale=(1.0 / (72.0 * sum_mask * world)) if want_grad else 0.0, partial=partial.data_ptr(),
                                 loss=loss.data_ptr(), sum_mask=sum_mask, dpred=_lib.ptr(dpred))
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.hsimae_loss(C.byref(p), stream), "hsimae_loss")
@@ -741,6 +744,19 @@ class HSIMAE(nn.Module):
         inside the backward schedule (overlapped with the remaining backward kernels)."""
         from .parallel import GradReducer
         self._reducer = GradReducer(process_group, bucket_bytes, force_collectives)
+        dev = next(self.parameters()).device
+        if dev.type == "cuda" and self._reducer.world_size > 1:
+            # the ranges arrive in the order the backward schedule enqueues them, and that order depends on whether the
+            # library forks the two axis stacks onto a side stream (rank-local: env switch, hipStreamCreate): ranks that
+            # disagree would issue different all-reduce slices.  Checked once, here.
+            import torch.distributed as dist
+            with torch.cuda.device(dev):
+                mine = int(_lib.load().hsimae_two_streams_active())
+            flags = [None] * self._reducer.world_size
+            dist.all_gather_object(flags, mine, group=process_group)
+            if len(set(flags)) != 1:
+                raise RuntimeError(f"hsimae_amd: ranks disagree on the two-stream backward schedule ({flags}); set "
+                                   "HSIMAE_TWO_STREAMS identically on every rank")
         if broadcast:
             dev = next(self.parameters()).device
             if dev.type == "cuda":

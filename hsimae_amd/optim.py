@@ -71,6 +71,30 @@ class FusedAdamW:
             elif p.grad is not None:
                 p.grad.zero_()
 
+    def _sync_grads(self):
+        """`.grad` is the contract, the flat gradient buffer only its usual home.  A parameter whose `.grad` is None (cleared
+        by zero_grad and not touched by this step's backward — e.g. the encoder after a decoder-only backward) is SKIPPED like
+        torch.optim.AdamW skips it: it is masked out of this step (group id 2: no update, no weight decay, moments kept), so a
+        stale range of the flat buffer is never applied.  A `.grad` that is some other tensor (assigned or accumulated by the
+        caller) is copied into its flat view first.  Returns the group-id tensor to use for this step."""
+        m = self.model
+        params, views = m._params_cache, m._grad_views
+        missing, foreign = [], []
+        for i in m._trainable:
+            g = params[i].grad
+            if g is None:
+                missing.append(i)
+            elif g.data_ptr() != views[i].data_ptr() or g.shape != views[i].shape:
+                foreign.append(i)
+        for i in foreign:
+            views[i].copy_(params[i].grad.to(views[i].dtype).reshape(views[i].shape))
+        if not missing:
+            return self._group
+        grp = self._group.clone()
+        for i in missing:
+            grp[m._offs[i]: m._offs[i] + m._sizes[i]] = 2
+        return grp
+
     @torch.no_grad()
     def step(self):
         self._bind()
@@ -79,9 +103,10 @@ class FusedAdamW:
         self.step_count += 1
         b1, b2 = g0["betas"]
         stream = torch.cuda.current_stream(m._flat.device).cuda_stream
+        group = self._sync_grads()
         _lib.check(_lib.load().hsimae_adamw_step(
             m._flat.data_ptr(), m._flat_grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-            self._group.data_ptr(), m._flat.numel(), float(g0["lr"]), float(b1), float(b2), float(g0["eps"]),
+            group.data_ptr(), m._flat.numel(), float(g0["lr"]), float(b1), float(b2), float(g0["eps"]),
             float(g0["weight_decay"]), self.step_count, stream), "hsimae_adamw_step")
         m._packed_version = -1                    # packed bf16 images are stale now
         if self._extra is not None:

@@ -37,6 +37,11 @@ def dp_context(device):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if dist.is_available() and dist.is_initialized():
+        # the launcher made the group: still one GPU per rank (RCCL refuses ranks that share a device)
+        if torch.device(device).type == "cuda" and dist.get_world_size() > 1 and dist.get_backend() == "nccl":
+            local = int(os.environ.get("LOCAL_RANK", str(dist.get_rank() % max(1, torch.cuda.device_count()))))
+            device = torch.device("cuda", local if torch.cuda.device_count() > local else 0)
+            torch.cuda.set_device(device)
         return dist.get_rank(), dist.get_world_size(), device
     if world <= 1:
         return 0, 1, device

@@ -45,6 +45,11 @@ extern "C" {
 
 int hsimae_version(void);
 const char* hsimae_strerror(int code);
+/* 1 if the library runs the two axis stacks of the encoder on two streams on the CURRENT device (the side stream is created
+ * on first use; HSIMAE_TWO_STREAMS=0 or a failed hipStreamCreate give 0).  The order in which hsimae_backward reports gradient
+ * ranges depends on it, so data-parallel callers check that every rank answers the same (hsimae_amd/model.py
+ * enable_data_parallel) before they issue collectives in callback order. */
+int hsimae_two_streams_active(void);
 
 /* ------------------------------------------------------------------ model geometry */
 /* Mirrors the HSIMAE constructor arguments that shape the tensors (Models.py:312-332) for the

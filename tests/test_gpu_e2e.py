@@ -260,8 +260,12 @@ def test_fused_decoder_matches_layerwise_decoder(bands, grid):
     x = torch.rand(N, 1, bands, 9, 9, generator=g).to(DEV)
     n = (torch.rand(N, bands // 8, generator=g), torch.rand(N, 9, generator=g))
     res = {}
-    for mode in ("0", "1"):
-        os.environ["HSIMAE_FUSED_DEC"] = mode
+    # "0": layer at a time; "1": fused, forward split into the in-register attention half + row-panel MLP half (default);
+    # "1-onekernel": fused, the one-kernel forward of rounds 1-2 (HSIMAE_DEC_SPLIT=0)
+    for mode in ("0", "1", "1-onekernel"):
+        os.environ["HSIMAE_FUSED_DEC"] = mode[0]
+        if mode.endswith("onekernel"):
+            os.environ["HSIMAE_DEC_SPLIT"] = "0"
         try:
             m.zero_grad()
             loss, pred, _ = m(x, 0.75, noise=n, grid=grid)
@@ -270,20 +274,22 @@ def test_fused_decoder_matches_layerwise_decoder(bands, grid):
             res[mode] = (loss.item(), pred.clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
         finally:
             os.environ.pop("HSIMAE_FUSED_DEC", None)
+            os.environ.pop("HSIMAE_DEC_SPLIT", None)
     l0, p0, g0 = res["0"]
-    l1, p1, g1 = res["1"]
-    print(f"[fused-dec {bands}] loss layerwise {l0:.7f} fused {l1:.7f}")
-    assert abs(l0 - l1) <= 5e-5 * abs(l0)
-    assert rms_rel(p1, p0) < 3e-3
-    worst = ("", 0.0)
-    for k in g0:
-        if k.endswith("attn.k.bias"):
-            continue
-        r = rms_rel(g1[k], g0[k])
-        if r > worst[1]:
-            worst = (k, r)
-        assert r < 3e-2, (k, r)     # two bf16 pipelines, each ~1.5e-2 from the fp32 oracle
-    print(f"[fused-dec {bands}] worst grad rms-rel vs layerwise {worst}")
+    for mode in ("1", "1-onekernel"):
+        l1, p1, g1 = res[mode]
+        print(f"[fused-dec {bands} {mode}] loss layerwise {l0:.7f} fused {l1:.7f}")
+        assert abs(l0 - l1) <= 5e-5 * abs(l0)
+        assert rms_rel(p1, p0) < 3e-3
+        worst = ("", 0.0)
+        for k in g0:
+            if k.endswith("attn.k.bias"):
+                continue
+            r = rms_rel(g1[k], g0[k])
+            if r > worst[1]:
+                worst = (k, r)
+            assert r < 3e-2, (k, r)     # two bf16 pipelines, each ~1.5e-2 from the fp32 oracle
+        print(f"[fused-dec {bands} {mode}] worst grad rms-rel vs layerwise {worst}")
 
 
 @pytest.mark.parametrize("bands,grid,N", [(48, (2, 7), 37), (96, (3, 9), 24), (96, (9, 3), 24)])
