@@ -79,13 +79,31 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def visible_gpus():
+    """GPUs this process would see, WITHOUT loading the HIP runtime: KFD topology nodes that have SIMDs, cut down by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  None when the topology cannot be read (the ranks then find out)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def launch_ranks(args, argv):
     """Parent of a `--gpus N` run: start N ranks with torch.distributed.run and relay their output.  This process never
-    initialises the GPU (device_count() does not on this image) and never re-execs."""
+    touches the HIP runtime (GPUs are counted from the KFD topology in sysfs) and never re-execs."""
     if not args.dry_run:
-        import torch
-        have = torch.cuda.device_count()
-        if have < args.gpus:
+        have = visible_gpus()
+        if have is not None and have < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
             return 2
     port = os.environ.get("MASTER_PORT") or str(_free_port())
@@ -245,6 +263,30 @@ def encoder_only_ms(model, imgs, iters=10):
     return ts[len(ts) // 2]
 
 
+def decoder_only_ms(model, imgs, iters=10):
+    """HIP-event times of the decoder alone, forward and backward separately: hsimae_decode (decoder_embed, assembly, the
+    decoder blocks, decoder_norm + decoder_pred) and hsimae_decode_backward from d(pred), per batch."""
+    import torch
+    with torch.no_grad():
+        latent, mask, ids_restore, _ = model.forward_encoder(imgs, 0.75)
+    fwd, bwd = [], []
+    dpred = None
+    for i in range(iters + 2):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        pred, st = model._run_decode(latent, ids_restore)
+        e1.record()
+        if dpred is None:
+            dpred = torch.randn_like(pred) * 1e-3
+        model._decode_backward(st, dpred)
+        e2.record()
+        fwd.append((e0, e1)); bwd.append((e1, e2))
+    torch.cuda.synchronize()
+    med = lambda ev: sorted(a.elapsed_time(b) for a, b in ev[2:])[len(ev[2:]) // 2]
+    model.zero_grad(set_to_none=True)
+    return med(fwd), med(bwd)
+
+
 def optimizer_step_ms(model, iters=10):
     """Not part of the metric (fwd+bwd only): the reference loop's optimizer.step() (Model_Pretraining.py:102) as
     stock torch AdamW over 535 tensors vs the one-launch FusedAdamW + packed-weight refresh."""
@@ -337,7 +379,11 @@ def cpu_baseline(bands):
     past a few dozen threads) — the better one is `value` — plus config 1 (Base, 48 bands, batch 64).  About 20 s in all."""
     allc = os.cpu_count() or 1
     tried = {}
-    for cores in sorted({min(allc, 32), allc}):
+    # thread counts: 32 (where torch's CPU ops on these small shapes stop scaling) and every core only on hosts with up to
+    # 64 of them — on the 256-thread GPU hosts the all-core setting never finished a batch-32 probe in 25 s (rounds 1-2),
+    # so it is no longer attempted (that probe alone was 25 s of every bench run)
+    cand = sorted({min(allc, 32), allc}) if allc <= 64 else [32]
+    for cores in cand:
         # every setting is probed at batch 32 in a child process with a time limit first: with all cores of a 256-core host
         # torch's intra-op pool can take minutes per step on these small shapes; such a setting is recorded as timed out
         t0 = time.perf_counter()
@@ -360,6 +406,8 @@ def cpu_baseline(bands):
             "sample": f"oracle fwd+bwd fp32, HSIMAE-Base 9x9x{bands}, batch 256, median of {tried[best][1]} steps after 1 warm-up",
             "threads_tried": {str(c): (round(r, 2) if r > 0 else "probe timed out (>25 s at batch 32)") for c, (r, _) in tried.items()},
             "host_cores": allc,
+            "not_tried": (f"{allc} threads: torch's intra-op pool does not finish a batch-32 probe in 25 s on this host class "
+                          "(measured in rounds 1-2)") if allc > 64 else None,
             "config1": {"value": round(c1_rate, 2), "unit": "patches/s", "cores": best,
                         "sample": f"oracle fwd+bwd fp32, HSIMAE-Base 9x9x48, batch 64, median of {c1_steps} steps after 1 warm-up"}}
 
@@ -495,6 +543,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     last_loss = float(loss.item())
+    comm = None
+    if use_ddp:
+        # what the gradient exchange costs this configuration: the same step with the reducer detached (no collectives,
+        # no callbacks), timed on every rank over a few steps; exposed = step(ddp) - step(no reduce)
+        red = model._reducer
+        launched = list(red.launched)
+        model._reducer = None
+        k = max(3, min(10, args.steps))
+        step(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tn = torch.tensor([(time.perf_counter() - t1) / k], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+        model._reducer = red
+        comm = {"buckets": len(launched), "bytes": int(sum(hi - lo for lo, hi in launched) * 4),
+                "step_ms_no_reduce": round(float(tn.item()) * 1e3, 3),
+                "exposed_ms": round(dt / args.steps * 1e3 - float(tn.item()) * 1e3, 3),
+                "transport": "RCCL all-reduce(sum) per bucket on the reducer's launch stream, fp32, pre-scaled by 1/world"}
 
     if rank == 0:
         h, hd = swiglu_hidden(D, 4.0), swiglu_hidden(64, 4.0)
@@ -530,6 +603,8 @@ def main():
                         "per_grid": {k: {"n": len(v), "median": round(pct(sorted(v), 0.5), 3)} for k, v in per_grid.items()},
                         "clock": "HIP events between consecutive steps on the launch stream"},
         }
+        if comm is not None:
+            out["comm"] = comm
         _log(f"step timing done: {dt / args.steps * 1e3:.3f} ms/step")
         if not args.no_extras:
             enc_ms = encoder_only_ms(model, imgs)
@@ -538,6 +613,18 @@ def main():
             out["encoder_mfma_frac"] = {"achieved": round(enc_tf, 1), "peak": peak, "unit": "TFLOP/s",
                                         "frac": round(enc_tf / peak, 4), "ms": round(enc_ms, 3),
                                         "what": "hsimae_encode + hsimae_encode_backward, algorithmic encoder FLOPs, HIP events"}
+            # the decoder group (the lowest MFMA fraction of the step): 8 blocks + embed / assembly / pred, forward and backward
+            dfw, dbw = decoder_only_ms(model, imgs)
+            fl_dec = fl - fl_enc
+            out["roofline_decoder"] = {
+                "bound": "mfma", "what": "hsimae_decode / hsimae_decode_backward, algorithmic decoder FLOPs (fwd 1/3, bwd 2/3), HIP events",
+                "fwd_ms": round(dfw, 3), "bwd_ms": round(dbw, 3), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "fwd_achieved": round(N * fl_dec / 3 / (dfw * 1e-3) / 1e12, 1), "bwd_achieved": round(N * fl_dec * 2 / 3 / (dbw * 1e-3) / 1e12, 1),
+                "achieved": round(N * fl_dec / ((dfw + dbw) * 1e-3) / 1e12, 1),
+                "frac": round(N * fl_dec / ((dfw + dbw) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "per_block_us": {"fwd": round(dfw * 1e3 / 8, 1), "bwd": round(dbw * 1e3 / 8, 1),
+                                 "note": "group time / 8 blocks (includes the embed / assembly / pred kernels' ~5 %)"}}
+            _log(f"decoder-only fwd {dfw:.3f} ms, bwd {dbw:.3f} ms")
             K_tok = lt0 * ll0
             kr = kernel_rooflines(model, N * K_tok, PEAK_BF16_TFLOPS)
             out["roofline_kernel"], out["roofline_kernel_hbm"] = kr[0]

@@ -283,6 +283,45 @@ def test_sub_entry_points_compose_under_autograd_like_forward():
     assert lat2.grad is not None and float(lat2.grad.abs().sum()) > 0
 
 
+def test_fused_adamw_skips_parameters_without_grad_after_a_partial_backward():
+    """FusedAdamW steps the flat gradient buffer; a decoder-only backward after zero_grad() leaves the encoder's
+    `.grad` None and the previous step's encoder gradients in the flat buffer.  Those parameters must be skipped exactly as
+    torch.optim.AdamW skips them (no update, no weight decay), and a caller-owned `.grad` tensor must be what is applied."""
+    from hsimae_amd import FusedAdamW
+    m = base48(3)
+    opt = FusedAdamW(m, lr=1e-2, weight_decay=5e-2, betas=(0.9, 0.95))
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(8, 1, 48, 9, 9, generator=g).to(DEV)
+    noise = (torch.rand(8, 6, generator=g), torch.rand(8, 9, generator=g))
+    loss, _, _ = m(x, 0.75, noise=noise, grid=(2, 7))
+    loss.backward()
+    opt.step()                                            # every trainable parameter has a gradient: the usual step
+    opt.zero_grad()
+    enc_before = {k: p.detach().clone() for k, p in m.named_parameters() if k.startswith(("blocks", "patch_embed", "norm."))}
+    dec_before = {k: p.detach().clone() for k, p in m.named_parameters() if k.startswith("decoder_blocks")}
+    with torch.no_grad():
+        latent, mask, ids_restore, _ = m.forward_encoder(x, 0.75, noise=noise, grid=(2, 7))
+    loss = m.forward_loss(x, m.forward_decoder(latent, ids_restore), mask)
+    loss.backward()                                       # decoder-only backward: writes the decoder's flat range only
+    named = dict(m.named_parameters())
+    assert named["blocks.0.mlp.w1.weight"].grad is None and named["decoder_blocks.0.mlp.w1.weight"].grad is not None
+    opt.step()
+    torch.cuda.synchronize()
+    for k, v in enc_before.items():
+        assert torch.equal(named[k].detach(), v), f"{k} moved although it had no gradient"
+    moved = sum(int(not torch.equal(named[k].detach(), v)) for k, v in dec_before.items())
+    assert moved == len(dec_before)
+    # a foreign `.grad` (assigned by the caller) is what the step applies: +1 everywhere on one bias -> it moves by ~ -lr
+    opt.zero_grad()
+    b = named["decoder_blocks.0.mlp.w2.bias"]
+    b0 = b.detach().clone()
+    b.grad = torch.ones_like(b)
+    opt2 = FusedAdamW(m, lr=1e-2, weight_decay=0.0)       # fresh moments: the first Adam step is -lr * sign(g)
+    opt2.step()
+    torch.cuda.synchronize()
+    assert torch.allclose(b.detach(), b0 - 1e-2, atol=1e-5)
+
+
 @pytest.mark.parametrize("dim,dec_dim,bands", [(64, 48, 32), (144, 72, 32)])
 def test_reference_default_widths_construct_and_match_oracle(dim, dec_dim, bands):
     """Model_Pretraining.py:57-58 (dim 64, dec_dim 48) and Model_Finetuning.py:66-67 (144 / 72): widths that are

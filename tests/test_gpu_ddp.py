@@ -39,12 +39,19 @@ def _inputs(N):
     return torch.rand(N, 1, 48, 9, 9, generator=g), torch.rand(N, 6, generator=g), torch.rand(N, 9, generator=g)
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, q, backend="gloo", split_api=False):
+    """backend "gloo": both ranks share cuda:0 (the 1-GPU box); "nccl": one GPU per rank over RCCL (needs >= 2 GPUs).
+    split_api: the step is composed from forward_encoder / forward_decoder / forward_loss (three autograd nodes, two
+    reducer-driven backward passes) instead of the one-node forward()."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     try:
-        torch.cuda.set_device(0)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        m = _model(seed=100 + rank).cuda()               # different weights per rank: the broadcast must fix that
+        dev = torch.device("cuda", rank if backend == "nccl" else 0)
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        m = _model(seed=100 + rank).to(dev)              # different weights per rank: the broadcast must fix that
         m.enable_data_parallel(bucket_bytes=1 << 20)
         m.deterministic = True                            # fixed-point reduction: the comparison is not blurred by atomics
         N = 32
@@ -54,7 +61,12 @@ def _worker(rank, world, port, q):
         losses = []
         for step in range(2):                             # two steps: the second reuses arena, events and launch stream
             m.zero_grad(set_to_none=True)
-            loss, _, _ = m(x[sl].cuda(), 0.75, noise=(n1[sl], n2[sl]), grid=(2, 7))
+            if split_api:
+                xs = x[sl].to(dev)
+                latent, mask, ids_restore, _ = m.forward_encoder(xs, 0.75, noise=(n1[sl], n2[sl]), grid=(2, 7))
+                loss = m.forward_loss(xs, m.forward_decoder(latent, ids_restore), mask)
+            else:
+                loss, _, _ = m(x[sl].to(dev), 0.75, noise=(n1[sl], n2[sl]), grid=(2, 7))
             loss.backward()
             torch.cuda.synchronize()
             losses.append(loss.item())
@@ -71,12 +83,22 @@ def _worker(rank, world, port, q):
             dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process_on_the_global_batch():
+def _two_gpus():
+    return torch.cuda.is_available() and torch.cuda.device_count() >= 2
+
+
+@pytest.mark.parametrize("backend,split_api", [
+    ("gloo", False),
+    ("gloo", True),          # the split API's loss gradient must carry 1/world too
+    pytest.param("nccl", False, marks=pytest.mark.skipif(not _two_gpus(), reason="RCCL needs one GPU per rank (>= 2 GPUs)")),
+    pytest.param("nccl", True, marks=pytest.mark.skipif(not _two_gpus(), reason="RCCL needs one GPU per rank (>= 2 GPUs)")),
+])
+def test_two_ranks_equal_one_process_on_the_global_batch(backend, split_api):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, split_api)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
@@ -86,7 +108,8 @@ def test_two_ranks_equal_one_process_on_the_global_batch():
     # rank 0's weights reached rank 1
     assert (res[0][5] == res[1][5]).all()
     # the collectives cover the trainable part of the flat buffer in a few buckets, identically on both ranks
-    assert res[0][4] == res[1][4] and 3 <= len(res[0][4]) <= 40
+    # (split API: `launched` is what the last of its two backward passes — the encoder's — issued)
+    assert res[0][4] == res[1][4] and (2 if split_api else 3) <= len(res[0][4]) <= 40
     # single process, whole batch, rank 0's weights
     m = _model(seed=100).cuda()
     m.deterministic = True
@@ -175,3 +198,21 @@ def test_mask_pretraining_two_ranks_tracks_the_single_process_run(tmp_path):
     assert np.allclose(res[0][2], losses, rtol=2e-3), (res[0][2], losses)
     w = model.state_dict()["blocks.0.mlp.w2.weight"].cpu().numpy()
     assert np.abs(res[0][3] - w).max() <= 2e-2 * np.abs(w).max()
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs >= 2 GPUs")
+def test_bench_two_gpus_prints_one_line_with_comm():
+    """`python bench.py --gpus 2` starts its own two ranks over RCCL and rank 0 prints ONE JSON line (n_gpus 2, weak scaling,
+    the `comm` object that explains the all-reduce cost)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["comm"]["buckets"] >= 1 and rec["comm"]["bytes"] > 0
