@@ -704,14 +704,18 @@ __global__ __launch_bounds__(256, 4) void dec_attn_fwd_kernel(DecAttnFwdArgs p) 
                 m = fmaxf(m, __shfl_xor(m, 16, 64));
                 m = fmaxf(m, __shfl_xor(m, 32, 64));
                 const float nm = -m * sc;
-                float lsum = 0.f;
+                const f32x2 sc2 = {sc, sc}, nm2 = {nm, nm};
+                f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
                 for (int kt = 0; kt < MT; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], sc, nm));
-                        s[kt][r] = e; lsum += e;
+                    for (int r = 0; r < 4; r += 2) {          // packed fp32: two scores per v_pk_fma / v_pk_add (the kernel is VALU-issue bound)
+                        const f32x2 t = __builtin_elementwise_fma(f32x2{s[kt][r], s[kt][r + 1]}, sc2, nm2);
+                        const f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                        s[kt][r] = e[0]; s[kt][r + 1] = e[1];
+                        ls2 += e;
                     }
+                float lsum = ls2[0] + ls2[1];
                 lsum += __shfl_xor(lsum, 16, 64);
                 lsum += __shfl_xor(lsum, 32, 64);
                 const float inv = __builtin_amdgcn_rcpf(lsum);

@@ -34,6 +34,22 @@ extern "C" int hsimae_debug_phases_enc(unsigned long long* out, int reset) {
 #define HS_NT_B 0      /* u2 / dY copy / dx1 / dx1 copy */
 #endif
 
+// Forward kernel occupancy (round 3, profiles/r03_d_*): without the fp32 LDS copy of the panel (the residual is re-read from
+// L2 in the store loop) a workgroup needs 27 KB and four fit a CU: <128, 352> 59.3 -> 57.0 us, <64, 192> 87.4 -> 80.2 us.
+// Five per CU (96 registers) spills: 115 us.  -D overrides for A/B builds.
+#ifndef HS_MLP_XR_128
+#define HS_MLP_XR_128 0
+#endif
+#ifndef HS_MLP_XR_64
+#define HS_MLP_XR_64 0
+#endif
+#ifndef HS_MLP_WPCF_128
+#define HS_MLP_WPCF_128 4
+#endif
+#ifndef HS_MLP_WPCF_64
+#define HS_MLP_WPCF_64 4
+#endif
+
 namespace {
 
 constexpr int MH = 2, NTH = 256;
@@ -58,7 +74,8 @@ struct MG {
     static constexpr int LPR = D / 8;           // lanes per row in the wide layout
     static constexpr int KA = KSH > 6 ? 6 : KSH, KB = KSH - KA;
     // forward: the panel's fp32 copy (residual) is kept in LDS at D = 128 only; wider panels re-read x1 (L2-hot) instead
-    static constexpr bool KEEP_XR = D <= 128;
+    static constexpr bool KEEP_XR = (D == 128 && HS_MLP_XR_128) || (D == 64 && HS_MLP_XR_64);
+    static constexpr int WPCF = D == 128 ? HS_MLP_WPCF_128 : (D == 64 ? HS_MLP_WPCF_64 : WPC);   // forward kernel
     static constexpr int LDS_FWD_IMG = R * LU * 2 + 2 * R * LC * 2;
     static constexpr int LDS_FWD = (LDS_FWD_IMG > R * LX * 4 ? LDS_FWD_IMG : R * LX * 4) + (KEEP_XR ? R * LX * 4 : 0);
     static constexpr int LDS_BWD = 2 * R * LU * 2 + 3 * R * LC * 2;
@@ -152,7 +169,7 @@ struct EncMlpFwdArgs { const float* x1; const float* res2; float* x2; int M; Enc
 // 46-KB panel image) and the residual is added from an L2-hot re-read in the store loop, so a workgroup needs 36 KB of
 // LDS and ~150 registers: three workgroups per CU instead of two.
 template <int D, int HPE>
-__global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
+__global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     using G = MG<D, HPE>;
     constexpr int R = G::R;
     constexpr int LU = G::LU, LX = G::LX, NCH = G::NCH, KSD = G::KSD, LPR = G::LPR;
