@@ -41,9 +41,13 @@ BlkP resolve(const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk,
     return b;
 }
 // encoder blocks under precision = FP8 (the decoder's blocks never are)
+bool fp8_unfused();
 BlkP resolve_enc(const Geo& g, const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk, const WLayout& WL) {
     BlkP b = resolve(o, w, P, wpk, WL);
-    b.prec = g.prec;
+    // fp8 where it pays: K >= 512.  At d = 256 the MX GEMMs (A quantised while it is staged) are no faster than the bf16 ones
+    // (Large: 37.8 vs 37.2 ms per step with the attention-half linears in fp8, r03_k), at d = 128 every linear sits inside a
+    // fused bf16 kernel; HSIMAE_FP8_UNFUSED=1 forces the MX GEMMs at every width (tests of the generic path).
+    b.prec = (g.prec == HSIMAE_PREC_FP8 && (g.D >= 512 || fp8_unfused())) ? HSIMAE_PREC_FP8 : HSIMAE_PREC_BF16;
     return b;
 }
 
@@ -123,6 +127,15 @@ bool dec_split_enabled() {
     return !(e && e[0] == '0');
 }
 
+// precision = FP8 puts the MX e4m3 images on the linears that run as stand-alone GEMMs.  Where a fused bf16 kernel covers
+// the shape (the attention half at d = 128, the MLP half at d = 128 / 256) it is kept: the fused bf16 form beats the
+// layer-at-a-time fp8 form (round 2: Base 26.9 vs 19.4 ms, Large 44.1 vs 39.5 ms with every fused kernel switched off).
+// HSIMAE_FP8_UNFUSED=1 restores that all-fp8 layer-at-a-time schedule (tests of the generic fp8 path at small widths).
+bool fp8_unfused() {
+    const char* e = getenv("HSIMAE_FP8_UNFUSED");
+    return e && e[0] == '1';
+}
+
 // HSIMAE_FUSED_MLP=0 forces the layer-at-a-time MLP half of the encoder blocks
 bool fused_mlp_enabled(int d, int h) {
     const char* e = getenv("HSIMAE_FUSED_MLP");
@@ -164,9 +177,10 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
               const float* rs_m = nullptr) {
     GemmParams p = gp();
     const int dp = rup(d, 32);                        // storage width of the rows (plan.h Geo::Dp); the fused kernels need dp == d
-    const bool f8 = P.prec == HSIMAE_PREC_FP8;        // the linears on MX e4m3 images, layer at a time (no fused kernels)
+    const bool f8 = P.prec == HSIMAE_PREC_FP8;        // the stand-alone linears on MX e4m3 images
+    const bool f8u = f8 && fp8_unfused();             // ... and no fused kernel at all (HSIMAE_FP8_UNFUSED=1)
     auto w8 = [&](GemmParams& q, const BlkP::I8& a) { if (f8) { q.prec = HSIMAE_PREC_FP8; q.W8 = a.w; q.S8 = a.s; } };
-    if (!f8 && hs_attn_block_fusable(d, heads, Ts)) {
+    if (!f8u && hs_attn_block_fusable(d, heads, Ts)) {
         // LN1 + q|k|v + attention + projection + residual in one persistent kernel (attn.hip blk128_fwd_kernel)
         CK(hs_attn_block_fwd(x_in, P.n1w, P.n1b, P.qkv, P.bqkv, P.p, P.pb, b.u, b.qkv, b.o, b.lse, b.x1, rs_a, Ts, nsamples, mode,
                              len_l, s));
@@ -179,7 +193,7 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
     AttnParams a; std::memset(&a, 0, sizeof(a));
     a.qkv = b.qkv; a.ld = 3 * dp; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
     a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = dp; a.lse = b.lse; a.kv_off = dp;
-    if (!f8 && hs_attn_proj_fusable(a)) {     // proj + residual inside the attention kernel (x1 = x + o Wp^T + b)
+    if (!f8u && hs_attn_proj_fusable(a)) {    // proj + residual inside the attention kernel (x1 = x + o Wp^T + b)
         a.proj_w = P.p; a.proj_b = P.pb; a.xres = x_in; a.x1 = b.x1; a.rowscale = rs_a;
         CK(hs_attn_fwd(a, s));
     } else {
@@ -191,7 +205,7 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
         CK(hs_gemm(p, A_BF16, E_RES_F32, s));
     }
     }
-    if (!f8 && fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
+    if (!f8u && fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
     p = gp();
     p.A = b.x1; p.lda = dp; p.M = (int)M; p.N = hp; p.K = dp; p.n_valid = h; p.W = P.w1; p.W2 = P.w3; p.bias = P.w1b;
     p.bias2 = P.w3b; p.gamma = P.n2w; p.beta = P.n2b; p.u_out = b.u2; p.ldu = dp; p.out = b.g; p.ldo = hp;
@@ -230,8 +244,9 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
     l.M = (int)M; l.d = d; l.ld = dp; l.det_base = grads; l.det_acc = det_acc;
     const bool f8 = P.prec == HSIMAE_PREC_FP8;
+    const bool f8u = f8 && fp8_unfused();
     auto w8 = [&](GemmParams& q, const BlkP::I8& a) { if (f8) { q.prec = HSIMAE_PREC_FP8; q.W8 = a.w; q.S8 = a.s; } };
-    const bool fmlp = !f8 && fused_mlp_enabled(d, h);
+    const bool fmlp = !f8u && fused_mlp_enabled(d, h);
     if (fmlp) {
         // recompute u2 / h1 / h3 / g inside the tile; emits dx1 and the wgrad operands u2, dh1|dh3, g, bf16 dY and dx1
         CK(hs_enc_mlp_bwd(b.x1, G0, G1, b.u2, w.dh13, b.g, w.g0b, w.g1b, (int)M, d, mlp_ptrs(P, h), grads + o.n2w,
@@ -300,7 +315,7 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     // du never goes to HBM), two otherwise.  HSIMAE_FUSED_LNBWD=0 forces the two-kernel form.
     static int fuse_ln = -1;
     if (fuse_ln < 0) { const char* e = getenv("HSIMAE_FUSED_LNBWD"); fuse_ln = !(e && e[0] == '0'); }
-    const bool ln_fused = fuse_ln && ((d == 128 && !f8) || wide_ln_fused(d, dp, f8));
+    const bool ln_fused = fuse_ln && ((d == 128 && !f8u) || wide_ln_fused(d, dp, f8));
     p = gp();
     p.A = w.dqkv; p.lda = 3 * dp; p.M = (int)M; p.N = dp; p.K = 3 * dp; p.n_valid = d; p.W = P.qkvT;
     if (ln_fused) {

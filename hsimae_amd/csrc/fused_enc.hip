@@ -34,20 +34,21 @@ extern "C" int hsimae_debug_phases_enc(unsigned long long* out, int reset) {
 #define HS_NT_B 0      /* u2 / dY copy / dx1 / dx1 copy */
 #endif
 
-// Forward kernel occupancy (round 3, profiles/r03_d_*): without the fp32 LDS copy of the panel (the residual is re-read from
-// L2 in the store loop) a workgroup needs 27 KB and four fit a CU: <128, 352> 59.3 -> 57.0 us, <64, 192> 87.4 -> 80.2 us.
-// Five per CU (96 registers) spills: 115 us.  -D overrides for A/B builds.
+// Forward kernel occupancy knobs (round 3, profiles/r03_d_variants.txt).  Default: the panel's fp32 copy stays in LDS for the
+// residual (XR) and three workgroups share a CU.  Without the copy (residual re-read from L2 in the store loop) a workgroup
+// needs 27 KB and four fit: <128, 352> 59.3 -> 57.0 us, <64, 192> 87.4 -> 80.2 us per launch, i.e. 0.1 ms per step, for
+// +1.9 GB of fetches per step (the re-reads are counted at the fabric) — not adopted; five per CU (96 registers) spill: 115 us.
 #ifndef HS_MLP_XR_128
-#define HS_MLP_XR_128 0
+#define HS_MLP_XR_128 1
 #endif
 #ifndef HS_MLP_XR_64
-#define HS_MLP_XR_64 0
+#define HS_MLP_XR_64 1
 #endif
 #ifndef HS_MLP_WPCF_128
-#define HS_MLP_WPCF_128 4
+#define HS_MLP_WPCF_128 3
 #endif
 #ifndef HS_MLP_WPCF_64
-#define HS_MLP_WPCF_64 4
+#define HS_MLP_WPCF_64 3
 #endif
 
 namespace {

@@ -186,9 +186,12 @@ def test_huge_fp8_against_oracle(grid):
     assert res["fp8"][1] <= 0.12
 
 
-def test_fp8_training_steps_track_bf16():
-    """Five AdamW steps in fp8 stay on the bf16 trajectory (loss within 2e-3 at every step), Base width (the path is generic)."""
+def test_fp8_training_steps_track_bf16(monkeypatch):
+    """Five AdamW steps in fp8 stay on the bf16 trajectory (loss within 2e-3 at every step), Base width (the path is generic).
+    HSIMAE_FP8_UNFUSED=1: every encoder linear on the MX GEMMs, layer at a time — by default the d = 128 blocks keep their fused
+    bf16 kernels under precision = fp8 (they are faster than the unfused fp8 form) and this test would compare bf16 with bf16."""
     from hsimae_amd import FusedAdamW
+    monkeypatch.setenv("HSIMAE_FP8_UNFUSED", "1")
     losses = {}
     for prec in ("bf16", "fp8"):
         torch.manual_seed(0)
@@ -213,3 +216,24 @@ def test_fp8_training_steps_track_bf16():
     for a, b in zip(losses["bf16"], losses["fp8"]):
         assert abs(a - b) <= 2e-3 * abs(a), (losses["bf16"], losses["fp8"])
     assert losses["fp8"][-1] < losses["fp8"][0]
+    assert losses["fp8"] != losses["bf16"]                # the fp8 leg really ran other arithmetic
+
+
+def test_fp8_default_schedule_keeps_fused_kernels_at_base_width():
+    """precision = fp8 at d = 128: every linear sits inside a fused bf16 kernel, so the default schedule computes exactly what
+    bf16 computes (deterministic mode: bit-identical loss) — fp8 is never slower than bf16 at a width it is allowed on."""
+    out = {}
+    for prec in ("bf16", "fp8"):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=48, b_patch_size=8, embed_dim=128, depth=12, num_heads=8,
+                       s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8, norm_pix_loss=True, trunc_init=True)
+        m = m.to(DEV).set_precision(prec)
+        m.deterministic = True
+        g = torch.Generator().manual_seed(3)
+        x = torch.rand(16, 1, 48, 9, 9, generator=g).to(DEV)
+        nz = (torch.rand(16, 6, generator=g), torch.rand(16, 9, generator=g))
+        loss, _, _ = m(x, 0.75, noise=nz, grid=(2, 7))
+        loss.backward()
+        out[prec] = (loss.item(), dict(m.named_parameters())["blocks_1.3.mlp.w1.weight"].grad.clone())
+    assert out["bf16"][0] == out["fp8"][0] and torch.equal(out["bf16"][1], out["fp8"][1])
