@@ -1,5 +1,7 @@
 #!/bin/bash
 # usage (GPU box): gpu_step_traffic.sh <model> [bench args]: FETCH_SIZE / WRITE_SIZE passes of a 2-step bench run -> gpurun_out/step_traffic_<model>.json
+# (single stream, so that the kernel names match the single-stream kernel stats that scripts/kernel_table.py joins them with)
+export HSIMAE_TWO_STREAMS=0
 model=$1; shift
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -29,7 +29,8 @@ ws, wper = collect(write_dir, "WRITE_SIZE")
 total = (2 * fs + ws) * 1024 / steps
 kern = {k: round((2 * fper.get(k, 0) + wper.get(k, 0)) * 1024 / steps) for k in set(fper) | set(wper)}
 top = dict(sorted(kern.items(), key=lambda kv: -kv[1])[:12])
+allk = {k: v for k, v in sorted(kern.items(), key=lambda kv: -kv[1]) if v > 0 and not k.startswith(("void at::", "__amd"))}
 json.dump({"hbm_bytes_per_step": round(total), "fetch_kb_per_step": round(fs / steps), "write_kb_per_step": round(ws / steps),
            "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 over all dispatches / steps", "steps_profiled": steps, "source": label,
-           "top_kernels_bytes_per_step": top}, open(out, "w"), indent=1)
+           "top_kernels_bytes_per_step": top, "kernels_bytes_per_step": allk}, open(out, "w"), indent=1)
 print(json.dumps({"hbm_GB_per_step": round(total / 1e9, 3), "top": {k: round(v / 1e9, 3) for k, v in list(top.items())[:6]}}))
