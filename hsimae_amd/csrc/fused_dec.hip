@@ -1116,7 +1116,7 @@ __device__ __forceinline__ bf16x4 tr4(const bf16_t* a) {
 // is directly the B operand of dq^T += K^T dS^T.  dk^T / dv^T contract over queries and need the tile transposed:
 // P and dS go through a per-wave LDS tile (8-byte writes, one transpose read each) instead of a second
 // score/exp pass.  delta and logsumexp come precomputed, so nothing waits on a full row.
-// Masking: lse = 1e30 for rows past Ts (P = 0 for dead queries); only the last key tile masks its dead rows.
+// Masking: lse = 1e30 for rows past Ts (P = 0 for dead queries); every key tile that reaches past Ts masks its dead rows.
 template <int MT>
 __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb, const bf16_t* dOb, const float* lse_h,
                                               const float* dlt_h, bf16_t* T, int head, int Ts, const Geo4& q,
@@ -1167,7 +1167,10 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
 #else
             for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn));
 #endif
-            if (kt == MT - 1) {                 // only the last key tile can hold rows past Ts
+            // key tiles that reach past Ts (uniform test: at 108 tokens only the last one; at 72 tokens tile 4 is partly and
+            // tiles 5, 6 are wholly padding).  Rounds 1-2 masked the LAST tile only: 65..96-token sequences (64 / 72 / 80 bands)
+            // let padded keys into dq / dk / dv — found in round 3 by the 64-band case of test_fused_decoder_matches_layerwise_decoder.
+            if ((kt + 1) * 16 > Ts) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (kt * 16 + q.g * 4 + r >= Ts) pv[r] = 0.f;

@@ -248,7 +248,8 @@ def test_c2_full_size_properties_n4096():
     assert rms_rel(small, pred[:64]) < 1e-6
 
 
-@pytest.mark.parametrize("bands,grid", [(48, (2, 7)), (96, (3, 9)), (192, (6, 9))])
+# 64 / 80 bands: 72 / 90 decoder tokens on the 7-tile kernels — key tiles that are partly or wholly padding, fewer query tiles
+@pytest.mark.parametrize("bands,grid", [(48, (2, 7)), (96, (3, 9)), (192, (6, 9)), (64, (3, 6)), (80, (3, 7))])
 def test_fused_decoder_matches_layerwise_decoder(bands, grid):
     """The fused decoder-block kernels (fused_dec.hip) against the layer-at-a-time kernels, same inputs:
     forward loss / predictions and every gradient.  Both compute in bf16-operand / fp32-accumulate arithmetic;
@@ -347,6 +348,30 @@ def test_tiny_and_odd_batches_against_oracle(N):
     named = dict(m.named_parameters())
     for k in ("blocks_1.3.mlp.w1.weight", "blocks_2.0.attn.q.weight", "decoder_blocks.2.mlp.w2.weight", "patch_embed.proj.weight"):
         assert grad_err(named, ref_g, k) < 2e-2, k
+
+
+@pytest.mark.parametrize("bands,grid", [(64, (3, 6)), (80, (3, 7)), (32, (2, 4)), (16, (2, 2))])
+def test_sequence_lengths_with_padded_key_tiles_against_oracle(bands, grid):
+    """Decoder sequences of 72 / 90 tokens (on the 7-tile fused kernels: key tiles partly or wholly padding) and 36 / 18 tokens
+    (on the 4-tile ones) against the oracle: loss, masks and decoder / encoder gradients.  Rounds 1-2 masked only the last key
+    tile in the fused attention backward, which is right for the named configurations (54 and 108 tokens) only."""
+    cfg = O.OracleConfig(bands=bands)
+    state = O.init_state(cfg, seed=4, std=0.04)
+    m = build(cfg, state)
+    N = 12
+    g = torch.Generator().manual_seed(bands)
+    x = torch.rand(N, 1, bands, 9, 9, generator=g)
+    n1, n2 = torch.rand(N, bands // 8, generator=g), torch.rand(N, 9, generator=g)
+    ref_loss, _, ref_mask, ref_g = O.forward_backward(state, cfg, x, n1.numpy(), n2.numpy(), *grid)
+    loss, _, mask = m(x.to(DEV), 0.75, noise=(n1, n2), grid=grid)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(mask.cpu(), ref_mask)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-4 * ref_loss.item()
+    named = dict(m.named_parameters())
+    for k in ("decoder_blocks.0.norm1.bias", "decoder_blocks.0.attn.q.weight", "decoder_blocks.3.attn.v.weight",
+              "decoder_blocks.5.attn.proj.weight", "decoder_blocks.7.mlp.w1.weight", "decoder_embed.weight", "blocks.1.mlp.w2.weight"):
+        assert grad_err(named, ref_g, k) < 3e-2, (k, grad_err(named, ref_g, k))      # (18-token sequences: few rows per gradient)
 
 
 @pytest.mark.parametrize("bands,grid", [(48, (2, 7)), (96, (9, 3))])
