@@ -642,7 +642,11 @@ static int decoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
             dg.det = HsDet{grads, reinterpret_cast<long long*>(io->det_acc)};
             // MLP half then attention half, both persistent with the block's weight gradients held in registers
             // (measured equal to "row-tile kernel + wgrad operands through HBM" at d = 64, with 0.7 GB less traffic)
-            CK(hs_dec_block_bwd(xin, w.bd[i].x1, w.G0, w.G1, w.G0, w.bd[i].o, w.bd[i].lse, c.N, g.TL, dec_ptrs(bp, g.hdec), dg, s));
+            // HSIMAE_DEC_SLAB=0: commit the in-register weight gradients with float atomics (rounds 1-2) instead of slab + reduce
+            static int use_slab = -1;
+            if (use_slab < 0) { const char* e = getenv("HSIMAE_DEC_SLAB"); use_slab = !(e && e[0] == '0'); }
+            CK(hs_dec_block_bwd(xin, w.bd[i].x1, w.G0, w.G1, w.G0, w.bd[i].o, w.bd[i].lse, c.N, g.TL, dec_ptrs(bp, g.hdec), dg, s,
+                                use_slab ? w.slab : nullptr));
         } else {
             CK(block_bwd(bp, L.bd[i], grads, xin, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, w.G0, w.sc, w.G0, 0, s, 1, nullptr, nullptr,
                          io->det_acc));
@@ -752,7 +756,9 @@ int hsimae_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2
                        hs_bf16* dx1b, int32_t M, int32_t d, const hsimae_mlp_weights* w, float* g_n2w, float* g_n2b,
                        const float* rs_mlp, const float* rs_attn, void* stream) {
     if (M <= 0) return HSIMAE_OK;
-    if (!x1 || !dy || !dx1 || !u2 || !dh13 || !g || !dyb || !dx1b || !w || !g_n2w || !g_n2b) return HSIMAE_ENULL;
+    if (!x1 || !dy || !dx1 || !w || !g_n2w || !g_n2b) return HSIMAE_ENULL;
+    // operand outputs are optional as groups: {u2, dyb} and {dh13, g} (NULL = not written: the data path alone), dx1b on its own
+    if ((!u2) != (!dyb) || (!dh13) != (!g)) return HSIMAE_ENULL;
     if (!hs_enc_mlp_fused_supported(d, w->hidden)) return HSIMAE_EUNSUPPORTED;
     return hs_enc_mlp_bwd(x1, dy, dx1, u2, dh13, g, dyb, dx1b, M, d, mlp_from_abi(w), g_n2w, g_n2b, S(stream), rs_mlp, rs_attn);
 }

@@ -78,6 +78,9 @@ __device__ __forceinline__ float wave_max(float v) {
 struct HsDet { const float* base; long long* acc; };
 #define HS_DET_SCALE 17592186044416.0f         /* 2^44 */
 __device__ __forceinline__ void hs_gadd(const HsDet& d, float* ptr, float v) {
+#ifdef HS_EXP_NO_COMMIT        /* timing experiment: what the gradient commits (global float atomics) cost each kernel */
+    if (v != 12345.678f) return;
+#endif
     if (d.acc) {
         // NaN / Inf / out-of-range addends must not vanish in the integer sum (__float2ll_rn(NaN) = 0, large values
         // saturate): poison the fp32 slot instead — it was zero-filled before the backward and det_convert_kernel ADDS the

@@ -54,6 +54,12 @@ constexpr int LG = HPD + 8;
 constexpr int LX = D + 4;        // fp32 staging row stride (floats)
 constexpr int WRM = HPD * LU;    // one row-major [192][LU] bf16 weight image staged in LDS (elements)
 constexpr int NT_ = 512;         // threads per workgroup (8 waves: one attention head per wave)
+constexpr int kDwSlotsMlp = 72, kDwSlotsAttn = 32, kDwSlots = kDwSlotsMlp + kDwSlotsAttn;   // in-register dW values per thread
+// bias / LayerNorm gradient sums of a workgroup (second part of the slab, [workgroup][kVec]): offsets of the vectors
+// (w1b / w3b: one 192-wide partial per wave row wm = 0..3 of the 4 x 2 wave grid — four waves hold sums of the same column)
+constexpr int kVN2W = 0, kVN2B = 64, kVW2B = 128, kVW1B = 192, kVW3B = 960, kVN1W = 1728, kVN1B = 1792, kVPB = 1856, kVQB = 1920,
+              kVKB = 1984, kVVB = 2048, kVec = 2112;
+constexpr size_t kSlabTileFloats = (size_t)256 * kDwSlots * NT_;    // the vector part starts here
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -815,7 +821,8 @@ __device__ __forceinline__ float red8(float v) {
 }
 
 // Commit per-thread column partials (wide layout: thread owns columns 8*(tid&7)..+7) with one atomic per column.
-__device__ __forceinline__ void flush_wide(float* red /* [NT_][8] LDS */, const float* part, float* dst, const HsDet& det) {
+__device__ __forceinline__ void flush_wide(float* red /* [NT_][8] LDS */, const float* part, float* dst, const HsDet& det,
+                                           float* vec = nullptr /* this workgroup's slab vector: plain store instead of an atomic */) {
     lds_barrier();
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = part[e];
@@ -824,7 +831,7 @@ __device__ __forceinline__ void flush_wide(float* red /* [NT_][8] LDS */, const 
         const int c = threadIdx.x, c8 = c >> 3, e = c & 7;
         float s = 0.f;
         for (int t = c8; t < NT_; t += 8) s += red[t * 8 + e];
-        hs_gadd(det, dst + c, s);
+        if (vec) vec[c] = s; else hs_gadd(det, dst + c, s);
     }
 }
 
@@ -832,6 +839,7 @@ struct DecBwdMlpArgs {
     const float* x1; const float* dy; float* dx1; int nsamples, Ts; DecW w; const bf16_t *w2T, *w13T; const float *w1f, *w3f;
     float *g_n2w, *g_n2b, *g_w1w, *g_w1b, *g_w3w, *g_w3b, *g_w2w, *g_w2b;
     HsDet det;
+    float* slab;                 // NULL: weight-gradient tiles committed with atomics; else [workgroup][kSlots][512] partials (dec_dw_reduce_kernel)
 };
 
 template <int MT>
@@ -1070,9 +1078,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
     PH_FLUSH(8)
     // ---- commit
     float* red = XS;
-    flush_wide(red, dgam, p.g_n2w, p.det);
-    flush_wide(red, dbet, p.g_n2b, p.det);
-    flush_wide(red, db2, p.g_w2b, p.det);
+    float* vec = p.slab ? p.slab + kSlabTileFloats + (size_t)blockIdx.x * kVec : nullptr;
+    flush_wide(red, dgam, p.g_n2w, p.det, vec ? vec + kVN2W : nullptr);
+    flush_wide(red, dbet, p.g_n2b, p.det, vec ? vec + kVN2B : nullptr);
+    flush_wide(red, db2, p.g_w2b, p.det, vec ? vec + kVW2B : nullptr);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -1081,8 +1090,27 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
             b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
             const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
-            if (q.g == 0 && col < p.w.h) { hs_gadd(p.det, p.g_w1b + col, a); hs_gadd(p.det, p.g_w3b + col, b); }
+            if (q.g == 0 && col < p.w.h) {
+                if (vec) { vec[kVW1B + q.wm * HPD + col] = a; vec[kVW3B + q.wm * HPD + col] = b; }
+                else { hs_gadd(p.det, p.g_w1b + col, a); hs_gadd(p.det, p.g_w3b + col, b); }
+            }
         }
+    if (p.slab) {
+        // The 72 accumulator registers of every thread leave as 72 fully coalesced 2-KB rows of this workgroup's slab
+        // ([slot][thread]); dec_dw_reduce_kernel sums the workgroups and scatters into dW1 / dW3 / dW2 with the index map below.
+        // (Committed with float atomics — 16 x 16 fragments = four 64-byte segments per instruction, 36,864 per workgroup — the
+        // commit was 86 us of this kernel's 377: scripts/gpu_nocommit.sh.)
+        float* sl = p.slab + (size_t)blockIdx.x * kDwSlots * NT_ + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sl[(size_t)(((c * 3 + t) * 2 + k2) * 4 + r) * NT_] = accW[c][t][k2][r];
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -1221,6 +1249,7 @@ struct DecBwdAttnArgs {
     const float *qf, *kf, *vf, *pf;
     float *g_n1w, *g_n1b, *g_qw, *g_qb, *g_kw, *g_kb, *g_vw, *g_vb, *g_pw, *g_pb;
     HsDet det;
+    float* slab;                 // see DecBwdMlpArgs
 };
 
 template <int MT>
@@ -1497,9 +1526,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     PH_FLUSH(0)
     // ---- commit
     float* red = XS;
-    flush_wide(red, dgam, p.g_n1w, p.det);
-    flush_wide(red, dbet, p.g_n1b, p.det);
-    flush_wide(red, dbp, p.g_pb, p.det);
+    float* vec = p.slab ? p.slab + kSlabTileFloats + (size_t)blockIdx.x * kVec : nullptr;
+    flush_wide(red, dgam, p.g_n1w, p.det, vec ? vec + kVN1W : nullptr);
+    flush_wide(red, dbet, p.g_n1b, p.det, vec ? vec + kVN1B : nullptr);
+    flush_wide(red, dbp, p.g_pb, p.det, vec ? vec + kVPB : nullptr);
     {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1507,8 +1537,25 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
             const int col = q.wave * HD + q.g * 4 + r;
-            if (q.c16 == 0 && q.g < 2) { hs_gadd(p.det, p.g_qb + col, a); hs_gadd(p.det, p.g_kb + col, b); hs_gadd(p.det, p.g_vb + col, c); }
+            if (q.c16 == 0 && q.g < 2) {
+                if (vec) { vec[kVQB + col] = a; vec[kVKB + col] = b; vec[kVVB + col] = c; }
+                else { hs_gadd(p.det, p.g_qb + col, a); hs_gadd(p.det, p.g_kb + col, b); hs_gadd(p.det, p.g_vb + col, c); }
+            }
         }
+    }
+    if (p.slab) {                 // slots 72..103 of this workgroup's slab: accP[k2][r] then accQ[t][k2][r]
+        float* sl = p.slab + ((size_t)blockIdx.x * kDwSlots + kDwSlotsMlp) * NT_ + threadIdx.x;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sl[(size_t)(k2 * 4 + r) * NT_] = accP[k2][r];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sl[(size_t)(8 + (t * 2 + k2) * 4 + r) * NT_] = accQ[t][k2][r];
+        return;
     }
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
@@ -1524,6 +1571,82 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 hs_gadd(p.det, dst + (size_t)(nt * 16 + q.g * 4 + r) * D + ((q.wave & 1) * 2 + k2) * 16 + q.c16, accQ[t][k2][r]);
+    }
+}
+
+// Sums the workgroups' weight-gradient partials of one decoder block ([workgroup][slot][thread], written by the two
+// persistent backward kernels) and adds them into the block's dW tensors: workgroup = slot, thread = the committing thread
+// of the backward kernels (same index map as their atomic commits).  Reads are coalesced 2-KB rows; the sum runs in a fixed
+// order, so these gradients are bit-reproducible without the fixed-point shadow buffer.
+struct DecDwReduceArgs {
+    const float* slab; int nwg; int h;
+    float *g_w1w, *g_w3w, *g_w2w, *g_qw, *g_kw, *g_vw, *g_pw;
+    float *g_n2w, *g_n2b, *g_w2b, *g_w1b, *g_w3b, *g_n1w, *g_n1b, *g_pb, *g_qb, *g_kb, *g_vb;
+};
+// fixed-order sum of src[w * stride], w < nwg, with 16 loads in flight per thread (the kernel is a pure latency-bound gather)
+__device__ __forceinline__ float slab_sum(const float* src, size_t stride, int nwg) {
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    int w = 0;
+    for (; w + 16 <= nwg; w += 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += src[(size_t)(w + i) * stride];
+    }
+    for (; w < nwg; ++w) acc[0] += src[(size_t)w * stride];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < o; ++i) acc[i] += acc[i + o];
+    return acc[0];
+}
+__global__ __launch_bounds__(NT_) void dec_dw_reduce_kernel(DecDwReduceArgs p) {
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    if (slot >= kDwSlots) {                               // the bias / LayerNorm vectors: [workgroup][kVec]
+        // thread -> one output element: 9 vectors of 64 and 2 of 192 (w1b, w3b: four per-wave-row partials each) = 960 elements
+        const int e = (slot - kDwSlots) * NT_ + tid;
+        if (e >= 9 * D + 2 * HPD) return;
+        int which, c;
+        if (e < 3 * D) { which = e / D; c = e % D; }                               // n2w, n2b, w2b
+        else if (e < 3 * D + 2 * HPD) { which = 3 + (e - 3 * D) / HPD; c = (e - 3 * D) % HPD; }   // w1b, w3b
+        else { which = 5 + (e - 3 * D - 2 * HPD) / D; c = (e - 3 * D - 2 * HPD) % D; }           // n1w, n1b, pb, qb, kb, vb
+        const int off[11] = {kVN2W, kVN2B, kVW2B, kVW1B, kVW3B, kVN1W, kVN1B, kVPB, kVQB, kVKB, kVVB};
+        float* const dst[11] = {p.g_n2w, p.g_n2b, p.g_w2b, p.g_w1b, p.g_w3b, p.g_n1w, p.g_n1b, p.g_pb, p.g_qb, p.g_kb, p.g_vb};
+        int o = off[0];
+        float* d = dst[0];
+#pragma unroll
+        for (int i = 1; i < 11; ++i) if (which == i) { o = off[i]; d = dst[i]; }
+        const bool wide = which == 3 || which == 4;
+        if (wide && c >= p.h) return;                    // w1b / w3b: padded to 192, valid below the hidden width
+        const float* src = p.slab + kSlabTileFloats + o + c;
+        float v = slab_sum(src, kVec, p.nwg);
+        if (wide) { v += slab_sum(src + HPD, kVec, p.nwg); v += slab_sum(src + 2 * HPD, kVec, p.nwg); v += slab_sum(src + 3 * HPD, kVec, p.nwg); }
+        d[c] += v;
+        return;
+    }
+    const float v = slab_sum(p.slab + (size_t)slot * NT_ + tid, (size_t)kDwSlots * NT_, p.nwg);
+    const int lane = tid & 63, c16 = lane & 15, g = lane >> 4, wave = tid >> 6;
+    if (slot < kDwSlotsMlp) {
+        const int r = slot & 3, k2 = (slot >> 2) & 1, ct = slot >> 3, t = ct % 3, c = ct / 3;
+        const int nt12 = (wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
+        const int n = nt * 16 + g * 4 + r, k = ((wave & 1) * 2 + k2) * 16 + c16;
+        if (mat == 0) {                                   // dW2[d][h]: row n (model dim), column c*64 + k (hidden)
+            if (c * 64 + k < p.h) p.g_w2w[(size_t)n * p.h + c * 64 + k] += v;
+        } else {                                          // dW1 / dW3 [h][d]: row c*64 + n (hidden), column k
+            float* dst = mat == 1 ? p.g_w1w : p.g_w3w;
+            if (c * 64 + n < p.h) dst[(size_t)(c * 64 + n) * D + k] += v;
+        }
+    } else {
+        const int a = slot - kDwSlotsMlp;
+        if (a < 8) {                                      // accP[k2][r]
+            const int r = a & 3, k2 = a >> 2;
+            p.g_pw[(size_t)((wave >> 1) * 16 + g * 4 + r) * D + ((wave & 1) * 2 + k2) * 16 + c16] += v;
+        } else {                                          // accQ[t][k2][r]
+            const int b = a - 8, r = b & 3, k2 = (b >> 2) & 1, t = b >> 3;
+            const int nt12 = (wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
+            float* dst = mat == 0 ? p.g_qw : (mat == 1 ? p.g_kw : p.g_vw);
+            dst[(size_t)(nt * 16 + g * 4 + r) * D + ((wave & 1) * 2 + k2) * 16 + c16] += v;
+        }
     }
 }
 
@@ -1574,6 +1697,14 @@ int launch_bwd(const DecBwdMlpArgs& a, const DecBwdAttnArgs& b, hipStream_t s) {
     const int grid = a.nsamples < 256 ? a.nsamples : 256;      // persistent: one workgroup per CU
     hipLaunchKernelGGL((dec_bwd_mlp_kernel<MT>), dim3(grid), dim3(NT_), LDS_A, s, a);
     hipLaunchKernelGGL((dec_bwd_attn_kernel<MT>), dim3(grid), dim3(NT_), LDS_B, s, b);
+    if (a.slab) {
+        DecDwReduceArgs r;
+        r.slab = a.slab; r.nwg = grid; r.h = a.w.h;
+        r.g_w1w = a.g_w1w; r.g_w3w = a.g_w3w; r.g_w2w = a.g_w2w; r.g_qw = b.g_qw; r.g_kw = b.g_kw; r.g_vw = b.g_vw; r.g_pw = b.g_pw;
+        r.g_n2w = a.g_n2w; r.g_n2b = a.g_n2b; r.g_w2b = a.g_w2b; r.g_w1b = a.g_w1b; r.g_w3b = a.g_w3b;
+        r.g_n1w = b.g_n1w; r.g_n1b = b.g_n1b; r.g_pb = b.g_pb; r.g_qb = b.g_qb; r.g_kb = b.g_kb; r.g_vb = b.g_vb;
+        hipLaunchKernelGGL(dec_dw_reduce_kernel, dim3(kDwSlots + (9 * D + 2 * HPD + NT_ - 1) / NT_), dim3(NT_), 0, s, r);
+    }
     return (int)hipGetLastError();
 }
 
@@ -1583,7 +1714,8 @@ bool hs_dec_fused_supported(int d, int heads, int hidden, int Ts) {
 }
 
 int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o,
-                     const float* lse, int nsamples, int Ts, const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s) {
+                     const float* lse, int nsamples, int Ts, const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s,
+                     float* slab) {
     DecW w;
     w.n1w = bp.n1w; w.n1b = bp.n1b; w.bqkv = bp.bqkv; w.pb = bp.pb; w.n2w = bp.n2w; w.n2b = bp.n2b;
     w.w1b = bp.w1b; w.w3b = bp.w3b; w.w2b = bp.w2b;
@@ -1592,12 +1724,12 @@ int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx
     a.x1 = x1; a.dy = dy; a.dx1 = dx1_tmp; a.nsamples = nsamples; a.Ts = Ts; a.w = w; a.w2T = bp.w2T; a.w13T = bp.w13T;
     a.w1f = bp.w1f; a.w3f = bp.w3f;
     a.g_n2w = g.n2w; a.g_n2b = g.n2b; a.g_w1w = g.w1w; a.g_w1b = g.w1b; a.g_w3w = g.w3w; a.g_w3b = g.w3b;
-    a.g_w2w = g.w2w; a.g_w2b = g.w2b; a.det = g.det;
+    a.g_w2w = g.w2w; a.g_w2b = g.w2b; a.det = g.det; a.slab = slab;
     DecBwdAttnArgs b;
     b.x = x; b.dx1 = dx1_tmp; b.dx = dx; b.o = o; b.lse_g = lse; b.nsamples = nsamples; b.Ts = Ts; b.w = w; b.qkvT = bp.qkvT; b.pT = bp.pT;
     b.qf = bp.qf; b.kf = bp.kf; b.vf = bp.vf; b.pf = bp.pf;
     b.g_n1w = g.n1w; b.g_n1b = g.n1b; b.g_qw = g.qw; b.g_qb = g.qb; b.g_kw = g.kw; b.g_kb = g.kb; b.g_vw = g.vw;
-    b.g_vb = g.vb; b.g_pw = g.pw; b.g_pb = g.pb; b.det = g.det;
+    b.g_vb = g.vb; b.g_pw = g.pw; b.g_pb = g.pb; b.det = g.det; b.slab = slab;
     const int mt = (Ts + 15) / 16;
     if (mt <= 4) return launch_bwd<4>(a, b, s);
     if (mt <= 7) return launch_bwd<7>(a, b, s);

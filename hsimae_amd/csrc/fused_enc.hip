@@ -394,7 +394,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
             }
             const bf16x8 dyb8 = cvt8(dyv);
             *reinterpret_cast<bf16x8*>(DYb + row * LU + c8) = dyb8;
-            if (ok) {
+            if (ok && p.u2) {                     // (NULL operands: data path only — the caller takes its weight gradients elsewhere)
                 HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.u2 + (size_t)(row0 + row) * D + c8), ub);     // wgrad operands
                 HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.dyb + (size_t)(row0 + row) * D + c8), dyb8);
             }
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
         wa.load(w.w13T, 2 * KSH, q.wave * NJO, 2 * c, D / 16, q.lane);
         wb.load(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * c, D / 16, q.lane);
         // weight-gradient operands of this chunk to HBM (row-contiguous 16-B stores), columns < 352 only
-        {
+        if (p.dh13) {
             const int ncol = (c * 64 + 64 <= HPE) ? 64 : HPE - c * 64;       // 64 or 32
             for (int pc = threadIdx.x; pc < R * 8; pc += NTH) {
                 const int row = pc >> 3, k8 = (pc & 7) * 8;
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] *= rs;
                 }
-                HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.dx1b + (size_t)(row0 + row) * D + c8), cvt8(o));
+                if (p.dx1b) HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.dx1b + (size_t)(row0 + row) * D + c8), cvt8(o));
             }
         }
     }

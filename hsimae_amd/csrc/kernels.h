@@ -62,8 +62,11 @@ bool hs_dec_fused_supported(int d, int heads, int hidden, int Ts);
 int hs_dec_block_fwd(const float* x, float* x1, float* x2, hs_bf16* o, float* lse, int nsamples, int Ts,
                      const DecBlockPtrs& bp, hipStream_t s);
 int hs_dec_attn_fwd(const float* x, float* x1, hs_bf16* o, float* lse, int nsamples, int Ts, const DecBlockPtrs& bp, hipStream_t s);
+// slab: NULL = the block's gradients are committed with float atomics; else >= 256 * (104 * 512 + 2112) floats of scratch
+// (plan.h kSlabBytes): per-workgroup partials, summed into the gradients by one reduce launch per block
 int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o,
-                     const float* lse, int nsamples, int Ts, const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s);
+                     const float* lse, int nsamples, int Ts, const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s,
+                     float* slab = nullptr);
 
 // ------------------------------------------------------------------ fused_enc.hip (MLP half of an encoder Block, D = 128)
 struct EncMlpPtrs {

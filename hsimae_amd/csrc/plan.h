@@ -211,8 +211,12 @@ struct Ws {
     std::vector<BlkBuf> b1, b2, bf, bd;
     hs_bf16* lat; float* y; float* yfull; hs_bf16* zn; float* pred; hs_bf16* dpred; float* partial;
     float *G0, *G1, *G2, *du; hs_bf16 *dh13, *dob, *dqkv, *dyb;
+    float* slab;                      // weight-gradient partials of the persistent kernels: [workgroup][slot][thread] (kSlabBytes)
     int64_t bytes;
 };
+// 256 workgroups x (72 + 32 accumulator registers per thread: fused decoder MLP / attention backward) x 512 threads x 4 B,
+// then 256 x 2112 floats of bias / LayerNorm gradient sums (fused_dec.hip kDwSlots, kVec)
+constexpr int64_t kSlabBytes = 256ll * 104 * 512 * 4 + 256ll * 2112 * 4;
 
 inline void carve(const Geo& g, int N, int K, char* base, Ws& w) {
     int64_t cur = 0;
@@ -253,6 +257,7 @@ inline void carve(const Geo& g, int N, int K, char* base, Ws& w) {
     w.sc2.dqkv = (hs_bf16*)take(Me * g.Dp * 3 * 2);
     w.sc.g0b = (hs_bf16*)take(gmax * 2); w.sc.g1b = (hs_bf16*)take(gmax * 2);     // (also decoder rows on the layer-at-a-time path)
     w.sc2.g0b = (hs_bf16*)take(Me * g.Dp * 2); w.sc2.g1b = (hs_bf16*)take(Me * g.Dp * 2);
+    w.slab = (float*)take(kSlabBytes);
     w.bytes = cur;
 }
 
