@@ -1603,8 +1603,10 @@ __device__ __forceinline__ float slab_sum(const float* src, size_t stride, int n
 __global__ __launch_bounds__(NT_) void dec_dw_reduce_kernel(DecDwReduceArgs p) {
     const int slot = blockIdx.x, tid = threadIdx.x;
     if (slot >= kDwSlots) {                               // the bias / LayerNorm vectors: [workgroup][kVec]
-        // thread -> one output element: 9 vectors of 64 and 2 of 192 (w1b, w3b: four per-wave-row partials each) = 960 elements
-        const int e = (slot - kDwSlots) * NT_ + tid;
+        // the bias / LayerNorm vectors: one WAVE per output element (9 vectors of 64 and 2 of 192 = 960 elements, 8 per
+        // workgroup): its 64 lanes split the workgroups' partials (w1b / w3b: x 4 per-wave-row partials), then a fixed-order
+        // lane tree — a thread per element walked up to 1,024 partials alone and was the launch's 35-us tail
+        const int e = (slot - kDwSlots) * (NT_ / 64) + (tid >> 6), lane = tid & 63;
         if (e >= 9 * D + 2 * HPD) return;
         int which, c;
         if (e < 3 * D) { which = e / D; c = e % D; }                               // n2w, n2b, w2b
@@ -1619,9 +1621,13 @@ __global__ __launch_bounds__(NT_) void dec_dw_reduce_kernel(DecDwReduceArgs p) {
         const bool wide = which == 3 || which == 4;
         if (wide && c >= p.h) return;                    // w1b / w3b: padded to 192, valid below the hidden width
         const float* src = p.slab + kSlabTileFloats + o + c;
-        float v = slab_sum(src, kVec, p.nwg);
-        if (wide) { v += slab_sum(src + HPD, kVec, p.nwg); v += slab_sum(src + 2 * HPD, kVec, p.nwg); v += slab_sum(src + 3 * HPD, kVec, p.nwg); }
-        d[c] += v;
+        float v = 0.f;
+        for (int w = lane; w < p.nwg; w += 64) {
+            const float* q = src + (size_t)w * kVec;
+            v += wide ? (q[0] + q[HPD]) + (q[2 * HPD] + q[3 * HPD]) : q[0];
+        }
+        v = wave_sum(v);
+        if (lane == 0) d[c] += v;
         return;
     }
     const float v = slab_sum(p.slab + (size_t)slot * NT_ + tid, (size_t)kDwSlots * NT_, p.nwg);
@@ -1703,7 +1709,7 @@ int launch_bwd(const DecBwdMlpArgs& a, const DecBwdAttnArgs& b, hipStream_t s) {
         r.g_w1w = a.g_w1w; r.g_w3w = a.g_w3w; r.g_w2w = a.g_w2w; r.g_qw = b.g_qw; r.g_kw = b.g_kw; r.g_vw = b.g_vw; r.g_pw = b.g_pw;
         r.g_n2w = a.g_n2w; r.g_n2b = a.g_n2b; r.g_w2b = a.g_w2b; r.g_w1b = a.g_w1b; r.g_w3b = a.g_w3b;
         r.g_n1w = b.g_n1w; r.g_n1b = b.g_n1b; r.g_pb = b.g_pb; r.g_qb = b.g_qb; r.g_kb = b.g_kb; r.g_vb = b.g_vb;
-        hipLaunchKernelGGL(dec_dw_reduce_kernel, dim3(kDwSlots + (9 * D + 2 * HPD + NT_ - 1) / NT_), dim3(NT_), 0, s, r);
+        hipLaunchKernelGGL(dec_dw_reduce_kernel, dim3(kDwSlots + (9 * D + 2 * HPD + NT_ / 64 - 1) / (NT_ / 64)), dim3(NT_), 0, s, r);
     }
     return (int)hipGetLastError();
 }
