@@ -306,6 +306,9 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     task(w.dh13 + hp, 0, 2 * hp, b.u2, dp, h, d, o.w3w, o.w3b);
     task(w.g0b, 0, dp, b.g, hp, d, h, o.w2w, o.w2b);
     g.M = (int)M; g.det_base = grads; g.det_acc = det_acc;
+    static int wslab = -1;                    // HSIMAE_WGRAD_SLAB=0: float atomics on dW also in the 256 x 256-tile launches
+    if (wslab < 0) { const char* e = getenv("HSIMAE_WGRAD_SLAB"); wslab = !(e && e[0] == '0'); }
+    g.slab = wslab ? w.slab : nullptr;        // this stream's slab
     int tiles = 0;
     for (int i = 0; i < g.ntasks; ++i) tiles += ((g.t[i].N + 127) / 128) * ((g.t[i].K + 127) / 128);
     g.msplit = wgrad_msplit(tiles, M, concurrent);

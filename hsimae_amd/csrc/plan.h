@@ -203,7 +203,7 @@ inline void pack_descs(const Geo& g, const PLayout& L, const WLayout& W, const f
 // ------------------------------------------------------------------ workspace
 struct BlkBuf { hs_bf16* u; hs_bf16* qkv; float* lse; hs_bf16* o; float* x1; hs_bf16* u2; hs_bf16* h13; hs_bf16* g; float* x2; };
 
-struct Scr { float* G1; float* du; hs_bf16* dh13; hs_bf16* dob; hs_bf16* dqkv; hs_bf16* g0b; hs_bf16* g1b; };   // per-stream backward scratch (g0b/g1b: bf16 dY / dx1)
+struct Scr { float* G1; float* du; hs_bf16* dh13; hs_bf16* dob; hs_bf16* dqkv; hs_bf16* g0b; hs_bf16* g1b; float* slab; };   // per-stream backward scratch (g0b/g1b: bf16 dY / dx1; slab: weight-gradient partials)
 
 struct Ws {
     Scr sc, sc2;                      // sc2: encoder-sized second set for the side stream (spectral stack)
@@ -214,9 +214,9 @@ struct Ws {
     float* slab;                      // weight-gradient partials of the persistent kernels: [workgroup][slot][thread] (kSlabBytes)
     int64_t bytes;
 };
-// 256 workgroups x (72 + 32 accumulator registers per thread: fused decoder MLP / attention backward) x 512 threads x 4 B,
-// then 256 x 2112 floats of bias / LayerNorm gradient sums (fused_dec.hip kDwSlots, kVec)
-constexpr int64_t kSlabBytes = 256ll * 104 * 512 * 4 + 256ll * 2112 * 4;
+// One slab per stream (kSlabBytes each).  Largest user: the 256 x 256-tile weight-gradient launch, 256 workgroups x 256 KB;
+// the fused decoder's backward needs 256 x (104 x 512 + 2112) floats (fused_dec.hip kDwSlots, kVec) of the first one.
+constexpr int64_t kSlabBytes = 256ll * 256 * 256 * 4;
 
 inline void carve(const Geo& g, int N, int K, char* base, Ws& w) {
     int64_t cur = 0;
@@ -258,6 +258,7 @@ inline void carve(const Geo& g, int N, int K, char* base, Ws& w) {
     w.sc.g0b = (hs_bf16*)take(gmax * 2); w.sc.g1b = (hs_bf16*)take(gmax * 2);     // (also decoder rows on the layer-at-a-time path)
     w.sc2.g0b = (hs_bf16*)take(Me * g.Dp * 2); w.sc2.g1b = (hs_bf16*)take(Me * g.Dp * 2);
     w.slab = (float*)take(kSlabBytes);
+    w.sc.slab = w.slab; w.sc2.slab = (float*)take(kSlabBytes);
     w.bytes = cur;
 }
 

@@ -291,6 +291,7 @@ __global__ __launch_bounds__(WT<BIG>::NTHR) void wgrad_dma_kernel(WgradParams p)
         if (!decode_wg(p, tiles, w, ms)) return;
     }
     const HsDet det{p.det_base, reinterpret_cast<long long*>(p.det_acc)};
+    const int w0 = w;                          // tile index of the launch (slab addressing)
     int ti = 0, ns = 0, ks = 0;
     for (; ti < p.ntasks; ++ti) {
         const int nsl = (p.t[ti].N + T - 1) / T, ksl = (p.t[ti].K + T - 1) / T;
@@ -387,6 +388,17 @@ __global__ __launch_bounds__(WT<BIG>::NTHR) void wgrad_dma_kernel(WgradParams p)
     }
 
     const int c16 = lane & 15, g = lane >> 4;
+    if (BIG && p.slab) {
+        // this workgroup's partial tile as NF * 8 * 4 coalesced 2-KB rows of its slab: [row slice ms][tile][slot][thread];
+        // wgrad_slab_reduce_kernel sums the row slices and scatters with the index map of the atomic commit below
+        float* sl = p.slab + ((size_t)(ms * tiles + (w0)) * (NF * 32)) * G::NTHR + tid;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sl[(size_t)((i * 8 + j) * 4 + r) * G::NTHR] = acc[i][j][r];
+    } else {
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
@@ -397,6 +409,7 @@ __global__ __launch_bounds__(WT<BIG>::NTHR) void wgrad_dma_kernel(WgradParams p)
                 const int k = k0 + wk * 128 + j * 16 + c16;
                 if (n < t.N && k < t.K) hs_gadd(det, t.dW + (size_t)n * t.ldw + k, acc[i][j][r]);
             }
+    }
     if (want_bias && c16 == 0) {
 #pragma unroll
         for (int i = 0; i < NF; ++i)
@@ -406,6 +419,39 @@ __global__ __launch_bounds__(WT<BIG>::NTHR) void wgrad_dma_kernel(WgradParams p)
                 if (n < t.N) hs_gadd(det, t.db + n, accb[i][r]);
             }
     }
+}
+
+// Sums the row slices' partial 256 x 256 tiles ([row slice][tile][slot][thread], wgrad_dma_kernel<DS, true> with p.slab) in a
+// fixed order and adds them into dW: workgroup = (tile, slot), thread = the committing thread of the main kernel.
+__global__ __launch_bounds__(512) void wgrad_slab_reduce_kernel(WgradParams p) {
+    constexpr int T = 256, NF = 4, NTHR = 512;
+    const int tiles = wg_tiles(p, T);
+    const int slot = blockIdx.x % (NF * 32);
+    int w = blockIdx.x / (NF * 32);
+    const int w0 = w;
+    int ti = 0, ns = 0, ks = 0;
+    for (; ti < p.ntasks; ++ti) {
+        const int nsl = (p.t[ti].N + T - 1) / T, ksl = (p.t[ti].K + T - 1) / T;
+        if (w < nsl * ksl) { ns = w / ksl; ks = w % ksl; break; }
+        w -= nsl * ksl;
+    }
+    if (ti >= p.ntasks) return;
+    const WgradTask& t = p.t[ti];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c16 = lane & 15, g = lane >> 4;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int r = slot & 3, j = (slot >> 2) & 7, i = slot >> 5;
+    const int n = ns * T + (wn * NF + i) * 16 + g * 4 + r, k = ks * T + wk * 128 + j * 16 + c16;
+    if (n >= t.N || k >= t.K) return;
+    const float* src = p.slab + ((size_t)w0 * (NF * 32) + slot) * NTHR + tid;
+    const size_t stride = (size_t)tiles * (NF * 32) * NTHR;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int m = 0;
+    for (; m + 4 <= p.msplit; m += 4) {
+        a0 += src[(size_t)m * stride]; a1 += src[(size_t)(m + 1) * stride];
+        a2 += src[(size_t)(m + 2) * stride]; a3 += src[(size_t)(m + 3) * stride];
+    }
+    for (; m < p.msplit; ++m) a0 += src[(size_t)m * stride];
+    t.dW[(size_t)n * t.ldw + k] += (a0 + a1) + (a2 + a3);
 }
 
 }  // namespace
@@ -446,8 +492,13 @@ int hs_wgrad(const WgradParams& p, hipStream_t s) {
         q.msplit = std::max(1, std::min(wgs / std::max(1, t256), nchunks));
         const int total = t256 * q.msplit;
         const dim3 grid(8 * ((total + 7) / 8));
+        // slab + reduce pays where many row slices meet in one tile (Large: 13 tiles x 19 slices, 264 -> 196 us of atomics out,
+        // 35.70 -> 35.27 ms per step); with few slices per tile (Huge: 52 tiles x 4) the atomics are uncontended and the extra
+        // 64 MB pass costs more than it saves (48.86 -> 49.06 ms): atomics there
+        if (total > 256 || q.msplit < 8) q.slab = nullptr;
         if (ds_env == 3) hipLaunchKernelGGL((wgrad_dma_kernel<3, true>), grid, dim3(512), 3 * WT<true>::STAGE_ELEMS * 2, s, q);
         else hipLaunchKernelGGL((wgrad_dma_kernel<4, true>), grid, dim3(512), 4 * WT<true>::STAGE_ELEMS * 2, s, q);
+        if (q.slab) hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(t256 * 128), dim3(512), 0, s, q);
         return (int)hipGetLastError();
     }
     const dim3 grid((p.msplit & 7) == 0 ? 8 * tiles * (p.msplit / 8) : 8 * ((tiles + 7) / 8) * p.msplit);      // decode_wg

@@ -280,6 +280,11 @@ typedef struct {
 typedef struct {
     hsimae_wgrad_task t[8]; int32_t ntasks; int32_t M; int32_t msplit;
     const float* det_base; int64_t* det_acc;      /* deterministic dW / db commits, as in hsimae_lnbwd_params; NULL = fp32 atomics */
+    /* optional scratch of >= 64 MiB (256 workgroups x 256 x 256 floats), private to the calling stream: a launch on 256 x 256
+       tiles then writes every workgroup's partial dW tile there as coalesced rows and a second launch sums the row slices in
+       a fixed order and adds them into dW — no float atomics on dW (they are ~6x slower per byte than stores, and with every
+       workgroup committing at once were 26 % of the launch at d = 256), bit-reproducible.  NULL = atomics. */
+    float* slab;
 } hsimae_wgrad_params;
 int hsimae_wgrad(const hsimae_wgrad_params* p, void* stream);
 /* The row split (msplit) hsimae_backward uses for a launch of `tiles` 128x128 dW tiles over M rows: one resident

@@ -13,7 +13,7 @@ for flags in "" "-DHS_EXP_NO_COMMIT"; do
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o hsimae_amd/libhsimae_hip.so $objs
   d=/tmp/nc_$RANDOM
-  (cd /tmp && TMPDIR=/tmp HSIMAE_TWO_STREAMS=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 2 --no-extras --no-cpu-baseline >/dev/null 2>&1)
+  (cd /tmp && TMPDIR=/tmp HSIMAE_TWO_STREAMS=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 "$GRAFT_REPO_ROOT/bench.py" $HS_BENCH_ARGS --steps 3 --warmup 2 --no-extras --no-cpu-baseline >/dev/null 2>&1)
   echo "[$flags]"; python3 - "$d" "$pat" <<'P'
 import csv, glob, re, sys
 f = glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv")
