@@ -370,7 +370,7 @@ int make_ctx(const hsimae_config* cfg, const hsimae_io* io, Ctx& c, bool need_ws
 // ====================================================================== C ABI
 extern "C" {
 
-int hsimae_version(void) { return 101; }
+int hsimae_version(void) { return 102; }
 
 int hsimae_two_streams_active(void) { return side().ok ? 1 : 0; }
 
