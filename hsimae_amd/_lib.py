@@ -72,6 +72,16 @@ class MlpWeights(C.Structure):
                 ("w1", vp), ("w3", vp), ("w2", vp), ("w2T", vp), ("w13T", vp), ("hidden", i32)]
 
 
+class DecBlockWeights(C.Structure):
+    _fields_ = [(n, vp) for n in ("n1w", "n1b", "bqkv", "pb", "n2w", "n2b", "w1b", "w3b", "w2b", "qkv", "p", "w1", "w3", "w2", "w2T",
+                                  "qf", "kf", "vf", "pf", "w1f", "w3f")] + [("hidden", i32)]
+
+
+class DecBlockGrads(C.Structure):
+    _fields_ = [(n, vp) for n in ("n1w", "n1b", "qw", "qb", "kw", "kb", "vw", "vb", "pw", "pb", "n2w", "n2b", "w1w", "w1b", "w2w",
+                                  "w2b", "w3w", "w3b")]
+
+
 class WgradTask(C.Structure):
     _fields_ = [("dO", vp), ("dO_f32", i32), ("ldo", i32), ("A", vp), ("lda", i32), ("N", i32), ("K", i32),
                 ("dW", vp), ("ldw", i32), ("db", vp), ("dO_rowscale", vp)]
@@ -126,6 +136,8 @@ SYMBOLS = {
     "hsimae_pack_matrix": (C.c_int, [vp, i32, i32, vp]),
     "hsimae_enc_mlp_fwd": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(MlpWeights), vp, vp]),
     "hsimae_enc_mlp_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(MlpWeights), vp, vp, vp, vp, vp]),
+    "hsimae_dec_block_fwd": (C.c_int, [C.POINTER(DecBlockWeights), vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "hsimae_dec_block_bwd": (C.c_int, [C.POINTER(DecBlockWeights), C.POINTER(DecBlockGrads), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "hsimae_attn_fwd": (C.c_int, [C.POINTER(AttnParams), vp]),
     "hsimae_attn_bwd": (C.c_int, [C.POINTER(AttnParams), vp]),
     "hsimae_wgrad": (C.c_int, [C.POINTER(WgradParams), vp]),

@@ -370,7 +370,7 @@ int make_ctx(const hsimae_config* cfg, const hsimae_io* io, Ctx& c, bool need_ws
 // ====================================================================== C ABI
 extern "C" {
 
-int hsimae_version(void) { return 102; }
+int hsimae_version(void) { return 103; }
 
 int hsimae_two_streams_active(void) { return side().ok ? 1 : 0; }
 
@@ -764,6 +764,41 @@ int hsimae_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2
     if ((!u2) != (!dyb) || (!dh13) != (!g)) return HSIMAE_ENULL;
     if (!hs_enc_mlp_fused_supported(d, w->hidden)) return HSIMAE_EUNSUPPORTED;
     return hs_enc_mlp_bwd(x1, dy, dx1, u2, dh13, g, dyb, dx1b, M, d, mlp_from_abi(w), g_n2w, g_n2b, S(stream), rs_mlp, rs_attn);
+}
+static DecBlockPtrs dec_from_abi(const hsimae_dec_block_weights* w) {
+    DecBlockPtrs d; std::memset(&d, 0, sizeof(d));
+    d.n1w = w->n1w; d.n1b = w->n1b; d.bqkv = w->bqkv; d.pb = w->pb; d.n2w = w->n2w; d.n2b = w->n2b;
+    d.w1b = w->w1b; d.w3b = w->w3b; d.w2b = w->w2b;
+    d.qkv = w->qkv; d.p = w->p; d.w1 = w->w1; d.w3 = w->w3; d.w2 = w->w2; d.w2T = w->w2T;
+    d.qf = w->qf; d.kf = w->kf; d.vf = w->vf; d.pf = w->pf; d.w1f = w->w1f; d.w3f = w->w3f; d.h = w->hidden;
+    return d;
+}
+int hsimae_dec_block_fwd(const hsimae_dec_block_weights* w, const float* x, float* x1, float* x2, hs_bf16* o, float* lse,
+                         int32_t nsamples, int32_t Ts, int32_t split, void* stream) {
+    if (nsamples <= 0) return HSIMAE_OK;
+    if (!w || !x || !x1 || !x2 || !o || !lse) return HSIMAE_ENULL;
+    if (!hs_dec_fused_supported(64, 8, w->hidden, Ts)) return HSIMAE_EUNSUPPORTED;
+    const DecBlockPtrs d = dec_from_abi(w);
+    if (split) {
+        CK(hs_dec_attn_fwd(x, x1, o, lse, nsamples, Ts, d, S(stream)));
+        EncMlpPtrs m;
+        m.n2w = d.n2w; m.n2b = d.n2b; m.w1b = d.w1b; m.w3b = d.w3b; m.w2b = d.w2b;
+        m.w1 = d.w1; m.w3 = d.w3; m.w2 = d.w2; m.w2T = d.w2T; m.w13T = nullptr; m.h = d.h;
+        return hs_enc_mlp_fwd(x1, nullptr, x2, nsamples * Ts, 64, m, S(stream));
+    }
+    return hs_dec_block_fwd(x, x1, x2, o, lse, nsamples, Ts, d, S(stream));
+}
+int hsimae_dec_block_bwd(const hsimae_dec_block_weights* w, const hsimae_dec_block_grads* g, const float* x, const float* x1,
+                         const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o, const float* lse, int32_t nsamples,
+                         int32_t Ts, float* slab, void* stream) {
+    if (nsamples <= 0) return HSIMAE_OK;
+    if (!w || !g || !x || !x1 || !dy || !dx1_tmp || !dx || !o || !lse) return HSIMAE_ENULL;
+    if (!hs_dec_fused_supported(64, 8, w->hidden, Ts)) return HSIMAE_EUNSUPPORTED;
+    DecBlockGrads dg;
+    dg.n1w = g->n1w; dg.n1b = g->n1b; dg.qw = g->qw; dg.qb = g->qb; dg.kw = g->kw; dg.kb = g->kb; dg.vw = g->vw; dg.vb = g->vb;
+    dg.pw = g->pw; dg.pb = g->pb; dg.n2w = g->n2w; dg.n2b = g->n2b; dg.w1w = g->w1w; dg.w1b = g->w1b; dg.w2w = g->w2w;
+    dg.w2b = g->w2b; dg.w3w = g->w3w; dg.w3b = g->w3b; dg.det = HsDet{nullptr, nullptr};
+    return hs_dec_block_bwd(x, x1, dy, dx1_tmp, dx, o, lse, nsamples, Ts, dec_from_abi(w), dg, S(stream), slab);
 }
 int hsimae_attn_fwd(const hsimae_attn_params* p, void* stream) { return p ? hs_attn_fwd(*p, S(stream)) : HSIMAE_ENULL; }
 int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream) { return p ? hs_attn_bwd(*p, S(stream)) : HSIMAE_ENULL; }

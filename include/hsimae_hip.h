@@ -265,6 +265,32 @@ typedef struct {
 int hsimae_attn_fwd(const hsimae_attn_params* p, void* stream);
 int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream);
 
+/* One fused decoder Block (Models.py:303-306 at width 64, 8 heads of 8, SwiGLU hidden <= 192; sequences of 16..112 tokens),
+   as hsimae_forward / hsimae_backward run it for every decoder block — exposed per kernel for the parity tests and the bench's
+   kernel replays.  Weights: fp32 vectors, packed bf16 images (hsimae_pack_matrix: qkv = q | k | v fused [192][64], p [64][64],
+   w1 / w3 [hp][64], w2 [64][hp], w2T [hp][64] = W2 transposed, hp = hidden rounded up to 32) and the fp32 row-major masters of
+   q, k, v, proj, w1, w3 (the backward stages those in LDS itself).  bqkv = bq | bk | bv.
+   forward : x [nsamples * Ts][64] fp32 -> x1 = x + proj(attention(LN1 x)), x2 = x1 + mlp(LN2 x1); keeps o (attention output,
+             bf16 [rows][64]) and lse (log2-domain logsumexp, [rows][8]) for the backward.  split != 0: the attention half with
+             q / k / v in registers + the row-panel MLP kernel (two launches, the default schedule); 0: one kernel.
+   backward: from dy = dL/dx2 -> dx = dL/dx (dx1_tmp: scratch [rows][64] fp32, dL/dx1) and the block's 18 parameter gradients,
+             ACCUMULATED into the given tensors.  slab: NULL = float atomics; else >= 256 * (104 * 512 + 2112) floats of scratch:
+             per-workgroup partials + one fixed-order reduce launch (bit-reproducible). */
+typedef struct {
+    const float *n1w, *n1b, *bqkv, *pb, *n2w, *n2b, *w1b, *w3b, *w2b;
+    const hs_bf16 *qkv, *p, *w1, *w3, *w2, *w2T;
+    const float *qf, *kf, *vf, *pf, *w1f, *w3f;
+    int32_t hidden;
+} hsimae_dec_block_weights;
+typedef struct {
+    float *n1w, *n1b, *qw, *qb, *kw, *kb, *vw, *vb, *pw, *pb, *n2w, *n2b, *w1w, *w1b, *w2w, *w2b, *w3w, *w3b;
+} hsimae_dec_block_grads;
+int hsimae_dec_block_fwd(const hsimae_dec_block_weights* w, const float* x, float* x1, float* x2, hs_bf16* o, float* lse,
+                         int32_t nsamples, int32_t Ts, int32_t split, void* stream);
+int hsimae_dec_block_bwd(const hsimae_dec_block_weights* w, const hsimae_dec_block_grads* g, const float* x, const float* x1,
+                         const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o, const float* lse, int32_t nsamples,
+                         int32_t Ts, float* slab, void* stream);
+
 /* Weight / bias gradients of up to 8 linears in one launch (autograd of F.linear).  msplit = number of row slices the
    128 x 128 dW tiles are split into (partial sums meet in dW through atomics).  When every task of a launch has N >= 256 and
    K >= 256 and bf16 operands, the launch runs on 256 x 256 tiles, one workgroup per CU, and sizes its own row split (msplit is

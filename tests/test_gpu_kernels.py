@@ -283,6 +283,82 @@ def test_fused_encoder_mlp_half_forward_backward(M, drop):
     assert rel_err(gw, (dgate_u * xh).sum(0)) < 2e-2 and rel_err(gb, dgate_u.sum(0)) < 2e-2
 
 
+# ----------------------------------------------------------------------------------------------- fused decoder Block
+@pytest.mark.parametrize("N,Ts,split,slab", [(5, 108, 1, True), (5, 108, 0, False), (3, 54, 1, True), (4, 72, 1, True), (2, 90, 0, True),
+                                             (7, 112, 1, False), (300, 108, 1, True), (3, 17, 1, True)])
+def test_fused_decoder_block_forward_backward(N, Ts, split, slab):
+    """hsimae_dec_block_fwd / _bwd (the decoder Block of hsimae_forward / hsimae_backward: attention half with q / k / v in
+    registers + row-panel MLP half, or the one-kernel forward; two persistent backward kernels + the slab reduce) against a
+    plain PyTorch fp32 Block (Models.py:303-306, 192-232) with the bf16-rounded weights, through autograd: x1, x2, O, dx and all
+    18 parameter gradients.  Sequence lengths with key tiles that are partly / wholly padding, 17-token sequences, more samples
+    than workgroups (300 > 256: a workgroup walks two samples)."""
+    torch.manual_seed(11 + Ts)
+    d, heads, hd, h = 64, 8, 8, 172
+    hp = rup(h, 32)
+    lib = _lib.load()
+    M = N * Ts
+    x = torch.randn(M, d, device=DEV)
+    dy = torch.randn(M, d, device=DEV) * 0.1
+    P = {k: torch.randn(d, d, device=DEV) * 0.15 for k in ("q", "k", "v", "p")}
+    P.update(w1=torch.randn(h, d, device=DEV) * 0.12, w3=torch.randn(h, d, device=DEV) * 0.12, w2=torch.randn(d, h, device=DEV) * 0.1)
+    B = {k: torch.randn(n, device=DEV) * 0.1 for k, n in (("q", d), ("k", d), ("v", d), ("p", d), ("w1", h), ("w3", h), ("w2", d))}
+    n1w, n1b, n2w, n2b = (1 + 0.1 * torch.randn(d, device=DEV), 0.1 * torch.randn(d, device=DEV),
+                          1 + 0.1 * torch.randn(d, device=DEV), 0.1 * torch.randn(d, device=DEV))
+    iqkv = pack([(P["q"], 0, 0, 0), (P["k"], 0, d, 0), (P["v"], 0, 2 * d, 0)], 3 * d, d)
+    ip = pack([(P["p"], 0, 0, 0)], d, d)
+    i1, i3 = pack([(P["w1"], 0, 0, 0)], hp, d), pack([(P["w3"], 0, 0, 0)], hp, d)
+    i2, i2T = pack([(P["w2"], 0, 0, 0)], d, hp), pack([(P["w2"], 1, 0, 0)], hp, d)
+    bqkv = torch.cat([B["q"], B["k"], B["v"]]).contiguous()
+    W = _lib.DecBlockWeights(n1w=n1w.data_ptr(), n1b=n1b.data_ptr(), bqkv=bqkv.data_ptr(), pb=B["p"].data_ptr(), n2w=n2w.data_ptr(),
+                             n2b=n2b.data_ptr(), w1b=B["w1"].data_ptr(), w3b=B["w3"].data_ptr(), w2b=B["w2"].data_ptr(),
+                             qkv=iqkv.data_ptr(), p=ip.data_ptr(), w1=i1.data_ptr(), w3=i3.data_ptr(), w2=i2.data_ptr(), w2T=i2T.data_ptr(),
+                             qf=P["q"].data_ptr(), kf=P["k"].data_ptr(), vf=P["v"].data_ptr(), pf=P["p"].data_ptr(),
+                             w1f=P["w1"].data_ptr(), w3f=P["w3"].data_ptr(), hidden=h)
+    x1, x2 = torch.full((M, d), float("nan"), device=DEV), torch.full((M, d), float("nan"), device=DEV)
+    o = torch.zeros(M, d, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(M, heads, device=DEV)
+    _lib.check(lib.hsimae_dec_block_fwd(C.byref(W), x.data_ptr(), x1.data_ptr(), x2.data_ptr(), o.data_ptr(), lse.data_ptr(),
+                                        N, Ts, split, stream()), "hsimae_dec_block_fwd")
+    # ---- reference: fp32, the weights the kernels multiply with (bf16-rounded), torch autograd
+    leaves = {k: bf(v).clone().requires_grad_(True) for k, v in P.items()}
+    bl = {k: v.clone().requires_grad_(True) for k, v in B.items()}
+    ln = {k: v.clone().requires_grad_(True) for k, v in (("n1w", n1w), ("n1b", n1b), ("n2w", n2w), ("n2b", n2b))}
+    xr = x.clone().requires_grad_(True)
+    u = torch.nn.functional.layer_norm(xr, (d,), ln["n1w"], ln["n1b"], 1e-5)
+    q, k, v = (u @ leaves[n].t() + bl[n] for n in ("q", "k", "v"))
+    sh = lambda z: z.reshape(N, Ts, heads, hd).permute(0, 2, 1, 3)
+    att = ((sh(q) @ sh(k).transpose(-1, -2)) * hd ** -0.5).softmax(-1) @ sh(v)
+    oref = att.permute(0, 2, 1, 3).reshape(M, d)
+    y1 = xr + oref @ leaves["p"].t() + bl["p"]
+    u2 = torch.nn.functional.layer_norm(y1, (d,), ln["n2w"], ln["n2b"], 1e-5)
+    y2 = y1 + (torch.nn.functional.silu(u2 @ leaves["w1"].t() + bl["w1"]) * (u2 @ leaves["w3"].t() + bl["w3"])) @ leaves["w2"].t() + bl["w2"]
+    torch.cuda.synchronize()
+    assert rel_err(o.float(), oref.detach()) < 1.5e-2            # bf16 q / k / v / P operands
+    assert rel_err(x1, y1.detach()) < 1e-2 and rel_err(x2, y2.detach()) < 1e-2
+    y2.backward(dy)
+    # ---- backward through the C ABI
+    names = ("n1w", "n1b", "qw", "qb", "kw", "kb", "vw", "vb", "pw", "pb", "n2w", "n2b", "w1w", "w1b", "w2w", "w2b", "w3w", "w3b")
+    shapes = dict(n1w=(d,), n1b=(d,), qw=(d, d), qb=(d,), kw=(d, d), kb=(d,), vw=(d, d), vb=(d,), pw=(d, d), pb=(d,), n2w=(d,), n2b=(d,),
+                  w1w=(h, d), w1b=(h,), w2w=(d, h), w2b=(d,), w3w=(h, d), w3b=(h,))
+    G_ = {n: torch.zeros(shapes[n], device=DEV) for n in names}
+    Gs = _lib.DecBlockGrads(**{n: G_[n].data_ptr() for n in names})
+    dx1, dx = torch.empty(M, d, device=DEV), torch.full((M, d), float("nan"), device=DEV)
+    sl = torch.empty(256 * (104 * 512 + 2112), device=DEV) if slab else None
+    _lib.check(lib.hsimae_dec_block_bwd(C.byref(W), C.byref(Gs), x.data_ptr(), x1.data_ptr(), dy.data_ptr(), dx1.data_ptr(), dx.data_ptr(),
+                                        o.data_ptr(), lse.data_ptr(), N, Ts, _lib.ptr(sl), stream()), "hsimae_dec_block_bwd")
+    torch.cuda.synchronize()
+    assert rel_err(dx, xr.grad) < 2e-2
+    ref = dict(n1w=ln["n1w"].grad, n1b=ln["n1b"].grad, qw=leaves["q"].grad, qb=bl["q"].grad, kw=leaves["k"].grad, kb=bl["k"].grad,
+               vw=leaves["v"].grad, vb=bl["v"].grad, pw=leaves["p"].grad, pb=bl["p"].grad, n2w=ln["n2w"].grad, n2b=ln["n2b"].grad,
+               w1w=leaves["w1"].grad, w1b=bl["w1"].grad, w2w=leaves["w2"].grad, w2b=bl["w2"].grad, w3w=leaves["w3"].grad, w3b=bl["w3"].grad)
+    for n in names:
+        if n == "kb":                                         # exactly zero in exact arithmetic (softmax shift invariance)
+            assert float(G_[n].abs().max()) <= 3e-2 * float(ref["qb"].abs().max()) + 1e-6
+            continue
+        e = float((G_[n].double() - ref[n].double()).pow(2).mean().sqrt() / ref[n].double().pow(2).mean().sqrt().clamp_min(1e-30))
+        assert e < 2.5e-2, (n, e)
+
+
 # ----------------------------------------------------------------------------------------------- attention
 def attn_reference(qkv, d, heads, Ts, mode, len_l):
     """fp32 masked attention over [nsamples, Ts] tokens; qkv fp32 leaf [rows, 3d] (values already bf16-exact)."""
