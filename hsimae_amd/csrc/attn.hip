@@ -54,12 +54,10 @@ __device__ __forceinline__ bf16x8 pack_pair(f32x4 a, f32x4 b) {
 }
 
 __device__ __forceinline__ float group_max(float v) {   // over the 4 lane groups sharing lane&15
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
+    return rows_max(v);
 }
 __device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
+    return rows_sum(v);
 }
 
 template <int HD, int NT>
@@ -780,7 +778,7 @@ __global__ __launch_bounds__(512) void attn128_bwd_kernel(AttnParams p) {
             float acc = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc += bf2f(d[i]) * bf2f(o[i]);
-            acc += __shfl_xor(acc, 1, 64);                               // the head's two 8-column pieces are adjacent lanes
+            acc = lanes_sum<2>(acc);                               // the head's two 8-column pieces are adjacent lanes
             if (!(pc & 1)) dlt_s[(pc >> 1) * L::ROWS + row] = acc;
         }
     }
@@ -810,7 +808,7 @@ __global__ __launch_bounds__(512) void attn128_bwd_kernel(AttnParams p) {
                 bf16_t* cell = Df + row * FS + hc + c16;
                 const bf16_t dob = (bf16_t)acc[r];
                 float v = bf2f(dob) * bf2f(*cell);
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                v = lanes_sum<16>(v);
                 if (c16 == 0) dlt_s[head * L::ROWS + row] = v;
                 *cell = dob;
             }
@@ -976,12 +974,12 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
                 float sm = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sm += xn[ps][e];
-                sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64); sm += __shfl_xor(sm, 8, 64);
+                sm = lanes_sum<16>(sm);
                 const float mean = sm * (1.f / 128.f);
                 float vq = 0.f, f[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { f[e] = xn[ps][e] - mean; vq += f[e] * f[e]; }
-                vq += __shfl_xor(vq, 1, 64); vq += __shfl_xor(vq, 2, 64); vq += __shfl_xor(vq, 4, 64); vq += __shfl_xor(vq, 8, 64);
+                vq = lanes_sum<16>(vq);
                 const float rstd = rsqrtf(vq * (1.f / 128.f) + 1e-5f);
                 {
                     const float4 g0 = *reinterpret_cast<const float4*>(vec_s + lc8), g1 = *reinterpret_cast<const float4*>(vec_s + lc8 + 4);

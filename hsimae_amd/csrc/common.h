@@ -58,17 +58,50 @@ __device__ __forceinline__ float silu_nr(float a) {
     return a * r;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Cross-lane reductions without the LDS crossbar.  `__shfl_xor` compiles to ds_bpermute_b32 on gfx950: an LDS instruction (and an
+// lgkmcnt round trip) per step, in kernels whose busiest unit is the LDS pipe (132 of them in dec_bwd_attn_kernel alone).  Inside a
+// 16-lane row the same sums are DPP modifiers on the v_add / v_max itself; across rows gfx950 has v_permlane16_swap / 32_swap.
+// scripts/micro/lane_reduce.hip checks every step bit for bit against __shfl_xor on the GPU.
+//   quad_perm [1,0,3,2] = lane ^ 1, quad_perm [2,3,0,1] = lane ^ 2; row_half_mirror (lane 7 - i of the half row) and row_mirror
+//   (lane 15 - i) stand in for ^ 4 and ^ 8 once the lanes of a quad / half row hold the same partial sum — so the steps run ascending.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
+// rows r and r ^ 1 (lanes ^ 16) / halves (lanes ^ 32) exchanged in place: a + b afterwards is v + partner in every lane.
+// (The __builtin_amdgcn_permlane16_swap / 32_swap builtins lose their second result in hipcc 7.2 when both operands derive
+//  from one value — inline asm with two tied registers; s_nop covers the VALU-write -> permlane read hazard.)
+__device__ __forceinline__ void swap_rows16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap_rows32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+struct OpSum { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
+struct OpMax { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
+
+// reduction over the aligned group of N adjacent lanes (N = 2 .. 64), result in every lane of the group
+template <int N, class Op>
+__device__ __forceinline__ float lanes_reduce(float v) {
+    static_assert(N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 64, "group size");
+    v = Op::f(v, dpp_mov<0xB1>(v));
+    if constexpr (N >= 4) v = Op::f(v, dpp_mov<0x4E>(v));
+    if constexpr (N >= 8) v = Op::f(v, dpp_mov<0x141>(v));
+    if constexpr (N >= 16) v = Op::f(v, dpp_mov<0x140>(v));
+    if constexpr (N >= 32) { float a = v, b = v; swap_rows16(a, b); v = Op::f(a, b); }
+    if constexpr (N >= 64) { float a = v, b = v; swap_rows32(a, b); v = Op::f(a, b); }
     return v;
 }
+template <int N> __device__ __forceinline__ float lanes_sum(float v) { return lanes_reduce<N, OpSum>(v); }
+template <int N> __device__ __forceinline__ float lanes_max(float v) { return lanes_reduce<N, OpMax>(v); }
+// reduction over the 4 lanes that share lane & 15 (the four 16-lane rows of the wave)
+template <class Op>
+__device__ __forceinline__ float rows_reduce(float v) {
+    float a = v, b = v; swap_rows16(a, b); v = Op::f(a, b);
+    a = v; b = v; swap_rows32(a, b); return Op::f(a, b);
+}
+__device__ __forceinline__ float rows_sum(float v) { return rows_reduce<OpSum>(v); }
+__device__ __forceinline__ float rows_max(float v) { return rows_reduce<OpMax>(v); }
+
+__device__ __forceinline__ float wave_sum(float v) { return lanes_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) { return lanes_max<64>(v); }
 
 // Gradient commits.  Default: fp32 global atomics (summation order varies from run to run in the last bits).  Deterministic
 // mode (hsimae_io.det_acc): every addend is converted to 64-bit fixed point (scale 2^44: 5.7e-14 resolution, +-5.2e5 range)

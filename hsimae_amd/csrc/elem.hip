@@ -127,14 +127,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += x[u][e];
-#pragma unroll
-            for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            s = lanes_sum<TPR>(s);
             const float mean = s * invd;
             float q = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float dl = cok ? x[u][e] - mean : 0.f; x[u][e] = dl; q += dl * dl; }
-#pragma unroll
-            for (int o = TPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            q = lanes_sum<TPR>(q);
             const float rstd = rsqrtf(q * invd + 1e-5f);
             float a = 0.f, b = 0.f;
 #pragma unroll
@@ -144,8 +142,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
                 a += t;
                 b += t * x[u][e];
             }
-#pragma unroll
-            for (int o = TPR / 2; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            a = lanes_sum<TPR>(a); b = lanes_sum<TPR>(b);
             a *= invd; b *= invd;
             if (cok && r < p.M) {
                 float v[8];

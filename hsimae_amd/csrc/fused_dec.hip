@@ -252,12 +252,12 @@ __device__ __forceinline__ void ln_rows(const float* src, int Ts, const float* g
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += f[e];
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            s = lanes_sum<8>(s);
             const float mean = s * (1.f / D);
             float v = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float dl = f[e] - mean; v += dl * dl; }
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+            v = lanes_sum<8>(v);
             const float rstd = rsqrtf(v * (1.f / D) + 1e-5f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd * gm[e] + bt[e];
@@ -361,8 +361,7 @@ __device__ __forceinline__ void attn_head_fwd(const bf16_t* Qb, const bf16_t* Kb
         for (int kt = 0; kt < MT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = rows_max(m);
         const float nm = -m * sc;
         const f32x2 sc2 = {sc, sc}, nm2 = {nm, nm};
         f32x2 ls2 = {0.f, 0.f};
@@ -376,8 +375,7 @@ __device__ __forceinline__ void attn_head_fwd(const bf16_t* Qb, const bf16_t* Kb
                 ls2 += e;
             }
         float lsum = ls2[0] + ls2[1];
-        lsum += __shfl_xor(lsum, 16, 64);
-        lsum += __shfl_xor(lsum, 32, 64);
+        lsum = rows_sum(lsum);
         const float inv = 1.f / lsum;
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -707,8 +705,7 @@ __global__ __launch_bounds__(256, 4) void dec_attn_fwd_kernel(DecAttnFwdArgs p) 
                 for (int kt = 0; kt < MT; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
-                m = fmaxf(m, __shfl_xor(m, 16, 64));
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                m = rows_max(m);
                 const float nm = -m * sc;
                 const f32x2 sc2 = {sc, sc}, nm2 = {nm, nm};
                 f32x2 ls2 = {0.f, 0.f};
@@ -722,8 +719,7 @@ __global__ __launch_bounds__(256, 4) void dec_attn_fwd_kernel(DecAttnFwdArgs p) 
                         ls2 += e;
                     }
                 float lsum = ls2[0] + ls2[1];
-                lsum += __shfl_xor(lsum, 16, 64);
-                lsum += __shfl_xor(lsum, 32, 64);
+                lsum = rows_sum(lsum);
                 const float inv = __builtin_amdgcn_rcpf(lsum);
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -816,7 +812,7 @@ __device__ __forceinline__ void st8(float* p, const float* v) {
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 __device__ __forceinline__ float red8(float v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    v = lanes_sum<8>(v);
     return v;
 }
 
@@ -1087,8 +1083,8 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float a = db1[c][j], b = db3[c][j];
-            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            a = rows_sum(a);
+            b = rows_sum(b);
             const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
             if (q.g == 0 && col < p.w.h) {
                 if (vec) { vec[kVW1B + q.wm * HPD + col] = a; vec[kVW3B + q.wm * HPD + col] = b; }
@@ -1396,6 +1392,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             for (int k2 = 0; k2 < 2; ++k2)
                 accP[k2] = mfma16(a, wg_frag<MT, true>(Ob, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accP[k2]);
         }
+        PH(2)
         // delta[head][row] = sum_keys P dP = sum_d dO[row][d] O[row][d] over the head's 8 columns (8 adjacent lanes)
         bf16_t dOb16[L::MH][2][4];
 #pragma unroll
@@ -1534,8 +1531,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float a = dbq[r], b = dbk[r], c = dbv[r];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
+            a = lanes_sum<16>(a); b = lanes_sum<16>(b); c = lanes_sum<16>(c);
             const int col = q.wave * HD + q.g * 4 + r;
             if (q.c16 == 0 && q.g < 2) {
                 if (vec) { vec[kVQB + col] = a; vec[kVKB + col] = b; vec[kVVB + col] = c; }

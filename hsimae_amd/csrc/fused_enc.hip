@@ -152,8 +152,7 @@ __device__ __forceinline__ void st8(float* p, const float* v) {
 }
 template <int LPR>
 __device__ __forceinline__ float redrow(float v) {          // sum over the LPR adjacent lanes that own one row
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
+    v = lanes_sum<LPR>(v);
     return v;
 }
 

@@ -92,8 +92,7 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM <= 64) ? 2 : 1) void ge
         float am = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(f[e]));
-        am = fmaxf(am, __shfl_xor(am, 1, 64));
-        am = fmaxf(am, __shfl_xor(am, 2, 64));
+        am = lanes_max<4>(am);
         int eb = (int)((__float_as_uint(am) >> 23) & 0xffu) - 8;          // floor(log2(amax)) - emax(e4m3), biased by 127
         eb = min(max(eb, 1), 254);
         const float inv = __uint_as_float((unsigned)(254 - eb) << 23);    // 2^-(eb - 127)
@@ -144,14 +143,12 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM <= 64) ? 2 : 1) void ge
                 float sm = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sm += f[i][e];
-#pragma unroll
-                for (int o = TPR / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+                sm = lanes_sum<TPR>(sm);
                 const float mean = sm * invk;
                 float q = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float dl = cv ? f[i][e] - mean : 0.f; q += dl * dl; }
-#pragma unroll
-                for (int o = TPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+                q = lanes_sum<TPR>(q);
                 const float rstd = rsqrtf(q * invk + 1e-5f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[i][e] = (f[i][e] - mean) * rstd * g[e] + bt[e];
@@ -422,20 +419,17 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM <= 64) ? 2 : 1) void ge
                     float sm = 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) sm += xr[i][e];
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+                    sm = lanes_sum<16>(sm);
                     const float mean = sm * (1.f / 128.f);
                     float q = 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { xr[i][e] -= mean; q += xr[i][e] * xr[i][e]; }
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+                    q = lanes_sum<16>(q);
                     const float rstd = rsqrtf(q * (1.f / 128.f) + 1e-5f);
                     float a = 0.f, b = 0.f, t[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { xr[i][e] *= rstd; t[e] = du[e] * gm[e]; a += t[e]; b += t[e] * xr[i][e]; }
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                    a = lanes_sum<16>(a); b = lanes_sum<16>(b);
                     a *= (1.f / 128.f); b *= (1.f / 128.f);
                     if (row < p.M) {
                         float v[8];
@@ -631,16 +625,14 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM <= 64) ? 2 : 1) void ge
                 for (int c = 0; c < NCH; ++c)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) sm += xr[c][e];
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+                sm = lanes_sum<16>(sm);
                 const float mean = sm * invn;
                 float q = 0.f;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { xr[c][e] -= mean; q += xr[c][e] * xr[c][e]; }
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+                q = lanes_sum<16>(q);
                 const float rstd = rsqrtf(q * invn + 1e-5f);
                 float a = 0.f, b = 0.f;
 #pragma unroll
@@ -656,8 +648,7 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM <= 64) ? 2 : 1) void ge
                         if (rok) { dgam[c][e] += du[e] * xr[c][e]; dbet[c][e] += du[e]; }
                     }
                 }
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                a = lanes_sum<16>(a); b = lanes_sum<16>(b);
                 a *= invn; b *= invn;
                 if (rok) {
 #pragma unroll

@@ -115,20 +115,17 @@ __global__ __launch_bounds__(256, 2) void lnbwd_dma_kernel(GemmParams p) {
             float sm = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) sm += xr[i][e];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            sm = lanes_sum<16>(sm);
             const float mean = sm * (1.f / 128.f);
             float q = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { xr[i][e] -= mean; q += xr[i][e] * xr[i][e]; }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            q = lanes_sum<16>(q);
             const float rstd = rsqrtf(q * (1.f / 128.f) + 1e-5f);
             float a = 0.f, b = 0.f, t[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { xr[i][e] *= rstd; t[e] = du[e] * gm[e]; a += t[e]; b += t[e] * xr[i][e]; }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            a = lanes_sum<16>(a); b = lanes_sum<16>(b);
             a *= (1.f / 128.f); b *= (1.f / 128.f);
             if (row < p.M) {
                 float v[8];
@@ -239,14 +236,12 @@ __global__ __launch_bounds__(256, 2) void lnqkv_kernel(GemmParams p) {
             float sm = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) sm += xa[i][e];
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            sm = lanes_sum<16>(sm);
             const float mean = sm * (1.f / 128.f);
             float q = 0.f, f[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { f[e] = xa[i][e] - mean; q += f[e] * f[e]; }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            q = lanes_sum<16>(q);
             const float rstd = rsqrtf(q * (1.f / 128.f) + 1e-5f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];

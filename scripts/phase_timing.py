@@ -75,7 +75,7 @@ def main():
         tot = sum(g[base:base + 3]) or 1
         print(f"{name}: wave-0 cycles {tot}: stage {100.0 * g[base] / tot:.1f} %  k-loop {100.0 * g[base + 1] / tot:.1f} %  epilogue {100.0 * g[base + 2] / tot:.1f} %")
     names = {
-        "dec_bwd_attn": (0, ["prologue (x dx1 O lse) + LN", "qkv mm", "-", "dO mm + dWp + delta", "dO store", "attention",
+        "dec_bwd_attn": (0, ["prologue (x dx1 O lse) + LN", "qkv mm", "dO mm + dWp", "delta (+ barrier)", "dO store", "attention",
                              "du mm + dWqkv", "epilogue LN bwd"]),
         "dec_bwd_mlp": (8, ["prologue LN", "gate mm + silu", "wgrad", "du2 stage", "epilogue LN bwd", "du2 mm", "-", "-"]),
         "dec_fwd": (16, ["LN1 + residual", "qkv", "attention", "o store + proj", "LN2", "gate chunks", "w2 mm", "store"]),
