@@ -139,6 +139,12 @@ struct FrN {
     }
 };
 
+__device__ __forceinline__ bf16x4 cvt4(f32x4 v) {
+    bf16x4 r;
+    r[0] = (bf16_t)v[0]; r[1] = (bf16_t)v[1]; r[2] = (bf16_t)v[2]; r[3] = (bf16_t)v[3];
+    return r;
+}
+
 template <class T>
 __device__ __forceinline__ const T* launder(const T* p) { asm volatile("" : "+s"(p)); return p; }
 
@@ -223,26 +229,30 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
     f2.load(w.w2, G::KSH, q.wave * NJO, 0, D / 16, q.lane);
     lds_barrier();
     PH(0)
+    // Every product runs with the MFMA operands swapped (weights as A, the panel as B): a lane then owns 4 consecutive
+    // COLUMNS of one row (token c16, columns 4g .. 4g+3 of the n-tile), so the gate leaves as one 8-byte LDS write per m-tile
+    // instead of four 2-byte ones and the result tile as 16-byte writes — same values, same accumulation order.
     f32x4 xr[MT4][NJO];                            // b2 + the W2 product, [m-tile][this wave's output n-tile]
 #pragma unroll
-    for (int mt = 0; mt < MT4; ++mt)
+    for (int j = 0; j < NJO; ++j) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(w.w2b + (q.wave * NJO + j) * 16 + q.g * 4);
 #pragma unroll
-        for (int j = 0; j < NJO; ++j) {
-            const float b = w.w2b[(q.wave * NJO + j) * 16 + q.c16];
-            xr[mt][j] = f32x4{b, b, b, b};
-        }
+        for (int mt = 0; mt < MT4; ++mt) xr[mt][j] = b;
+    }
     PH(1)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int nt = c * 4 + q.wave;                                  // this wave's n-tile of the chunk
         const bool live = nt < nt_h;                                    // last chunk: only waves 0, 1 have columns
-        const int col = nt * 16 + q.c16;
+        const int col = nt * 16 + q.g * 4;                              // this lane's 4 hidden columns
         bf16_t* Gi = Gc + (c & 1) * R * LC;
         f32x4 h1[MT4], h3[MT4];
         {
-            const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
+            f32x4 b1, b3;
 #pragma unroll
-            for (int mt = 0; mt < MT4; ++mt) { h1[mt] = f32x4{b1, b1, b1, b1}; h3[mt] = f32x4{b3, b3, b3, b3}; }
+            for (int r = 0; r < 4; ++r) { b1[r] = col + r < w.h ? w.w1b[col + r] : 0.f; b3[r] = col + r < w.h ? w.w3b[col + r] : 0.f; }
+#pragma unroll
+            for (int mt = 0; mt < MT4; ++mt) { h1[mt] = b1; h3[mt] = b3; }
         }
         if (live) {
 #pragma unroll
@@ -250,8 +260,8 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
 #pragma unroll
                 for (int mt = 0; mt < MT4; ++mt) {                      // one A fragment feeds both products
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(U2 + (mt * 16 + q.c16) * LU + ks * 32 + q.g * 8);
-                    h1[mt] = mfma16(a, f1.b[ks][0], h1[mt]);
-                    h3[mt] = mfma16(a, f3.b[ks][0], h3[mt]);
+                    h1[mt] = mfma16(f1.b[ks][0], a, h1[mt]);
+                    h3[mt] = mfma16(f3.b[ks][0], a, h3[mt]);
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -261,13 +271,13 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < MT4; ++mt)
+        for (int mt = 0; mt < MT4; ++mt) {
+            f32x4 gv;
+            // columns past the hidden width: the packed W1 / W3 rows and the biases read as zero -> h1 = h3 = 0 -> g = 0
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // columns past the hidden width: the packed W1 / W3 rows and the biases read as zero -> h1 = h3 = 0 -> g = 0
-                const float gv = silu_nr(h1[mt][r]) * h3[mt][r];
-                Gi[(mt * 16 + q.g * 4 + r) * LC + q.wave * 16 + q.c16] = (bf16_t)gv;
-            }
+            for (int r = 0; r < 4; ++r) gv[r] = silu_nr(h1[mt][r]) * h3[mt][r];
+            *reinterpret_cast<bf16x4*>(Gi + (mt * 16 + q.c16) * LC + q.wave * 16 + q.g * 4) = cvt4(gv);
+        }
         lds_barrier();                             // chunk image complete; the other image is free again after this barrier
         // x2 += g_c W2_c^T : this wave's NJO output n-tiles, all 4 m-tiles; the last chunk of 352 is half full
         constexpr bool kHalfLast = (HPE % 64) != 0;
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
             for (int mt = 0; mt < MT4; ++mt) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(Gi + (mt * 16 + q.c16) * LC + ks * 32 + q.g * 8);
 #pragma unroll
-                for (int j = 0; j < NJO; ++j) xr[mt][j] = mfma16(a, f2.b[ks][j], xr[mt][j]);
+                for (int j = 0; j < NJO; ++j) xr[mt][j] = mfma16(f2.b[ks][j], a, xr[mt][j]);
             }
         }
         if (c + 1 < NCH) f2 = f2n;
@@ -292,9 +302,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
     for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
         for (int j = 0; j < NJO; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                XS[(mt * 16 + q.g * 4 + r) * LX + (q.wave * NJO + j) * 16 + q.c16] = xr[mt][j][r];
+            *reinterpret_cast<f32x4*>(XS + (mt * 16 + q.c16) * LX + (q.wave * NJO + j) * 16 + q.g * 4) = xr[mt][j];
     lds_barrier();
 #pragma unroll
     for (int i = 0; i < R * LPR / NTH; ++i) {
@@ -412,11 +420,14 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
         const int nt = c * 4 + q.wave;
         const bool live = nt < nt_h;
         {
-            const int col = nt * 16 + q.c16, lc = q.wave * 16 + q.c16;
+            // operands swapped as in the forward kernel: a lane owns 4 consecutive hidden columns of one row
+            const int col = nt * 16 + q.g * 4, lc = q.wave * 16 + q.g * 4;
             f32x4 h1[MT4], h3[MT4], dg[MT4];
-            const float b1 = col < w.h ? w.w1b[col] : 0.f, b3 = col < w.h ? w.w3b[col] : 0.f;
+            f32x4 b1, b3;
 #pragma unroll
-            for (int mt = 0; mt < MT4; ++mt) { h1[mt] = f32x4{b1, b1, b1, b1}; h3[mt] = f32x4{b3, b3, b3, b3}; dg[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int r = 0; r < 4; ++r) { b1[r] = col + r < w.h ? w.w1b[col + r] : 0.f; b3[r] = col + r < w.h ? w.w3b[col + r] : 0.f; }
+#pragma unroll
+            for (int mt = 0; mt < MT4; ++mt) { h1[mt] = b1; h3[mt] = b3; dg[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             if (live) {
 #pragma unroll
                 for (int ks = 0; ks < KSD; ++ks)
@@ -424,9 +435,9 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                     for (int mt = 0; mt < MT4; ++mt) {
                         const bf16x8 au = *reinterpret_cast<const bf16x8*>(U2 + (mt * 16 + q.c16) * LU + ks * 32 + q.g * 8);
                         const bf16x8 ad = *reinterpret_cast<const bf16x8*>(DYb + (mt * 16 + q.c16) * LU + ks * 32 + q.g * 8);
-                        h1[mt] = mfma16(au, f1.b[ks][0], h1[mt]);
-                        h3[mt] = mfma16(au, f3.b[ks][0], h3[mt]);
-                        dg[mt] = mfma16(ad, f2.b[ks][0], dg[mt]);
+                        h1[mt] = mfma16(f1.b[ks][0], au, h1[mt]);
+                        h3[mt] = mfma16(f3.b[ks][0], au, h3[mt]);
+                        dg[mt] = mfma16(f2.b[ks][0], ad, dg[mt]);
                     }
             }
             if (c + 1 < NCH) {
@@ -435,19 +446,24 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                 f2.load(w.w2T, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
             }
 #pragma unroll
-            for (int mt = 0; mt < MT4; ++mt)
+            for (int mt = 0; mt < MT4; ++mt) {
+                f32x4 gv, d1, d3;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float a1 = h1[mt][r], a3 = h3[mt][r], dv = dg[mt][r];
                     const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-a1));
                     const float sl = a1 * sg;
-                    const int o = (mt * 16 + q.g * 4 + r) * LC + lc;
                     // columns past the hidden width: packed W1 / W3 / W2^T rows and the biases are zero -> a1 = a3 = dv = 0 ->
                     // g = dh1 = dh3 = 0 without a select
-                    Gc[o] = (bf16_t)(sl * a3);
-                    DH1[o] = (bf16_t)(dv * a3 * sg * (1.f + a1 * (1.f - sg)));
-                    DH3[o] = (bf16_t)(dv * sl);
+                    gv[r] = sl * a3;
+                    d1[r] = dv * a3 * sg * (1.f + a1 * (1.f - sg));
+                    d3[r] = dv * sl;
                 }
+                const int o = (mt * 16 + q.c16) * LC + lc;
+                *reinterpret_cast<bf16x4*>(Gc + o) = cvt4(gv);
+                *reinterpret_cast<bf16x4*>(DH1 + o) = cvt4(d1);
+                *reinterpret_cast<bf16x4*>(DH3 + o) = cvt4(d3);
+            }
         }
         lds_barrier();
         PH(1)
@@ -482,8 +498,8 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                 const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(DH3 + (mt * 16 + q.c16) * LC + ks * 32 + q.g * 8);
 #pragma unroll
                 for (int j = 0; j < NJO; ++j) {
-                    du2[mt][j] = mfma16(a1, wa.b[ks][j], du2[mt][j]);
-                    du2[mt][j] = mfma16(a3, wb.b[ks][j], du2[mt][j]);
+                    du2[mt][j] = mfma16(wa.b[ks][j], a1, du2[mt][j]);
+                    du2[mt][j] = mfma16(wb.b[ks][j], a3, du2[mt][j]);
                 }
             }
         }
@@ -494,9 +510,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
     for (int mt = 0; mt < MT4; ++mt)
 #pragma unroll
         for (int j = 0; j < NJO; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                XS[(mt * 16 + q.g * 4 + r) * LX + (q.wave * NJO + j) * 16 + q.c16] = du2[mt][j][r];
+            *reinterpret_cast<f32x4*>(XS + (mt * 16 + q.c16) * LX + (q.wave * NJO + j) * 16 + q.g * 4) = du2[mt][j];
     lds_barrier();
     float dgam[8], dbet[8];
 #pragma unroll
