@@ -1140,7 +1140,8 @@ __device__ __forceinline__ bf16x4 tr4(const bf16_t* a) {
 // is directly the B operand of dq^T += K^T dS^T.  dk^T / dv^T contract over queries and need the tile transposed:
 // P and dS go through a per-wave LDS tile (8-byte writes, one transpose read each) instead of a second
 // score/exp pass.  delta and logsumexp come precomputed, so nothing waits on a full row.
-// Masking: lse = 1e30 for rows past Ts (P = 0 for dead queries); every key tile that reaches past Ts masks its dead rows.
+// Masking: lse = 1e30 for rows past Ts (P = 0 for dead queries); dead KEYS are handled by data, not by selects: the K / V image
+// rows past Ts are zero on entry and the dk / dv rows past Ts are written as zero (see the loop body).
 template <int MT>
 __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb, const bf16_t* dOb, const float* lse_h,
                                               const float* dlt_h, bf16_t* T, int head, int Ts, const Geo4& q,
@@ -1191,14 +1192,10 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
 #else
             for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn));
 #endif
-            // key tiles that reach past Ts (uniform test: at 108 tokens only the last one; at 72 tokens tile 4 is partly and
-            // tiles 5, 6 are wholly padding).  Rounds 1-2 masked the LAST tile only: 65..96-token sequences (64 / 72 / 80 bands)
-            // let padded keys into dq / dk / dv — found in round 3 by the 64-band case of test_fused_decoder_matches_layerwise_decoder.
-            if ((kt + 1) * 16 > Ts) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kt * 16 + q.g * 4 + r >= Ts) pv[r] = 0.f;
-            }
+            // No key mask in here (rounds 1-2 masked the last tile only — wrong for 65..96-token sequences, found in round 3 by the
+            // 64-band case of test_fused_decoder_matches_layerwise_decoder — and the general per-tile form compiled to 8 selects
+            // per tile on ALL tiles, a quarter of this loop's VALU work): the caller zeroes the K and V image rows past Ts, so a
+            // padded key has s = 0, dP = 0 and a finite garbage P / dS that meets K = 0 in dq and is dropped from dk / dv below.
 #pragma unroll
             for (int r = 0; r < 4; ++r) ds[r] = pv[r] * (dp[r] - dl);
             if (kt > 0) {                       // previous tile's transposed operands, a VALU phase after their reads were issued
@@ -1228,9 +1225,10 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
 #pragma unroll
         for (int kt = 0; kt < MT; ++kt) {
             bf16x4 vk, vv;
+            const bool live = kt * 16 + q.c16 < Ts;          // padded keys carry garbage (see the loop): their dk / dv rows are zero
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float xk = dkT[kt][r] * scale, xv = dvT[kt][r];
+                const float xk = live ? dkT[kt][r] * scale : 0.f, xv = live ? dvT[kt][r] : 0.f;
                 vk[r] = (bf16_t)xk; vv[r] = (bf16_t)xv;
                 dbk[r] += xk; dbv[r] += xv;
             }
@@ -1420,6 +1418,12 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     Ob[(mt * 16 + q.g * 4 + r) * LU + (q.wn * 2 + j) * 16 + q.c16] = dOb16[mi][j][r];
+        }
+        // K / V rows of the padding keys -> 0 (every wave's q | k | v columns are in the images since the barrier above):
+        // what keeps padded keys out of dq without a mask in the attention loop
+        for (int i = threadIdx.x; i < (R - p.Ts) * 16; i += NT_) {
+            const int row = p.Ts + (i >> 4), k8 = (i & 7) * 8;
+            *reinterpret_cast<bf16x8*>(((i & 8) ? Vb : Kb) + row * LU + k8) = zero8();
         }
         lds_barrier();
         PH(4)
