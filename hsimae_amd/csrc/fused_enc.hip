@@ -128,12 +128,15 @@ __device__ __forceinline__ void mm_f(const bf16_t* A, int lda, int kofs, const F
 template <int KS, int NJ>
 struct FrN {
     bf16x8 b[KS][NJ];
+    // CHK_N = false: the caller knows every n-tile is inside the matrix (with the wave index in nt0 the compiler cannot, and
+    // guards every fragment with a zero fill and a branch — 500 of the 2,700 instructions of enc_mlp_fwd_kernel<128, 352>)
+    template <bool CHK_N = true>
     __device__ __forceinline__ void load(const bf16_t* W, int KS_total, int nt0, int ks0, int nt_total, int lane) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                b[ks][j] = (nt0 + j < nt_total && ks0 + ks < KS_total)
+                b[ks][j] = ((!CHK_N || nt0 + j < nt_total) && ks0 + ks < KS_total)
                                ? *reinterpret_cast<const bf16x8*>(W + (((size_t)(nt0 + j) * KS_total + ks0 + ks) * 64 + lane) * 8)
                                : zero8();
     }
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
 
     PH_DECL
     FrN<KSD, 1> f1, f3;                                 // this wave's n-tile of the current hidden chunk
-    f1.load(w.w1, KSD, q.wave, 0, nt_h, q.lane);
-    f3.load(w.w3, KSD, q.wave, 0, nt_h, q.lane);
+    f1.template load<false>(w.w1, KSD, q.wave, 0, nt_h, q.lane);          // chunk 0: all four n-tiles exist (HPE >= 64)
+    f3.template load<false>(w.w3, KSD, q.wave, 0, nt_h, q.lane);
     __builtin_amdgcn_sched_barrier(0);           // keep the fetches here: hipcc otherwise sinks them next to the MFMAs
     {   // LayerNorm-2 in the wide layout (16 lanes per row)
         float gm[8], bt[8];
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
         }
     }
     FrN<2, NJO> f2;                                     // W2 fragments of the current chunk (k-steps 2c, 2c+1)
-    f2.load(w.w2, G::KSH, q.wave * NJO, 0, D / 16, q.lane);
+    f2.template load<false>(w.w2, G::KSH, q.wave * NJO, 0, D / 16, q.lane);
     lds_barrier();
     PH(0)
     // Every product runs with the MFMA operands swapped (weights as A, the panel as B): a lane then owns 4 consecutive
@@ -243,7 +246,8 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int nt = c * 4 + q.wave;                                  // this wave's n-tile of the chunk
-        const bool live = nt < nt_h;                                    // last chunk: only waves 0, 1 have columns
+        const bool full = c * 4 + 3 < nt_h;                             // (compile-time per unrolled chunk) all four waves have columns
+        const bool live = full || nt < nt_h;                            // last chunk: only waves 0, 1 have columns
         const int col = nt * 16 + q.g * 4;                              // this lane's 4 hidden columns
         bf16_t* Gi = Gc + (c & 1) * R * LC;
         f32x4 h1[MT4], h3[MT4];
@@ -266,8 +270,13 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
         }
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < NCH) {
-            f1.load(w.w1, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
-            f3.load(w.w3, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+            if ((c + 1) * 4 + 3 < nt_h) {
+                f1.template load<false>(w.w1, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+                f3.template load<false>(w.w3, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+            } else {
+                f1.load(w.w1, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+                f3.load(w.w3, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
         // x2 += g_c W2_c^T : this wave's NJO output n-tiles, all 4 m-tiles; the last chunk of 352 is half full
         constexpr bool kHalfLast = (HPE % 64) != 0;
         FrN<2, NJO> f2n;
-        if (c + 1 < NCH) f2n.load(w.w2, G::KSH, q.wave * NJO, 2 * (c + 1), D / 16, q.lane);
+        if (c + 1 < NCH) f2n.template load<false>(w.w2, G::KSH, q.wave * NJO, 2 * (c + 1), D / 16, q.lane);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (kHalfLast && c == NCH - 1 && ks == 1) continue;
@@ -360,9 +369,9 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
     // n-tiles {2w, 2w+1} of the data gradient, each for all 4 m-tiles of the panel
     constexpr int MT4 = R / 16, NJO = D / 64;
     FrN<KSD, 1> f1, f3, f2;
-    f1.load(w.w1, KSD, q.wave, 0, nt_h, q.lane);
-    f3.load(w.w3, KSD, q.wave, 0, nt_h, q.lane);
-    f2.load(w.w2T, KSD, q.wave, 0, nt_h, q.lane);
+    f1.template load<false>(w.w1, KSD, q.wave, 0, nt_h, q.lane);
+    f3.template load<false>(w.w3, KSD, q.wave, 0, nt_h, q.lane);
+    f2.template load<false>(w.w2T, KSD, q.wave, 0, nt_h, q.lane);
     {
         float gm[8], bt[8];
         ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
@@ -418,7 +427,8 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int nt = c * 4 + q.wave;
-        const bool live = nt < nt_h;
+        const bool full = c * 4 + 3 < nt_h;                     // (compile-time per unrolled chunk)
+        const bool live = full || nt < nt_h;
         {
             // operands swapped as in the forward kernel: a lane owns 4 consecutive hidden columns of one row
             const int col = nt * 16 + q.g * 4, lc = q.wave * 16 + q.g * 4;
@@ -441,9 +451,15 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                     }
             }
             if (c + 1 < NCH) {
-                f1.load(w.w1, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
-                f3.load(w.w3, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
-                f2.load(w.w2T, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+                if ((c + 1) * 4 + 3 < nt_h) {
+                    f1.template load<false>(w.w1, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+                    f3.template load<false>(w.w3, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+                    f2.template load<false>(w.w2T, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+                } else {
+                    f1.load(w.w1, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+                    f3.load(w.w3, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+                    f2.load(w.w2T, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
+                }
             }
 #pragma unroll
             for (int mt = 0; mt < MT4; ++mt) {
@@ -470,8 +486,8 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
         // W1^T | W3^T fragments of this chunk's data gradient (this wave's output n-tiles): issued before the operand
         // stores so that their L2 round trip overlaps them
         FrN<2, NJO> wa, wb;
-        wa.load(w.w13T, 2 * KSH, q.wave * NJO, 2 * c, D / 16, q.lane);
-        wb.load(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * c, D / 16, q.lane);
+        wa.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, 2 * c, D / 16, q.lane);
+        wb.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * c, D / 16, q.lane);
         // weight-gradient operands of this chunk to HBM (row-contiguous 16-B stores), columns < 352 only
         if (p.dh13) {
             const int ncol = (c * 64 + 64 <= HPE) ? 64 : HPE - c * 64;       // 64 or 32
