@@ -179,7 +179,7 @@ __device__ __forceinline__ void mm_rm(const bf16_t* A, int lda, const bf16_t* Wr
 
 // Wide layout: piece p -> (row p>>3, columns 8*(p&7)..+7); the 8 lanes of a row are adjacent.
 // (mm_wt below needs wg_frag, declared further down)
-template <int MT, bool TAIL>
+template <int MT, bool TAIL, bool ZERO = true>
 __device__ __forceinline__ bf16x8 wg_frag(const bf16_t* img, int col0, int kk, const Geo4& q);
 
 // acc += A[:, 0:64] * W with W row-major bf16 [64 k-rows][LU] resident in LDS (n contiguous): the B fragment needs
@@ -784,7 +784,9 @@ typedef __attribute__((address_space(3))) bf16x4* lds_b64;
 // the image rows, 32 per MFMA): element j of lane group g = img[kk*32 + 8g + j][col0 + c16], zeroed past row R.
 // TAIL = the k-step that runs past row R (R % 32 == 16): lane groups 2,3 would read rows >= R and supply zeros
 // instead.  Full k-steps skip the per-element selects (they were ~40 % of the backward kernels' VALU work).
-template <int MT, bool TAIL>
+// ZERO = false (tail step only): lane groups 2, 3 return the rows of groups 0, 1 again instead of zeros — for the second operand
+// of a product whose first operand is already zero there (4 selects per fragment saved; the data is finite image content).
+template <int MT, bool TAIL, bool ZERO>
 __device__ __forceinline__ bf16x8 wg_frag(const bf16_t* img, int col0, int kk, const Geo4& q) {
     constexpr int R = MT * 16;
     const int q4 = q.c16 >> 2, p4 = q.c16 & 3;
@@ -799,6 +801,7 @@ __device__ __forceinline__ bf16x8 wg_frag(const bf16_t* img, int col0, int kk, c
         const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + (rb + q4) * LU + col0 + 4 * p4));
         const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + (rb + 4 + q4) * LU + col0 + 4 * p4));
         const bf16x8 v = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (!ZERO) return v;
         return ok ? v : zero8();
     }
 }
@@ -999,7 +1002,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                     const bf16x8 a = wg_frag<MT, true>(dOi, nt * 16, R / 32, q);
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2)
-                        accW[c][t][k2] = mfma16(a, wg_frag<MT, true>(Ai, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accW[c][t][k2]);
+                        accW[c][t][k2] = mfma16(a, wg_frag<MT, true, false>(Ai, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accW[c][t][k2]);
                 }
             }
             PH(2)
@@ -1388,7 +1391,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             const bf16x8 a = wg_frag<MT, true>(DXb, (q.wave >> 1) * 16, R / 32, q);
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
-                accP[k2] = mfma16(a, wg_frag<MT, true>(Ob, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accP[k2]);
+                accP[k2] = mfma16(a, wg_frag<MT, true, false>(Ob, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accP[k2]);
         }
         PH(2)
         // delta[head][row] = sum_keys P dP = sum_d dO[row][d] O[row][d] over the head's 8 columns (8 adjacent lanes)
@@ -1470,7 +1473,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         if constexpr (R % 32 != 0) {
             bf16x8 b[2];
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) b[k2] = wg_frag<MT, true>(U, ((q.wave & 1) * 2 + k2) * 16, R / 32, q);
+            for (int k2 = 0; k2 < 2; ++k2) b[k2] = wg_frag<MT, true, false>(U, ((q.wave & 1) * 2 + k2) * 16, R / 32, q);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
