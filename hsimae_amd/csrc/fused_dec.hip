@@ -156,7 +156,7 @@ __device__ __forceinline__ void mm_f(const bf16_t* A, int lda, int kofs, const F
 }
 
 // acc += A * W^T with W row-major bf16 [n][LU] resident in LDS (k contiguous): B fragment = 16-byte row pieces
-template <int MH, int KS>
+template <int MH, int KS, bool SW = false>
 __device__ __forceinline__ void mm_rm(const bf16_t* A, int lda, const bf16_t* Wr, int nt0, int mt0, int MT, const Geo4& q,
                                       f32x4 (&acc)[MH][2]) {
     bf16x8 b[KS][2];
@@ -172,7 +172,7 @@ __device__ __forceinline__ void mm_rm(const bf16_t* A, int lda, const bf16_t* Wr
             if (mt < MT) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + q.c16) * lda + ks * 32 + q.g * 8);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[mi][j] = mfma16(a, b[ks][j], acc[mi][j]);
+                for (int j = 0; j < 2; ++j) acc[mi][j] = SW ? mfma16(b[ks][j], a, acc[mi][j]) : mfma16(a, b[ks][j], acc[mi][j]);
             }
         }
 }
@@ -184,7 +184,7 @@ __device__ __forceinline__ bf16x8 wg_frag(const bf16_t* img, int col0, int kk, c
 
 // acc += A[:, 0:64] * W with W row-major bf16 [64 k-rows][LU] resident in LDS (n contiguous): the B fragment needs
 // 8 consecutive k of one column, i.e. a transpose read of the same image the forward-orientation product reads by rows
-template <int MH>
+template <int MH, bool SW = false>
 __device__ __forceinline__ void mm_wt(const bf16_t* A, int lda, const bf16_t* Wr, int mt0, int MT, const Geo4& q,
                                       f32x4 (&acc)[MH][2]) {
 #pragma unroll
@@ -198,7 +198,7 @@ __device__ __forceinline__ void mm_wt(const bf16_t* A, int lda, const bf16_t* Wr
             if (mt < MT) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + q.c16) * lda + ks * 32 + q.g * 8);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[mi][j] = mfma16(a, b[j], acc[mi][j]);
+                for (int j = 0; j < 2; ++j) acc[mi][j] = SW ? mfma16(b[j], a, acc[mi][j]) : mfma16(a, b[j], acc[mi][j]);
             }
         }
     }
@@ -1350,18 +1350,18 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         }
         lds_barrier();
         PH(0)
-        // q | k | v, all row-major
+        // q | k | v, all row-major.  Operands swapped (here and in the dO / du products below): a lane owns 4 consecutive columns
+        // of one token, so tiles reach the images as 8-byte writes, the bias is one 16-byte LDS read and delta needs no 8-lane sums
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             f32x4 acc[L::MH][2];
 #pragma unroll
-            for (int mi = 0; mi < L::MH; ++mi)
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(CBl + c * D + (q.wn * 2 + j) * 16 + q.g * 4);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float b = *(lds_cf32)(CBl + c * D + (q.wn * 2 + j) * 16 + q.c16);
-                    acc[mi][j] = f32x4{b, b, b, b};
-                }
-            mm_rm<L::MH, 2>(U, LU, WQl, c * 4 + q.wn * 2, mt0, MT, q, acc);
+                for (int mi = 0; mi < L::MH; ++mi) acc[mi][j] = b;
+            }
+            mm_rm<L::MH, 2, true>(U, LU, WQl, c * 4 + q.wn * 2, mt0, MT, q, acc);
             bf16_t* dst = c == 0 ? Qb : (c == 1 ? Kb : Vb);
 #pragma unroll
             for (int mi = 0; mi < L::MH; ++mi) {
@@ -1369,9 +1369,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 if (mt >= MT) continue;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        dst[(mt * 16 + q.g * 4 + r) * LU + (q.wn * 2 + j) * 16 + q.c16] = (bf16_t)acc[mi][j][r];
+                    *reinterpret_cast<bf16x4*>(dst + (mt * 16 + q.c16) * LU + (q.wn * 2 + j) * 16 + q.g * 4) = cvt4(acc[mi][j]);
             }
         }
         PH(1)
@@ -1379,7 +1377,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         f32x4 dO[L::MH][2];
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) { dO[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dO[mi][1] = dO[mi][0]; }
-        mm_wt<L::MH>(DXb, LU, WPl, mt0, MT, q, dO);
+        mm_wt<L::MH, true>(DXb, LU, WPl, mt0, MT, q, dO);
 #pragma unroll 1
         for (int kk = 0; kk < R / 32; ++kk) {
             const bf16x8 a = wg_frag<MT, false>(DXb, (q.wave >> 1) * 16, kk, q);
@@ -1395,20 +1393,24 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         }
         PH(2)
         // delta[head][row] = sum_keys P dP = sum_d dO[row][d] O[row][d] over the head's 8 columns (8 adjacent lanes)
-        bf16_t dOb16[L::MH][2][4];
+        // (a lane holds 4 of a head's 8 columns of one token: 4 products in the lane + the lane group next door, g ^ 1)
+        bf16x4 dOb16[L::MH][2];
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) {
             const int mt = mt0 + mi;
             if (mt >= MT) continue;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                const int row = mt * 16 + q.c16, col = (q.wn * 2 + j) * 16 + q.g * 4;
+                dOb16[mi][j] = cvt4(dO[mi][j]);
+                const bf16x4 ob = *reinterpret_cast<const bf16x4*>(Ob + row * LU + col);
+                float v = bf2f(dOb16[mi][j][0]) * bf2f(ob[0]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = mt * 16 + q.g * 4 + r, col = (q.wn * 2 + j) * 16 + q.c16;
-                    dOb16[mi][j][r] = (bf16_t)dO[mi][j][r];
-                    const float v = red8(bf2f(dOb16[mi][j][r]) * bf2f(Ob[row * LU + col]));
-                    if ((q.c16 & 7) == 0) dlt[(col >> 3) * R + row] = v;
-                }
+                for (int r = 1; r < 4; ++r) v = fmaf(bf2f(dOb16[mi][j][r]), bf2f(ob[r]), v);
+                float a = v, b = v;
+                swap_rows16(a, b);
+                if ((q.g & 1) == 0) dlt[(col >> 3) * R + row] = a + b;
+            }
         }
         lds_barrier();
         PH(3)
@@ -1418,9 +1420,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             if (mt >= MT) continue;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    Ob[(mt * 16 + q.g * 4 + r) * LU + (q.wn * 2 + j) * 16 + q.c16] = dOb16[mi][j][r];
+                *reinterpret_cast<bf16x4*>(Ob + (mt * 16 + q.c16) * LU + (q.wn * 2 + j) * 16 + q.g * 4) = dOb16[mi][j];
         }
         // K / V rows of the padding keys -> 0 (every wave's q | k | v columns are in the images since the barrier above):
         // what keeps padded keys out of dq without a mask in the attention loop
@@ -1453,9 +1453,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) { du[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; du[mi][1] = du[mi][0]; }
         asm volatile("" :: "v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]));
-        mm_wt<L::MH>(Qb, LU, WQl, mt0, MT, q, du);
-        mm_wt<L::MH>(Kb, LU, WQl + D * LU, mt0, MT, q, du);
-        mm_wt<L::MH>(Vb, LU, WQl + 2 * D * LU, mt0, MT, q, du);
+        mm_wt<L::MH, true>(Qb, LU, WQl, mt0, MT, q, du);
+        mm_wt<L::MH, true>(Kb, LU, WQl + D * LU, mt0, MT, q, du);
+        mm_wt<L::MH, true>(Vb, LU, WQl + 2 * D * LU, mt0, MT, q, du);
 #pragma unroll 1
         for (int kk = 0; kk < R / 32; ++kk) {
             bf16x8 b[2];
@@ -1483,7 +1483,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 for (int k2 = 0; k2 < 2; ++k2) accQ[t][k2] = mfma16(a, b[k2], accQ[t][k2]);
             }
         }
-        acc_to_xs<L::MH>(XS, mt0, MT, q, du);
+        acc_to_xs<L::MH, true>(XS, mt0, MT, q, du);
         float xe[NPW][8], d1e[NPW][8];                // L2-hot re-reads for the LayerNorm backward, in flight over the barrier
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
