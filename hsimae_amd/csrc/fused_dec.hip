@@ -882,11 +882,18 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
         for (int b = 0; b < 3; ++b)
 #pragma unroll
             for (int c = 0; c < 2; ++c) accW[a][b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float dgam[8], dbet[8], db2[8], db1[3][2], db3[3][2];
+    // Bias gradients (b2 = column sums of dY, b1 / b3 = column sums of dh1 / dh3) come out of the weight-gradient phase as one more
+    // MFMA of the same dO^T fragment against ones: dbw[c][t] belongs to that phase's n-tile t of chunk c (even waves only; the
+    // lane keeps column 4 g + (c16 & 3) of the tile).  Nothing in the gate or the prologue accumulates them any more.
+    float dgam[8], dbet[8], dbw[3][3];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; db2[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { db1[c][0] = db1[c][1] = db3[c][0] = db3[c][1] = 0.f; }
+    for (int c = 0; c < 3; ++c) { dbw[c][0] = dbw[c][1] = dbw[c][2] = 0.f; }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+    const bool bias_wave = (q.wave & 1) == 0;
 
     PH_DECL
     for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
@@ -923,7 +930,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                 const float rstd = rsqrtf(red8(v) * (1.f / D) + 1e-5f);
                 float u[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { u[e] = f[e] * rstd * gm[e] + bt[e]; db2[e] += dyv[e]; }
+                for (int e = 0; e < 8; ++e) u[e] = f[e] * rstd * gm[e] + bt[e];
                 *reinterpret_cast<bf16x8*>(U2 + row * LU + c8) = cvt8(u);
                 *reinterpret_cast<bf16x8*>(DYb + row * LU + c8) = cvt8(dyv);
             }
@@ -947,39 +954,45 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             for (int mi = 0; mi < L::MH; ++mi) {
                 const int mt = mt0 + mi;
                 if (mt >= MT) continue;
+                // operands swapped: a lane owns 4 consecutive hidden columns of one token (8-byte image writes, 16-byte bias reads)
                 f32x4 h1[1][2], h3[1][2], dg[1][2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
-                    const float b1 = *(lds_cf32)(BL + wl + col), b3 = *(lds_cf32)(BL + HPD + wl + col);
-                    h1[0][j] = f32x4{b1, b1, b1, b1};
-                    h3[0][j] = f32x4{b3, b3, b3, b3};
+                    const int col = c * 64 + (q.wn * 2 + j) * 16 + q.g * 4;
+                    h1[0][j] = *reinterpret_cast<const f32x4*>(BL + wl + col);
+                    h3[0][j] = *reinterpret_cast<const f32x4*>(BL + HPD + wl + col);
                     dg[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                mm_rm<1, 2>(U2, LU, w1L, c * 4 + q.wn * 2, mt, MT, q, h1);
-                mm_rm<1, 2>(U2, LU, w3L, c * 4 + q.wn * 2, mt, MT, q, h3);
-                mm_f<1, 2>(DYb, LU, 0, f2, mt, MT, q, dg);
+                mm_rm<1, 2, true>(U2, LU, w1L, c * 4 + q.wn * 2, mt, MT, q, h1);
+                mm_rm<1, 2, true>(U2, LU, w3L, c * 4 + q.wn * 2, mt, MT, q, h3);
+                mm_f<1, 2, true>(DYb, LU, 0, f2, mt, MT, q, dg);
                 // columns past the hidden width: W1/W3 rows and biases are zero-padded, so g = d1 = d3 = 0 there
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int lc = (q.wn * 2 + j) * 16 + q.c16;
+                    f32x4 gv, d1, d3;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float a1 = h1[0][j][r], a3 = h3[0][j][r], dv = dg[0][j][r];
                         const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-a1));
                         const float sl = a1 * sg;
-                        const float d1 = dv * a3 * sg * (1.f + a1 * (1.f - sg));
-                        const float d3 = dv * sl;
-                        const int o = (mt * 16 + q.g * 4 + r) * LU + lc;
-                        Gc[o] = (bf16_t)(sl * a3); DH1[o] = (bf16_t)d1; DH3[o] = (bf16_t)d3;
-                        db1[c][j] += d1; db3[c][j] += d3;
+                        gv[r] = sl * a3;
+                        d1[r] = dv * a3 * sg * (1.f + a1 * (1.f - sg));
+                        d3[r] = dv * sl;
                     }
+                    const int o = (mt * 16 + q.c16) * LU + (q.wn * 2 + j) * 16 + q.g * 4;
+                    *reinterpret_cast<bf16x4*>(Gc + o) = cvt4(gv);
+                    *reinterpret_cast<bf16x4*>(DH1 + o) = cvt4(d1);
+                    *reinterpret_cast<bf16x4*>(DH3 + o) = cvt4(d3);
                 }
             }
             if (c < 2) f2.load(w2T, 2, (c + 1) * 4 + q.wn * 2, 0, q);
             lds_barrier();
         PH(1)
-            // weight gradients of this hidden chunk: 12 (n-tile) x 4 (k-tile) output tiles, 3 x 2 per wave
+            // weight gradients of this hidden chunk: 12 (n-tile) x 4 (k-tile) output tiles, 3 x 2 per wave; on the even waves the
+            // dO^T fragment also meets a tile of ones: the column sums of dY / dh1 / dh3 = this sample's bias-gradient addends
+            f32x4 accb[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) accb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int kk = 0; kk < R / 32; ++kk) {
 #pragma unroll
@@ -988,6 +1001,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                     const bf16_t* dOi = mat == 0 ? DYb : (mat == 1 ? DH1 : DH3);
                     const bf16_t* Ai = mat == 0 ? Gc : U2;
                     const bf16x8 a = wg_frag<MT, false>(dOi, nt * 16, kk, q);
+                    if (bias_wave) accb[t] = mfma16(a, ones, accb[t]);
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2)
                         accW[c][t][k2] = mfma16(a, wg_frag<MT, false>(Ai, ((q.wave & 1) * 2 + k2) * 16, kk, q), accW[c][t][k2]);
@@ -1000,9 +1014,19 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                     const bf16_t* dOi = mat == 0 ? DYb : (mat == 1 ? DH1 : DH3);
                     const bf16_t* Ai = mat == 0 ? Gc : U2;
                     const bf16x8 a = wg_frag<MT, true>(dOi, nt * 16, R / 32, q);
+                    if (bias_wave) accb[t] = mfma16(a, ones, accb[t]);
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2)
                         accW[c][t][k2] = mfma16(a, wg_frag<MT, true, false>(Ai, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accW[c][t][k2]);
+                }
+            }
+            if (bias_wave) {
+                const int r4 = q.c16 & 3;                  // every lane of a row holds the same 4 sums: keep column 4 g + (c16 & 3)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int mat = ((q.wave >> 1) * 3 + t) >> 2;
+                    const float v = r4 == 0 ? accb[t][0] : (r4 == 1 ? accb[t][1] : (r4 == 2 ? accb[t][2] : accb[t][3]));
+                    if (mat != 0 || c == 0) dbw[c][t] += v;              // dY is the same image in all three chunks: count it once
                 }
             }
             PH(2)
@@ -1022,14 +1046,14 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                         if (mt >= MT) continue;
                         const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ai + (mt * 16 + q.c16) * LU + ks * 32 + q.g * 8);
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) du2[mi][j] = mfma16(a, b[j], du2[mi][j]);
+                        for (int j = 0; j < 2; ++j) du2[mi][j] = mfma16(b[j], a, du2[mi][j]);     // swapped: see the gate products
                     }
                 }
             }
             lds_barrier();
         PH(5)
         }
-        acc_to_xs<L::MH>(XS, mt0, MT, q, du2);
+        acc_to_xs<L::MH, true>(XS, mt0, MT, q, du2);
         asm volatile("" :: "v"(touch0), "v"(touch1));
         float xe[NPW][8], dye[NPW][8];                // L2-hot re-reads for the LayerNorm backward, in flight over the barrier
 #pragma unroll
@@ -1080,20 +1104,21 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
     float* vec = p.slab ? p.slab + kSlabTileFloats + (size_t)blockIdx.x * kVec : nullptr;
     flush_wide(red, dgam, p.g_n2w, p.det, vec ? vec + kVN2W : nullptr);
     flush_wide(red, dbet, p.g_n2b, p.det, vec ? vec + kVN2B : nullptr);
-    flush_wide(red, db2, p.g_w2b, p.det, vec ? vec + kVW2B : nullptr);
+    if (bias_wave && (q.c16 >> 2) == 0) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float a = db1[c][j], b = db3[c][j];
-            a = rows_sum(a);
-            b = rows_sum(b);
-            const int col = c * 64 + (q.wn * 2 + j) * 16 + q.c16;
-            if (q.g == 0 && col < p.w.h) {
-                if (vec) { vec[kVW1B + q.wm * HPD + col] = a; vec[kVW3B + q.wm * HPD + col] = b; }
-                else { hs_gadd(p.det, p.g_w1b + col, a); hs_gadd(p.det, p.g_w3b + col, b); }
+            for (int t = 0; t < 3; ++t) {
+                const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
+                const int ci = nt * 16 + q.g * 4 + (q.c16 & 3), col = c * 64 + ci;      // column inside the chunk / of the hidden width
+                if (mat == 0) {
+                    if (c == 0) { if (vec) vec[kVW2B + ci] = dbw[c][t]; else hs_gadd(p.det, p.g_w2b + ci, dbw[c][t]); }
+                } else if (col < p.w.h) {
+                    if (vec) vec[(mat == 1 ? kVW1B : kVW3B) + col] = dbw[c][t];
+                    else hs_gadd(p.det, (mat == 1 ? p.g_w1b : p.g_w3b) + col, dbw[c][t]);
+                }
             }
-        }
+    }
     if (p.slab) {
         // The 72 accumulator registers of every thread leave as 72 fully coalesced 2-KB rows of this workgroup's slab
         // ([slot][thread]); dec_dw_reduce_kernel sums the workgroups and scatters into dW1 / dW3 / dW2 with the index map below.
@@ -1607,7 +1632,7 @@ __global__ __launch_bounds__(NT_) void dec_dw_reduce_kernel(DecDwReduceArgs p) {
     const int slot = blockIdx.x, tid = threadIdx.x;
     if (slot >= kDwSlots) {                               // the bias / LayerNorm vectors: [workgroup][kVec]
         // the bias / LayerNorm vectors: one WAVE per output element (9 vectors of 64 and 2 of 192 = 960 elements, 8 per
-        // workgroup): its 64 lanes split the workgroups' partials (w1b / w3b: x 4 per-wave-row partials), then a fixed-order
+        // workgroup): its 64 lanes split the workgroups' partials, then a fixed-order
         // lane tree — a thread per element walked up to 1,024 partials alone and was the launch's 35-us tail
         const int e = (slot - kDwSlots) * (NT_ / 64) + (tid >> 6), lane = tid & 63;
         if (e >= 9 * D + 2 * HPD) return;
@@ -1627,7 +1652,7 @@ __global__ __launch_bounds__(NT_) void dec_dw_reduce_kernel(DecDwReduceArgs p) {
         float v = 0.f;
         for (int w = lane; w < p.nwg; w += 64) {
             const float* q = src + (size_t)w * kVec;
-            v += wide ? (q[0] + q[HPD]) + (q[2 * HPD] + q[3 * HPD]) : q[0];
+            v += q[0];
         }
         v = wave_sum(v);
         if (lane == 0) d[c] += v;
