@@ -1172,8 +1172,7 @@ __device__ __forceinline__ bf16x4 tr4(const bf16_t* a) {
 // rows past Ts are zero on entry and the dk / dv rows past Ts are written as zero (see the loop body).
 template <int MT>
 __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb, const bf16_t* dOb, const float* lse_h,
-                                              const float* dlt_h, bf16_t* T, int head, int Ts, const Geo4& q,
-                                              float (&dbq)[4], float (&dbk)[4], float (&dbv)[4]) {
+                                              const float* dlt_h, bf16_t* T, int head, int Ts, const Geo4& q) {
     const float sc = 0.35355339059327373f * 1.4426950408889634f, scale = 0.35355339059327373f;
     const int hc = head * HD;
     const int q4 = q.c16 >> 2, p4 = q.c16 & 3;
@@ -1245,7 +1244,7 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
         if (q.g < 2) {
             bf16x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float x = dqT[r] * scale; v[r] = (bf16_t)x; dbq[r] += x; }
+            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dqT[r] * scale);
             *reinterpret_cast<bf16x4*>(Qb + query * LU + hc + 4 * q.g) = v;
         }
     }
@@ -1258,7 +1257,6 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
             for (int r = 0; r < 4; ++r) {
                 const float xk = live ? dkT[kt][r] * scale : 0.f, xv = live ? dvT[kt][r] : 0.f;
                 vk[r] = (bf16_t)xk; vv[r] = (bf16_t)xv;
-                dbk[r] += xk; dbv[r] += xv;
             }
             *reinterpret_cast<bf16x4*>(Kb + (kt * 16 + q.c16) * LU + hc + 4 * q.g) = vk;
             *reinterpret_cast<bf16x4*>(Vb + (kt * 16 + q.c16) * LU + hc + 4 * q.g) = vv;
@@ -1316,12 +1314,16 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) accQ[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float dgam[8], dbet[8], dbp[8];
-    float dbq[4], dbk[4], dbv[4];
+    // bias gradients (bp = column sums of dx1; bq / bk / bv = column sums of dq / dk / dv) as in dec_bwd_mlp_kernel: the dO^T
+    // fragment of the weight-gradient products against a tile of ones, on the even waves; the lane keeps column 4 g + (c16 & 3)
+    float dgam[8], dbet[8], dbpw = 0.f, dbqw[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; dbp[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; }
+    bf16x8 ones;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { dbq[r] = 0.f; dbk[r] = 0.f; dbv[r] = 0.f; }
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+    const bool bias_wave = (q.wave & 1) == 0;
+    const int r4 = q.c16 & 3;
 
     PH_DECL
     for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
@@ -1368,7 +1370,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 const float rstd = rsqrtf(red8(v) * (1.f / D) + 1e-5f);
                 float u[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { u[e] = f[e] * rstd * gm[e] + bt[e]; dbp[e] += d1[e]; }
+                for (int e = 0; e < 8; ++e) u[e] = f[e] * rstd * gm[e] + bt[e];
                 *reinterpret_cast<bf16x8*>(U + row * LU + c8) = cvt8(u);
                 *reinterpret_cast<bf16x8*>(DXb + row * LU + c8) = cvt8(d1);
             }
@@ -1403,19 +1405,23 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) { dO[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dO[mi][1] = dO[mi][0]; }
         mm_wt<L::MH, true>(DXb, LU, WPl, mt0, MT, q, dO);
+        f32x4 accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int kk = 0; kk < R / 32; ++kk) {
             const bf16x8 a = wg_frag<MT, false>(DXb, (q.wave >> 1) * 16, kk, q);
+            if (bias_wave) accb = mfma16(a, ones, accb);
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
                 accP[k2] = mfma16(a, wg_frag<MT, false>(Ob, ((q.wave & 1) * 2 + k2) * 16, kk, q), accP[k2]);
         }
         if constexpr (R % 32 != 0) {
             const bf16x8 a = wg_frag<MT, true>(DXb, (q.wave >> 1) * 16, R / 32, q);
+            if (bias_wave) accb = mfma16(a, ones, accb);
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
                 accP[k2] = mfma16(a, wg_frag<MT, true, false>(Ob, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accP[k2]);
         }
+        dbpw += r4 == 0 ? accb[0] : (r4 == 1 ? accb[1] : (r4 == 2 ? accb[2] : accb[3]));
         PH(2)
         // delta[head][row] = sum_keys P dP = sum_d dO[row][d] O[row][d] over the head's 8 columns (8 adjacent lanes)
         // (a lane holds 4 of a head's 8 columns of one token: 4 products in the lane + the lane group next door, g ^ 1)
@@ -1469,8 +1475,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         }
         // attention backward, one head per wave, dq/dk/dv written in place over q/k/v
         // (a half-tile start stagger of waves 4-7, MI355X_MICROARCH.md "two waves per SIMD" item 9, measured neutral here)
-        attn_head_bwd<MT>(Qb, Kb, Vb, Ob, lse + q.wave * R, dlt + q.wave * R, TT + q.wave * TT_WAVE, q.wave, p.Ts, q,
-                          dbq, dbk, dbv);
+        attn_head_bwd<MT>(Qb, Kb, Vb, Ob, lse + q.wave * R, dlt + q.wave * R, TT + q.wave * TT_WAVE, q.wave, p.Ts, q);
         lds_barrier();
         PH(5)
         // du = dq Wq + dk Wk + dv Wv ; dWq|dWk|dWv += d{q,k,v}^T u
@@ -1481,6 +1486,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         mm_wt<L::MH, true>(Qb, LU, WQl, mt0, MT, q, du);
         mm_wt<L::MH, true>(Kb, LU, WQl + D * LU, mt0, MT, q, du);
         mm_wt<L::MH, true>(Vb, LU, WQl + 2 * D * LU, mt0, MT, q, du);
+        f32x4 accqb[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) accqb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int kk = 0; kk < R / 32; ++kk) {
             bf16x8 b[2];
@@ -1491,6 +1499,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
                 const bf16_t* dOi = mat == 0 ? Qb : (mat == 1 ? Kb : Vb);
                 const bf16x8 a = wg_frag<MT, false>(dOi, nt * 16, kk, q);
+                if (bias_wave) accqb[t] = mfma16(a, ones, accqb[t]);
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) accQ[t][k2] = mfma16(a, b[k2], accQ[t][k2]);
             }
@@ -1504,10 +1513,13 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
                 const bf16_t* dOi = mat == 0 ? Qb : (mat == 1 ? Kb : Vb);
                 const bf16x8 a = wg_frag<MT, true>(dOi, nt * 16, R / 32, q);
+                if (bias_wave) accqb[t] = mfma16(a, ones, accqb[t]);
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) accQ[t][k2] = mfma16(a, b[k2], accQ[t][k2]);
             }
         }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) dbqw[t] += r4 == 0 ? accqb[t][0] : (r4 == 1 ? accqb[t][1] : (r4 == 2 ? accqb[t][2] : accqb[t][3]));
         acc_to_xs<L::MH, true>(XS, mt0, MT, q, du);
         float xe[NPW][8], d1e[NPW][8];                // L2-hot re-reads for the LayerNorm backward, in flight over the barrier
 #pragma unroll
@@ -1558,17 +1570,15 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     float* vec = p.slab ? p.slab + kSlabTileFloats + (size_t)blockIdx.x * kVec : nullptr;
     flush_wide(red, dgam, p.g_n1w, p.det, vec ? vec + kVN1W : nullptr);
     flush_wide(red, dbet, p.g_n1b, p.det, vec ? vec + kVN1B : nullptr);
-    flush_wide(red, dbp, p.g_pb, p.det, vec ? vec + kVPB : nullptr);
-    {
+    if (bias_wave && (q.c16 >> 2) == 0) {
+        const int ci = q.g * 4 + r4;
+        const int cp = (q.wave >> 1) * 16 + ci;
+        if (vec) vec[kVPB + cp] = dbpw; else hs_gadd(p.det, p.g_pb + cp, dbpw);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float a = dbq[r], b = dbk[r], c = dbv[r];
-            a = lanes_sum<16>(a); b = lanes_sum<16>(b); c = lanes_sum<16>(c);
-            const int col = q.wave * HD + q.g * 4 + r;
-            if (q.c16 == 0 && q.g < 2) {
-                if (vec) { vec[kVQB + col] = a; vec[kVKB + col] = b; vec[kVVB + col] = c; }
-                else { hs_gadd(p.det, p.g_qb + col, a); hs_gadd(p.det, p.g_kb + col, b); hs_gadd(p.det, p.g_vb + col, c); }
-            }
+        for (int t = 0; t < 3; ++t) {
+            const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, col = (nt12 & 3) * 16 + ci;
+            if (vec) vec[(mat == 0 ? kVQB : (mat == 1 ? kVKB : kVVB)) + col] = dbqw[t];
+            else hs_gadd(p.det, (mat == 0 ? p.g_qb : (mat == 1 ? p.g_kb : p.g_vb)) + col, dbqw[t]);
         }
     }
     if (p.slab) {                 // slots 72..103 of this workgroup's slab: accP[k2][r] then accQ[t][k2][r]
