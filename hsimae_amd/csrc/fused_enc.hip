@@ -165,6 +165,17 @@ __device__ __forceinline__ float redrow(float v) {          // sum over the LPR 
     return v;
 }
 
+// b1 | b3 of the 4 hidden columns a lane owns in the swapped-operand products (zero past the hidden width: the padded W1 / W3
+// rows are zero too).  Fetched one chunk ahead with the weight fragments: loaded where they are used, every chunk began with an
+// exposed L2 round trip (s_waitcnt vmcnt(0) in front of the first MFMA).
+struct Bias13 {
+    f32x4 b1, b3;
+    __device__ __forceinline__ void load(const float* w1b, const float* w3b, int col, int h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { b1[r] = col + r < h ? w1b[col + r] : 0.f; b3[r] = col + r < h ? w3b[col + r] : 0.f; }
+    }
+};
+
 struct EncMlpW {
     const float *n2w, *n2b, *w1b, *w3b, *w2b;
     const bf16_t *w1, *w3, *w2, *w2T, *w13T;
@@ -200,6 +211,8 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
     FrN<KSD, 1> f1, f3;                                 // this wave's n-tile of the current hidden chunk
     f1.template load<false>(w.w1, KSD, q.wave, 0, nt_h, q.lane);          // chunk 0: all four n-tiles exist (HPE >= 64)
     f3.template load<false>(w.w3, KSD, q.wave, 0, nt_h, q.lane);
+    Bias13 bn;                                          // biases of the NEXT chunk (see Bias13)
+    bn.load(w.w1b, w.w3b, q.wave * 16 + q.g * 4, w.h);
     __builtin_amdgcn_sched_barrier(0);           // keep the fetches here: hipcc otherwise sinks them next to the MFMAs
     {   // LayerNorm-2 in the wide layout (16 lanes per row)
         float gm[8], bt[8];
@@ -248,16 +261,10 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
         const int nt = c * 4 + q.wave;                                  // this wave's n-tile of the chunk
         const bool full = c * 4 + 3 < nt_h;                             // (compile-time per unrolled chunk) all four waves have columns
         const bool live = full || nt < nt_h;                            // last chunk: only waves 0, 1 have columns
-        const int col = nt * 16 + q.g * 4;                              // this lane's 4 hidden columns
         bf16_t* Gi = Gc + (c & 1) * R * LC;
         f32x4 h1[MT4], h3[MT4];
-        {
-            f32x4 b1, b3;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { b1[r] = col + r < w.h ? w.w1b[col + r] : 0.f; b3[r] = col + r < w.h ? w.w3b[col + r] : 0.f; }
-#pragma unroll
-            for (int mt = 0; mt < MT4; ++mt) { h1[mt] = b1; h3[mt] = b3; }
-        }
+        for (int mt = 0; mt < MT4; ++mt) { h1[mt] = bn.b1; h3[mt] = bn.b3; }
         if (live) {
 #pragma unroll
             for (int ks = 0; ks < KSD; ++ks)
@@ -277,6 +284,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
                 f1.load(w.w1, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
                 f3.load(w.w3, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
             }
+            bn.load(w.w1b, w.w3b, ((c + 1) * 4 + q.wave) * 16 + q.g * 4, w.h);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -372,6 +380,9 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
     f1.template load<false>(w.w1, KSD, q.wave, 0, nt_h, q.lane);
     f3.template load<false>(w.w3, KSD, q.wave, 0, nt_h, q.lane);
     f2.template load<false>(w.w2T, KSD, q.wave, 0, nt_h, q.lane);
+    constexpr bool BPF = D == 128;                      // bias prefetch: at the other widths the 8 registers spill
+    [[maybe_unused]] Bias13 bn;                         // biases of the NEXT chunk (see Bias13)
+    if constexpr (BPF) bn.load(w.w1b, w.w3b, q.wave * 16 + q.g * 4, w.h);
     {
         float gm[8], bt[8];
         ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
@@ -431,13 +442,19 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
         const bool live = full || nt < nt_h;
         {
             // operands swapped as in the forward kernel: a lane owns 4 consecutive hidden columns of one row
-            const int col = nt * 16 + q.g * 4, lc = q.wave * 16 + q.g * 4;
+            const int lc = q.wave * 16 + q.g * 4;
             f32x4 h1[MT4], h3[MT4], dg[MT4];
-            f32x4 b1, b3;
+            if constexpr (BPF) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { b1[r] = col + r < w.h ? w.w1b[col + r] : 0.f; b3[r] = col + r < w.h ? w.w3b[col + r] : 0.f; }
+                for (int mt = 0; mt < MT4; ++mt) { h1[mt] = bn.b1; h3[mt] = bn.b3; dg[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            } else {
+                const int col = nt * 16 + q.g * 4;
+                f32x4 b1, b3;
 #pragma unroll
-            for (int mt = 0; mt < MT4; ++mt) { h1[mt] = b1; h3[mt] = b3; dg[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int r = 0; r < 4; ++r) { b1[r] = col + r < w.h ? w.w1b[col + r] : 0.f; b3[r] = col + r < w.h ? w.w3b[col + r] : 0.f; }
+#pragma unroll
+                for (int mt = 0; mt < MT4; ++mt) { h1[mt] = b1; h3[mt] = b3; dg[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
             if (live) {
 #pragma unroll
                 for (int ks = 0; ks < KSD; ++ks)
@@ -460,6 +477,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                     f3.load(w.w3, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
                     f2.load(w.w2T, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
                 }
+                if constexpr (BPF) bn.load(w.w1b, w.w3b, ((c + 1) * 4 + q.wave) * 16 + q.g * 4, w.h);
             }
 #pragma unroll
             for (int mt = 0; mt < MT4; ++mt) {
