@@ -71,8 +71,8 @@ __device__ __forceinline__ float dpp_mov(float v) {
 // rows r and r ^ 1 (lanes ^ 16) / halves (lanes ^ 32) exchanged in place: a + b afterwards is v + partner in every lane.
 // (The __builtin_amdgcn_permlane16_swap / 32_swap builtins lose their second result in hipcc 7.2 when both operands derive
 //  from one value — inline asm with two tied registers; s_nop covers the VALU-write -> permlane read hazard.)
-__device__ __forceinline__ void swap_rows16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void swap_rows32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap_rows16(float& a, float& b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap_rows32(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 
 struct OpSum { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
 struct OpMax { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
