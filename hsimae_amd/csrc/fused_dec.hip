@@ -1325,6 +1325,28 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     const bool bias_wave = (q.wave & 1) == 0;
     const int r4 = q.c16 & 3;
 
+    float fa[NPW][8], d1a[NPW][8];
+    f32x4 l4a;
+    bf16x8 ova[NPW];
+    // (unconditional with a validity flag: under an `if` the old values would stay live through the whole iteration)
+    auto fetch_sample = [&](int smp) {               // every load of a sample in flight before the first use
+        const bool valid = smp < p.nsamples;
+        const size_t nb = (size_t)smp * p.Ts;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int row = (threadIdx.x + NT_ * i) >> 3;
+            ova[i] = zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { fa[i][e] = 0.f; d1a[i][e] = 0.f; }
+            if (valid && row < p.Ts) {
+                ld8(p.x + (nb + row) * D + c8, fa[i]); ld8(p.dx1 + (nb + row) * D + c8, d1a[i]);
+                ova[i] = *reinterpret_cast<const bf16x8*>(p.o + (nb + row) * D + c8);
+            }
+        }
+        l4a = f32x4{1e30f, 1e30f, 1e30f, 1e30f};      // rows past Ts: exp2(s - 1e30) = 0
+        if (valid && (threadIdx.x >> 1) < p.Ts) l4a = *reinterpret_cast<const f32x4*>(p.lse_g + (nb + (threadIdx.x >> 1)) * 8 + (threadIdx.x & 1) * 4);
+    };
+    fetch_sample(blockIdx.x);
     PH_DECL
     for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
         const size_t rb = (size_t)sample * p.Ts;
@@ -1332,21 +1354,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         const bf16_t* WQl = WQ + wl;
         const bf16_t* WPl = WP + wl;
         const float* CBl = CB + wl;
-        // x, dx1, O and logsumexp of this sample: the only exposed HBM round trip of the iteration
-        float fa[NPW][8], d1a[NPW][8], l8a[NPW][8];
-        bf16x8 ova[NPW];
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) {               // every load of the sample in flight before the first use
-            const int row = (threadIdx.x + NT_ * i) >> 3;
-            ova[i] = zero8();
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { fa[i][e] = 0.f; d1a[i][e] = 0.f; l8a[i][e] = 1e30f; }   // rows past Ts: exp2(s - 1e30) = 0
-            if (row < p.Ts) {
-                ld8(p.x + (rb + row) * D + c8, fa[i]); ld8(p.dx1 + (rb + row) * D + c8, d1a[i]);
-                ova[i] = *reinterpret_cast<const bf16x8*>(p.o + (rb + row) * D + c8);
-                if (c8 == 0) ld8(p.lse_g + (rb + row) * 8, l8a[i]);
-            }
-        }
+        // x, dx1, O and logsumexp of this sample are in registers already: fetch_sample() ran in front of the PREVIOUS sample's
+        // LayerNorm-backward epilogue, so the HBM round trip is under that epilogue instead of exposed here (17 % of the kernel
+        // before).  Works since the kernel no longer spills: scratch reloads share vmcnt with these loads and used to drain them.
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pc = threadIdx.x + NT_ * i;
@@ -1355,14 +1365,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 float gm[8], bt[8];
                 float (&f)[8] = fa[i];
                 float (&d1)[8] = d1a[i];
-                float (&l8)[8] = l8a[i];
                 const bf16x8 ov = ova[i];
                 ld8(CBl + 3 * D + c8, gm); ld8(CBl + 4 * D + c8, bt);
                 *reinterpret_cast<bf16x8*>(Ob + row * LU + c8) = ov;
-                if (c8 == 0) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) lse[e * R + row] = l8[e];
-                }
                 const float mean = red8(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
                 float v = 0.f;
 #pragma unroll
@@ -1374,6 +1379,11 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 *reinterpret_cast<bf16x8*>(U + row * LU + c8) = cvt8(u);
                 *reinterpret_cast<bf16x8*>(DXb + row * LU + c8) = cvt8(d1);
             }
+        }
+        if (threadIdx.x < 2 * R) {                     // logsumexp [row][8 heads] -> [head][row]
+            const int row = threadIdx.x >> 1, h4 = (threadIdx.x & 1) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lse[(h4 + e) * R + row] = l4a[e];
         }
         lds_barrier();
         PH(0)
@@ -1478,6 +1488,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         attn_head_bwd<MT>(Qb, Kb, Vb, Ob, lse + q.wave * R, dlt + q.wave * R, TT + q.wave * TT_WAVE, q.wave, p.Ts, q);
         lds_barrier();
         PH(5)
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_sample(sample + (int)gridDim.x);          // ~4 us (du + dWqkv + epilogue) ahead of its use
+        __builtin_amdgcn_sched_barrier(0);
         // du = dq Wq + dk Wk + dv Wv ; dWq|dWk|dWv += d{q,k,v}^T u
         f32x4 du[L::MH][2];
 #pragma unroll
