@@ -65,7 +65,11 @@ template <int D, int HP, int R_ = (D == 64 ? 64 : 48)>
 struct MG {
     static constexpr int R = R_;
     static constexpr int WPC = D <= 128 ? 3 : 2;            // workgroups per CU the kernels are compiled for
-    static constexpr int LU = D + 8;            // bf16 panel row stride (elements)
+    // bf16 panel row stride (elements).  A pitch of 16 mod 64 elements makes the 16-byte A-fragment reads conflict-free in the bank
+    // model of scripts/micro/lds_banks.py (4 instead of 8 cycles; D + 8 is 2-way conflicted) at the price of 4-way conflicts on the
+    // 8-byte transposed-tile writes, which are 6 x rarer: enc_mlp_fwd<64,192> 82 -> 80 us, <128,352> 55.0 -> 54.2.  Not at D = 256:
+    // the backward kernel there spills more with the wider panel (375 -> 387 us).
+    static constexpr int LU = D <= 128 ? D + 16 : D + 8;
     static constexpr int LX = D + 4;            // fp32 staging row stride (floats)
     static constexpr int LG = HP + 8;           // gate image row stride
     static constexpr int NCH = (HP + 63) / 64;  // hidden chunks (the last one may be half full)
