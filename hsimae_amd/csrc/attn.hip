@@ -392,7 +392,7 @@ __device__ __forceinline__ void store16_wg(bf16_t* dst, int ld, int Ts, int nhea
     }
 }
 
-template <int NT, int HD = 16, int HPW = 4>
+template <int NT, int HD = 16, int HPW = 4, bool MODE0 = false>      // MODE0: one class (p.mode == 0), chosen at launch
 __global__ __launch_bounds__(64 * HPW) void attn16_fwd_kernel(AttnParams p) {
     using L = Lay16<NT, HD, HPW>;
     constexpr int RS16 = L::RS;                 // (shadows the head-dim-16 constant: every image access below uses the layout's stride)
@@ -432,6 +432,24 @@ __global__ __launch_bounds__(64 * HPW) void attn16_fwd_kernel(AttnParams p) {
         const bf16x4 bq = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Qi + query * RS16 + 4 * g) : zero4_();
         f32x4 s[NT];
         float m = -INFINITY;
+        if constexpr (MODE0) {
+            // one class (the decoder, the fusion blocks): the only mask is the sequence end, and only key tiles that reach past it
+            // need it (the per-element class compare below was a quarter of this loop's VALU work)
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const bf16x4 ak = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Ki + (kt * 16 + c16) * RS16 + 4 * g) : zero4_();
+                s[kt] = mfma_k16(ak, bq, z4);
+                if ((kt + 1) * 16 > p.Ts) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[kt][r] = (kt * 16 + g * 4 + r < p.Ts) ? s[kt][r] * sc : -INFINITY;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[kt][r] *= sc;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, s[kt][r]);
+            }
+        } else {
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             const bf16x4 ak = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Ki + (kt * 16 + c16) * RS16 + 4 * g) : zero4_();
@@ -444,6 +462,7 @@ __global__ __launch_bounds__(64 * HPW) void attn16_fwd_kernel(AttnParams p) {
                 s[kt][r] = ok ? s[kt][r] * sc : -INFINITY;
                 m = fmaxf(m, s[kt][r]);
             }
+        }
         }
         m = group_max(m);
         if (m == -INFINITY) m = 0.f;
@@ -477,7 +496,7 @@ __global__ __launch_bounds__(64 * HPW) void attn16_fwd_kernel(AttnParams p) {
     store16_wg<NT, HD, HPW>(p.o + row_base * p.ldo + head0 * HD, p.ldo, p.Ts, nheads, img0, WSTR);
 }
 
-template <int NT, int HD = 16, int HPW = 4>
+template <int NT, int HD = 16, int HPW = 4, bool MODE0 = false>
 __global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
     using L = Lay16<NT, HD, HPW>;
     constexpr int RS16 = L::RS;
@@ -557,14 +576,24 @@ __global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
             const bf16x4 av = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Vi + (kt * 16 + c16) * RS16 + 4 * g) : zero4_();
             const f32x4 s = mfma_k16(ak, bq, z4);                // S^T[key 4g + r][query c16]
             const f32x4 dp = mfma_k16(av, bdo, z4);
-            const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
-            const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
             f32x4 pv, ds;
+            if constexpr (MODE0) {
+                // one class: no mask.  The K / V image rows past Ts are zero (load16_wg), so a padded key has s = 0, dP = 0 and a
+                // finite garbage P / dS that meets K = 0 in dq; its dk / dv rows are never stored (store16_wg stops at Ts)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
-                pv[r] = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn)) : 0.f;
-                ds[r] = pv[r] * (dp[r] - dl);
+                for (int r = 0; r < 4; ++r) {
+                    pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn));
+                    ds[r] = pv[r] * (dp[r] - dl);
+                }
+            } else {
+                const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
+                const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
+                    pv[r] = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn)) : 0.f;
+                    ds[r] = pv[r] * (dp[r] - dl);
+                }
             }
             const bf16x4 pb = cvt4(pv), dsb = cvt4(ds);
             dqT = mfma_k16(KT[kt], dsb, dqT);
@@ -1148,14 +1177,23 @@ int launch_attn16(const AttnParams& p, hipStream_t s) {
     const size_t lds = L::CLS + HPW * (size_t)(BWD ? L::BWD_WAVE : L::FWD_WAVE) + 32;      // + the last transposed read's overhang at HD = 8
     if (lds > 160 * 1024) return HS_EUNSUPPORTED;
     static bool attr_set = false;
+    const dim3 grid(p.nsamples * hgroups), blk(64 * HPW);
     if constexpr (BWD) {
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<NT, HD, HPW>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-        hipLaunchKernelGGL((attn16_bwd_kernel<NT, HD, HPW>), dim3(p.nsamples * hgroups), dim3(64 * HPW), lds, s, p);
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<NT, HD, HPW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<NT, HD, HPW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        if (p.mode == 0) hipLaunchKernelGGL((attn16_bwd_kernel<NT, HD, HPW, true>), grid, blk, lds, s, p);
+        else hipLaunchKernelGGL((attn16_bwd_kernel<NT, HD, HPW, false>), grid, blk, lds, s, p);
     } else {
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_fwd_kernel<NT, HD, HPW>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-        hipLaunchKernelGGL((attn16_fwd_kernel<NT, HD, HPW>), dim3(p.nsamples * hgroups), dim3(64 * HPW), lds, s, p);
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_fwd_kernel<NT, HD, HPW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_fwd_kernel<NT, HD, HPW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        if (p.mode == 0) hipLaunchKernelGGL((attn16_fwd_kernel<NT, HD, HPW, true>), grid, blk, lds, s, p);
+        else hipLaunchKernelGGL((attn16_fwd_kernel<NT, HD, HPW, false>), grid, blk, lds, s, p);
     }
     return (int)hipGetLastError();
 }
