@@ -989,6 +989,20 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
     };
     fetch(blockIdx.x * SPW);
     lds_barrier();                                                // vec_s / cls visible
+    // The class / padding mask of a (query tile, key tile) pair is the same for every sample and slot: built once, as the
+    // accumulator the score MFMA starts from (0 or -inf) — the per-element compares and selects leave the sample loop.
+    f32x4 cm[NT][NT];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+        const int qc = cls[qt * 16 + c16];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kc = cls[kt * 16 + g * 4 + r];
+                cm[qt][kt][r] = (kc >= 0 && kc == qc) ? 0.f : -INFINITY;
+            }
+    }
     for (int first = blockIdx.x * SPW; first < p.nsamples; first += gridDim.x * SPW) {
         // global row of image row i (slot-major), or -1
         auto grow = [&](int irow) -> int64_t {
@@ -1048,20 +1062,16 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
             for (int qt = 0; qt < NT; ++qt) {
                 if (qt * 16 >= p.Ts) break;
                 const int query = r0 + qt * 16 + c16;
-                const int qcls = cls[query];
                 const bf16x4 bqf = *reinterpret_cast<const bf16x4*>(Qf + query * FS + hc + 4 * g);
                 f32x4 sv[NT];
                 float m = -INFINITY;
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) {
                     const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (r0 + kt * 16 + c16) * FS + hc + 4 * g);
-                    sv[kt] = mfma_k16(ak, bqf, z4);
-                    const int4 kc = *reinterpret_cast<const int4*>(cls + r0 + kt * 16 + g * 4);
-                    const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
+                    sv[kt] = mfma_k16(ak, bqf, cm[qt][kt]);           // masked pairs start (and stay) at -inf
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
-                        sv[kt][r] = ok ? sv[kt][r] * sc : -INFINITY;
+                        sv[kt][r] *= sc;
                         m = fmaxf(m, sv[kt][r]);
                     }
                 }
