@@ -15,6 +15,8 @@ resident in HBM (mask ratio 0.75), including the RCCL gradient all-reduce when N
   encoder_mfma_frac    encoder fwd+bwd alone (hsimae_encode + hsimae_encode_backward), HIP events, same peak.
   roofline_kernel      the kernel with the largest share of the step, replayed through the C ABI with HIP events:
                        its algorithmic FLOPs against the MFMA peak, and (roofline_kernel_hbm) its bytes against HBM.
+  roofline_decoder     the decoder group (hsimae_decode / hsimae_decode_backward) with HIP events; roofline_decoder_block = ONE fused
+                       decoder Block replayed through hsimae_dec_block_fwd / _bwd (forward pair; two backward kernels + reduce).
   step_ms              HIP-event duration of every timed step: median / p10 / p90, and per (len_t, len_l) grid.
   cpu_baseline         the CPU oracle on a bounded sample of the same workload (C1 and C2 shapes), on the host cores.
 """
@@ -208,6 +210,55 @@ def wgrad_launch(model, M):
     launch.compulsory_bytes = launch.design_bytes            # every operand read once; the operands themselves are a design choice
     launch.name = "wgrad_dma_kernel (encoder block: dW/db of q,k,v,proj,w1,w3,w2 in one launch)"
     return launch
+
+
+def decoder_block_replay(model, N, Ts, peak_tflops, iters=10):
+    """One fused decoder Block through the C ABI (`hsimae_dec_block_fwd` / `_bwd`: the attention-half + MLP-half forward pair, the
+    two persistent backward kernels + the slab reduce) on synthetic rows, HIP events, algorithmic FLOPs.  None where the fused
+    decoder does not cover the sequence length (216 tokens)."""
+    import torch
+    from hsimae_amd import _lib, swiglu_hidden
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d, h = 64, swiglu_hidden(64, model.mlp_ratio)
+    hp = (h + 31) // 32 * 32
+    M = N * Ts
+    f32 = dict(dtype=torch.float32, device=dev)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    x, dy = torch.randn(M, d, **f32), torch.randn(M, d, **f32) * 1e-3
+    x1, x2, dx1, dx = (torch.empty(M, d, **f32) for _ in range(4))
+    o, lse = torch.empty(M, d, **bf), torch.empty(M, 8, **f32)
+    vec = {k: torch.zeros(n, **f32) for k, n in (("n1b", d), ("bqkv", 3 * d), ("pb", d), ("n2b", d), ("w1b", hp), ("w3b", hp), ("w2b", d))}
+    vec.update(n1w=torch.ones(d, **f32), n2w=torch.ones(d, **f32))
+    img = {k: torch.randn(n, **bf) * 0.05 for k, n in (("qkv", 3 * d * d), ("p", d * d), ("w1", hp * d), ("w3", hp * d), ("w2", d * hp), ("w2T", hp * d))}
+    mas = {k: torch.randn(r, d, **f32) * 0.05 for k, r in (("qf", d), ("kf", d), ("vf", d), ("pf", d), ("w1f", h), ("w3f", h))}
+    W = _lib.DecBlockWeights(hidden=h, **{k: v.data_ptr() for k, v in {**vec, **img, **mas}.items()})
+    shapes = dict(n1w=(d,), n1b=(d,), qw=(d, d), qb=(d,), kw=(d, d), kb=(d,), vw=(d, d), vb=(d,), pw=(d, d), pb=(d,), n2w=(d,), n2b=(d,),
+                  w1w=(h, d), w1b=(h,), w2w=(d, h), w2b=(d,), w3w=(h, d), w3b=(h,))
+    G_ = {k: torch.zeros(s, **f32) for k, s in shapes.items()}
+    Gs = _lib.DecBlockGrads(**{k: v.data_ptr() for k, v in G_.items()})
+    slab = torch.empty(256 * (104 * 512 + 2112), **f32)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def fwd():
+        return lib.hsimae_dec_block_fwd(C.byref(W), x.data_ptr(), x1.data_ptr(), x2.data_ptr(), o.data_ptr(), lse.data_ptr(), N, Ts, 1, s)
+
+    def bwd():
+        return lib.hsimae_dec_block_bwd(C.byref(W), C.byref(Gs), x.data_ptr(), x1.data_ptr(), dy.data_ptr(), dx1.data_ptr(), dx.data_ptr(),
+                                        o.data_ptr(), lse.data_ptr(), N, Ts, slab.data_ptr(), s)
+    if fwd() != 0:
+        return None
+    _lib.check(bwd(), "hsimae_dec_block_bwd")
+    tf, tb = _timed_interleaved([fwd, bwd], iters)
+    fl_f = float(N) * (Ts * 2.0 * (4 * d * d + 3 * d * h) + 2 * 2.0 * Ts * Ts * d)      # linears + QK^T and PV
+    keep = (x, dy, x1, x2, dx1, dx, o, lse, vec, img, mas, G_, slab, W, Gs)
+    del keep
+    return {"bound": "mfma", "what": "one fused decoder Block replayed through hsimae_dec_block_fwd / _bwd (forward: attention-half + "
+            "MLP-half kernels; backward: dec_bwd_mlp + dec_bwd_attn + dec_dw_reduce), HIP events, algorithmic FLOPs (backward = 2 x forward)",
+            "fwd_us": round(tf * 1e3, 1), "bwd_us": round(tb * 1e3, 1), "peak": peak_tflops, "unit": "TFLOP/s",
+            "fwd_achieved": round(fl_f / (tf * 1e-3) / 1e12, 1), "bwd_achieved": round(2 * fl_f / (tb * 1e-3) / 1e12, 1),
+            "frac": round(3 * fl_f / ((tf + tb) * 1e-3) / 1e12 / peak_tflops, 4), "flops_fwd": fl_f,
+            "compulsory_bytes": {"fwd": float(M) * (4 * 4 * d + 2 * 2 * d + 2 * 32), "bwd": float(M) * (6 * 4 * d + 2 * d + 32)}}
 
 
 def kernel_rooflines(model, M, peak_tflops, iters=20):
@@ -625,6 +676,9 @@ def main():
                 "per_block_us": {"fwd": round(dfw * 1e3 / 8, 1), "bwd": round(dbw * 1e3 / 8, 1),
                                  "note": "group time / 8 blocks (includes the embed / assembly / pred kernels' ~5 %)"}}
             _log(f"decoder-only fwd {dfw:.3f} ms, bwd {dbw:.3f} ms")
+            blk = decoder_block_replay(model, N, (bands // 8) * 9, PEAK_BF16_TFLOPS)
+            if blk is not None:
+                out["roofline_decoder_block"] = blk
             K_tok = lt0 * ll0
             kr = kernel_rooflines(model, N * K_tok, PEAK_BF16_TFLOPS)
             out["roofline_kernel"], out["roofline_kernel_hbm"] = kr[0]
