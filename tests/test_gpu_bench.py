@@ -1,0 +1,32 @@
+"""bench.py on one GPU: the one-line JSON contract of the driver and the roofline objects it carries."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    d = json.loads(lines[-1])                                     # the LAST line of stdout is the JSON line
+    assert sum(l.lstrip().startswith("{") for l in lines) == 1
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "patches/s" and d["dtype"] == "bf16" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("mfma", "hbm") and rf["unit"] in ("TFLOP/s", "GB/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # per-kernel and per-group evidence: the dominant encoder kernels, the decoder group and one fused decoder Block
+    for k in ("roofline_kernel", "roofline_kernel_hbm", "roofline_decoder", "roofline_decoder_block", "encoder_mfma_frac", "step_ms"):
+        assert k in d, k
+    blk = d["roofline_decoder_block"]
+    assert 50 < blk["fwd_us"] < 1000 and 100 < blk["bwd_us"] < 3000 and 0 < blk["frac"] < 1
