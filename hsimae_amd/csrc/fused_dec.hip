@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                     const bf16_t* dOi = mat == 0 ? DYb : (mat == 1 ? DH1 : DH3);
                     const bf16_t* Ai = mat == 0 ? Gc : U2;
                     const bf16x8 a = wg_frag<MT, false>(dOi, nt * 16, kk, q);
-                    if (bias_wave) accb[t] = mfma16(a, ones, accb[t]);
+                    accb[t] = mfma16(a, ones, accb[t]);                 // (every wave: a branch here costs more than the odd waves' unused MFMAs)
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2)
                         accW[c][t][k2] = mfma16(a, wg_frag<MT, false>(Ai, ((q.wave & 1) * 2 + k2) * 16, kk, q), accW[c][t][k2]);
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                     const bf16_t* dOi = mat == 0 ? DYb : (mat == 1 ? DH1 : DH3);
                     const bf16_t* Ai = mat == 0 ? Gc : U2;
                     const bf16x8 a = wg_frag<MT, true>(dOi, nt * 16, R / 32, q);
-                    if (bias_wave) accb[t] = mfma16(a, ones, accb[t]);
+                    accb[t] = mfma16(a, ones, accb[t]);                 // (every wave: a branch here costs more than the odd waves' unused MFMAs)
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2)
                         accW[c][t][k2] = mfma16(a, wg_frag<MT, true, false>(Ai, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accW[c][t][k2]);
