@@ -367,10 +367,10 @@ __global__ __launch_bounds__(WT<BIG>::NTHR) void wgrad_dma_kernel(WgradParams p)
         bf16x8 a[NF];
 #pragma unroll
         for (int ii = 0; ii < NF; ++ii) a[ii] = join(fa[ii]);
-        if (want_bias) {                       // column sums of dO as one more MFMA against ones: no extra LDS traffic
+        // column sums of dO as one more MFMA against ones: no extra LDS traffic.  On every workgroup, wanted or not: under a branch
+        // hipcc moves the bias accumulators between AGPRs and VGPRs around every iteration (16 moves + waits per chunk)
 #pragma unroll
-            for (int ii = 0; ii < NF; ++ii) accb[ii] = mfma16(a[ii], ones, accb[ii]);
-        }
+        for (int ii = 0; ii < NF; ++ii) accb[ii] = mfma16(a[ii], ones, accb[ii]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bf16x8 b = join(fb0[j]);
