@@ -156,7 +156,9 @@ __device__ __forceinline__ void mm_f(const bf16_t* A, int lda, int kofs, const F
 }
 
 // acc += A * W^T with W row-major bf16 [n][LU] resident in LDS (k contiguous): B fragment = 16-byte row pieces
-template <int MH, int KS, bool SW = false>
+// CHK = false: m-tiles past MT are multiplied too (image rows past R: whatever follows the image in LDS — finite or not, the
+// caller never uses those accumulators); without the uniform branch per m-tile the loads and MFMAs of a call schedule as one block
+template <int MH, int KS, bool SW = false, bool CHK = true>
 __device__ __forceinline__ void mm_rm(const bf16_t* A, int lda, const bf16_t* Wr, int nt0, int mt0, int MT, const Geo4& q,
                                       f32x4 (&acc)[MH][2]) {
     bf16x8 b[KS][2];
@@ -169,7 +171,7 @@ __device__ __forceinline__ void mm_rm(const bf16_t* A, int lda, const bf16_t* Wr
 #pragma unroll
         for (int mi = 0; mi < MH; ++mi) {
             const int mt = mt0 + mi;
-            if (mt < MT) {
+            if (!CHK || mt < MT) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + q.c16) * lda + ks * 32 + q.g * 8);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[mi][j] = SW ? mfma16(b[ks][j], a, acc[mi][j]) : mfma16(a, b[ks][j], acc[mi][j]);
@@ -184,7 +186,7 @@ __device__ __forceinline__ bf16x8 wg_frag(const bf16_t* img, int col0, int kk, c
 
 // acc += A[:, 0:64] * W with W row-major bf16 [64 k-rows][LU] resident in LDS (n contiguous): the B fragment needs
 // 8 consecutive k of one column, i.e. a transpose read of the same image the forward-orientation product reads by rows
-template <int MH, bool SW = false>
+template <int MH, bool SW = false, bool CHK = true>
 __device__ __forceinline__ void mm_wt(const bf16_t* A, int lda, const bf16_t* Wr, int mt0, int MT, const Geo4& q,
                                       f32x4 (&acc)[MH][2]) {
 #pragma unroll
@@ -195,7 +197,7 @@ __device__ __forceinline__ void mm_wt(const bf16_t* A, int lda, const bf16_t* Wr
 #pragma unroll
         for (int mi = 0; mi < MH; ++mi) {
             const int mt = mt0 + mi;
-            if (mt < MT) {
+            if (!CHK || mt < MT) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + q.c16) * lda + ks * 32 + q.g * 8);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[mi][j] = SW ? mfma16(b[j], a, acc[mi][j]) : mfma16(a, b[j], acc[mi][j]);
@@ -1398,7 +1400,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
                 for (int mi = 0; mi < L::MH; ++mi) acc[mi][j] = b;
             }
-            mm_rm<L::MH, 2, true>(U, LU, WQl, c * 4 + q.wn * 2, mt0, MT, q, acc);
+            mm_rm<L::MH, 2, true, false>(U, LU, WQl, c * 4 + q.wn * 2, mt0, MT, q, acc);
             bf16_t* dst = c == 0 ? Qb : (c == 1 ? Kb : Vb);
 #pragma unroll
             for (int mi = 0; mi < L::MH; ++mi) {
@@ -1414,7 +1416,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         f32x4 dO[L::MH][2];
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) { dO[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dO[mi][1] = dO[mi][0]; }
-        mm_wt<L::MH, true>(DXb, LU, WPl, mt0, MT, q, dO);
+        mm_wt<L::MH, true, false>(DXb, LU, WPl, mt0, MT, q, dO);
         f32x4 accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int kk = 0; kk < R / 32; ++kk) {
@@ -1496,9 +1498,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) { du[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; du[mi][1] = du[mi][0]; }
         asm volatile("" :: "v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]));
-        mm_wt<L::MH, true>(Qb, LU, WQl, mt0, MT, q, du);
-        mm_wt<L::MH, true>(Kb, LU, WQl + D * LU, mt0, MT, q, du);
-        mm_wt<L::MH, true>(Vb, LU, WQl + 2 * D * LU, mt0, MT, q, du);
+        mm_wt<L::MH, true, false>(Qb, LU, WQl, mt0, MT, q, du);
+        mm_wt<L::MH, true, false>(Kb, LU, WQl + D * LU, mt0, MT, q, du);
+        mm_wt<L::MH, true, false>(Vb, LU, WQl + 2 * D * LU, mt0, MT, q, du);
         f32x4 accqb[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) accqb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
