@@ -1044,8 +1044,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                     for (int j = 0; j < 2; ++j) b[j] = wg_frag<4, false>(Wc, (q.wn * 2 + j) * 16, ks, q);
 #pragma unroll
                     for (int mi = 0; mi < L::MH; ++mi) {
-                        const int mt = mt0 + mi;
-                        if (mt >= MT) continue;
+                        const int mt = mt0 + mi;           // (a tile past MT multiplies image overrun: never stored, see mm_rm CHK)
                         const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ai + (mt * 16 + q.c16) * LU + ks * 32 + q.g * 8);
 #pragma unroll
                         for (int j = 0; j < 2; ++j) du2[mi][j] = mfma16(b[j], a, du2[mi][j]);     // swapped: see the gate products
