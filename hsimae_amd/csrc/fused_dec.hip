@@ -995,7 +995,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             f32x4 accb[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) accb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+#pragma unroll
             for (int kk = 0; kk < R / 32; ++kk) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
