@@ -76,6 +76,9 @@ struct DL {
     // backward attention kernel: fp32 staging tile, aliased by the per-wave transposition tiles of the attention core
     static constexpr int BWD_ATTN_LDS = 6 * U_BYTES + 2 * 8 * R * 4 + 8 * 2 * 16 * 24 * 2 + 4 * D * LU * 2 + 5 * D * 4;
     static_assert(2 * U_BYTES >= R * LX * 4, "fp32 staging tile must fit over Ob|DXb");
+    // the unguarded m-tile products (mm_rm / mm_wt CHK = false) read one m-tile (16 rows) past an image: every image of the
+    // backward kernels is followed by at least that much of the same LDS allocation (logsumexp / delta / tiles / weights)
+    static_assert(BWD_ATTN_LDS - 6 * U_BYTES >= 16 * LU * 2, "image overrun of the unguarded products must stay inside the allocation");
 };
 constexpr int TTS = 24;                    // transposition tile row stride (elements)
 constexpr int TT_WAVE = 2 * 16 * TTS;      // per wave: [P | dS][16 queries][TTS]
@@ -1743,6 +1746,7 @@ int launch_bwd(const DecBwdMlpArgs& a, const DecBwdAttnArgs& b, hipStream_t s) {
     constexpr int IMG = L::R * LU * 2;
     constexpr int LDS_A = 5 * IMG + 2 * WRM * 2 + 2 * HPD * 4;
     static_assert(2 * IMG >= L::R * LX * 4, "fp32 staging tile must fit over Gc|DH1");
+    static_assert(LDS_A - 5 * IMG >= 16 * LU * 2, "image overrun of the unguarded du2 product must stay inside the allocation");
     constexpr int LDS_B = L::BWD_ATTN_LDS;
     static bool attr_set = false;
     if (!attr_set) {
