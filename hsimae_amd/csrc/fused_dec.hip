@@ -18,7 +18,7 @@
 // Per-phase cycle accounting for scripts/phase_timing.py (compiled only with -DHS_PHASE_TIMING; never in the shipped library)
 #ifdef HS_PHASE_TIMING
 __device__ unsigned long long hs_phase_cycles[32];
-extern "C" int hsimae_debug_phases(unsigned long long* out, int reset) {
+extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases(unsigned long long* out, int reset) {
     int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hs_phase_cycles), sizeof(unsigned long long) * 32);
     if (reset) { unsigned long long z[32] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(hs_phase_cycles), z, sizeof(z)); }
     return rc;
@@ -60,6 +60,7 @@ constexpr int kDwSlotsMlp = 72, kDwSlotsAttn = 32, kDwSlots = kDwSlotsMlp + kDwS
 constexpr int kVN2W = 0, kVN2B = 64, kVW2B = 128, kVW1B = 192, kVW3B = 960, kVN1W = 1728, kVN1B = 1792, kVPB = 1856, kVQB = 1920,
               kVKB = 1984, kVVB = 2048, kVec = 2112;
 constexpr size_t kSlabTileFloats = (size_t)256 * kDwSlots * NT_;    // the vector part starts here
+static_assert(kDecSlabFloats == 256ll * (kDwSlots * NT_ + kVec), "kernels.h kDecSlabFloats must cover the slab these kernels write");
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -73,14 +74,18 @@ struct DL {
     static constexpr int QKV_BYTES = 2 * U_BYTES + D * VST * 2;
     static constexpr int REG2 = cmax(cmax(QKV_BYTES, R * LG * 2), R * LX * 4);
     static constexpr int FWD_TOTAL = U_BYTES + REG2;
-    // backward attention kernel: fp32 staging tile, aliased by the per-wave transposition tiles of the attention core
-    static constexpr int BWD_ATTN_LDS = 6 * U_BYTES + 2 * 8 * R * 4 + 8 * 2 * 16 * 24 * 2 + 4 * D * LU * 2 + 5 * D * 4;
-    static_assert(2 * U_BYTES >= R * LX * 4, "fp32 staging tile must fit over Ob|DXb");
-    // the unguarded m-tile products (mm_rm / mm_wt CHK = false) read one m-tile (16 rows) past an image: every image of the
+    // backward kernels (round 4 layouts, see "backward: LDS layouts" below): images are R x 128 B (no pad, XOR-swizzled chunks)
+    static constexpr int IMGB = R * 64 * 2;
+    // attention backward: 6 images, logsumexp + delta [8][R] fp32, 8 per-wave transposition tile pairs, Wq|Wk|Wv|Wp at pitch
+    // D + 16, bq|bk|bv + LayerNorm-1 gamma / beta
+    static constexpr int BWD_ATTN_LDS = 6 * IMGB + 2 * 8 * R * 4 + 8 * 2 * 16 * 16 * 2 + 4 * D * (D + 16) * 2 + 5 * D * 4;
+    // the fp32 staging tile of du goes over Ob | DXb and the first bytes of the logsumexp table (all dead by then)
+    static_assert(2 * IMGB + 8 * R * 4 >= R * LX * 4, "fp32 staging tile must fit over Ob|DXb|lse");
+    // the unguarded m-tile products (CHK = false) read one m-tile (16 rows) past an image: every image of the
     // backward kernels is followed by at least that much of the same LDS allocation (logsumexp / delta / tiles / weights)
-    static_assert(BWD_ATTN_LDS - 6 * U_BYTES >= 16 * LU * 2, "image overrun of the unguarded products must stay inside the allocation");
+    static_assert(BWD_ATTN_LDS - 6 * IMGB >= 16 * 64 * 2, "image overrun of the unguarded products must stay inside the allocation");
 };
-constexpr int TTS = 24;                    // transposition tile row stride (elements)
+constexpr int TTS = 16;                    // transposition tile row stride (elements): 32-B rows, rotation-swizzled 8-B chunks
 constexpr int TT_WAVE = 2 * 16 * TTS;      // per wave: [P | dS][16 queries][TTS]
 
 struct Geo4 { int lane, c16, g, wave, wm, wn; };
@@ -156,57 +161,6 @@ __device__ __forceinline__ void mm_f(const bf16_t* A, int lda, int kofs, const F
                 for (int j = 0; j < 2; ++j) acc[mi][j] = SW ? mfma16(f.b[ks][j], a, acc[mi][j]) : mfma16(a, f.b[ks][j], acc[mi][j]);
             }
         }
-}
-
-// acc += A * W^T with W row-major bf16 [n][LU] resident in LDS (k contiguous): B fragment = 16-byte row pieces
-// CHK = false: m-tiles past MT are multiplied too (image rows past R: whatever follows the image in LDS — finite or not, the
-// caller never uses those accumulators); without the uniform branch per m-tile the loads and MFMAs of a call schedule as one block
-template <int MH, int KS, bool SW = false, bool CHK = true>
-__device__ __forceinline__ void mm_rm(const bf16_t* A, int lda, const bf16_t* Wr, int nt0, int mt0, int MT, const Geo4& q,
-                                      f32x4 (&acc)[MH][2]) {
-    bf16x8 b[KS][2];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[ks][j] = *(lds_cb128)(Wr + ((nt0 + j) * 16 + q.c16) * LU + ks * 32 + q.g * 8);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int mi = 0; mi < MH; ++mi) {
-            const int mt = mt0 + mi;
-            if (!CHK || mt < MT) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + q.c16) * lda + ks * 32 + q.g * 8);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[mi][j] = SW ? mfma16(b[ks][j], a, acc[mi][j]) : mfma16(a, b[ks][j], acc[mi][j]);
-            }
-        }
-}
-
-// Wide layout: piece p -> (row p>>3, columns 8*(p&7)..+7); the 8 lanes of a row are adjacent.
-// (mm_wt below needs wg_frag, declared further down)
-template <int MT, bool TAIL, bool ZERO = true>
-__device__ __forceinline__ bf16x8 wg_frag(const bf16_t* img, int col0, int kk, const Geo4& q);
-
-// acc += A[:, 0:64] * W with W row-major bf16 [64 k-rows][LU] resident in LDS (n contiguous): the B fragment needs
-// 8 consecutive k of one column, i.e. a transpose read of the same image the forward-orientation product reads by rows
-template <int MH, bool SW = false, bool CHK = true>
-__device__ __forceinline__ void mm_wt(const bf16_t* A, int lda, const bf16_t* Wr, int mt0, int MT, const Geo4& q,
-                                      f32x4 (&acc)[MH][2]) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 b[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = wg_frag<4, false>(Wr, (q.wn * 2 + j) * 16, ks, q);
-#pragma unroll
-        for (int mi = 0; mi < MH; ++mi) {
-            const int mt = mt0 + mi;
-            if (!CHK || mt < MT) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (mt * 16 + q.c16) * lda + ks * 32 + q.g * 8);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[mi][j] = SW ? mfma16(b[j], a, acc[mi][j]) : mfma16(a, b[j], acc[mi][j]);
-            }
-        }
-    }
 }
 
 // Loads rows of `src` (global fp32 [Ts,64]; rows >= Ts read as zero), optionally mirrors them into the fp32
@@ -785,29 +739,120 @@ __global__ __launch_bounds__(256, 4) void dec_attn_fwd_kernel(DecAttnFwdArgs p) 
 // Everything else (u, q, k, v, P, o, h1, h3, g) is recomputed from x / x1 inside the tile.
 typedef __attribute__((address_space(3))) bf16x4* lds_b64;
 
+// ---------------------------------------------------------------------- backward: LDS layouts (round 4)
+// Bank model: MI355X_MICROARCH.md "LDS" / scripts/micro/lds_banks.py; the audit of every access pattern of the two backward
+// kernels under the round-3 layout (pitch D + 8) and this one is scripts/micro/lds_audit_dec.py.  Round 3 measured 2.5 / 2.2
+// bank-conflict cycles per LDS instruction here: with a 144-byte pitch the 16-byte row fragments and the transpose reads are both
+// 2-way conflicted, and no single pad fixes both (row fragments want a pitch of 32 mod 64 bytes... 8-byte row reads of the
+// attention core one of 16 mod 32).
+//   * activation images ([R tokens][64] bf16): UNPADDED 128-byte rows — even rows own banks 0..31, odd rows banks 32..63 — and
+//     the 16-byte chunk c of row r lives at chunk c ^ swz(r).  swz is a bijection of the 8 even (odd) rows of a 16-row tile
+//     onto 0..7 chosen (brute force over the 8! candidates, lds_audit_dec.py) so that all of these are conflict-free:
+//     16-byte row fragments (MFMA A / B operands), the attention core's 8-byte row reads of one head, transpose reads of 8
+//     consecutive rows x 32 bytes (ds_read_b64_tr_b16), 16-byte row-contiguous fills.  The 8-byte tile writes of the
+//     swapped-operand accumulators stay 2-way (16 rows x 8 bytes meet in 32 banks x 4 bytes: one row of this layout).
+//   * transposed fragments of a weight-gradient product contract over the image ROWS; both operands come from the same
+//     function, so the row order inside a 32-row k-step is free: lane group g takes rows 4g..4g+3 and 16+4g..16+4g+3 (a
+//     32-lane bank group then reads 8 consecutive rows) instead of 8g..8g+7 (rows 0-3 and 8-11: 2-way at every pitch tried).
+//     In the tail step (R % 32 == 16) the second half is simply absent.
+//   * weight images (row-major bf16 [n][D], read by rows AND by transpose reads): pitch D + 16, and row k of every 32-row
+//     group is stored at wrow(k) so that the transpose read above returns k = 8g..8g+7 — the order of the 16-byte row
+//     fragment it meets in the MFMA.
+//   * the per-wave transposition tiles of the attention core: 32-byte rows, 8-byte chunk c of row r at (c + (r >> 2)) & 3:
+//     the 8-byte writes (16 rows, one chunk) and the transpose reads (8 rows x 4 chunks) are both conflict-free
+//     (pitch 48 bytes: 2-way both ways).
+constexpr int IR = 64;                     // activation image row pitch (elements)
+constexpr int LW = D + 16;                 // weight image row pitch (elements)
+constexpr int WRB = HPD * LW;              // one [192][LW] weight image (elements)
+
+__host__ __device__ constexpr int swz(int row) { return (((row >> 1) & 3) << 1) ^ (((row >> 3) & 1) * 5); }
+__host__ __device__ constexpr int wrow(int n) { return (n & ~31) + 4 * ((n & 31) >> 3) + (n & 3) + 16 * ((n >> 2) & 1); }
+
+struct GeoB : Geo4 {
+    int q4, p4;
+    int fr;        // swz of the row c16 (+ 16 k): row fragments, tile writes, 8-byte row reads
+    int ft;        // swz of the row 4 g + q4 (+ 16 k): transpose reads
+    int pc;        // wrow(c16) - the lane's weight row inside a 16-row n-tile (+ 8 for odd n-tiles, + 32 per tile pair)
+};
+__device__ __forceinline__ GeoB geob() {
+    GeoB q;
+    static_cast<Geo4&>(q) = geo();
+    q.q4 = q.c16 >> 2; q.p4 = q.c16 & 3;
+    q.fr = swz(q.c16); q.ft = swz(4 * q.g + q.q4);
+    q.pc = 4 * (q.c16 >> 3) + (q.c16 & 3) + 16 * ((q.c16 >> 2) & 1);
+    return q;
+}
+
+// 16-byte row fragment of an activation image: row mt*16 + c16, columns ks*32 + 8g .. + 7
+__device__ __forceinline__ bf16x8 rowfrag(const bf16_t* img, int mt, int ks, const GeoB& q) {
+    return *reinterpret_cast<const bf16x8*>(img + (mt * 16 + q.c16) * IR + (((ks * 4 + q.g) ^ q.fr) << 3));
+}
+// element offset of the 4 columns nt*16 + 4g .. + 3 of row mt*16 + c16: where a swapped-operand accumulator tile lives
+__device__ __forceinline__ int tile_off(int mt, int nt, const GeoB& q) {
+    return (mt * 16 + q.c16) * IR + (((2 * nt + (q.g >> 1)) ^ q.fr) << 3) + (q.g & 1) * 4;
+}
+typedef __attribute__((address_space(3))) bf16x4* lds_w64;
+__device__ __forceinline__ void st4(bf16_t* p, bf16x4 v) { *(lds_w64)(p) = v; }      // LDS address space + 8-byte type: ds_write_b64
+
+// 4 consecutive image rows of one column per lane: element j of lane (c16, g) = img[row0(g) + j][col0 + c16];
+// `a` is the lane's own 8-byte piece img[row0(g) + (c16 >> 2)][col0 + 4 (c16 & 3) ..].
+__device__ __forceinline__ bf16x4 tr4(const bf16_t* a) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(a));
+}
+
 // Row (token) fragment pair for one k-step of a weight-gradient product  dO[:, n0..]^T * A[:, k0..]  (contraction over
-// the image rows, 32 per MFMA): element j of lane group g = img[kk*32 + 8g + j][col0 + c16], zeroed past row R.
-// TAIL = the k-step that runs past row R (R % 32 == 16): lane groups 2,3 would read rows >= R and supply zeros
-// instead.  Full k-steps skip the per-element selects (they were ~40 % of the backward kernels' VALU work).
-// ZERO = false (tail step only): lane groups 2, 3 return the rows of groups 0, 1 again instead of zeros — for the second operand
-// of a product whose first operand is already zero there (4 selects per fragment saved; the data is finite image content).
-template <int MT, bool TAIL, bool ZERO>
-__device__ __forceinline__ bf16x8 wg_frag(const bf16_t* img, int col0, int kk, const Geo4& q) {
-    constexpr int R = MT * 16;
-    const int q4 = q.c16 >> 2, p4 = q.c16 & 3;
-    if constexpr (!TAIL) {
-        const bf16_t* a = img + (kk * 32 + 8 * q.g + q4) * LU + col0 + 4 * p4;
-        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(a));
-        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(a + 4 * LU));
-        return __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-    } else {
-        const bool ok = kk * 32 + 8 * q.g < R;
-        const int rb = ok ? kk * 32 + 8 * q.g : kk * 32;
-        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + (rb + q4) * LU + col0 + 4 * p4));
-        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(img + (rb + 4 + q4) * LU + col0 + 4 * p4));
-        const bf16x8 v = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-        if constexpr (!ZERO) return v;
-        return ok ? v : zero8();
+// the image rows, 32 per MFMA) from an activation image: element j of lane group g = img[kk*32 + 4g + (j & 3) + 16 (j >> 2)][nt*16 + c16].
+// TAIL = the k-step that runs past row R (R % 32 == 16): rows kk*32 + 16.. do not exist, the second half is zero.
+template <bool TAIL>
+__device__ __forceinline__ bf16x8 wg_frag(const bf16_t* img, int nt, int kk, const GeoB& q) {
+    const bf16_t* a = img + (kk * 32 + 4 * q.g + q.q4) * IR + (((2 * nt + (q.p4 >> 1)) ^ q.ft) << 3) + (q.p4 & 1) * 4;
+    const bf16x4 a0 = tr4(a);
+    if constexpr (TAIL) return __builtin_shufflevector(a0, zero4(), 0, 1, 2, 3, 4, 5, 6, 7);
+    else return __builtin_shufflevector(a0, tr4(a + 16 * IR), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// The same fragment of a weight image (rows = the contraction index, stored at wrow()): element j of lane group g =
+// W[k0 + 8g + j][nt*16 + c16] — the k order of a 16-byte row fragment.  `Wk` = the image at (physical = logical) row k0, a multiple of 32.
+__device__ __forceinline__ bf16x8 wt_frag(const bf16_t* Wk, int nt, const GeoB& q) {
+    const bf16_t* a = Wk + (4 * q.g + q.q4) * LW + nt * 16 + 4 * q.p4;
+    return __builtin_shufflevector(tr4(a), tr4(a + 16 * LW), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// acc += A * W^T with W row-major bf16 [n][LW] resident in LDS (k contiguous, rows at wrow()): B fragment = 16-byte row pieces.
+// Operands swapped (weights as A): acc[r] = C[row c16][column 4 g + r].  m-tiles past MT are multiplied too (image rows past R:
+// whatever follows the image in LDS — finite or not, the caller never uses those accumulators).
+template <int MH, int KS>
+__device__ __forceinline__ void mm_rows(const bf16_t* A, const bf16_t* Wr, int nt0, int mt0, const GeoB& q, f32x4 (&acc)[MH][2]) {
+    bf16x8 b[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            b[ks][j] = *(lds_cb128)(Wr + (32 * ((nt0 + j) >> 1) + 8 * ((nt0 + j) & 1) + q.pc) * LW + ks * 32 + q.g * 8);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi) {
+            const bf16x8 a = rowfrag(A, mt0 + mi, ks, q);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[mi][j] = mfma16(b[ks][j], a, acc[mi][j]);
+        }
+}
+
+// acc += A[:, 0:64] * W with W row-major bf16 [64 k-rows][LW] resident in LDS (n contiguous): the B fragment needs 8 consecutive k
+// of one column, i.e. a transpose read of the same image the forward-orientation product reads by rows.  Swapped, unguarded (see mm_rows).
+template <int MH>
+__device__ __forceinline__ void mm_cols(const bf16_t* A, const bf16_t* Wr, int mt0, const GeoB& q, f32x4 (&acc)[MH][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = wt_frag(Wr + ks * 32 * LW, q.wn * 2 + j, q);
+#pragma unroll
+        for (int mi = 0; mi < MH; ++mi) {
+            const bf16x8 a = rowfrag(A, mt0 + mi, ks, q);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[mi][j] = mfma16(b[j], a, acc[mi][j]);
+        }
     }
 }
 
@@ -849,19 +894,20 @@ struct DecBwdMlpArgs {
 template <int MT>
 __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
     using L = DL<MT>;
-    constexpr int R = L::R, IMG = R * LU, NPW = (R * 8 + NT_ - 1) / NT_;
+    constexpr int R = L::R, IMG = R * IR, NPW = (R * 8 + NT_ - 1) / NT_;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
     bf16_t* DYb = U2 + IMG;
     bf16_t* Gc = DYb + IMG;
     bf16_t* DH1 = Gc + IMG;
     bf16_t* DH3 = DH1 + IMG;
-    float* XS = reinterpret_cast<float*>(Gc);            // fp32 staging aliases Gc|DH1 (dead once the chunk loop is done)
-    bf16_t* WL = DH3 + IMG;                              // W1 | W3 as row-major bf16 [192][LU] (rows past h zero), resident
-    float* BL = reinterpret_cast<float*>(WL + 2 * WRM);  // b1 | b3, zero-padded to 192
-    const Geo4 q = geo();
+    float* XS = reinterpret_cast<float*>(Gc);            // fp32 staging aliases Gc|DH1|DH3 (dead once the chunk loop is done)
+    bf16_t* WL = DH3 + IMG;                              // W1 | W3 as row-major bf16 [192][LW] (rows past h zero, row k at wrow(k)), resident
+    float* BL = reinterpret_cast<float*>(WL + 2 * WRB);  // b1 | b3, zero-padded to 192
+    const GeoB q = geob();
     const int mt0 = q.wm * L::MH;
     const int c8 = (threadIdx.x & 7) * 8;
+    const int wide = ((threadIdx.x & 7) ^ swz(threadIdx.x >> 3)) << 3;   // this thread's 16-byte chunk in the wide layout (row = tid >> 3 + 64 i)
     // The weights are the same for every sample this workgroup walks: stage W1 and W3 once, row-major.  The gate
     // products read them as 16-byte row pieces and the data gradient (which needs the transposed operand) reads the
     // same image with transpose reads, so the per-sample body fetches only the W2^T fragments from L2.
@@ -873,7 +919,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             ld8((m == 0 ? p.w1f : p.w3f) + (size_t)row * D + k8, f);
             v = cvt8(f);
         }
-        *reinterpret_cast<bf16x8*>(WL + m * WRM + row * LU + k8) = v;
+        *reinterpret_cast<bf16x8*>(WL + m * WRB + wrow(row) * LW + k8) = v;
     }
     for (int i = threadIdx.x; i < 2 * HPD; i += NT_) {
         const int m = i / HPD, o = i % HPD;
@@ -905,7 +951,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
         const size_t rb = (size_t)sample * p.Ts;
         const int wl = launder_i(0);                   // keeps the LDS weight reads inside the sample loop (no LICM + spill)
         const bf16_t* w1L = WL + wl;
-        const bf16_t* w3L = WL + WRM + wl;
+        const bf16_t* w3L = WL + WRB + wl;
         const bf16_t* w2T = launder(p.w2T);
         Fr<2> f2;                                      // W2^T fragments of the next hidden chunk (the only global weights)
         f2.load(w2T, 2, q.wn * 2, 0, q);
@@ -936,8 +982,8 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                 float u[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) u[e] = f[e] * rstd * gm[e] + bt[e];
-                *reinterpret_cast<bf16x8*>(U2 + row * LU + c8) = cvt8(u);
-                *reinterpret_cast<bf16x8*>(DYb + row * LU + c8) = cvt8(dyv);
+                *reinterpret_cast<bf16x8*>(U2 + row * IR + wide) = cvt8(u);
+                *reinterpret_cast<bf16x8*>(DYb + row * IR + wide) = cvt8(dyv);
             }
         }
         lds_barrier();
@@ -960,34 +1006,39 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                 const int mt = mt0 + mi;
                 if (mt >= MT) continue;
                 // operands swapped: a lane owns 4 consecutive hidden columns of one token (8-byte image writes, 16-byte bias reads)
-                f32x4 h1[1][2], h3[1][2], dg[1][2];
+                f32x4 h1[1][2], h3[1][2], dg[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int col = c * 64 + (q.wn * 2 + j) * 16 + q.g * 4;
                     h1[0][j] = *reinterpret_cast<const f32x4*>(BL + wl + col);
                     h3[0][j] = *reinterpret_cast<const f32x4*>(BL + HPD + wl + col);
-                    dg[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    dg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                mm_rm<1, 2, true>(U2, LU, w1L, c * 4 + q.wn * 2, mt, MT, q, h1);
-                mm_rm<1, 2, true>(U2, LU, w3L, c * 4 + q.wn * 2, mt, MT, q, h3);
-                mm_f<1, 2, true>(DYb, LU, 0, f2, mt, MT, q, dg);
+                mm_rows<1, 2>(U2, w1L, c * 4 + q.wn * 2, mt, q, h1);
+                mm_rows<1, 2>(U2, w3L, c * 4 + q.wn * 2, mt, q, h3);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 a = rowfrag(DYb, mt, ks, q);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) dg[j] = mfma16(f2.b[ks][j], a, dg[j]);
+                }
                 // columns past the hidden width: W1/W3 rows and biases are zero-padded, so g = d1 = d3 = 0 there
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     f32x4 gv, d1, d3;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float a1 = h1[0][j][r], a3 = h3[0][j][r], dv = dg[0][j][r];
+                        const float a1 = h1[0][j][r], a3 = h3[0][j][r], dv = dg[j][r];
                         const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-a1));
                         const float sl = a1 * sg;
                         gv[r] = sl * a3;
                         d1[r] = dv * a3 * sg * (1.f + a1 * (1.f - sg));
                         d3[r] = dv * sl;
                     }
-                    const int o = (mt * 16 + q.c16) * LU + (q.wn * 2 + j) * 16 + q.g * 4;
-                    *reinterpret_cast<bf16x4*>(Gc + o) = cvt4(gv);
-                    *reinterpret_cast<bf16x4*>(DH1 + o) = cvt4(d1);
-                    *reinterpret_cast<bf16x4*>(DH3 + o) = cvt4(d3);
+                    const int o = tile_off(mt, q.wn * 2 + j, q);
+                    st4(Gc + o, cvt4(gv));
+                    st4(DH1 + o, cvt4(d1));
+                    st4(DH3 + o, cvt4(d3));
                 }
             }
             if (c < 2) f2.load(w2T, 2, (c + 1) * 4 + q.wn * 2, 0, q);
@@ -1005,11 +1056,11 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                     const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;   // mat 0: dW2, 1: dW1, 2: dW3
                     const bf16_t* dOi = mat == 0 ? DYb : (mat == 1 ? DH1 : DH3);
                     const bf16_t* Ai = mat == 0 ? Gc : U2;
-                    const bf16x8 a = wg_frag<MT, false>(dOi, nt * 16, kk, q);
+                    const bf16x8 a = wg_frag<false>(dOi, nt, kk, q);
                     accb[t] = mfma16(a, ones, accb[t]);                 // (every wave: a branch here costs more than the odd waves' unused MFMAs)
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2)
-                        accW[c][t][k2] = mfma16(a, wg_frag<MT, false>(Ai, ((q.wave & 1) * 2 + k2) * 16, kk, q), accW[c][t][k2]);
+                        accW[c][t][k2] = mfma16(a, wg_frag<false>(Ai, (q.wave & 1) * 2 + k2, kk, q), accW[c][t][k2]);
                 }
             }
             if constexpr (R % 32 != 0) {
@@ -1018,11 +1069,11 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                     const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;   // mat 0: dW2, 1: dW1, 2: dW3
                     const bf16_t* dOi = mat == 0 ? DYb : (mat == 1 ? DH1 : DH3);
                     const bf16_t* Ai = mat == 0 ? Gc : U2;
-                    const bf16x8 a = wg_frag<MT, true>(dOi, nt * 16, R / 32, q);
-                    accb[t] = mfma16(a, ones, accb[t]);                 // (every wave: a branch here costs more than the odd waves' unused MFMAs)
+                    const bf16x8 a = wg_frag<true>(dOi, nt, R / 32, q);
+                    accb[t] = mfma16(a, ones, accb[t]);
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2)
-                        accW[c][t][k2] = mfma16(a, wg_frag<MT, true, false>(Ai, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accW[c][t][k2]);
+                        accW[c][t][k2] = mfma16(a, wg_frag<true>(Ai, (q.wave & 1) * 2 + k2, R / 32, q), accW[c][t][k2]);
                 }
             }
             if (bias_wave) {
@@ -1035,20 +1086,19 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                 }
             }
             PH(2)
-            // data gradient through W1 / W3
+            // data gradient through W1 / W3 (this chunk's 64 hidden rows are the contraction index: transpose reads of the images)
 #pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2) {          // (spelled out: two mm_wt calls here cost 170 B/lane of scratch)
+            for (int m2 = 0; m2 < 2; ++m2) {          // (spelled out: two helper calls here cost 170 B/lane of scratch)
                 const bf16_t* Ai = m2 == 0 ? DH1 : DH3;
-                const bf16_t* Wc = (m2 == 0 ? w1L : w3L) + c * 64 * LU;      // this chunk's 64 hidden rows
+                const bf16_t* Wc = (m2 == 0 ? w1L : w3L) + c * 64 * LW;      // this chunk's 64 hidden rows
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     bf16x8 b[2];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) b[j] = wg_frag<4, false>(Wc, (q.wn * 2 + j) * 16, ks, q);
+                    for (int j = 0; j < 2; ++j) b[j] = wt_frag(Wc + ks * 32 * LW, q.wn * 2 + j, q);
 #pragma unroll
                     for (int mi = 0; mi < L::MH; ++mi) {
-                        const int mt = mt0 + mi;           // (a tile past MT multiplies image overrun: never stored, see mm_rm CHK)
-                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ai + (mt * 16 + q.c16) * LU + ks * 32 + q.g * 8);
+                        const bf16x8 a = rowfrag(Ai, mt0 + mi, ks, q);     // (a tile past MT multiplies image overrun: never stored)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) du2[mi][j] = mfma16(b[j], a, du2[mi][j]);     // swapped: see the gate products
                     }
@@ -1161,12 +1211,6 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
 }
 
 
-// 4 consecutive image rows of one column per lane: element j of lane (c16, g) = img[row0(g) + j][col0 + c16];
-// `a` is the lane's own 8-byte piece img[row0(g) + (c16 >> 2)][col0 + 4 (c16 & 3) ..].
-__device__ __forceinline__ bf16x4 tr4(const bf16_t* a) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64)(a));
-}
-
 // One head of the decoder attention backward, single pass over the (query tile, key tile) grid.
 // Scores are formed key-major (S^T[key 4g+r][query c16], K = 16 MFMAs over the 8 head dims): that accumulator layout
 // is directly the B operand of dq^T += K^T dS^T.  dk^T / dv^T contract over queries and need the tile transposed:
@@ -1174,45 +1218,58 @@ __device__ __forceinline__ bf16x4 tr4(const bf16_t* a) {
 // score/exp pass.  delta and logsumexp come precomputed, so nothing waits on a full row.
 // Masking: lse = 1e30 for rows past Ts (P = 0 for dead queries); dead KEYS are handled by data, not by selects: the K / V image
 // rows past Ts are zero on entry and the dk / dv rows past Ts are written as zero (see the loop body).
+// LDS addressing: "backward: LDS layouts" above (swizzled 128-byte rows; this head's 8 columns are chunk `head` of a row).
 template <int MT>
 __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb, const bf16_t* dOb, const float* lse_h,
-                                              const float* dlt_h, bf16_t* T, int head, int Ts, const Geo4& q) {
+                                              const float* dlt_h, bf16_t* T, int head, int Ts, const GeoB& q) {
     const float sc = 0.35355339059327373f * 1.4426950408889634f, scale = 0.35355339059327373f;
-    const int hc = head * HD;
-    const int q4 = q.c16 >> 2, p4 = q.c16 & 3;
-    const int colw = (hc + 4 * q.g) & 63;       // head-dim fragment column; lane groups 2,3 read finite filler (x 0)
-    const int troff = (4 * q.g + q4) * LU + hc + 4 * p4;
+    // 8-byte row reads: lane group g takes head dims 4g .. 4g+3 of row 16 t + c16 (groups 2, 3: the next head's columns — finite filler, x 0)
+    const int rcol = q.c16 * IR + ((((head + (q.g >> 1)) & 7) ^ q.fr) << 3) + (q.g & 1) * 4;
+    // the V / dO reads get their own copy of the offset: from one base register hipcc merges each K | V (Q | dO) pair into a
+    // ds_read2_b64, which is banked like an 8-byte WRITE (16 lanes = 16 rows against 32 banks = one row of this layout): 16 LDS
+    // cycles instead of 2 x 2 (round-4 counters: 1.31 conflict cycles per LDS instruction with the merge, the model's 0.29 without)
+    int rcol2 = rcol;
+    asm volatile("" : "+v"(rcol2));
+    // transpose reads: rows 4g + q4 of a 16-row tile, columns head*8 + 4 p4 .. (p4 >= 2: the next head's — output rows nobody stores)
+    const int troff = (4 * q.g + q.q4) * IR + ((((head + (q.p4 >> 1)) & 7) ^ q.ft) << 3) + (q.p4 & 1) * 4;
+    const int wcol = q.c16 * IR + ((head ^ q.fr) << 3) + (q.g & 1) * 4;       // g < 2: this lane's 4 dims of a dq / dk / dv row
+    const int tw = q.c16 * TTS + (((q.g + q.q4) & 3) << 2);                   // tile write: row c16, keys 4g.. at chunk (g + (c16 >> 2)) & 3
+    const int trd = (4 * q.g + q.q4) * TTS + (((q.p4 + q.g) & 3) << 2);       // tile transpose read: row 4g + q4, chunk p4
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // key tiles that can reach past the sequence (the launchers use MT = 7 for 65..112 tokens, MT = 4 for 16..64): their
+    // exponent is clamped at 0 — P <= 1 holds for every real key anyway, and a padded key (K row = 0 => s = 0) of a query whose
+    // logsumexp is very negative (diverging run) would otherwise produce P = inf and poison dq through inf * 0
+    constexpr int KCL = MT > 4 ? 4 : 1;
     f32x4 dkT[MT], dvT[MT];
     bf16x4 KT[MT];
 #pragma unroll
     for (int kt = 0; kt < MT; ++kt) {
         dkT[kt] = z4; dvT[kt] = z4;
-        KT[kt] = tr4(Kb + kt * 16 * LU + troff);
+        KT[kt] = tr4(Kb + kt * 16 * IR + troff);
     }
 #pragma unroll 1
     for (int qt = 0; qt < MT; ++qt) {
         const int query = qt * 16 + q.c16;
-        bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qb + query * LU + colw);
-        bf16x4 bdo = *reinterpret_cast<const bf16x4*>(dOb + query * LU + colw);
+        bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qb + qt * 16 * IR + rcol);
+        bf16x4 bdo = *reinterpret_cast<const bf16x4*>(dOb + qt * 16 * IR + rcol2);
         if (q.g >= 2) { bq = zero4(); bdo = zero4(); }
         const float lqn = -lse_h[query], dl = dlt_h[query];
-        const bf16x4 QT = tr4(Qb + qt * 16 * LU + troff);
-        const bf16x4 dOT = tr4(dOb + qt * 16 * LU + troff);
+        const bf16x4 QT = tr4(Qb + qt * 16 * IR + troff);
+        const bf16x4 dOT = tr4(dOb + qt * 16 * IR + troff);
         f32x4 dqT = z4;
         // Software pipeline over the key tiles: the transposed operands of tile kt-1 (LDS write -> transpose read, ~200
         // cycles of latency) are consumed after the score MFMAs of tile kt have been issued, and those MFMAs' own
         // latency is covered by the dk/dv MFMAs of tile kt-1.
         bf16x4 Bp = zero4(), Bds = zero4();
         // K / V row fragments one tile ahead as well: their LDS latency is off the per-tile dependency chain
-        bf16x4 Kn = *reinterpret_cast<const bf16x4*>(Kb + q.c16 * LU + colw);
-        bf16x4 Vn = *reinterpret_cast<const bf16x4*>(Vb + q.c16 * LU + colw);
+        bf16x4 Kn = *reinterpret_cast<const bf16x4*>(Kb + rcol);
+        bf16x4 Vn = *reinterpret_cast<const bf16x4*>(Vb + rcol2);
 #pragma unroll
         for (int kt = 0; kt < MT; ++kt) {
             const bf16x4 Kf = Kn, Vf = Vn;
             if (kt + 1 < MT) {
-                Kn = *reinterpret_cast<const bf16x4*>(Kb + ((kt + 1) * 16 + q.c16) * LU + colw);
-                Vn = *reinterpret_cast<const bf16x4*>(Vb + ((kt + 1) * 16 + q.c16) * LU + colw);
+                Kn = *reinterpret_cast<const bf16x4*>(Kb + (kt + 1) * 16 * IR + rcol);
+                Vn = *reinterpret_cast<const bf16x4*>(Vb + (kt + 1) * 16 * IR + rcol2);
             }
             const f32x4 s = mfma16k16(Kf, bq, z4);
             const f32x4 dp = mfma16k16(Vf, bdo, z4);
@@ -1221,12 +1278,16 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
 #ifdef HS_EXPERIMENT_NOEXP      /* timing experiment only (scripts/phase_timing.py): what the exps cost */
             for (int r = 0; r < 4; ++r) pv[r] = fmaf(s[r], sc, lqn);
 #else
-            for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn));
+            for (int r = 0; r < 4; ++r) {
+                const float e = fmaf(s[r], sc, lqn);
+                pv[r] = __builtin_amdgcn_exp2f(kt >= KCL ? fminf(e, 0.f) : e);
+            }
 #endif
             // No key mask in here (rounds 1-2 masked the last tile only — wrong for 65..96-token sequences, found in round 3 by the
             // 64-band case of test_fused_decoder_matches_layerwise_decoder — and the general per-tile form compiled to 8 selects
             // per tile on ALL tiles, a quarter of this loop's VALU work): the caller zeroes the K and V image rows past Ts, so a
-            // padded key has s = 0, dP = 0 and a finite garbage P / dS that meets K = 0 in dq and is dropped from dk / dv below.
+            // padded key has s = 0, dP = 0 and a finite (clamped, see KCL) garbage P / dS that meets K = 0 in dq and is dropped
+            // from dk / dv below.
 #pragma unroll
             for (int r = 0; r < 4; ++r) ds[r] = pv[r] * (dp[r] - dl);
             if (kt > 0) {                       // previous tile's transposed operands, a VALU phase after their reads were issued
@@ -1237,11 +1298,11 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
             dqT = mfma16k16(KT[kt], dsb, dqT);
             bf16_t* tp = T;                     // one tile pair per wave: LDS executes a wave's accesses in order
             bf16_t* td = tp + 16 * TTS;
-            *reinterpret_cast<bf16x4*>(tp + q.c16 * TTS + 4 * q.g) = pb;
-            *reinterpret_cast<bf16x4*>(td + q.c16 * TTS + 4 * q.g) = dsb;
+            st4(tp + tw, pb);
+            st4(td + tw, dsb);
             asm volatile("" ::: "memory");
-            Bp = tr4(tp + (4 * q.g + q4) * TTS + 4 * p4);
-            Bds = tr4(td + (4 * q.g + q4) * TTS + 4 * p4);
+            Bp = tr4(tp + trd);
+            Bds = tr4(td + trd);
         }
         dkT[MT - 1] = mfma16k16(QT, Bds, dkT[MT - 1]);
         dvT[MT - 1] = mfma16k16(dOT, Bp, dvT[MT - 1]);
@@ -1249,7 +1310,7 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
             bf16x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dqT[r] * scale);
-            *reinterpret_cast<bf16x4*>(Qb + query * LU + hc + 4 * q.g) = v;
+            st4(Qb + qt * 16 * IR + wcol, v);
         }
     }
     if (q.g < 2) {
@@ -1262,8 +1323,8 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
                 const float xk = live ? dkT[kt][r] * scale : 0.f, xv = live ? dvT[kt][r] : 0.f;
                 vk[r] = (bf16_t)xk; vv[r] = (bf16_t)xv;
             }
-            *reinterpret_cast<bf16x4*>(Kb + (kt * 16 + q.c16) * LU + hc + 4 * q.g) = vk;
-            *reinterpret_cast<bf16x4*>(Vb + (kt * 16 + q.c16) * LU + hc + 4 * q.g) = vv;
+            st4(Kb + kt * 16 * IR + wcol, vk);
+            st4(Vb + kt * 16 * IR + wcol, vv);
         }
     }
 }
@@ -1279,7 +1340,7 @@ struct DecBwdAttnArgs {
 template <int MT>
 __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) {
     using L = DL<MT>;
-    constexpr int R = L::R, IMG = R * LU, NPW = (R * 8 + NT_ - 1) / NT_;
+    constexpr int R = L::R, IMG = R * IR, NPW = (R * 8 + NT_ - 1) / NT_;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* U = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Qb = U + IMG;
@@ -1287,14 +1348,15 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     bf16_t* Vb = Kb + IMG;
     bf16_t* Ob = Vb + IMG;            // attention output, later the image of dO
     bf16_t* DXb = Ob + IMG;           // bf16 image of dx1
-    float* XS = reinterpret_cast<float*>(Ob);                     // fp32 staging tile aliases Ob|DXb (both dead by then)
+    float* XS = reinterpret_cast<float*>(Ob);                     // fp32 staging tile aliases Ob|DXb and the head of lse (all dead by then)
     float* lse = reinterpret_cast<float*>(DXb + IMG);             // [8][R]
     float* dlt = lse + 8 * R;         // [8][R]
     bf16_t* TT = reinterpret_cast<bf16_t*>(dlt + 8 * R);          // per-wave transposition tiles of the attention core
-    bf16_t* WQ = TT + 8 * TT_WAVE;                                // Wq|Wk|Wv row-major bf16 [192][LU], resident
-    bf16_t* WP = WQ + 3 * D * LU;                                 // Wp row-major bf16 [64][LU], resident
-    float* CB = reinterpret_cast<float*>(WP + D * LU);            // bq|bk|bv (192), LN1 gamma (64), beta (64)
-    const Geo4 q = geo();
+    bf16_t* WQ = TT + 8 * TT_WAVE;                                // Wq|Wk|Wv row-major bf16 [192][LW] (row k at wrow(k)), resident
+    bf16_t* WP = WQ + 3 * D * LW;                                 // Wp row-major bf16 [64][LW], resident
+    float* CB = reinterpret_cast<float*>(WP + D * LW);            // bq|bk|bv (192), LN1 gamma (64), beta (64)
+    const GeoB q = geob();
+    const int wide = ((threadIdx.x & 7) ^ swz(threadIdx.x >> 3)) << 3;   // this thread's 16-byte chunk in the wide layout (row = tid >> 3 + 64 i)
     const int mt0 = q.wm * L::MH;
     const int c8 = (threadIdx.x & 7) * 8;
     // Weights staged once per workgroup (see dec_bwd_mlp_kernel): q|k|v read them as row pieces, the data gradients
@@ -1303,7 +1365,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         const int m = i / (D * 8), row = (i % (D * 8)) >> 3, k8 = (i & 7) * 8;
         float f[8];
         ld8((m == 0 ? p.qf : (m == 1 ? p.kf : (m == 2 ? p.vf : p.pf))) + (size_t)row * D + k8, f);
-        *reinterpret_cast<bf16x8*>(WQ + (m * D + row) * LU + k8) = cvt8(f);
+        *reinterpret_cast<bf16x8*>(WQ + (m * D + wrow(row)) * LW + k8) = cvt8(f);
     }
     for (int i = threadIdx.x; i < 5 * D; i += NT_) CB[i] = i < 3 * D ? p.w.bqkv[i] : (i < 4 * D ? p.w.n1w[i - 3 * D] : p.w.n1b[i - 4 * D]);
     // The first sample's LayerNorm reads gamma / beta from CB before the loop's first barrier: without this one a fast wave
@@ -1371,7 +1433,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 float (&d1)[8] = d1a[i];
                 const bf16x8 ov = ova[i];
                 ld8(CBl + 3 * D + c8, gm); ld8(CBl + 4 * D + c8, bt);
-                *reinterpret_cast<bf16x8*>(Ob + row * LU + c8) = ov;
+                *reinterpret_cast<bf16x8*>(Ob + row * IR + wide) = ov;
                 const float mean = red8(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
                 float v = 0.f;
 #pragma unroll
@@ -1380,8 +1442,8 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 float u[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) u[e] = f[e] * rstd * gm[e] + bt[e];
-                *reinterpret_cast<bf16x8*>(U + row * LU + c8) = cvt8(u);
-                *reinterpret_cast<bf16x8*>(DXb + row * LU + c8) = cvt8(d1);
+                *reinterpret_cast<bf16x8*>(U + row * IR + wide) = cvt8(u);
+                *reinterpret_cast<bf16x8*>(DXb + row * IR + wide) = cvt8(d1);
             }
         }
         if (threadIdx.x < 2 * R) {                     // logsumexp [row][8 heads] -> [head][row]
@@ -1402,7 +1464,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
                 for (int mi = 0; mi < L::MH; ++mi) acc[mi][j] = b;
             }
-            mm_rm<L::MH, 2, true, false>(U, LU, WQl, c * 4 + q.wn * 2, mt0, MT, q, acc);
+            mm_rows<L::MH, 2>(U, WQl, c * 4 + q.wn * 2, mt0, q, acc);
             bf16_t* dst = c == 0 ? Qb : (c == 1 ? Kb : Vb);
 #pragma unroll
             for (int mi = 0; mi < L::MH; ++mi) {
@@ -1410,7 +1472,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                 if (mt >= MT) continue;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    *reinterpret_cast<bf16x4*>(dst + (mt * 16 + q.c16) * LU + (q.wn * 2 + j) * 16 + q.g * 4) = cvt4(acc[mi][j]);
+                    st4(dst + tile_off(mt, q.wn * 2 + j, q), cvt4(acc[mi][j]));
             }
         }
         PH(1)
@@ -1418,22 +1480,22 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         f32x4 dO[L::MH][2];
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) { dO[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dO[mi][1] = dO[mi][0]; }
-        mm_wt<L::MH, true, false>(DXb, LU, WPl, mt0, MT, q, dO);
+        mm_cols<L::MH>(DXb, WPl, mt0, q, dO);
         f32x4 accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int kk = 0; kk < R / 32; ++kk) {
-            const bf16x8 a = wg_frag<MT, false>(DXb, (q.wave >> 1) * 16, kk, q);
+            const bf16x8 a = wg_frag<false>(DXb, q.wave >> 1, kk, q);
             if (bias_wave) accb = mfma16(a, ones, accb);
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
-                accP[k2] = mfma16(a, wg_frag<MT, false>(Ob, ((q.wave & 1) * 2 + k2) * 16, kk, q), accP[k2]);
+                accP[k2] = mfma16(a, wg_frag<false>(Ob, (q.wave & 1) * 2 + k2, kk, q), accP[k2]);
         }
         if constexpr (R % 32 != 0) {
-            const bf16x8 a = wg_frag<MT, true>(DXb, (q.wave >> 1) * 16, R / 32, q);
+            const bf16x8 a = wg_frag<true>(DXb, q.wave >> 1, R / 32, q);
             if (bias_wave) accb = mfma16(a, ones, accb);
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2)
-                accP[k2] = mfma16(a, wg_frag<MT, true, false>(Ob, ((q.wave & 1) * 2 + k2) * 16, R / 32, q), accP[k2]);
+                accP[k2] = mfma16(a, wg_frag<true>(Ob, (q.wave & 1) * 2 + k2, R / 32, q), accP[k2]);
         }
         dbpw += r4 == 0 ? accb[0] : (r4 == 1 ? accb[1] : (r4 == 2 ? accb[2] : accb[3]));
         PH(2)
@@ -1448,7 +1510,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             for (int j = 0; j < 2; ++j) {
                 const int row = mt * 16 + q.c16, col = (q.wn * 2 + j) * 16 + q.g * 4;
                 dOb16[mi][j] = cvt4(dO[mi][j]);
-                const bf16x4 ob = *reinterpret_cast<const bf16x4*>(Ob + row * LU + col);
+                const bf16x4 ob = *reinterpret_cast<const bf16x4*>(Ob + tile_off(mt, q.wn * 2 + j, q));
                 float v = bf2f(dOb16[mi][j][0]) * bf2f(ob[0]);
 #pragma unroll
                 for (int r = 1; r < 4; ++r) v = fmaf(bf2f(dOb16[mi][j][r]), bf2f(ob[r]), v);
@@ -1465,13 +1527,13 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             if (mt >= MT) continue;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                *reinterpret_cast<bf16x4*>(Ob + (mt * 16 + q.c16) * LU + (q.wn * 2 + j) * 16 + q.g * 4) = dOb16[mi][j];
+                st4(Ob + tile_off(mt, q.wn * 2 + j, q), dOb16[mi][j]);
         }
         // K / V rows of the padding keys -> 0 (every wave's q | k | v columns are in the images since the barrier above):
         // what keeps padded keys out of dq without a mask in the attention loop
         for (int i = threadIdx.x; i < (R - p.Ts) * 16; i += NT_) {
             const int row = p.Ts + (i >> 4), k8 = (i & 7) * 8;
-            *reinterpret_cast<bf16x8*>(((i & 8) ? Vb : Kb) + row * LU + k8) = zero8();
+            *reinterpret_cast<bf16x8*>(((i & 8) ? Vb : Kb) + row * IR + k8) = zero8();
         }
         lds_barrier();
         PH(4)
@@ -1500,9 +1562,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) { du[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; du[mi][1] = du[mi][0]; }
         asm volatile("" :: "v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]));
-        mm_wt<L::MH, true, false>(Qb, LU, WQl, mt0, MT, q, du);
-        mm_wt<L::MH, true, false>(Kb, LU, WQl + D * LU, mt0, MT, q, du);
-        mm_wt<L::MH, true, false>(Vb, LU, WQl + 2 * D * LU, mt0, MT, q, du);
+        mm_cols<L::MH>(Qb, WQl, mt0, q, du);
+        mm_cols<L::MH>(Kb, WQl + D * LW, mt0, q, du);
+        mm_cols<L::MH>(Vb, WQl + 2 * D * LW, mt0, q, du);
         f32x4 accqb[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) accqb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1510,12 +1572,12 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         for (int kk = 0; kk < R / 32; ++kk) {
             bf16x8 b[2];
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) b[k2] = wg_frag<MT, false>(U, ((q.wave & 1) * 2 + k2) * 16, kk, q);
+            for (int k2 = 0; k2 < 2; ++k2) b[k2] = wg_frag<false>(U, (q.wave & 1) * 2 + k2, kk, q);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
                 const bf16_t* dOi = mat == 0 ? Qb : (mat == 1 ? Kb : Vb);
-                const bf16x8 a = wg_frag<MT, false>(dOi, nt * 16, kk, q);
+                const bf16x8 a = wg_frag<false>(dOi, nt, kk, q);
                 if (bias_wave) accqb[t] = mfma16(a, ones, accqb[t]);
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) accQ[t][k2] = mfma16(a, b[k2], accQ[t][k2]);
@@ -1524,12 +1586,12 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         if constexpr (R % 32 != 0) {
             bf16x8 b[2];
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) b[k2] = wg_frag<MT, true, false>(U, ((q.wave & 1) * 2 + k2) * 16, R / 32, q);
+            for (int k2 = 0; k2 < 2; ++k2) b[k2] = wg_frag<true>(U, (q.wave & 1) * 2 + k2, R / 32, q);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int nt12 = (q.wave >> 1) * 3 + t, mat = nt12 >> 2, nt = nt12 & 3;
                 const bf16_t* dOi = mat == 0 ? Qb : (mat == 1 ? Kb : Vb);
-                const bf16x8 a = wg_frag<MT, true>(dOi, nt * 16, R / 32, q);
+                const bf16x8 a = wg_frag<true>(dOi, nt, R / 32, q);
                 if (bias_wave) accqb[t] = mfma16(a, ones, accqb[t]);
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) accQ[t][k2] = mfma16(a, b[k2], accQ[t][k2]);
@@ -1743,10 +1805,10 @@ int launch_attn_fwd(const DecAttnFwdArgs& a, hipStream_t s) {
 template <int MT>
 int launch_bwd(const DecBwdMlpArgs& a, const DecBwdAttnArgs& b, hipStream_t s) {
     using L = DL<MT>;
-    constexpr int IMG = L::R * LU * 2;
-    constexpr int LDS_A = 5 * IMG + 2 * WRM * 2 + 2 * HPD * 4;
-    static_assert(2 * IMG >= L::R * LX * 4, "fp32 staging tile must fit over Gc|DH1");
-    static_assert(LDS_A - 5 * IMG >= 16 * LU * 2, "image overrun of the unguarded du2 product must stay inside the allocation");
+    constexpr int IMG = L::IMGB;
+    constexpr int LDS_A = 5 * IMG + 2 * WRB * 2 + 2 * HPD * 4;
+    static_assert(3 * IMG >= L::R * LX * 4, "fp32 staging tile must fit over Gc|DH1|DH3");
+    static_assert(LDS_A - 5 * IMG >= 16 * IR * 2, "image overrun of the unguarded du2 product must stay inside the allocation");
     constexpr int LDS_B = L::BWD_ATTN_LDS;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1771,8 +1833,11 @@ int launch_bwd(const DecBwdMlpArgs& a, const DecBwdAttnArgs& b, hipStream_t s) {
 }
 
 bool hs_dec_fused_supported(int d, int heads, int hidden, int Ts) {
-    // the backward kernels keep 5-6 bf16 images + an fp32 tile of the sample in LDS: up to 7 m-tiles (112 tokens)
-    return d == D && heads == 8 && hidden <= HPD && hidden % 4 == 0 && Ts <= 112 && Ts >= 16;
+    // the backward kernels keep 5-6 bf16 images + an fp32 tile of the sample in LDS: up to 7 m-tiles (112 tokens).
+    // Every kernel of this file is compiled for HPD = 192-row hidden images (w1 / w3 / w2 / w2T packed to rup(hidden, 32) = 192
+    // rows, 6 k-steps): a narrower hidden width would be read with the wrong k-step layout and past the caller's images
+    // (ADVICE r03), so it is refused here — the layer-at-a-time schedule covers it.
+    return d == D && heads == 8 && (hidden + 31) / 32 * 32 == HPD && hidden % 4 == 0 && Ts <= 112 && Ts >= 16;
 }
 
 int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o,
