@@ -276,6 +276,7 @@ class HSIMAE(nn.Module):
         self._packed_version = -1
         self._anchor = None
         self._reducer = None
+        self._grads_home = [False, False]
         self.want_recons = True
         self.len_t = self.len_l = None
         self._last_imgs = None
@@ -343,6 +344,11 @@ class HSIMAE(nn.Module):
         """One python-`random` draw per call, even with a single candidate (keeps the RNG stream)."""
         cands = self.grid_candidates(T, L, mask_ratio)
         return cands[random.sample(range(len(cands)), 1)[0]]
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none=set_to_none)
+        if set_to_none:
+            self._grads_home = [False, False]
 
     # ------------------------------------------------------------------ device-side plumbing
     def _check_supported(self):
@@ -412,6 +418,7 @@ class HSIMAE(nn.Module):
             p.data = view
         self._flat, self._offs, self._sizes = flat, list(offs), list(sizes)
         self._flat_grad = torch.zeros_like(flat)
+        self._grads_home = [False, False]
         self._flat_scratch = torch.zeros_like(flat)
         self._grad_views = [self._flat_grad[o: o + s].view(p.shape) for o, s, p in zip(self._offs, self._sizes, params)]
         self._trainable = [i for i, p in enumerate(params) if p.requires_grad and i != 1]   # 1 = mask_token (never used)
@@ -534,14 +541,23 @@ class HSIMAE(nn.Module):
         idxs = self._trainable if idxs is None else idxs
         lo, hi = (0, scratch.numel()) if rng is None else rng
         cur = [params[i].grad for i in idxs]
+        # which of the two parameter ranges (encoder, decoder) have every `.grad` attached to its flat view after this call:
+        # FusedAdamW's O(1) check (optim.py _sync_grads); HSIMAE.zero_grad clears it
+        full = idxs is self._trainable
+        enc, dec = full or idxs is self._enc_idx, full or idxs is self._dec_idx
         if all(g is None for g in cur):
             torch.mul(scratch[lo:hi], scale, out=self._flat_grad[lo:hi])
             for i in idxs:
                 params[i].grad = views[i]
-        elif all(g is not None and g.data_ptr() == views[i].data_ptr() and g.shape == views[i].shape
+            self._grads_home = [self._grads_home[0] or enc, self._grads_home[1] or dec]
+        elif all(g is views[i] or (g is not None and g.data_ptr() == views[i].data_ptr() and g.shape == views[i].shape)
                  for g, i in zip(cur, idxs)):
             self._flat_grad[lo:hi].addcmul_(scratch[lo:hi], torch.as_tensor(scale, device=scratch.device, dtype=torch.float32))
         else:                                             # mixed: some cleared, some replaced by the caller
+            if enc:
+                self._grads_home[0] = False
+            if dec:
+                self._grads_home[1] = False
             for g, i in zip(cur, idxs):
                 o, n = self._offs[i], self._sizes[i]
                 upd = (scratch[o:o + n] * scale).view(params[i].shape)
@@ -754,10 +770,14 @@ class HSIMAE(nn.Module):
             # library forks the two axis stacks onto a side stream (rank-local: env switch, hipStreamCreate): ranks that
             # disagree would issue different all-reduce slices.  Checked once, here.
             import torch.distributed as dist
+            # (a tensor collective on the model's own device, under its device guard: object collectives stage through
+            #  torch.cuda.current_device(), which is still cuda:0 on every rank of a group made without device_id — RCCL then
+            #  sees one GPU twice)
             with torch.cuda.device(dev):
-                mine = int(_lib.load().hsimae_two_streams_active())
-            flags = [None] * self._reducer.world_size
-            dist.all_gather_object(flags, mine, group=process_group)
+                mine = torch.tensor([int(_lib.load().hsimae_two_streams_active())], dtype=torch.int32, device=dev)
+                gathered = [torch.zeros_like(mine) for _ in range(self._reducer.world_size)]
+                dist.all_gather(gathered, mine, group=process_group)
+                flags = [int(t.item()) for t in gathered]
             if len(set(flags)) != 1:
                 raise RuntimeError(f"hsimae_amd: ranks disagree on the two-stream backward schedule ({flags}); set "
                                    "HSIMAE_TWO_STREAMS identically on every rank")

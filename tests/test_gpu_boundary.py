@@ -100,6 +100,40 @@ def test_c1_summary_consumed_directly_perturbed_weights():
     assert rms_rel(lat.detach()[:4], torch.from_numpy(z["latent"])) <= 5e-3
 
 
+def test_loss_error_is_the_bf16_operand_rounding():
+    """VERDICT r03 weak spot 1: with non-degenerate weights (the F5 stress fixture, ~3.5x the reference's scale) the HIP loss is
+    only within ~1e-4 of the fp32 reference.  This test shows that gap IS the rounding of the matrix-product operands to bf16 and
+    nothing else: the oracle re-run with its operands rounded where the kernels round theirs (`oracle.operands_bf16`: LayerNorm
+    outputs, q | k | v, softmax numerators, attention output, gate product, patch values, weights; fp32 everywhere else) lands
+    on the HIP loss an order of magnitude closer than the fp32 oracle does.  Gates: |HIP - bf16-operand oracle| <= 3e-5 relative
+    (accumulation order, v_exp / v_rcp / v_rsq at 1 ulp: what is left), <= 1e-3 to the fp32 reference record, and the rounding
+    itself is visible: |bf16-operand oracle - fp32 oracle| >= 3e-5."""
+    s = json.load(open(os.path.join(G, "c1_summary.json")))
+    z = np.load(os.path.join(G, "c1_summary.npz"))
+    torch.manual_seed(0); random.seed(0)
+    m = base48(0)
+    perturb_like_fixture(m, s["perturb_seed"])
+    torch.manual_seed(s["x_seed"])
+    x = torch.rand(s["N"], 1, 48, 9, 9)
+    P = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    cfg = O.OracleConfig(bands=48)
+    args = (P, cfg, x, z["noise_1"], z["noise_2"], s["len_t"], s["len_l"])
+    l32 = O.forward(*args)[0].item()
+    with O.operands_bf16():
+        lb = O.forward(*args)[0].item()
+    assert abs(l32 - s["loss_fp32"]) <= 2e-6 * s["loss_fp32"]                 # the oracle is the reference here
+    with torch.no_grad():
+        loss, _, _ = m(x.to(DEV), 0.75, noise=(torch.from_numpy(z["noise_1"]), torch.from_numpy(z["noise_2"])),
+                       grid=(s["len_t"], s["len_l"]))
+    lh = loss.item()
+    e_b, e_32, gap = abs(lh - lb) / lb, abs(lh - l32) / l32, abs(lb - l32) / l32
+    print(f"[bf16-operand oracle] HIP {lh:.7f}  bf16-operand oracle {lb:.7f} (rel {e_b:.2e})  fp32 oracle {l32:.7f} (rel {e_32:.2e}); "
+          f"oracle-to-oracle {gap:.2e}")
+    assert gap >= 3e-5
+    assert e_32 <= 1e-3
+    assert e_b <= 3e-5 and e_b <= 0.5 * gap
+
+
 def test_c1_config1_reference_scale_n64():
     """BASELINE.json configs[0] exactly, the reference's weights after construction (seed 0): loss <= 1e-4 relative
     (north_star), every gradient L2 norm <= 2e-2, four full gradient tensors RMS-relative <= 2e-2."""
@@ -321,6 +355,56 @@ def test_fused_adamw_skips_parameters_without_grad_after_a_partial_backward():
     opt2.step()
     torch.cuda.synchronize()
     assert torch.allclose(b.detach(), b0 - 1e-2, atol=1e-5)
+
+
+def test_fused_adamw_common_path_is_one_launch_and_no_torch_ops():
+    """after a whole backward every trainable `.grad` is at home in the flat buffer — FusedAdamW.step() must
+    then be ONE library launch: no ATen op at all on the way (round 3 issued a device fill per parameter when gradients were
+    missing, and walked 532 `.grad` objects on every step).  Counted with a TorchDispatchMode (every ATen call, views included);
+    the partial-backward pattern is allowed one mask upload the first time and nothing afterwards (cached per pattern)."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from hsimae_amd import FusedAdamW
+
+    class Count(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.ops = []
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            self.ops.append(str(func))
+            return func(*args, **(kwargs or {}))
+
+    m = base48(3)
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=5e-2, betas=(0.9, 0.95))
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(8, 1, 48, 9, 9, generator=g).to(DEV)
+    noise = (torch.rand(8, 6, generator=g), torch.rand(8, 9, generator=g))
+    opt.zero_grad()
+    m(x, 0.75, noise=noise, grid=(2, 7))[0].backward()
+    opt.step()                                            # the first step binds the optimizer to the flat buffer (moments, group table)
+    for strict in (False, True):
+        opt.strict = strict
+        for _ in range(2):
+            opt.zero_grad()
+            m(x, 0.75, noise=noise, grid=(2, 7))[0].backward()
+            before = {k: p.detach().clone() for k, p in list(m.named_parameters())[2:6]}
+            with Count() as c:
+                opt.step()
+            torch.cuda.synchronize()
+            assert c.ops == [], f"strict={strict}: the common path issued torch ops: {c.ops[:8]}"
+            assert all(not torch.equal(p.detach(), before[k]) for k, p in list(m.named_parameters())[2:6] if p.requires_grad)
+    opt.strict = False
+    # decoder-only backward: the encoder's gradients are missing -> one host-built mask, uploaded once and cached
+    counts = []
+    for _ in range(3):
+        opt.zero_grad()
+        with torch.no_grad():
+            latent, mask, ids_restore, _ = m.forward_encoder(x, 0.75, noise=noise, grid=(2, 7))
+        m.forward_loss(x, m.forward_decoder(latent, ids_restore), mask).backward()
+        with Count() as c:
+            opt.step()
+        counts.append(len(c.ops))
+    assert counts[0] <= 4 and counts[1] == 0 and counts[2] == 0, counts
 
 
 @pytest.mark.parametrize("dim,dec_dim,bands", [(64, 48, 32), (144, 72, 32)])
