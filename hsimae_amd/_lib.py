@@ -121,6 +121,8 @@ SYMBOLS = {
     "hsimae_version": (C.c_int, []),
     "hsimae_strerror": (C.c_char_p, [C.c_int]),
     "hsimae_two_streams_active": (C.c_int, []),
+    "hsimae_effective_precision": (C.c_int, [C.POINTER(Config)]),
+    "hsimae_dec_block_slab_floats": (i64, []),
     "hsimae_param_layout": (C.c_int, [C.POINTER(Config), C.POINTER(i64), C.POINTER(i64), C.c_int]),
     "hsimae_wpk_elems": (i64, [C.POINTER(Config)]),
     "hsimae_pack_table_bytes": (i64, [C.POINTER(Config)]),

@@ -9,11 +9,25 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhsimae_hip.so")
-UNITS = ["gemm", "gemm_dma", "attn", "wgrad", "elem", "pack", "fused_dec", "fused_enc", "loader", "api"]
+UNITS = ["gemm", "gemm_dma", "attn", "attn_wide", "wgrad", "elem", "pack", "fused_dec", "fused_enc", "loader", "api"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # HSIMAE_HIPCC_EXTRA: extra hipcc flags for experiments (e.g. "-Xclang -target-feature -Xclang -packed-fp32-ops",
 # which removes the v_pk_*_f32 forms: measured neutral on the step, so not the default)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"] + os.environ.get("HSIMAE_HIPCC_EXTRA", "").split()
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-fvisibility=hidden"] + os.environ.get("HSIMAE_HIPCC_EXTRA", "").split()
+
+
+def kernel_source_hash() -> str:
+    """sha256 (16 hex digits) over every kernel source and header the library is built from.  Measurement files under
+    profiles/ (step traffic) record it, and bench.py flags them as stale when the kernels have changed since."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp")))
+    files.append(os.path.join(HERE, "..", "include", "hsimae_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def _stale(target: str, deps: list[str]) -> bool:

@@ -185,6 +185,10 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
         CK(hs_attn_block_fwd(x_in, P.n1w, P.n1b, P.qkv, P.bqkv, P.p, P.pb, b.u, b.qkv, b.o, b.lse, b.x1, rs_a, Ts, nsamples, mode,
                              len_l, s));
         if (fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
+    } else if (!f8 && dp == d && hs_attn_block256_fusable(d, heads, Ts)) {
+        // the same half at D = 256 (attn_wide.hip blk256_fwd_kernel: 16 waves = 16 heads, weights streamed from L2)
+        CK(hs_attn_block256_fwd(x_in, P.n1w, P.n1b, P.qkv, P.bqkv, P.p, P.pb, b.u, b.qkv, b.o, b.lse, b.x1, rs_a, Ts, nsamples, mode,
+                                len_l, s));
     } else {
     p.A = x_in; p.lda = dp; p.M = (int)M; p.N = 3 * dp; p.K = dp; p.n_valid = 3 * dp; p.W = P.qkv; p.bias = P.bqkv;
     p.gamma = P.n1w; p.beta = P.n1b; p.u_out = b.u; p.ldu = dp; p.out = b.qkv; p.ldo = 3 * dp; p.ln_width = d;
@@ -373,6 +377,11 @@ extern "C" {
 int hsimae_version(void) { return 103; }
 
 int hsimae_two_streams_active(void) { return side().ok ? 1 : 0; }
+int hsimae_effective_precision(const hsimae_config* cfg) {
+    if (!cfg) return HSIMAE_ENULL;
+    Geo g; CK(make_geo(cfg, g));
+    return (g.prec == HSIMAE_PREC_FP8 && (g.D >= 512 || fp8_unfused())) ? HSIMAE_PREC_FP8 : HSIMAE_PREC_BF16;
+}
 
 const char* hsimae_strerror(int code) {
     switch (code) {
@@ -788,6 +797,7 @@ int hsimae_dec_block_fwd(const hsimae_dec_block_weights* w, const float* x, floa
     }
     return hs_dec_block_fwd(x, x1, x2, o, lse, nsamples, Ts, d, S(stream));
 }
+int64_t hsimae_dec_block_slab_floats(void) { return kDecSlabFloats; }
 int hsimae_dec_block_bwd(const hsimae_dec_block_weights* w, const hsimae_dec_block_grads* g, const float* x, const float* x1,
                          const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o, const float* lse, int32_t nsamples,
                          int32_t Ts, float* slab, void* stream) {

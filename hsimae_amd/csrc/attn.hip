@@ -579,10 +579,12 @@ __global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
             f32x4 pv, ds;
             if constexpr (MODE0) {
                 // one class: no mask.  The K / V image rows past Ts are zero (load16_wg), so a padded key has s = 0, dP = 0 and a
-                // finite garbage P / dS that meets K = 0 in dq; its dk / dv rows are never stored (store16_wg stops at Ts)
+                // finite garbage P / dS that meets K = 0 in dq; its dk / dv rows are never stored (store16_wg stops at Ts).
+                // The exponent is clamped at 0 (P <= 1 holds for every real key): a padded key of a query whose logsumexp is
+                // very negative (diverging run: every real score below about -88) would otherwise give P = inf and inf * 0 = NaN in dq
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pv[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn));
+                    pv[r] = __builtin_amdgcn_exp2f(fminf(fmaf(s[r], sc, lqn), 0.f));
                     ds[r] = pv[r] * (dp[r] - dl);
                 }
             } else {

@@ -1,0 +1,361 @@
+// The attention half of an encoder Block at D = 256 (HSIMAE-Large: 16 heads of 16, <= 32 kept tokens per sample) in ONE
+// persistent kernel — the wide counterpart of blk128_fwd_kernel (attn.hip):
+//   u = LN1(x);  q|k|v = u Wqkv^T + b;  o = softmax(q k^T / 4) v per head;  x1 = x + rs * (o Wp^T + bp)
+// (Models.py:303-304 with Attention.forward :192-219 at enc_paras = [12, 256, 9], Model_Pretraining.py:130).
+//
+// Round 3 ran this half layer at a time at D = 256: LN1 + q|k|v GEMM (130 us), attn16_fwd (55 us), proj + residual GEMM (77 us)
+// = 262 us per block with q|k|v and o making a round trip through HBM between the launches (byte floor of the three at
+// 5 TB/s: 68 + 45 + 57 us).  Why the D = 128 form does not carry over: there wave h keeps head h's 48 columns of Wqkv and 16 of Wp
+// in 64 registers for the whole launch; at D = 256 that is 128 registers for 16 waves (4 per SIMD => 128 in all).  Here:
+//   * one workgroup = 16 waves = 16 heads, walking groups of SPW = 2 samples (64 image rows, 4 m-tiles);
+//   * the weights are STREAMED: wave h fetches its three 16-column n-tiles of Wqkv one k-step (3 KB) ahead of the MFMAs that
+//     use it and multiplies it against all 4 m-tiles of the group — 512 KB of L2 -> register traffic per group, 4 MB per CU and
+//     launch, against ~0.5 GB of HBM traffic for the whole launch;
+//   * operands swapped (weights as A): a lane owns 4 consecutive head dims of one token, which IS the A / B fragment of the
+//     K = 16 MFMA whose contraction runs over the head dim — q^T and k^T go from the accumulators into the score MFMAs without
+//     touching LDS; q | k | v are also written (8-byte pieces) into a staging image from which (a) V^T is read back with transpose
+//     reads and (b) the rows leave for HBM as whole 1,536-byte rows for the backward;
+//   * the attention output goes into the image LN1 occupied (dead once every wave has its q | k | v), the projection reads it
+//     as row fragments; x is read once for LayerNorm and once more (L2-hot) as the residual.
+// LDS: cls 0.25 + U/O image 34.8 + staging 99.3 + lse 4 + vectors 6 = 144.4 KB => one workgroup per CU, 4 waves per SIMD.
+#include "common.h"
+#include "kernels.h"
+#include <cstdlib>
+
+#ifndef HS_NT_C
+#define HS_NT_C 1      /* u / q|k|v / o saved for the backward: streaming stores (as blk128_fwd) */
+#endif
+#ifndef HS_W256_PF2
+#define HS_W256_PF2 0  /* q|k|v weight fragments two k-steps ahead instead of one (12 more registers) */
+#endif
+#ifndef HS_W256_EARLY
+#define HS_W256_EARLY 0 /* projection weights (first half) and residual pieces fetched in front of the attention */
+#endif
+
+namespace {
+
+constexpr int DW = 256, HW = 16, HDW = 16;          // width, heads, head dim
+constexpr int PU = DW + 16;                         // U / O image row pitch (elements): 16 mod 64 elements => conflict-free 16-byte row fragments
+constexpr int PS = 3 * DW + 8;                      // staging image row pitch: 8-byte tile writes 2-way, transpose reads 2-way (scripts/micro/lds_banks.py)
+constexpr int NTHW = 1024;
+constexpr int KSW = DW / 32;                        // k-steps over the model width
+
+typedef __attribute__((ext_vector_type(4))) short s16x4w;
+typedef __attribute__((address_space(3))) bf16x4* lds_b64w;
+__device__ __forceinline__ f32x4 mfma_k16w(bf16x4 a, bf16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4w, a), __builtin_bit_cast(s16x4w, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4 tr4w(const bf16_t* a) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64w)(a)); }
+__device__ __forceinline__ bf16x4 cvt4w(f32x4 v) {
+    bf16x4 r;
+    r[0] = (bf16_t)v[0]; r[1] = (bf16_t)v[1]; r[2] = (bf16_t)v[2]; r[3] = (bf16_t)v[3];
+    return r;
+}
+
+struct Blk256Args {
+    const float* x; const float* n1w; const float* n1b;
+    const bf16_t* wqkv; const float* bqkv; const bf16_t* wp; const float* pb;
+    bf16_t* u; bf16_t* qkv; bf16_t* o; float* lse; float* x1; const float* rowscale;
+    int Ts, nsamples, mode, len_l;
+};
+
+template <int NT, int SPW>
+struct LayW {
+    static constexpr int ROWS = NT * 16;                 // rows of one slot (sample)
+    static constexpr int RT = SPW * ROWS;                // rows of the images
+    static constexpr int OFF_U = RT * 4;                 // after cls
+    static constexpr int OFF_S = OFF_U + RT * PU * 2;
+    static constexpr int OFF_LSE = OFF_S + RT * PS * 2;
+    static constexpr int OFF_VEC = OFF_LSE + RT * HW * 4;
+    static constexpr int TOTAL = OFF_VEC + (2 * DW + 3 * DW + DW) * 4;      // gamma | beta | bqkv | bp
+    static_assert(TOTAL <= 160 * 1024, "LDS");
+};
+
+template <int NT, int SPW>
+__global__ __launch_bounds__(NTHW, 1) void blk256_fwd_kernel(Blk256Args p) {
+    using L = LayW<NT, SPW>;
+    constexpr int ROWS = L::ROWS, RT = L::RT, MTT = SPW * NT;
+    constexpr int PASSES = (RT * 32 + NTHW - 1) / NTHW;           // LayerNorm passes: 32 lanes per row, 32 rows per pass
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int* cls = reinterpret_cast<int*>(smem);
+    bf16_t* Uf = reinterpret_cast<bf16_t*>(smem + L::OFF_U);      // LN1 image, later the attention output image
+    bf16_t* Sf = reinterpret_cast<bf16_t*>(smem + L::OFF_S);      // q | k | v rows [RT][PS]
+    float* lse_s = reinterpret_cast<float*>(smem + L::OFF_LSE);   // [RT][16]
+    float* vec_s = reinterpret_cast<float*>(smem + L::OFF_VEC);   // gamma[256] | beta[256] | bqkv[768] | bp[256]
+    const int c16_ = lane & 15, g_ = lane >> 4, hc = head * HDW;
+    const float sc = 0.25f * 1.4426950408889634f;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int i = threadIdx.x; i < 6 * DW; i += NTHW)
+        vec_s[i] = i < DW ? p.n1w[i] : i < 2 * DW ? p.n1b[i - DW] : i < 5 * DW ? p.bqkv[i - 2 * DW] : p.pb[i - 5 * DW];
+    for (int i = threadIdx.x; i < RT; i += NTHW) {                // class of an image row: -1 = padding; slots never mix
+        const int slot = i / ROWS, r = i - slot * ROWS;
+        int c = -1;
+        if (r < p.Ts) c = slot * 64 + ((p.mode == 1) ? r / p.len_l : (p.mode == 2) ? r % p.len_l : 0);
+        cls[i] = c;
+    }
+
+    float xn[PASSES][8];                                          // next group's row pieces, in flight during this group
+    auto fetch = [&](int first) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int irow = ps * 32 + (threadIdx.x >> 5), slot = irow / ROWS, r = irow - slot * ROWS;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xn[ps][e] = 0.f;
+            if (irow < RT && first + slot < p.nsamples && r < p.Ts) {
+                const float* src = p.x + ((unsigned)((first + slot) * p.Ts + r) * DW + (threadIdx.x & 31) * 8);
+                const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+                xn[ps][0] = a.x; xn[ps][1] = a.y; xn[ps][2] = a.z; xn[ps][3] = a.w;
+                xn[ps][4] = b.x; xn[ps][5] = b.y; xn[ps][6] = b.z; xn[ps][7] = b.w;
+            }
+        }
+    };
+    fetch(blockIdx.x * SPW);
+    lds_barrier();                                                // vec_s / cls visible
+    // this wave's weight fragments: n-tiles head (q), 16 + head (k), 32 + head (v) of the packed [768][256] image
+    auto wfrag = [&](int m, int ks) {
+        return *reinterpret_cast<const bf16x8*>(p.wqkv + ((size_t)((m * HW + head) * KSW + ks) * 64 + lane) * 8);
+    };
+
+    for (int first = blockIdx.x * SPW; first < p.nsamples; first += gridDim.x * SPW) {
+        // The per-lane address pieces are laundered once per group: left alone, hipcc hoists ~25 registers of loop-invariant
+        // addresses out of this loop and spills them; their scratch reloads then queue behind the group's HBM stores
+        // (loads and stores share one in-order counter) — measured 212 vs 188 us per launch.
+        int lz = 0;
+        asm volatile("" : "+v"(lz));
+        const int c16 = c16_ + lz, g = g_ + lz, q4 = c16 >> 2, p4 = c16 & 3, tid = (int)threadIdx.x + lz, lc8 = (tid & 31) * 8;
+        // global row of image row i (slot-major), or -1.  Rows and element offsets are 32-bit (the launcher checks the sizes): with
+        // 64-bit row numbers hipcc precomputes every per-thread pointer of the copy loops outside the group loop and spills them
+        auto grow = [&](int irow) -> int {
+            const int slot = irow / ROWS, r = irow - slot * ROWS;
+            return (first + slot < p.nsamples && r < p.Ts) ? (first + slot) * p.Ts + r : -1;
+        };
+        // first two k-steps of this wave's q | k | v weights: in flight under the LayerNorm.  (gfx950 counts loads and stores
+        // with ONE in-order counter: a load that is issued behind a store cannot be waited for before that store has landed in
+        // HBM.  Every load below that is needed soon is therefore issued in front of the stores of its phase.)
+        bf16x8 wc[3], wn[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { wc[m] = wfrag(m, 0); if (HS_W256_PF2) wn[m] = wfrag(m, 1); }
+        // ---- LN1 -> U image (+ u to HBM: the q / k / v weight gradients' operand)
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int irow = ps * 32 + (tid >> 5);
+            if (irow < RT) {
+                float sm = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm += xn[ps][e];
+                sm = lanes_sum<32>(sm);
+                const float mean = sm * (1.f / DW);
+                float vq = 0.f, f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f[e] = xn[ps][e] - mean; vq += f[e] * f[e]; }
+                vq = lanes_sum<32>(vq);
+                const float rstd = rsqrtf(vq * (1.f / DW) + 1e-5f);
+                {
+                    const float4 g0 = *reinterpret_cast<const float4*>(vec_s + lc8), g1 = *reinterpret_cast<const float4*>(vec_s + lc8 + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(vec_s + DW + lc8), b1 = *reinterpret_cast<const float4*>(vec_s + DW + lc8 + 4);
+                    const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
+                }
+                const int gr = grow(irow);
+                const bf16x8 ub = gr >= 0 ? cvt8(f) : zero8();
+                *reinterpret_cast<bf16x8*>(Uf + irow * PU + lc8) = ub;
+                if (gr >= 0) HS_NT(HS_NT_C, reinterpret_cast<bf16x8*>(p.u + ((unsigned)gr * DW + lc8)), ub);
+            }
+        }
+        lds_barrier();                                            // B1: U complete
+        // ---- q | k | v of this head over all m-tiles of the group, weights streamed two k-steps ahead
+        f32x4 acc[3][MTT];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(vec_s + 2 * DW + m * DW + hc + 4 * g);
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) acc[m][mt] = bias;
+        }
+#pragma unroll 1
+        for (int ks = 0; ks < KSW; ++ks) {                        // (not unrolled: unrolled, hipcc hoists every fragment load to the top and spills 109 registers)
+            bf16x8 wf[3];
+            if (ks + 1 + HS_W256_PF2 < KSW) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) wf[m] = wfrag(m, ks + 1 + HS_W256_PF2);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Uf + (mt * 16 + c16) * PU + ks * 32 + g * 8);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) acc[m][mt] = mfma16(wc[m], a, acc[m][mt]);
+            }
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                if (HS_W256_PF2) { wc[m] = wn[m]; if (ks + 2 < KSW) wn[m] = wf[m]; }
+                else if (ks + 1 < KSW) wc[m] = wf[m];
+            }
+        }
+        // q^T / k^T stay in registers (lane = token, 4 head dims: the fragment of the K = 16 score MFMA); all three go to staging
+        bf16x4 qT[MTT], kT[MTT];
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) {
+            qT[mt] = cvt4w(acc[0][mt]); kT[mt] = cvt4w(acc[1][mt]);
+            bf16_t* dst = Sf + (mt * 16 + c16) * PS + hc + 4 * g;
+            *reinterpret_cast<bf16x4*>(dst) = qT[mt];
+            *reinterpret_cast<bf16x4*>(dst + DW) = kT[mt];
+            *reinterpret_cast<bf16x4*>(dst + 2 * DW) = cvt4w(acc[2][mt]);
+        }
+        // loads first (see above): the projection weights of this wave's 16 output columns, the residual pieces of its output
+        // tiles (L2-hot: the LayerNorm read the same rows) and the next group's rows — all in flight under the attention
+        auto pfrag = [&](int ks) { return *reinterpret_cast<const bf16x8*>(p.wp + ((size_t)(head * KSW + ks) * 64 + lane) * 8); };
+        bf16x8 wpj[KSW / 2];                                      // (the second half follows after the attention: 32 more registers here spill)
+        f32x4 xr[MTT];
+        auto early = [&]() {
+#pragma unroll
+            for (int ks = 0; ks < KSW / 2; ++ks) wpj[ks] = pfrag(ks);
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) {
+                const int gr = grow(mt * 16 + c16);
+                xr[mt] = gr >= 0 ? *reinterpret_cast<const f32x4*>(p.x + ((unsigned)gr * DW + hc + 4 * g)) : z4;
+            }
+        };
+        if (HS_W256_EARLY) early();
+        fetch(first + gridDim.x * SPW);
+        lds_barrier();                                            // B2: every wave is done with U; the staging image is complete
+        // ---- saved q | k | v leave as whole rows (three 512-byte thirds of 32 16-byte pieces); the stores drain under the attention
+        for (int idx = tid; idx < RT * 32; idx += NTHW) {
+            const int irow = idx >> 5, pc = idx & 31;
+            const int gr = grow(irow);
+            if (gr >= 0) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+                    HS_NT(HS_NT_C, reinterpret_cast<bf16x8*>(p.qkv + ((unsigned)gr * (3 * DW) + m * DW + pc * 8)),
+                          *reinterpret_cast<const bf16x8*>(Sf + irow * PS + m * DW + pc * 8));
+            }
+        }
+        // ---- attention of this head; O into the (dead) U image.  The class / padding mask of a (query tile, key tile) pair is
+        //      the same in every slot: built once per query tile as the accumulator the score MFMA starts from (0 or -inf)
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            if (qt * 16 >= p.Ts) break;
+            const int qc = cls[qt * 16 + c16];                     // class of this lane's query (slot 0's classes: the same in every slot)
+            f32x4 cmk[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
+                cmk[kt][0] = (kc.x >= 0 && kc.x == qc) ? 0.f : -INFINITY; cmk[kt][1] = (kc.y >= 0 && kc.y == qc) ? 0.f : -INFINITY;
+                cmk[kt][2] = (kc.z >= 0 && kc.z == qc) ? 0.f : -INFINITY; cmk[kt][3] = (kc.w >= 0 && kc.w == qc) ? 0.f : -INFINITY;
+            }
+#pragma unroll
+            for (int slot = 0; slot < SPW; ++slot) {
+                const int r0 = slot * ROWS;
+                const int query = r0 + qt * 16 + c16;
+                f32x4 sv[NT];
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    sv[kt] = mfma_k16w(kT[slot * NT + kt], qT[slot * NT + qt], cmk[kt]);     // masked pairs start (and stay) at -inf
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sv[kt][r] *= sc;
+                        m = fmaxf(m, sv[kt][r]);
+                    }
+                }
+                m = rows_max(m);
+                if (m == -INFINITY) m = 0.f;
+                float lsum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(sv[kt][r] - m);
+                        sv[kt][r] = e;
+                        lsum += e;
+                    }
+                lsum = rows_sum(lsum);
+                const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+                f32x4 o = z4;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+                    o = mfma_k16w(tr4w(Sf + (r0 + kt * 16 + 4 * g + q4) * PS + 2 * DW + hc + 4 * p4), cvt4w(sv[kt]), o);
+                bf16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
+                *reinterpret_cast<bf16x4*>(Uf + query * PU + hc + 4 * g) = ov;
+                if (g == 0) lse_s[query * HW + head] = m + __builtin_amdgcn_logf(fmaxf(lsum, 1e-30f));
+            }
+        }
+        lds_barrier();                                            // B3: O image and logsumexp table complete
+        if (!HS_W256_EARLY) early();
+        bf16x8 wpk[KSW / 2];                                      // second half of the projection weights (loads in front of the stores)
+#pragma unroll
+        for (int ks = 0; ks < KSW / 2; ++ks) wpk[ks] = pfrag(KSW / 2 + ks);
+        // ---- o and lse leave as whole rows
+        for (int idx = tid; idx < RT * 32; idx += NTHW) {
+            const int irow = idx >> 5, pc = idx & 31;
+            const int gr = grow(irow);
+            if (gr >= 0) HS_NT(HS_NT_C, reinterpret_cast<bf16x8*>(p.o + ((unsigned)gr * DW + pc * 8)), *reinterpret_cast<const bf16x8*>(Uf + irow * PU + pc * 8));
+        }
+        for (int idx = tid; idx < RT * 4; idx += NTHW) {
+            const int irow = idx >> 2;
+            const int gr = grow(irow);
+            if (gr >= 0) *reinterpret_cast<float4*>(p.lse + ((unsigned)gr * HW + (idx & 3) * 4)) = *reinterpret_cast<const float4*>(lse_s + idx * 4);
+        }
+        // ---- projection: this wave's 16 output columns; transposed accumulators -> x1 leaves as 16-byte pieces
+        const f32x4 pbias = *reinterpret_cast<const f32x4*>(vec_s + 5 * DW + hc + 4 * g);
+        f32x4 pav[MTT];
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) {
+            pav[mt] = pbias;
+#pragma unroll
+            for (int ks = 0; ks < KSW / 2; ++ks)
+                pav[mt] = mfma16(wpj[ks], *reinterpret_cast<const bf16x8*>(Uf + (mt * 16 + c16) * PU + ks * 32 + g * 8), pav[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) {
+            f32x4 pa = pav[mt];
+#pragma unroll
+            for (int ks = 0; ks < KSW / 2; ++ks)
+                pa = mfma16(wpk[ks], *reinterpret_cast<const bf16x8*>(Uf + (mt * 16 + c16) * PU + (KSW / 2 + ks) * 32 + g * 8), pa);
+            const int gr = grow(mt * 16 + c16);
+            if (gr >= 0) {
+                const float rs = p.rowscale ? p.rowscale[gr] : 1.f;              // DropPath: x + scale * attn(x)
+                f32x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = fmaf(pa[r], rs, xr[mt][r]);
+                *reinterpret_cast<f32x4*>(p.x1 + ((unsigned)gr * DW + hc + 4 * g)) = ov;
+            }
+        }
+        lds_barrier();                                            // B4: the O image is read; the next group's LayerNorm may overwrite it
+    }
+}
+
+template <int NT, int SPW>
+int launch_blk256(const Blk256Args& a, hipStream_t s) {
+    using L = LayW<NT, SPW>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk256_fwd_kernel<NT, SPW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::TOTAL); attr_set = true; }
+    static int wgs = 0;                       // persistent, one 16-wave workgroup per CU (HSIMAE_BLK256_WGS overrides)
+    if (!wgs) { const char* e = getenv("HSIMAE_BLK256_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 1) wgs = 256; }
+    const int groups = (a.nsamples + SPW - 1) / SPW;
+    hipLaunchKernelGGL((blk256_fwd_kernel<NT, SPW>), dim3(groups < wgs ? groups : wgs), dim3(NTHW), (size_t)L::TOTAL, s, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool hs_attn_block256_fusable(int d, int heads, int Ts) {
+    const char* e = getenv("HSIMAE_FUSED_ATTN_BLOCK256");     // =0: the layer-at-a-time kernels (A/B runs; read per call like HSIMAE_FUSED_ATTN_BLOCK)
+    return !(e && e[0] == '0') && d == DW && heads == HW && Ts >= 1 && Ts <= 32;
+}
+
+int hs_attn_block256_fwd(const float* x, const float* n1w, const float* n1b, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* wp,
+                         const float* pb, hs_bf16* u, hs_bf16* qkv, hs_bf16* o, float* lse, float* x1, const float* rowscale, int Ts,
+                         int nsamples, int mode, int len_l, hipStream_t s) {
+    if (nsamples <= 0) return HS_OK;
+    if (Ts < 1 || Ts > 32) return HS_EUNSUPPORTED;
+    if ((int64_t)nsamples * Ts * 3 * DW >= (1ll << 31)) return HS_EUNSUPPORTED;      // 32-bit element offsets inside the kernel
+    Blk256Args a;
+    a.x = x; a.n1w = n1w; a.n1b = n1b; a.wqkv = wqkv; a.bqkv = bqkv; a.wp = wp; a.pb = pb; a.u = u; a.qkv = qkv; a.o = o;
+    a.lse = lse; a.x1 = x1; a.rowscale = rowscale; a.Ts = Ts; a.nsamples = nsamples; a.mode = mode; a.len_l = len_l;
+    return Ts <= 16 ? launch_blk256<1, 2>(a, s) : launch_blk256<2, 2>(a, s);
+}

@@ -609,7 +609,7 @@ int hs_loss(const LossParams& p, hipStream_t s) {
 }
 // 'AGG' pooling of the fine-tuning head (Models.py:962-970, 1150-1156): latent [N, T*L, D] -> [N, T*D], mean over the
 // L spatial tokens of each spectral group (x.reshape(N,T,L,C).permute(0,2,1,3).reshape(N,L,T*C).mean(1)).
-__global__ __launch_bounds__(256) void agg_pool_kernel(const float* __restrict__ latent, float* __restrict__ pooled, int T, int L,
+static __global__ __launch_bounds__(256) void agg_pool_kernel(const float* __restrict__ latent, float* __restrict__ pooled, int T, int L,
                                                         int D) {
     const int n = blockIdx.x;
     for (int e = threadIdx.x; e < T * D; e += 256) {
@@ -628,7 +628,7 @@ int hs_agg_pool(const float* latent, float* pooled, int N, int T, int L, int D, 
 
 // fp32 rows -> bf16 copy (optionally times a per-row factor): the layer-at-a-time backward's dY / dx1 as operands of the
 // LDS-DMA weight-gradient kernel, which takes bf16 only (the register-staged fp32 path runs at half its bandwidth).
-__global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n8, int d8,
+static __global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n8, int d8,
                                                            const float* __restrict__ rowscale) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
         const float4 a = *reinterpret_cast<const float4*>(src + i * 8), b = *reinterpret_cast<const float4*>(src + i * 8 + 4);
@@ -652,7 +652,7 @@ int hs_rows_to_bf16(const float* src, hs_bf16* dst, int64_t rows, int d, const f
 }
 
 // fp32 rows [rows][cols] -> bf16 rows [rows][ldd] zero-padded (dL/dpred of a stand-alone decode backward: 72 -> 96)
-__global__ __launch_bounds__(256) void rows_pad_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows, int cols,
+static __global__ __launch_bounds__(256) void rows_pad_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows, int cols,
                                                             int ldd) {
     const int64_t n = rows * ldd;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -671,7 +671,7 @@ int hs_rows_pad_bf16(const float* src, hs_bf16* dst, int64_t rows, int cols, int
 }
 
 // deterministic mode: fixed-point shadow sums of grads[off, off + n) -> fp32 (added onto what the plain stores left there)
-__global__ __launch_bounds__(256) void det_convert_kernel(const long long* __restrict__ acc, float* __restrict__ g, int64_t n) {
+static __global__ __launch_bounds__(256) void det_convert_kernel(const long long* __restrict__ acc, float* __restrict__ g, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         g[i] += (float)((double)acc[i] * (1.0 / (double)HS_DET_SCALE));
 }

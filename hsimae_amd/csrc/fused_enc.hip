@@ -13,7 +13,7 @@
 // Per-phase cycle accounting for scripts/phase_timing.py (compiled only with -DHS_PHASE_TIMING; never in the shipped library)
 #ifdef HS_PHASE_TIMING
 __device__ unsigned long long hs_phase_cycles_enc[32];
-extern "C" int hsimae_debug_phases_enc(unsigned long long* out, int reset) {
+extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases_enc(unsigned long long* out, int reset) {
     int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hs_phase_cycles_enc), sizeof(unsigned long long) * 32);
     if (reset) { unsigned long long z[32] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(hs_phase_cycles_enc), z, sizeof(z)); }
     return rc;

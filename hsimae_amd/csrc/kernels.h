@@ -62,8 +62,10 @@ bool hs_dec_fused_supported(int d, int heads, int hidden, int Ts);
 int hs_dec_block_fwd(const float* x, float* x1, float* x2, hs_bf16* o, float* lse, int nsamples, int Ts,
                      const DecBlockPtrs& bp, hipStream_t s);
 int hs_dec_attn_fwd(const float* x, float* x1, hs_bf16* o, float* lse, int nsamples, int Ts, const DecBlockPtrs& bp, hipStream_t s);
-// slab: NULL = the block's gradients are committed with float atomics; else >= 256 * (104 * 512 + 2112) floats of scratch
-// (plan.h kSlabBytes): per-workgroup partials, summed into the gradients by one reduce launch per block
+// slab: NULL = the block's gradients are committed with float atomics; else >= kDecSlabFloats floats of scratch
+// (plan.h slab_bytes(); C ABI: hsimae_dec_block_slab_floats()): per-workgroup partials, summed into the gradients by one
+// reduce launch per block.  256 workgroups x (104 in-register dW values x 512 threads + 2112 bias / LayerNorm sums).
+constexpr long long kDecSlabFloats = HSIMAE_DEC_BLOCK_SLAB_FLOATS;
 int hs_dec_block_bwd(const float* x, const float* x1, const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o,
                      const float* lse, int nsamples, int Ts, const DecBlockPtrs& bp, const DecBlockGrads& g, hipStream_t s,
                      float* slab = nullptr);
@@ -78,6 +80,11 @@ bool hs_attn_block_fusable(int d, int heads, int Ts);
 int hs_attn_block_fwd(const float* x, const float* n1w, const float* n1b, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* wp,
                       const float* pb, hs_bf16* u, hs_bf16* qkv, hs_bf16* o, float* lse, float* x1, const float* rowscale, int Ts,
                       int nsamples, int mode, int len_l, hipStream_t s);
+// the same half at D = 256 (16 heads of 16, <= 32 tokens): attn_wide.hip.  HSIMAE_FUSED_ATTN_BLOCK256=0 disables.
+bool hs_attn_block256_fusable(int d, int heads, int Ts);
+int hs_attn_block256_fwd(const float* x, const float* n1w, const float* n1b, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* wp,
+                         const float* pb, hs_bf16* u, hs_bf16* qkv, hs_bf16* o, float* lse, float* x1, const float* rowscale, int Ts,
+                         int nsamples, int mode, int len_l, hipStream_t s);
 bool hs_enc_mlp_fused_supported(int d, int hidden);
 int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, const EncMlpPtrs& b, hipStream_t s,
                    const float* rowscale = nullptr);

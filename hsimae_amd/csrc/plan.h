@@ -211,12 +211,19 @@ struct Ws {
     std::vector<BlkBuf> b1, b2, bf, bd;
     hs_bf16* lat; float* y; float* yfull; hs_bf16* zn; float* pred; hs_bf16* dpred; float* partial;
     float *G0, *G1, *G2, *du; hs_bf16 *dh13, *dob, *dqkv, *dyb;
-    float* slab;                      // weight-gradient partials of the persistent kernels: [workgroup][slot][thread] (kSlabBytes)
+    float* slab;                      // weight-gradient partials of the persistent kernels: [workgroup][slot][thread] (slab_bytes())
     int64_t bytes;
 };
-// One slab per stream (kSlabBytes each).  Largest user: the 256 x 256-tile weight-gradient launch, 256 workgroups x 256 KB;
-// the fused decoder's backward needs 256 x (104 x 512 + 2112) floats (fused_dec.hip kDwSlots, kVec) of the first one.
+// Weight-gradient slabs, sized from the geometry (every arena used to carry 2 x 64 MiB whatever ran in it):
+//   * the 256 x 256-tile weight-gradient launch (wgrad.hip, all matrices >= 256 wide: Large / Huge): 256 workgroups x 256 KB,
+//     one slab per stream — the caller's and, for the forked spectral stack, the side stream's;
+//   * the fused decoder's backward: HSIMAE_DEC_BLOCK_SLAB_FLOATS (checked against fused_dec.hip's own constants there), caller's stream.
 constexpr int64_t kSlabBytes = 256ll * 256 * 256 * 4;
+inline int64_t slab_bytes(const Geo& g, bool side_stream) {
+    const int64_t wg = g.Dp >= 256 ? kSlabBytes : 0;
+    if (side_stream) return g.has_axis ? wg : 0;
+    return std::max<int64_t>(wg, HSIMAE_DEC_BLOCK_SLAB_FLOATS * 4);
+}
 
 inline void carve(const Geo& g, int N, int K, char* base, Ws& w) {
     int64_t cur = 0;
@@ -257,8 +264,9 @@ inline void carve(const Geo& g, int N, int K, char* base, Ws& w) {
     w.sc2.dqkv = (hs_bf16*)take(Me * g.Dp * 3 * 2);
     w.sc.g0b = (hs_bf16*)take(gmax * 2); w.sc.g1b = (hs_bf16*)take(gmax * 2);     // (also decoder rows on the layer-at-a-time path)
     w.sc2.g0b = (hs_bf16*)take(Me * g.Dp * 2); w.sc2.g1b = (hs_bf16*)take(Me * g.Dp * 2);
-    w.slab = (float*)take(kSlabBytes);
-    w.sc.slab = w.slab; w.sc2.slab = (float*)take(kSlabBytes);
+    w.slab = (float*)take(slab_bytes(g, false));
+    w.sc.slab = w.slab;
+    w.sc2.slab = slab_bytes(g, true) ? (float*)take(slab_bytes(g, true)) : nullptr;      // (NULL: that launch commits with atomics)
     w.bytes = cur;
 }
 

@@ -36,6 +36,8 @@ typedef uint16_t hs_bf16;
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: only what this header declares is exported. */
+#pragma GCC visibility push(default)
 
 #define HSIMAE_OK 0
 #define HSIMAE_EDIMS (-1)        /* bad dimensions / strides */
@@ -69,6 +71,11 @@ typedef struct {
     int32_t norm_pix_loss;
     int32_t precision;      /* HSIMAE_PREC_BF16 (0) or HSIMAE_PREC_FP8: operand type of the encoder linears (see below) */
 } hsimae_config;
+/* Operand type the encoder blocks' stand-alone linears actually run in for this configuration: HSIMAE_PREC_FP8 only when
+   cfg->precision is FP8 AND the width is one where the MX GEMMs are used (embed_dim >= 512, or HSIMAE_FP8_UNFUSED=1 in the
+   environment); otherwise HSIMAE_PREC_BF16 — precision = FP8 at embed_dim 128 / 256 computes exactly what BF16 computes.
+   < 0: invalid configuration.  (bench.py prices its roofline against the peak of THIS type.) */
+int hsimae_effective_precision(const hsimae_config* cfg);
 /* precision: BF16 = bf16 MFMA operands everywhere.  FP8 = the encoder blocks' linears (q|k|v, proj, w1|w3, w2 and their
  * data gradients) run on the MX block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4) with OCP e4m3 operands: weights are
  * quantised at pack time, activations as they are staged, both with one e8m0 scale per 32 consecutive K elements (MX),
@@ -265,7 +272,8 @@ typedef struct {
 int hsimae_attn_fwd(const hsimae_attn_params* p, void* stream);
 int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream);
 
-/* One fused decoder Block (Models.py:303-306 at width 64, 8 heads of 8, SwiGLU hidden <= 192; sequences of 16..112 tokens),
+/* One fused decoder Block (Models.py:303-306 at width 64, 8 heads of 8, SwiGLU hidden 164..192 — hp = 192, the image height
+   the kernels are compiled for; any other hidden width returns HSIMAE_EUNSUPPORTED; sequences of 16..112 tokens),
    as hsimae_forward / hsimae_backward run it for every decoder block — exposed per kernel for the parity tests and the bench's
    kernel replays.  Weights: fp32 vectors, packed bf16 images (hsimae_pack_matrix: qkv = q | k | v fused [192][64], p [64][64],
    w1 / w3 [hp][64], w2 [64][hp], w2T [hp][64] = W2 transposed, hp = hidden rounded up to 32) and the fp32 row-major masters of
@@ -274,8 +282,8 @@ int hsimae_attn_bwd(const hsimae_attn_params* p, void* stream);
              bf16 [rows][64]) and lse (log2-domain logsumexp, [rows][8]) for the backward.  split != 0: the attention half with
              q / k / v in registers + the row-panel MLP kernel (two launches, the default schedule); 0: one kernel.
    backward: from dy = dL/dx2 -> dx = dL/dx (dx1_tmp: scratch [rows][64] fp32, dL/dx1) and the block's 18 parameter gradients,
-             ACCUMULATED into the given tensors.  slab: NULL = float atomics; else >= 256 * (104 * 512 + 2112) floats of scratch:
-             per-workgroup partials + one fixed-order reduce launch (bit-reproducible). */
+             ACCUMULATED into the given tensors.  slab: NULL = float atomics; else >= hsimae_dec_block_slab_floats() floats of
+             scratch: per-workgroup partials + one fixed-order reduce launch (bit-reproducible). */
 typedef struct {
     const float *n1w, *n1b, *bqkv, *pb, *n2w, *n2b, *w1b, *w3b, *w2b;
     const hs_bf16 *qkv, *p, *w1, *w3, *w2, *w2T;
@@ -287,6 +295,8 @@ typedef struct {
 } hsimae_dec_block_grads;
 int hsimae_dec_block_fwd(const hsimae_dec_block_weights* w, const float* x, float* x1, float* x2, hs_bf16* o, float* lse,
                          int32_t nsamples, int32_t Ts, int32_t split, void* stream);
+#define HSIMAE_DEC_BLOCK_SLAB_FLOATS (256ll * (104 * 512 + 2112))   /* workgroups x (in-register dW values x threads + bias / LayerNorm sums) */
+int64_t hsimae_dec_block_slab_floats(void);     /* = HSIMAE_DEC_BLOCK_SLAB_FLOATS of the library that is loaded: size of `slab` above */
 int hsimae_dec_block_bwd(const hsimae_dec_block_weights* w, const hsimae_dec_block_grads* g, const float* x, const float* x1,
                          const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o, const float* lse, int32_t nsamples,
                          int32_t Ts, float* slab, void* stream);
@@ -395,6 +405,7 @@ typedef struct {
 } hsimae_cube_params;
 int hsimae_cube_gather(const hsimae_cube_params* p, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -202,6 +202,31 @@ def unpatchify(x: torch.Tensor, cfg: OracleConfig) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- blocks
+# Operand rounding (test infrastructure for tests/test_gpu_boundary.py::test_loss_error_is_the_bf16_operand_rounding):
+# `with operands_bf16():` makes the forward below round every MATRIX-PRODUCT OPERAND to bf16 at exactly the places where the HIP
+# path does (LayerNorm outputs, q | k | v, the unnormalised softmax numerators exp(s - max), the attention
+# output, the SwiGLU gate product, the patch values, all weight matrices) and keep everything else — accumulation, residual
+# stream, LayerNorm statistics, softmax sums, biases, loss — in the working dtype.  It is NOT what the reference computes; it
+# separates the error the bf16 operands make inherent from anything else the kernels might add.
+_ROUND = None
+
+
+class operands_bf16:
+    def __enter__(self):
+        global _ROUND
+        self._prev, _ROUND = _ROUND, (lambda t: t.to(torch.bfloat16).to(t.dtype))
+        return self
+
+    def __exit__(self, *exc):
+        global _ROUND
+        _ROUND = self._prev
+        return False
+
+
+def _r(t):
+    return t if _ROUND is None else _ROUND(t)
+
+
 def layer_norm(x, w, b, eps=1e-5):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
@@ -211,23 +236,30 @@ def attention(x, P, pre, heads):
     Bs, S, C = x.shape
     hd = C // heads
 
+    xr = _r(x)
+
     def lin(name):
-        return F.linear(x, P[f"{pre}.{name}.weight"], P.get(f"{pre}.{name}.bias"))
+        return _r(F.linear(xr, _r(P[f"{pre}.{name}.weight"]), P.get(f"{pre}.{name}.bias")))
 
     q = lin("q").reshape(Bs, S, heads, hd).permute(0, 2, 1, 3)
     k = lin("k").reshape(Bs, S, heads, hd).permute(0, 2, 1, 3)
     v = lin("v").reshape(Bs, S, heads, hd).permute(0, 2, 1, 3)
     attn = (q @ k.transpose(-2, -1)) * hd ** -0.5
-    attn = attn.softmax(dim=-1)
-    o = (attn @ v).transpose(1, 2).reshape(Bs, S, C)
-    return F.linear(o, P[f"{pre}.proj.weight"], P[f"{pre}.proj.bias"])
+    if _ROUND is None:
+        attn = attn.softmax(dim=-1)
+        o = (attn @ v).transpose(1, 2).reshape(Bs, S, C)
+    else:       # the kernels multiply the bf16-rounded numerators exp(s - max) with v and divide by the fp32 sum afterwards
+        e = torch.exp(attn - attn.amax(dim=-1, keepdim=True))
+        o = ((_r(e) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(Bs, S, C)
+    return F.linear(_r(o), _r(P[f"{pre}.proj.weight"]), P[f"{pre}.proj.bias"])
 
 
 def swiglu(x, P, pre):
     """Models.py:231-232."""
-    h1 = F.linear(x, P[f"{pre}.w1.weight"], P[f"{pre}.w1.bias"])
-    h3 = F.linear(x, P[f"{pre}.w3.weight"], P[f"{pre}.w3.bias"])
-    return F.linear(F.silu(h1) * h3, P[f"{pre}.w2.weight"], P[f"{pre}.w2.bias"])
+    xr = _r(x)
+    h1 = F.linear(xr, _r(P[f"{pre}.w1.weight"]), P[f"{pre}.w1.bias"])
+    h3 = F.linear(xr, _r(P[f"{pre}.w3.weight"]), P[f"{pre}.w3.bias"])
+    return F.linear(_r(F.silu(h1) * h3), _r(P[f"{pre}.w2.weight"]), P[f"{pre}.w2.bias"])
 
 
 def block(x, P, pre, heads, drop=None):
@@ -265,7 +297,7 @@ def forward(P: dict, cfg: OracleConfig, imgs: torch.Tensor, noise_1, noise_2, le
     # 1. tokenise == Conv3d(k=s=(u,p,p)) (Models.py:151-160)
     Pm = patchify(imgs, cfg)                                           # [N,TL,72]
     Wpe = P["patch_embed.proj.weight"].reshape(D, -1)
-    X0 = Pm @ Wpe.t() + P["patch_embed.proj.bias"]
+    X0 = _r(Pm) @ _r(Wpe).t() + P["patch_embed.proj.bias"]
     tap("patch_embed", X0)
 
     # 2-4. masking (Models.py:495-535)
@@ -302,7 +334,7 @@ def forward(P: dict, cfg: OracleConfig, imgs: torch.Tensor, noise_1, noise_2, le
     tap("latent", latent)
 
     # 9. decoder input (Models.py:579-592)
-    Y = F.linear(latent, P["decoder_embed.weight"], P["decoder_embed.bias"])
+    Y = F.linear(_r(latent), _r(P["decoder_embed.weight"]), P["decoder_embed.bias"])
     Dd = Y.shape[-1]
     m = Y.mean(1, keepdim=True)
     Yall = torch.cat([Y, m.expand(N, TL - K, Dd)], dim=1)
@@ -315,7 +347,7 @@ def forward(P: dict, cfg: OracleConfig, imgs: torch.Tensor, noise_1, noise_2, le
         Z = block(Z, P, f"decoder_blocks.{i}", cfg.decoder_num_heads)
     tap("dec_out", Z)
     Z = layer_norm(Z, P["decoder_norm.weight"], P["decoder_norm.bias"])
-    pred = F.linear(Z, P["decoder_pred.weight"], P["decoder_pred.bias"])
+    pred = F.linear(_r(Z), _r(P["decoder_pred.weight"]), P["decoder_pred.bias"])
     tap("pred", pred)
 
     # 11. loss (Models.py:603-616)

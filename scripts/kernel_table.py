@@ -54,6 +54,68 @@ def work(name, s):
     for k, v in t.items():
         if name.startswith(k):
             return v
+    return generic_work(name, s)
+
+
+def generic_work(name, s):
+    """The layer-at-a-time kernels (every linear / attention that is not inside a fused kernel): the shape follows from the
+    template arguments and the schedule of csrc/api.hip (block_fwd / block_bwd / decode).  gemm_kernel<AK, EPI, KC, BM, F8, NCH>:
+    AK 0 = bf16 A, 1 = fp32 A, 2 = fp32 A + LayerNorm prologue; EPI 0 bf16, 1 fp32, 2 + residual, 3 + pos-embed, 4 SwiGLU gate,
+    5 gate backward, 6 LayerNorm backward; KC = 128 marks the decoder-width / embedding launches, NCH > 1 the deep-K (k-outer)
+    products.  An instantiation that serves two shapes gets the mean of the two.  Compulsory bytes = operands in + result out
+    (saved activations — u, h1|h3 — are this design's choice and are not counted)."""
+    D, h, Me, Md, Dd, hd, TL, K = s["D"], s["h"], s["Me"], s["Md"], s["Dd"], s["hd"], s["TL"], s["K"]
+    hp, hpd = (h + 31) // 32 * 32, (hd + 31) // 32 * 32
+    m = re.match(r"gemm_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", name)
+    if m:
+        ak, epi, kc, bm, f8, nch = (int(x) for x in m.groups())
+        enc = kc != 128 or D == 128                   # encoder-width launch (at Base every launch is 128 wide: decided by role below)
+        M, d, hh = (Me, D, h) if (kc != 128) else (Md, Dd, hd)
+        lin = lambda M, N, Kd, inb, outb: (2.0 * M * N * Kd, M * (inb + outb))
+        if kc == 128 and D == 128:                    # Base: only the embedding / prediction launches run layer at a time
+            roles = {(2, 1): [lin(Me, Dd, D, 4 * D, 4 * Dd), lin(Md, 72, Dd, 4 * Dd, 4 * 72)],       # norm + decoder_embed, decoder_norm + decoder_pred
+                     (0, 1): [lin(Md, Dd, 72, 2 * 96, 4 * Dd), lin(Me, D, Dd, 2 * Dd, 4 * D)],       # their data gradients
+                     (0, 6): [lin(Md, Dd, 72, 2 * 96 + 4 * Dd, 4 * Dd)],                             # d(pred) -> decoder_norm backward
+                     (0, 3): [lin(Me, D, 72, 2 * 96, 4 * D)]}                                        # patch embedding (+ pos)
+            r = roles.get((ak, epi))
+            return (sum(x[0] for x in r) / len(r), sum(x[1] for x in r) / len(r)) if r else None
+        table = {
+            (2, 0): [lin(M, 3 * d, d, 4 * d, 2 * 3 * d)],                                  # LN1 + q|k|v
+            (0, 0): [lin(M, d, d, 2 * d, 2 * d)],                                          # dO = dx1 Wp
+            (2, 4): [lin(M, 2 * hh, d, 4 * d, 2 * hh)],                                    # LN2 + W1|W3 + gate
+            (1, 5): [lin(M, hh, d, 4 * d + 2 * 2 * hh, 2 * 2 * hh)],                       # gate backward (dg = dY W2^T)
+            (2, 1): [lin(Me, Dd, D, 4 * D, 4 * Dd), lin(Md, 72, Dd, 4 * Dd, 4 * 72)],
+            (0, 3): [lin(Me, D, 72, 2 * 96, 4 * D)],
+        }
+        if (ak, epi) == (0, 2):                                                            # + residual: w2 (deep K) or proj
+            r = [lin(M, d, hh, 2 * hh + 4 * d, 4 * d)] if (nch > 1 or (kc == 128 and False)) else [lin(M, d, d, 2 * d + 4 * d, 4 * d)]
+            if kc == 128:                                                                  # decoder width, 128-deep chunks serve both
+                r = [lin(M, d, hh, 2 * hh + 4 * d, 4 * d), lin(M, d, d, 2 * d + 4 * d, 4 * d)]
+        elif (ak, epi) == (0, 6):                                                          # LayerNorm backward epilogue: du2 (K = 2 h) and du (K = 3 d)
+            r = [lin(M, d, 2 * hh, 2 * 2 * hh + 8 * d, 4 * d), lin(M, d, 3 * d, 2 * 3 * d + 8 * d, 4 * d)]
+            if D == 256 and kc != 128:
+                r = r[1:]                                                                  # Large: the MLP half is fused, only du + LN1 backward is left
+        elif (ak, epi) == (0, 1):                                                          # fp32 result, no LayerNorm epilogue: du2 / du at the decoder width
+            r = [lin(M, d, 2 * hh, 2 * 2 * hh, 4 * d), lin(M, d, 3 * d, 2 * 3 * d, 4 * d)] if kc == 128 else [lin(M, d, 3 * d, 2 * 3 * d, 4 * d)]
+        else:
+            r = table.get((ak, epi))
+        return (sum(x[0] for x in r) / len(r), sum(x[1] for x in r) / len(r)) if r else None
+    m = re.match(r"attn16_(fwd|bwd)_kernel<(\d+), (\d+), (\d+), (true|false)>", name)
+    if m:
+        bwd, nt, hdim = m.group(1) == "bwd", int(m.group(2)), int(m.group(3))
+        if hdim == 8:                                 # the decoder's attention (8 heads of 8) over all TL tokens
+            fl, M, d = 2.0 * 2 * Md * Dd * TL, Md, Dd
+        else:                                         # encoder: ~13 keys per query on average over the 9 + 9 + 3 blocks
+            fl, M, d = 2.0 * 2 * Me * D * 13, Me, D
+        return (2 * fl, M * (2 * 3 * d + 2 * d + 2 * d + 2 * 3 * d)) if bwd else (fl, M * (2 * 3 * d + 2 * d))
+    if name.startswith("ln_bwd_kernel"):
+        tpr = int(re.search(r"<(\d+)>", name).group(1))
+        d, M = tpr * 8, (Md if tpr * 8 == Dd else Me)
+        return (0.0, M * d * 12)          # x, dres in, dx out (du is L2-hot from the GEMM in front of it)
+    if name.startswith("rows_to_bf16_kernel"):
+        return (0.0, Me * D * 6)
+    if name.startswith("loss_sample_kernel"):
+        return (0.0, s["N"] * (TL * 72 * 4 * 3 + TL * 96 * 2 + TL * 72 * 4))    # cube in, pred in, two images + dpred out
     return None
 
 
@@ -93,8 +155,8 @@ def table(tag, model):
             w = None
         key = next((k for k in traffic if k.replace("void ", "") == n), None)
         mb = traffic[key] / calls / 1e6 if key and calls else None
-        fl = f"{w[0] / 1e9:.1f}" if w else "—"
-        fr = f"{w[0] / (us * 1e-6) / 1e12 / PEAK_TF:.3f}" if w else "—"
+        fl = f"{w[0] / 1e9:.1f}" if (w and w[0]) else "—"
+        fr = f"{w[0] / (us * 1e-6) / 1e12 / PEAK_TF:.3f}" if (w and w[0]) else "—"
         cb = f"{w[1] / 1e6:.0f}" if w else "—"
         ratio = f"{mb / (w[1] / 1e6):.1f}×" if (w and mb) else "—"
         out.append(f"| `{n}` | {calls:g} | {us:.1f} | {ms:.2f} | {fl} | {fr} | {mb:.0f} | {cb} | {ratio} | {mb / us:.2f} |" if mb else

@@ -7,7 +7,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hsimae_amd.build import kernel_source_hash  # noqa: E402
 
 fetch_dir, write_dir, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 label = sys.argv[5] if len(sys.argv) > 5 else ""
@@ -32,5 +36,6 @@ top = dict(sorted(kern.items(), key=lambda kv: -kv[1])[:12])
 allk = {k: v for k, v in sorted(kern.items(), key=lambda kv: -kv[1]) if v > 0 and not k.startswith(("void at::", "__amd"))}
 json.dump({"hbm_bytes_per_step": round(total), "fetch_kb_per_step": round(fs / steps), "write_kb_per_step": round(ws / steps),
            "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 over all dispatches / steps", "steps_profiled": steps, "source": label,
+           "kernel_source_sha": kernel_source_hash(),
            "top_kernels_bytes_per_step": top, "kernels_bytes_per_step": allk}, open(out, "w"), indent=1)
 print(json.dumps({"hbm_GB_per_step": round(total / 1e9, 3), "top": {k: round(v / 1e9, 3) for k, v in list(top.items())[:6]}}))

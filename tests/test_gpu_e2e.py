@@ -447,7 +447,47 @@ def test_fused_attention_half_matches_separate_kernels(bands, grid, N):
     print(f"[fused-attn-half {bands}] worst grad rms-rel vs separate {worst}")
 
 
-@pytest.mark.parametrize("name,bands,dim,grid,N", [("C3-Large", 96, 256, (3, 9), 12), ("C5-Huge@512", 192, 512, (6, 9), 6),
+@pytest.mark.parametrize("bands,grid,N", [(96, (3, 9), 21), (96, (9, 3), 21), (48, (2, 7), 9), (96, (3, 9), 1)])
+def test_fused_attention_half_d256_matches_separate_kernels(bands, grid, N):
+    """blk256_fwd_kernel (attn_wide.hip: LN1 -> q|k|v -> attention -> projection + residual of a D = 256 block in one persistent
+    launch, 16 waves = 16 heads, weights streamed) against the layer-at-a-time kernels it replaces (LN1 + q|k|v GEMM, attn16_fwd,
+    projection + residual GEMM) on the same inputs, both axis-class modes and the whole-sample fusion blocks, odd sample counts
+    (the kernel walks pairs of samples) and 14-token sequences (one key tile): loss, predictions and every gradient (the
+    backward consumes the u / qkv / o / lse / x1 the forward saved, so it checks those too)."""
+    cfg = O.OracleConfig(bands=bands, embed_dim=256, num_heads=16)
+    m = build(cfg, O.init_state(cfg, seed=13, std=0.05))
+    g = torch.Generator().manual_seed(29)
+    x = torch.rand(N, 1, bands, 9, 9, generator=g).to(DEV)
+    n = (torch.rand(N, bands // 8, generator=g), torch.rand(N, 9, generator=g))
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["HSIMAE_FUSED_ATTN_BLOCK256"] = mode
+        try:
+            m.zero_grad()
+            loss, pred, _ = m(x, 0.75, noise=n, grid=grid)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = (loss.item(), pred.clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        finally:
+            os.environ.pop("HSIMAE_FUSED_ATTN_BLOCK256", None)
+    l0, p0, g0 = res["0"]
+    l1, p1, g1 = res["1"]
+    print(f"[fused-attn-half-256 {bands} {grid} N={N}] loss separate {l0:.7f} fused {l1:.7f}")
+    assert abs(l0 - l1) <= 5e-5 * abs(l0)
+    assert rms_rel(p1, p0) < 3e-3
+    worst = ("", 0.0)
+    for k in g0:
+        if k.endswith("attn.k.bias"):
+            continue
+        r = rms_rel(g1[k], g0[k])
+        if r > worst[1]:
+            worst = (k, r)
+        assert r < 3e-2, (k, r)
+    print(f"[fused-attn-half-256 {bands}] worst grad rms-rel vs separate {worst}")
+
+
+@pytest.mark.parametrize("name,bands,dim,grid,N", [("C3-Large", 96, 256, (3, 9), 12), ("C3-Large", 96, 256, (9, 3), 12),
+                                                   ("C5-Huge@512", 192, 512, (6, 9), 6), ("C5-Huge@512", 192, 512, (9, 6), 6),
                                                    ("C5-Huge@512", 192, 512, (18, 3), 6)])
 def test_large_and_huge_widths_against_oracle(name, bands, dim, grid, N):
     """Configs C3 (Large, D = 256, 16 heads) and C5 ("Huge" is not defined by the reference: D = 512, 32 heads,

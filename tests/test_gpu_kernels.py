@@ -343,7 +343,7 @@ def test_fused_decoder_block_forward_backward(N, Ts, split, slab):
     G_ = {n: torch.zeros(shapes[n], device=DEV) for n in names}
     Gs = _lib.DecBlockGrads(**{n: G_[n].data_ptr() for n in names})
     dx1, dx = torch.empty(M, d, device=DEV), torch.full((M, d), float("nan"), device=DEV)
-    sl = torch.empty(256 * (104 * 512 + 2112), device=DEV) if slab else None
+    sl = torch.empty(lib.hsimae_dec_block_slab_floats(), device=DEV) if slab else None
     _lib.check(lib.hsimae_dec_block_bwd(C.byref(W), C.byref(Gs), x.data_ptr(), x1.data_ptr(), dy.data_ptr(), dx1.data_ptr(), dx.data_ptr(),
                                         o.data_ptr(), lse.data_ptr(), N, Ts, _lib.ptr(sl), stream()), "hsimae_dec_block_bwd")
     torch.cuda.synchronize()

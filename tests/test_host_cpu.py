@@ -140,6 +140,24 @@ def test_layout_helpers_agree_with_module_tree():
     assert lib.hsimae_param_layout(C.byref(bad2), None, None, 0) == -2          # head dim 48: unsupported
 
 
+def test_fused_decoder_block_refuses_hidden_widths_it_is_not_compiled_for():
+    """ADVICE r03: hsimae_dec_block_fwd / _bwd launch kernels compiled for 192-row hidden images (hp = rup(hidden, 32) = 192);
+    a narrower hidden width would be read past the caller's images with the wrong k-step layout.  The ABI wrappers must
+    refuse it (argument validation only: nothing is launched, so this runs without a GPU)."""
+    lib = _lib.load()
+    dummy = C.c_void_p(4096)             # never dereferenced: the width check comes before any launch
+    for hidden, ok in [(128, False), (160, False), (96, False), (200, False)]:
+        W = _lib.DecBlockWeights(hidden=hidden)
+        G_ = _lib.DecBlockGrads()
+        rc = lib.hsimae_dec_block_fwd(C.byref(W), dummy, dummy, dummy, dummy, dummy, 4, 108, 1, None)
+        assert rc == -2, (hidden, rc)
+        rc = lib.hsimae_dec_block_bwd(C.byref(W), C.byref(G_), dummy, dummy, dummy, dummy, dummy, dummy, dummy, 4, 108, None, None)
+        assert rc == -2, (hidden, rc)
+    assert lib.hsimae_dec_block_slab_floats() == 256 * (104 * 512 + 2112)
+    hdr = open(os.path.join(ROOT, "include", "hsimae_hip.h")).read()
+    assert "HSIMAE_DEC_BLOCK_SLAB_FLOATS (256ll * (104 * 512 + 2112))" in hdr
+
+
 def test_bucket_plan_covers_every_element_once():
     # ranges arrive back to front, as hsimae_backward reports them
     sizes = [5, 40, 40, 3, 40, 40, 40, 7]

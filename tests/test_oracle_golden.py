@@ -90,6 +90,33 @@ def test_tiny_model_all_stages_and_grads(tag):
         close(grads[k], z["grad_" + k], 2e-5)
 
 
+def test_bf16_operand_mode_is_off_by_default_and_only_rounds_operands():
+    """`oracle.operands_bf16()` (the rounding-attribution mode used by tests/test_gpu_boundary.py) must leave the pinned fp32
+    oracle untouched outside the `with` block, move the loss by roughly the bf16 operand rounding (1e-5 .. 1e-2 relative at
+    this tiny width) inside it, and be a no-op on inputs that are already bf16-representable in every operand position it
+    touches (weights of +-0.25, patch values of 0 / 0.5)."""
+    z = np.load(os.path.join(G, "tiny_model_r75.npz"))
+    cfg = O.OracleConfig(bands=32, embed_dim=32, depth=3, num_heads=2, s_depth=2, decoder_embed_dim=32,
+                         decoder_depth=2, decoder_num_heads=4)
+    P = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd_")}
+    x = torch.from_numpy(z["x"])
+    lt, ll = (int(v) for v in z["len_tl"])
+    args = (P, cfg, x, z["noise_1"], z["noise_2"], lt, ll)
+    l0 = O.forward(*args)[0].item()
+    with O.operands_bf16():
+        lb = O.forward(*args)[0].item()
+        assert O._ROUND is not None
+    assert O._ROUND is None
+    l1 = O.forward(*args)[0].item()
+    assert l1 == l0 and abs(l0 - float(z["loss"])) <= 1e-6 * abs(float(z["loss"]))
+    assert 1e-6 <= abs(lb - l0) / abs(l0) <= 1e-2, (lb, l0)
+    r = O._r
+    t = torch.tensor([0.25, -0.5, 1.0009765625, 3.0e-5])
+    assert torch.equal(r(t), t)                                       # mode off: identity
+    with O.operands_bf16():
+        assert torch.equal(O._r(t)[:2], t[:2]) and O._r(t)[2].item() == 1.0 and O._r(t).dtype == t.dtype
+
+
 def test_strided_band_fastest_input_is_value_equivalent():
     z = np.load(os.path.join(G, "tiny_model_r50.npz"))
     cfg = O.OracleConfig(bands=32, embed_dim=32, depth=3, num_heads=2, s_depth=2, decoder_embed_dim=32,
