@@ -32,6 +32,23 @@
 #define HS_W256_EARLY 0 /* projection weights (first half) and residual pieces fetched in front of the attention */
 #endif
 
+// Per-phase cycle accounting for scripts/phase_wide.py (compiled only with -DHS_PHASE_TIMING; never in the shipped library)
+#ifdef HS_PHASE_TIMING
+__device__ unsigned long long hs_phase_cycles_wide[16];
+extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases_wide(unsigned long long* out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hs_phase_cycles_wide), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(hs_phase_cycles_wide), z, sizeof(z)); }
+    return rc;
+}
+#define PH_DECL unsigned long long ph_t0 = __builtin_readcyclecounter(), ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PH(i) { const unsigned long long ph_t = __builtin_readcyclecounter(); ph_acc[i] += ph_t - ph_t0; ph_t0 = ph_t; }
+#define PH_FLUSH() if (threadIdx.x == 64 * 5) { for (int i = 0; i < 12; ++i) atomicAdd(&hs_phase_cycles_wide[i], ph_acc[i]); }
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_FLUSH()
+#endif
+
 namespace {
 
 constexpr int DW = 256, HW = 16, HDW = 16;          // width, heads, head dim
@@ -118,7 +135,9 @@ __global__ __launch_bounds__(NTHW, 1) void blk256_fwd_kernel(Blk256Args p) {
         return *reinterpret_cast<const bf16x8*>(p.wqkv + ((size_t)((m * HW + head) * KSW + ks) * 64 + lane) * 8);
     };
 
+    PH_DECL
     for (int first = blockIdx.x * SPW; first < p.nsamples; first += gridDim.x * SPW) {
+        PH(11)
         // The per-lane address pieces are laundered once per group: left alone, hipcc hoists ~25 registers of loop-invariant
         // addresses out of this loop and spills them; their scratch reloads then queue behind the group's HBM stores
         // (loads and stores share one in-order counter) — measured 212 vs 188 us per launch.
@@ -165,7 +184,9 @@ __global__ __launch_bounds__(NTHW, 1) void blk256_fwd_kernel(Blk256Args p) {
                 if (gr >= 0) HS_NT(HS_NT_C, reinterpret_cast<bf16x8*>(p.u + ((unsigned)gr * DW + lc8)), ub);
             }
         }
+        PH(0)
         lds_barrier();                                            // B1: U complete
+        PH(1)
         // ---- q | k | v of this head over all m-tiles of the group, weights streamed two k-steps ahead
         f32x4 acc[3][MTT];
 #pragma unroll
@@ -193,6 +214,7 @@ __global__ __launch_bounds__(NTHW, 1) void blk256_fwd_kernel(Blk256Args p) {
                 else if (ks + 1 < KSW) wc[m] = wf[m];
             }
         }
+        PH(2)
         // q^T / k^T stay in registers (lane = token, 4 head dims: the fragment of the K = 16 score MFMA); all three go to staging
         bf16x4 qT[MTT], kT[MTT];
 #pragma unroll
@@ -219,7 +241,9 @@ __global__ __launch_bounds__(NTHW, 1) void blk256_fwd_kernel(Blk256Args p) {
         };
         if (HS_W256_EARLY) early();
         fetch(first + gridDim.x * SPW);
+        PH(3)
         lds_barrier();                                            // B2: every wave is done with U; the staging image is complete
+        PH(4)
         // ---- saved q | k | v leave as whole rows (three 512-byte thirds of 32 16-byte pieces); the stores drain under the attention
         for (int idx = tid; idx < RT * 32; idx += NTHW) {
             const int irow = idx >> 5, pc = idx & 31;
@@ -231,6 +255,7 @@ __global__ __launch_bounds__(NTHW, 1) void blk256_fwd_kernel(Blk256Args p) {
                           *reinterpret_cast<const bf16x8*>(Sf + irow * PS + m * DW + pc * 8));
             }
         }
+        PH(5)
         // ---- attention of this head; O into the (dead) U image.  The class / padding mask of a (query tile, key tile) pair is
         //      the same in every slot: built once per query tile as the accumulator the score MFMA starts from (0 or -inf)
 #pragma unroll
@@ -283,7 +308,9 @@ __global__ __launch_bounds__(NTHW, 1) void blk256_fwd_kernel(Blk256Args p) {
                 if (g == 0) lse_s[query * HW + head] = m + __builtin_amdgcn_logf(fmaxf(lsum, 1e-30f));
             }
         }
+        PH(6)
         lds_barrier();                                            // B3: O image and logsumexp table complete
+        PH(7)
         if (!HS_W256_EARLY) early();
         bf16x8 wpk[KSW / 2];                                      // second half of the projection weights (loads in front of the stores)
 #pragma unroll
@@ -299,6 +326,7 @@ __global__ __launch_bounds__(NTHW, 1) void blk256_fwd_kernel(Blk256Args p) {
             const int gr = grow(irow);
             if (gr >= 0) *reinterpret_cast<float4*>(p.lse + ((unsigned)gr * HW + (idx & 3) * 4)) = *reinterpret_cast<const float4*>(lse_s + idx * 4);
         }
+        PH(8)
         // ---- projection: this wave's 16 output columns; transposed accumulators -> x1 leaves as 16-byte pieces
         const f32x4 pbias = *reinterpret_cast<const f32x4*>(vec_s + 5 * DW + hc + 4 * g);
         f32x4 pav[MTT];
@@ -324,8 +352,11 @@ __global__ __launch_bounds__(NTHW, 1) void blk256_fwd_kernel(Blk256Args p) {
                 *reinterpret_cast<f32x4*>(p.x1 + ((unsigned)gr * DW + hc + 4 * g)) = ov;
             }
         }
+        PH(9)
         lds_barrier();                                            // B4: the O image is read; the next group's LayerNorm may overwrite it
+        PH(10)
     }
+    PH_FLUSH()
 }
 
 template <int NT, int SPW>

@@ -54,7 +54,22 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases_enc(un
 namespace {
 
 constexpr int MH = 2, NTH = 256;
-constexpr int LC = 64 + 8;         // 64-column chunk image row stride
+template <int D> constexpr int LCd = D <= 128 ? 64 : 64 + 8;      // 64-column chunk image row stride (D <= 128: unpadded + swizzled, see below)
+
+// LDS layouts (round 4; bank model: scripts/micro/lds_banks.py, audit of the same scheme: scripts/micro/lds_audit_dec.py).  Round 3
+// padded the panel rows (D + 16 at D <= 128: conflict-free 16-byte row fragments, 4-way 8-byte tile writes; D + 8 at D = 256:
+// both 2-way) and the chunk images (64 + 8: both 2-way): 1.8-3.9 bank-conflict cycles per LDS instruction at the counters.
+// Now no pad and an XOR swizzle of the 16-byte chunks:
+//   * 128-byte rows (chunk images, the D = 64 panels): swz64, the map of the decoder backward kernels (fused_dec.hip);
+//   * 256- / 512-byte rows (D = 128 / 256 panels): chunk c of row r at c ^ (r & 15) — the 16 lanes of a 16-byte row-fragment
+//     group ({rows 0-3, 12-15 | chunk c} u {rows 4-11 | chunk c ^ 1}) then hit 16 different 16-byte bank slots.
+// Row-contiguous 16-byte fills stay conflict-free, the 8-byte tile writes are 2-way (16 rows x 8 bytes against 32 banks).
+// Measured (profiles/r04_j_swizzle_ab.txt, same box): the conflicts were not what these kernels wait for — <128,352> backward
+// 139.4 -> 139.4 us, forward 55.2 -> 55.1, <64,192> forward 83.4 -> 82.1 — and at D = 256 the extra address arithmetic costs the
+// backward kernel 6 more spilled registers (376 -> 424 us): D = 256 keeps the round-3 padded layout (no swizzle).
+__host__ __device__ constexpr int swz64(int row) { return (((row >> 1) & 3) << 1) ^ (((row >> 3) & 1) * 5); }
+template <int D> __host__ __device__ constexpr int swzp(int row) { return D == 64 ? swz64(row) : (D == 128 ? (row & 15) : 0); }
+template <int D> __host__ __device__ constexpr int swzc(int row) { return D <= 128 ? swz64(row) : 0; }
 
 // Geometry for model width D, padded hidden width HP (multiples of 64 / 32) and R_-row panels.
 //   D = 128: 48-row panels, three 4-wave workgroups per CU (2304 = 3 x 768 workgroups at M = 110,592)
@@ -65,11 +80,9 @@ template <int D, int HP, int R_ = (D == 64 ? 64 : 48)>
 struct MG {
     static constexpr int R = R_;
     static constexpr int WPC = D <= 128 ? 3 : 2;            // workgroups per CU the kernels are compiled for
-    // bf16 panel row stride (elements).  A pitch of 16 mod 64 elements makes the 16-byte A-fragment reads conflict-free in the bank
-    // model of scripts/micro/lds_banks.py (4 instead of 8 cycles; D + 8 is 2-way conflicted) at the price of 4-way conflicts on the
-    // 8-byte transposed-tile writes, which are 6 x rarer: enc_mlp_fwd<64,192> 82 -> 80 us, <128,352> 55.0 -> 54.2.  Not at D = 256:
-    // the backward kernel there spills more with the wider panel (375 -> 387 us).
-    static constexpr int LU = D <= 128 ? D + 16 : D + 8;
+    // bf16 panel row stride (elements)
+    static constexpr int LU = D <= 128 ? D : D + 8;      // (see "LDS layouts" above; was D + 16 at D <= 128)
+    static constexpr int LC = LCd<D>;
     static constexpr int LX = D + 4;            // fp32 staging row stride (floats)
     static constexpr int LG = HP + 8;           // gate image row stride
     static constexpr int NCH = (HP + 63) / 64;  // hidden chunks (the last one may be half full)
@@ -91,13 +104,29 @@ struct MG {
     static_assert(2 * R * LU * 2 >= 2 * NTH * 8 * 4, "reduction scratch must fit in the two panels");
 };
 
-struct G8 { int lane, c16, g, wave, wm, wn; };
+struct G8 { int lane, c16, g, wave, wm, wn; int fp, fc; };     // fp / fc: swizzle of row c16 (+ 16 k) in a panel / a chunk image
+template <int D>
 __device__ __forceinline__ G8 geo8() {
     G8 q;
     q.lane = threadIdx.x & 63; q.c16 = q.lane & 15; q.g = q.lane >> 4;
     q.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: SGPR, scalar branches
     q.wm = q.wave >> 1; q.wn = q.wave & 1;
+    q.fp = swzp<D>(q.c16); q.fc = swzc<D>(q.c16);
     return q;
+}
+// 16-byte row fragment (MFMA operand) of a panel / of a chunk image: row mt*16 + c16, columns ks*32 + 8g .. + 7
+template <int LU>
+__device__ __forceinline__ bf16x8 pfrag(const bf16_t* img, int mt, int ks, const G8& q) {
+    return *reinterpret_cast<const bf16x8*>(img + (mt * 16 + q.c16) * LU + (((ks * 4 + q.g) ^ q.fp) << 3));
+}
+template <int LC>
+__device__ __forceinline__ bf16x8 cfrag(const bf16_t* img, int mt, int ks, const G8& q) {
+    return *reinterpret_cast<const bf16x8*>(img + (mt * 16 + q.c16) * LC + (((ks * 4 + q.g) ^ q.fc) << 3));
+}
+// element offset in a chunk image of the 4 columns wave*16 + 4g .. of row mt*16 + c16 (a swapped-operand accumulator tile)
+template <int LC>
+__device__ __forceinline__ int ctile(int mt, const G8& q) {
+    return (mt * 16 + q.c16) * LC + (((2 * q.wave + (q.g >> 1)) ^ q.fc) << 3) + (q.g & 1) * 4;
 }
 
 template <int KS>
@@ -113,18 +142,6 @@ struct Fr {
                                : zero8();
     }
 };
-
-template <int KS>
-__device__ __forceinline__ void mm_f(const bf16_t* A, int lda, int kofs, const Fr<KS>& f, const G8& q, f32x4 (&acc)[MH][2]) {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int mi = 0; mi < MH; ++mi) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + ((q.wm * MH + mi) * 16 + q.c16) * lda + kofs + ks * 32 + q.g * 8);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[mi][j] = mfma16(a, f.b[ks][j], acc[mi][j]);
-        }
-}
 
 // Column-split decomposition (forward kernel): the 4 waves split the COLUMNS of every product and each covers all
 // 4 m-tiles of the 64-row panel, so no weight fragment is fetched by two waves.  (In the 2 x 2 split each wave
@@ -196,7 +213,7 @@ template <int D, int HPE>
 __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     using G = MG<D, HPE>;
     constexpr int R = G::R;
-    constexpr int LU = G::LU, LX = G::LX, NCH = G::NCH, KSD = G::KSD, LPR = G::LPR;
+    constexpr int LU = G::LU, LC = G::LC, LX = G::LX, NCH = G::NCH, KSD = G::KSD, LPR = G::LPR;
     constexpr int MT4 = R / 16;                         // every wave covers all m-tiles of the panel
     constexpr int NJO = D / 64;                         // output n-tiles per wave (D / 16 over 4 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -205,7 +222,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
     float* XS = reinterpret_cast<float*>(smem);         // fp32 store tile over U2 | Gc once the products are done
     float* XR = reinterpret_cast<float*>(smem + (G::LDS_FWD_IMG > R * LX * 4 ? G::LDS_FWD_IMG : R * LX * 4));   // the panel's x1 in fp32: the
                                                 // residual (25 KB at D = 128; a re-read from L2 missed: 57 MB of extra fetches per launch)
-    const G8 q = geo8();
+    const G8 q = geo8<D>();
     const int row0 = blockIdx.x * R;
     const EncMlpW& w = p.w;
     const int nt_h = HPE / 16;
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
             const float rstd = rsqrtf(redrow<LPR>(v) * (1.f / D) + 1e-5f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
-            *reinterpret_cast<bf16x8*>(U2 + row * LU + c8) = cvt8(f);
+            *reinterpret_cast<bf16x8*>(U2 + row * LU + (((c8 >> 3) ^ swzp<D>(row)) << 3)) = cvt8(f);
         }
     }
     FrN<2, NJO> f2;                                     // W2 fragments of the current chunk (k-steps 2c, 2c+1)
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
             for (int ks = 0; ks < KSD; ++ks)
 #pragma unroll
                 for (int mt = 0; mt < MT4; ++mt) {                      // one A fragment feeds both products
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(U2 + (mt * 16 + q.c16) * LU + ks * 32 + q.g * 8);
+                    const bf16x8 a = pfrag<LU>(U2, mt, ks, q);
                     h1[mt] = mfma16(f1.b[ks][0], a, h1[mt]);
                     h3[mt] = mfma16(f3.b[ks][0], a, h3[mt]);
                 }
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
             // columns past the hidden width: the packed W1 / W3 rows and the biases read as zero -> h1 = h3 = 0 -> g = 0
 #pragma unroll
             for (int r = 0; r < 4; ++r) gv[r] = silu_nr(h1[mt][r]) * h3[mt][r];
-            *reinterpret_cast<bf16x4*>(Gi + (mt * 16 + q.c16) * LC + q.wave * 16 + q.g * 4) = cvt4(gv);
+            *reinterpret_cast<bf16x4*>(Gi + ctile<LC>(mt, q)) = cvt4(gv);
         }
         lds_barrier();                             // chunk image complete; the other image is free again after this barrier
         // x2 += g_c W2_c^T : this wave's NJO output n-tiles, all 4 m-tiles; the last chunk of 352 is half full
@@ -309,7 +326,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
             if (kHalfLast && c == NCH - 1 && ks == 1) continue;
 #pragma unroll
             for (int mt = 0; mt < MT4; ++mt) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Gi + (mt * 16 + q.c16) * LC + ks * 32 + q.g * 8);
+                const bf16x8 a = cfrag<LC>(Gi, mt, ks, q);
 #pragma unroll
                 for (int j = 0; j < NJO; ++j) xr[mt][j] = mfma16(f2.b[ks][j], a, xr[mt][j]);
             }
@@ -362,7 +379,7 @@ template <int D, int HPE>
 __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     using G = MG<D, HPE>;
     constexpr int R = G::R;
-    constexpr int LU = G::LU, LX = G::LX, NCH = G::NCH, KSD = G::KSD, KSH = G::KSH, LPR = G::LPR;
+    constexpr int LU = G::LU, LC = G::LC, LX = G::LX, NCH = G::NCH, KSD = G::KSD, KSH = G::KSH, LPR = G::LPR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);
     bf16_t* DYb = U2 + R * LU;
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
     bf16_t* DH3 = DH1 + R * LC;
     bf16_t* Gc = DH3 + R * LC;
     float* XS = reinterpret_cast<float*>(G::XS_AT_DY ? reinterpret_cast<char*>(DYb) : smem);   // after the chunk loop: fp32 tile of du2
-    const G8 q = geo8();
+    const G8 q = geo8<D>();
     const int row0 = blockIdx.x * R;
     const EncMlpW& w = p.w;
     const int nt_h = HPE / 16;
@@ -414,7 +431,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
             const bf16x8 ub = cvt8(f);
-            *reinterpret_cast<bf16x8*>(U2 + row * LU + c8) = ub;
+            *reinterpret_cast<bf16x8*>(U2 + row * LU + (((c8 >> 3) ^ swzp<D>(row)) << 3)) = ub;
             if (p.rs_mlp && ok) {
                 const float rs = p.rs_mlp[row0 + row];
                 float sv[8];
@@ -424,7 +441,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                 for (int e = 0; e < 8; ++e) dyv[e] = sv[e];
             }
             const bf16x8 dyb8 = cvt8(dyv);
-            *reinterpret_cast<bf16x8*>(DYb + row * LU + c8) = dyb8;
+            *reinterpret_cast<bf16x8*>(DYb + row * LU + (((c8 >> 3) ^ swzp<D>(row)) << 3)) = dyb8;
             if (ok && p.u2) {                     // (NULL operands: data path only — the caller takes its weight gradients elsewhere)
                 HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.u2 + (size_t)(row0 + row) * D + c8), ub);     // wgrad operands
                 HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.dyb + (size_t)(row0 + row) * D + c8), dyb8);
@@ -446,7 +463,6 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
         const bool live = full || nt < nt_h;
         {
             // operands swapped as in the forward kernel: a lane owns 4 consecutive hidden columns of one row
-            const int lc = q.wave * 16 + q.g * 4;
             f32x4 h1[MT4], h3[MT4], dg[MT4];
             if constexpr (BPF) {
 #pragma unroll
@@ -464,8 +480,8 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                 for (int ks = 0; ks < KSD; ++ks)
 #pragma unroll
                     for (int mt = 0; mt < MT4; ++mt) {
-                        const bf16x8 au = *reinterpret_cast<const bf16x8*>(U2 + (mt * 16 + q.c16) * LU + ks * 32 + q.g * 8);
-                        const bf16x8 ad = *reinterpret_cast<const bf16x8*>(DYb + (mt * 16 + q.c16) * LU + ks * 32 + q.g * 8);
+                        const bf16x8 au = pfrag<LU>(U2, mt, ks, q);
+                        const bf16x8 ad = pfrag<LU>(DYb, mt, ks, q);
                         h1[mt] = mfma16(f1.b[ks][0], au, h1[mt]);
                         h3[mt] = mfma16(f3.b[ks][0], au, h3[mt]);
                         dg[mt] = mfma16(f2.b[ks][0], ad, dg[mt]);
@@ -497,7 +513,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                     d1[r] = dv * a3 * sg * (1.f + a1 * (1.f - sg));
                     d3[r] = dv * sl;
                 }
-                const int o = (mt * 16 + q.c16) * LC + lc;
+                const int o = ctile<LC>(mt, q);
                 *reinterpret_cast<bf16x4*>(Gc + o) = cvt4(gv);
                 *reinterpret_cast<bf16x4*>(DH1 + o) = cvt4(d1);
                 *reinterpret_cast<bf16x4*>(DH3 + o) = cvt4(d3);
@@ -507,9 +523,15 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
         PH(1)
         // W1^T | W3^T fragments of this chunk's data gradient (this wave's output n-tiles): issued before the operand
         // stores so that their L2 round trip overlaps them
-        FrN<2, NJO> wa, wb;
+        // (D = 256: the W3^T fragments of the second k-step — 16 registers — are fetched in front of the first k-step's products
+        //  instead: all 64 at once pushed this instantiation into scratch — 15 spilled registers in round 3, 3 now; moving the
+        //  W1^T half as well makes hipcc spill 17)
+        constexpr bool LATE = D >= 256;
+        FrN<2, NJO> wa;
+        FrN<1, NJO> wb0, wb1;
         wa.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, 2 * c, D / 16, q.lane);
-        wb.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * c, D / 16, q.lane);
+        wb0.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * c, D / 16, q.lane);
+        if constexpr (!LATE) wb1.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * c + 1, D / 16, q.lane);
         // weight-gradient operands of this chunk to HBM (row-contiguous 16-B stores), columns < 352 only
         if (p.dh13) {
             const int ncol = (c * 64 + 64 <= HPE) ? 64 : HPE - c * 64;       // 64 or 32
@@ -517,9 +539,9 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                 const int row = pc >> 3, k8 = (pc & 7) * 8;
                 if (row0 + row < p.M && k8 < ncol) {
                     const size_t gr = (size_t)(row0 + row);
-                    HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.g + gr * HPE + c * 64 + k8), *reinterpret_cast<const bf16x8*>(Gc + row * LC + k8));
-                    HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.dh13 + gr * 2 * HPE + c * 64 + k8), *reinterpret_cast<const bf16x8*>(DH1 + row * LC + k8));
-                    HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.dh13 + gr * 2 * HPE + HPE + c * 64 + k8), *reinterpret_cast<const bf16x8*>(DH3 + row * LC + k8));
+                    HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.g + gr * HPE + c * 64 + k8), *reinterpret_cast<const bf16x8*>(Gc + row * LC + (((k8 >> 3) ^ swzc<D>(row)) << 3)));
+                    HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.dh13 + gr * 2 * HPE + c * 64 + k8), *reinterpret_cast<const bf16x8*>(DH1 + row * LC + (((k8 >> 3) ^ swzc<D>(row)) << 3)));
+                    HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.dh13 + gr * 2 * HPE + HPE + c * 64 + k8), *reinterpret_cast<const bf16x8*>(DH3 + row * LC + (((k8 >> 3) ^ swzc<D>(row)) << 3)));
                 }
             }
         }
@@ -530,14 +552,17 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (kHalfLast && c == NCH - 1 && ks == 1) continue;
+            if constexpr (LATE) {
+                if (ks == 0 && !(kHalfLast && c == NCH - 1)) wb1.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * c + 1, D / 16, q.lane);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT4; ++mt) {
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(DH1 + (mt * 16 + q.c16) * LC + ks * 32 + q.g * 8);
-                const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(DH3 + (mt * 16 + q.c16) * LC + ks * 32 + q.g * 8);
+                const bf16x8 a1 = cfrag<LC>(DH1, mt, ks, q);
+                const bf16x8 a3 = cfrag<LC>(DH3, mt, ks, q);
 #pragma unroll
                 for (int j = 0; j < NJO; ++j) {
                     du2[mt][j] = mfma16(wa.b[ks][j], a1, du2[mt][j]);
-                    du2[mt][j] = mfma16(wb.b[ks][j], a3, du2[mt][j]);
+                    du2[mt][j] = mfma16(ks == 0 ? wb0.b[0][j] : wb1.b[0][j], a3, du2[mt][j]);
                 }
             }
         }
