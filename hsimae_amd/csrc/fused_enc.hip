@@ -9,6 +9,7 @@
 // 64-column chunk.  Weight fragments are prefetched one chunk ahead.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 // Per-phase cycle accounting for scripts/phase_timing.py (compiled only with -DHS_PHASE_TIMING; never in the shipped library)
 #ifdef HS_PHASE_TIMING
@@ -49,6 +50,12 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases_enc(un
 #endif
 #ifndef HS_MLP_WPCF_64
 #define HS_MLP_WPCF_64 3
+#endif
+#ifndef HS_MLP_FWD_PERSIST
+#define HS_MLP_FWD_PERSIST 0     /* 1: the forward kernel walks panels with the next panel's rows prefetched into registers.  Measured
+                                    (r04_l, same box): <128,352> 57.9 -> 62.1 us, <64,192> 88.3 -> 93.6 us — slower: gfx950 counts loads with
+                                    one in-order counter, so every weight-fragment wait of the panel in hand first waits for the prefetched
+                                    HBM rows in front of it; the round trip moves from the prologue into the first k-step.  Not the default. */
 #endif
 
 namespace {
@@ -94,6 +101,7 @@ struct MG {
     // forward: the panel's fp32 copy (residual) is kept in LDS at D = 128 only; wider panels re-read x1 (L2-hot) instead
     static constexpr bool KEEP_XR = (D == 128 && HS_MLP_XR_128) || (D == 64 && HS_MLP_XR_64);
     static constexpr int WPCF = D == 128 ? HS_MLP_WPCF_128 : (D == 64 ? HS_MLP_WPCF_64 : WPC);   // forward kernel
+    static constexpr bool PERSIST = D <= 128 && HS_MLP_FWD_PERSIST;   // forward kernel walks panels with the next one's rows prefetched
     static constexpr int LDS_FWD_IMG = R * LU * 2 + 2 * R * LC * 2;
     static constexpr int LDS_FWD = (LDS_FWD_IMG > R * LX * 4 ? LDS_FWD_IMG : R * LX * 4) + (KEEP_XR ? R * LX * 4 : 0);
     static constexpr int LDS_BWD = 2 * R * LU * 2 + 3 * R * LC * 2;
@@ -222,13 +230,43 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
     float* XS = reinterpret_cast<float*>(smem);         // fp32 store tile over U2 | Gc once the products are done
     float* XR = reinterpret_cast<float*>(smem + (G::LDS_FWD_IMG > R * LX * 4 ? G::LDS_FWD_IMG : R * LX * 4));   // the panel's x1 in fp32: the
                                                 // residual (25 KB at D = 128; a re-read from L2 missed: 57 MB of extra fetches per launch)
-    const G8 q = geo8<D>();
-    const int row0 = blockIdx.x * R;
-    const EncMlpW& w = p.w;
+    const G8 q0 = geo8<D>();
     const int nt_h = HPE / 16;
-    const int c8 = (threadIdx.x % LPR) * 8;
+    const int c8_0 = (threadIdx.x % LPR) * 8;
+    // HS_MLP_FWD_PERSIST (round-4 experiment, off): the units of this kernel run one after the other (DESIGN 7 budget table:
+    // bytes 19 + MFMA 12 + VALU 18 + LDS 10 us = 59 us against 55 measured) because all 768 resident workgroups of a round
+    // start together, wait for their rows together and compute together.  In the persistent form a workgroup walks panels
+    // blockIdx.x, + gridDim.x, ... and fetches the NEXT panel's rows into registers (24 at D = 128) as soon as the LayerNorm has
+    // consumed the current ones.  It measured 7 % slower (see the knob): the prefetched loads sit in front of the weight-fragment
+    // loads in the in-order vmcnt queue.  D = 256 never has the registers (230 of 256 at two workgroups per CU).
+    constexpr bool PERSIST = G::PERSIST;
+    constexpr int NI = R * LPR / NTH;
+    const int npanels = (p.M + R - 1) / R;
+    float fa[NI][8];
+    auto fetch_panel = [&](int panel) {                   // the whole panel in flight at once
+        const int r0 = panel * R;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = (threadIdx.x + NTH * i) / LPR;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fa[i][e] = 0.f;
+            if (panel < npanels && r0 + row < p.M) ld8(p.x1 + (size_t)(r0 + row) * D + c8_0, fa[i]);
+        }
+    };
+    fetch_panel(blockIdx.x);
 
     PH_DECL
+  int panel = blockIdx.x;
+  do {
+    const int row0 = panel * R;
+    // (the weight images are the same for every panel: left alone, hipcc hoists their fragment loads out of the panel loop and
+    //  spills them — 82 registers; laundering the pointers once per panel keeps the loads where they are used)
+    // (... and the per-lane address pieces, which it would otherwise precompute for every access of the body and keep live)
+    G8 q = q0;
+    int c8 = c8_0;
+    if constexpr (PERSIST) asm volatile("" : "+v"(q.lane), "+v"(q.c16), "+v"(q.g), "+v"(q.fp), "+v"(q.fc), "+v"(c8));
+    EncMlpW w = p.w;
+    if constexpr (PERSIST) { w.w1 = launder(p.w.w1); w.w3 = launder(p.w.w3); w.w2 = launder(p.w.w2); w.w1b = launder(p.w.w1b); w.w3b = launder(p.w.w3b); w.w2b = launder(p.w.w2b); }
     FrN<KSD, 1> f1, f3;                                 // this wave's n-tile of the current hidden chunk
     f1.template load<false>(w.w1, KSD, q.wave, 0, nt_h, q.lane);          // chunk 0: all four n-tiles exist (HPE >= 64)
     f3.template load<false>(w.w3, KSD, q.wave, 0, nt_h, q.lane);
@@ -238,19 +276,12 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
     {   // LayerNorm-2 in the wide layout (16 lanes per row)
         float gm[8], bt[8];
         ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
-        constexpr int NI = R * LPR / NTH;
-        float fa[NI][8];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {                 // the whole panel in flight at once
-            const int row = (threadIdx.x + NTH * i) / LPR;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) fa[i][e] = 0.f;
-            if (row0 + row < p.M) ld8(p.x1 + (size_t)(row0 + row) * D + c8, fa[i]);
-        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int pc = threadIdx.x + NTH * i, row = pc / LPR;
-            float (&f)[8] = fa[i];
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fa[i][e];
             if constexpr (G::KEEP_XR) st8(XR + row * LX + c8, f);
             const float mean = redrow<LPR>(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
             float v = 0.f;
@@ -264,6 +295,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
     }
     FrN<2, NJO> f2;                                     // W2 fragments of the current chunk (k-steps 2c, 2c+1)
     f2.template load<false>(w.w2, G::KSH, q.wave * NJO, 0, D / 16, q.lane);
+    if constexpr (PERSIST) fetch_panel(panel + (int)gridDim.x);          // next panel's rows: in flight under this panel's products
     lds_barrier();
     PH(0)
     // Every product runs with the MFMA operands swapped (weights as A, the panel as B): a lane then owns 4 consecutive
@@ -362,6 +394,8 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
         }
     }
     PH(4)
+    if constexpr (PERSIST) lds_barrier();               // XS / XR are read: the next panel's LayerNorm may overwrite them
+  } while (PERSIST && (panel += (int)gridDim.x) < npanels);
     PH_FLUSH(8)
 }
 
@@ -668,6 +702,15 @@ static void set_attrs() {
     done = true;
 }
 
+template <int D, int HP>
+static int fwd_grid(int M) {
+    const int panels = (M + MG<D, HP>::R - 1) / MG<D, HP>::R;
+    if (!MG<D, HP>::PERSIST) return panels;
+    static int slots = 0;                     // resident workgroups: WPCF per CU (HSIMAE_MLP_FWD_WGS overrides)
+    if (!slots) { const char* e = getenv("HSIMAE_MLP_FWD_WGS"); slots = e ? atoi(e) : 256 * MG<D, HP>::WPCF; if (slots < 1) slots = 256 * MG<D, HP>::WPCF; }
+    return panels < slots ? panels : slots;
+}
+
 int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, const EncMlpPtrs& b, hipStream_t s,
                    const float* rowscale) {
     if (M <= 0) return HS_OK;
@@ -675,7 +718,7 @@ int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, 
     if (d == 128) {
         constexpr int R = MG<128, 352>::R;
         set_attrs<128, 352>();
-        hipLaunchKernelGGL((enc_mlp_fwd_kernel<128, 352>), dim3((M + R - 1) / R), dim3(NTH), (MG<128, 352>::LDS_FWD), s, a);
+        hipLaunchKernelGGL((enc_mlp_fwd_kernel<128, 352>), dim3(fwd_grid<128, 352>(M)), dim3(NTH), (MG<128, 352>::LDS_FWD), s, a);
     } else if (d == 256) {
         constexpr int R = MG<256, 704>::R;
         set_attrs<256, 704>();
@@ -683,7 +726,7 @@ int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, 
     } else if (d == 64) {
         constexpr int R = MG<64, 192>::R;
         set_attrs<64, 192>();
-        hipLaunchKernelGGL((enc_mlp_fwd_kernel<64, 192>), dim3((M + R - 1) / R), dim3(NTH), (MG<64, 192>::LDS_FWD), s, a);
+        hipLaunchKernelGGL((enc_mlp_fwd_kernel<64, 192>), dim3(fwd_grid<64, 192>(M)), dim3(NTH), (MG<64, 192>::LDS_FWD), s, a);
     } else {
         return HS_EUNSUPPORTED;
     }
