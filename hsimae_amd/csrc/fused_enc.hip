@@ -55,7 +55,10 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases_enc(un
 #define HS_MLP_FWD_PERSIST 0     /* 1: the forward kernel walks panels with the next panel's rows prefetched into registers.  Measured
                                     (r04_l, same box): <128,352> 57.9 -> 62.1 us, <64,192> 88.3 -> 93.6 us — slower: gfx950 counts loads with
                                     one in-order counter, so every weight-fragment wait of the panel in hand first waits for the prefetched
-                                    HBM rows in front of it; the round trip moves from the prologue into the first k-step.  Not the default. */
+                                    HBM rows in front of it; the round trip moves from the prologue into the first k-step.  With the
+                                    prefetch issued behind the panel's last fragment load instead (r04_l2, no spill): 55.2 -> 57.1 us and
+                                    84.2 -> 89.1 us — the hardware's own workgroup dispatch (a new panel starts the moment a slot frees)
+                                    overlaps better than the loop.  Not the default. */
 #endif
 
 namespace {
