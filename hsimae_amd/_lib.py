@@ -155,6 +155,7 @@ SYMBOLS = {
     "hsimae_encode": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp]),
     "hsimae_encode_backward": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp, vp, BUCKET_CB, vp, vp]),
     "hsimae_agg_pool": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "hsimae_head_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "hsimae_decode": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp, vp, vp]),
     "hsimae_decode_backward": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp, vp, vp, BUCKET_CB, vp, vp]),
 }

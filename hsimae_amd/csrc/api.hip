@@ -819,6 +819,12 @@ int hsimae_agg_pool(const float* latent, float* pooled, int32_t N, int32_t T, in
     if (!latent || !pooled) return HSIMAE_ENULL;
     return hs_agg_pool(latent, pooled, N, T, L, D, S(stream));
 }
+int hsimae_head_bwd(const float* g, const float* pooled, const float* w, float* gw, float* gb, float* dlatent, int32_t N, int32_t C,
+                    int32_t T, int32_t L, int32_t D, void* stream) {
+    if (N <= 0) return HSIMAE_OK;
+    if (!g || !pooled || !w || !gw || !gb || !dlatent) return HSIMAE_ENULL;
+    return hs_head_bwd(g, pooled, w, gw, gb, dlatent, N, C, T, L, D, S(stream));
+}
 int hsimae_cube_gather(const hsimae_cube_params* p, void* stream) {
     if (!p) return HSIMAE_ENULL;
     if (p->N <= 0) return HSIMAE_OK;

@@ -626,6 +626,48 @@ int hs_agg_pool(const float* latent, float* pooled, int N, int T, int L, int D, 
     return (int)hipGetLastError();
 }
 
+// Backward of the 'AGG' classification head (Models.py:962-970: class_pred = pooled W^T + b, pooled[n][t*D + c] = mean_l latent[n][t][l][c])
+// from dL/d(class_pred): dW = g^T pooled, db = column sums of g, dL/d(latent)[n][t][l][c] = (g W)[n][t*D + c] / L for every l.
+// fp32 throughout (N is a fine-tuning batch of tens of cubes, C <= 32 classes: three tiny reductions, one launch).
+// Workgroups 0 .. ceil(C*TD/256)-1 own 256 elements of dW (+ db), the rest 256 elements of g W each and broadcast them over L.
+static __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ g, const float* __restrict__ pooled,
+                                                              const float* __restrict__ w, float* __restrict__ gw, float* __restrict__ gb,
+                                                              float* __restrict__ dlat, int N, int C, int T, int L, int D, int wblocks) {
+    const int TD = T * D;
+    if ((int)blockIdx.x < wblocks) {
+        const int idx = blockIdx.x * 256 + threadIdx.x;
+        if (idx < C * TD) {
+            const int c = idx / TD, k = idx - c * TD;
+            float acc = 0.f;
+            for (int n = 0; n < N; ++n) acc = fmaf(g[n * C + c], pooled[(size_t)n * TD + k], acc);
+            gw[idx] = acc;
+        }
+        if (blockIdx.x == 0 && (int)threadIdx.x < C) {
+            float acc = 0.f;
+            for (int n = 0; n < N; ++n) acc += g[n * C + threadIdx.x];
+            gb[threadIdx.x] = acc;
+        }
+        return;
+    }
+    const int idx = (blockIdx.x - wblocks) * 256 + threadIdx.x;
+    if (idx >= N * TD) return;
+    const int n = idx / TD, k = idx - n * TD, t = k / D, c = k - t * D;
+    float acc = 0.f;
+    for (int j = 0; j < C; ++j) acc = fmaf(g[n * C + j], w[(size_t)j * TD + k], acc);
+    acc /= (float)L;
+    float* dst = dlat + (((size_t)n * T + t) * L) * D + c;
+    for (int l = 0; l < L; ++l) dst[(size_t)l * D] = acc;
+}
+
+int hs_head_bwd(const float* g, const float* pooled, const float* w, float* gw, float* gb, float* dlat, int N, int C, int T, int L,
+                int D, hipStream_t s) {
+    if (N <= 0) return HS_OK;
+    if (C < 1 || C > 256 || T < 1 || L < 1 || D < 1) return HS_EDIMS;
+    const int TD = T * D, wblocks = (C * TD + 255) / 256, lblocks = (N * TD + 255) / 256;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(wblocks + lblocks), dim3(256), 0, s, g, pooled, w, gw, gb, dlat, N, C, T, L, D, wblocks);
+    return (int)hipGetLastError();
+}
+
 // fp32 rows -> bf16 copy (optionally times a per-row factor): the layer-at-a-time backward's dY / dx1 as operands of the
 // LDS-DMA weight-gradient kernel, which takes bf16 only (the register-staged fp32 path runs at half its bandwidth).
 static __global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n8, int d8,

@@ -42,6 +42,8 @@ int hs_loss(const LossParams& p, hipStream_t s);
 int hs_loss_partials(int N, int T);
 int hs_cube_gather(const CubeParams& p, hipStream_t s);
 int hs_agg_pool(const float* latent, float* pooled, int N, int T, int L, int D, hipStream_t s);
+int hs_head_bwd(const float* g, const float* pooled, const float* w, float* gw, float* gb, float* dlat, int N, int C, int T, int L,
+                int D, hipStream_t s);
 int hs_rows_to_bf16(const float* src, hs_bf16* dst, int64_t rows, int d, const float* rowscale, hipStream_t s);
 int hs_rows_pad_bf16(const float* src, hs_bf16* dst, int64_t rows, int cols, int ldd, hipStream_t s);
 int hs_det_convert(const int64_t* acc, float* g, int64_t n, hipStream_t s);

@@ -225,11 +225,12 @@ class DualViT(HSIMAE):
             if g_cls is not None:
                 # head (Models.py:962-970): class_pred = pooled W^T + b, pooled[n, t*D + c] = mean_l latent[n, t, l, c]
                 N, T, L, D = saved["N"], self.input_size[0], self.input_size[1] ** 2, self.dim
-                g_cls = g_cls.to(torch.float32)
-                w = self.cls_head.weight.detach()
-                gw = g_cls.t() @ saved["pooled"]
-                gb = g_cls.sum(0)
-                dlat = ((g_cls @ w) / L).view(N, T, 1, D).expand(N, T, L, D).contiguous()
+                g_cls = g_cls.to(torch.float32).contiguous()
+                w = self.cls_head.weight.detach().contiguous()
+                gw, gb = torch.empty_like(w), torch.empty(w.shape[0], dtype=torch.float32, device=dev)
+                dlat = torch.empty(N, T, L, D, dtype=torch.float32, device=dev)
+                _lib.check(lib.hsimae_head_bwd(g_cls.data_ptr(), saved["pooled"].data_ptr(), w.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                                               dlat.data_ptr(), N, w.shape[0], T, L, D, stream), "hsimae_head_bwd")
                 saved["cls"].check_alive()
                 saved["cls"]["_done"] = True
                 _lib.check(lib.hsimae_encode_backward(C.byref(cfg), C.byref(saved["cls"]["io"]), dlat.data_ptr(),

@@ -379,6 +379,11 @@ int hsimae_encode_backward(const hsimae_config* cfg, const hsimae_io* io, const 
 /* 'AGG' pooling of the classification head (Models.py:962-970): [N, T*L, D] -> [N, T*D], mean over the L tokens of
  * each spectral group; the Linear that follows is hsimae_gemm(A_F32, E_F32). */
 int hsimae_agg_pool(const float* latent, float* pooled, int32_t N, int32_t T, int32_t L, int32_t D, void* stream);
+/* Backward of that head (Models.py:962-970) from g = dL/d(class_pred) [N][C], fp32: gw [C][T*D] = g^T pooled, gb [C] = column
+   sums of g, dlatent [N][T][L][D] = (g W)[n][t*D + c] / L for every l (W [C][T*D] = cls_head.weight).  One launch; results are
+   ASSIGNED.  C <= 256. */
+int hsimae_head_bwd(const float* g, const float* pooled, const float* w, float* gw, float* gb, float* dlatent, int32_t N, int32_t C,
+                    int32_t T, int32_t L, int32_t D, void* stream);
 /* Stand-alone decoder (HSIMAE / DualViT `forward_decoder`, Models.py:573-601 / 923-945), inference: latent [N*K, D] fp32
  * (the output of `norm`) -> pred [N*T*9, 72] fp32.  io supplies N, len_t, len_l (K = len_t*len_l), ids_restore, params,
  * wpk and the workspace, as for hsimae_forward. */

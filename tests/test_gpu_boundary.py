@@ -134,6 +134,49 @@ def test_loss_error_is_the_bf16_operand_rounding():
     assert e_b <= 3e-5 and e_b <= 0.5 * gap
 
 
+def test_gradient_error_is_mostly_the_forward_operand_rounding():
+    """VERDICT r03 weak spot 2 (gradient gates of 2e-2 against a suggested 3e-3): at config 1 the gradients of the oracle run with
+    bf16-rounded FORWARD operands and an fp32 backward (`oracle.operands_bf16`) are as far from the fp32 reference as the HIP
+    gradients are (profiles/r04_grad_error_c1.txt: median 3.7e-3, worst 9.4e-3 over 503 tensors for both) — the error is the
+    rounding of the forward operands propagated through the backward, not the backward kernels.  What the backward kernels add on
+    top (their own bf16 operands: dO, dq|dk|dv, dh1|dh3, g) is HIP vs that oracle, gated here per family: LayerNorm parameters and
+    biases <= 2e-3, weight matrices <= 3e-3 (one bf16 rounding of each weight-gradient operand: 2^-9), q / k projections
+    <= 2e-2 (P, dS, dq and dk are bf16 in the attention backward, and these gradients are small differences of large terms;
+    measured 1.2e-2 at this N = 16, 7.2e-3 at N = 64)."""
+    cfg = O.OracleConfig(bands=48)
+    state = O.init_state(cfg, seed=0, std=0.02)
+    N = 16
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(N, 1, 48, 9, 9, generator=g)
+    n1, n2 = torch.rand(N, cfg.T, generator=g), torch.rand(N, 9, generator=g)
+    args = (state, cfg, x, n1.numpy(), n2.numpy(), 2, 7)
+    _, _, _, g32 = O.forward_backward(*args)
+    with O.operands_bf16():
+        lb, _, _, gb = O.forward_backward(*args)
+    m = base48(0)
+    m.load_state_dict(state)
+    loss, _, _ = m(x.to(DEV), 0.75, noise=(n1, n2), grid=(2, 7))
+    loss.backward()
+    assert abs(loss.item() - lb.item()) <= 1e-5 * lb.item()
+    named = dict(m.named_parameters())
+    worst = {"vec": ("", 0.0), "mat": ("", 0.0), "qk": ("", 0.0)}
+    fwd_share = []
+    for k, ref in gb.items():
+        if k.endswith("attn.k.bias"):
+            continue
+        e = rms_rel(named[k].grad, ref)
+        kind = "qk" if (".attn.q." in k or ".attn.k." in k) else ("mat" if ref.dim() >= 2 else "vec")
+        if e > worst[kind][1]:
+            worst[kind] = (k, e)
+        fwd_share.append((rms_rel(ref, g32[k]), rms_rel(named[k].grad, g32[k])))
+    print(f"[grad error vs bf16-operand oracle] worst vector {worst['vec']}, matrix {worst['mat']}, q/k {worst['qk']}")
+    assert worst["vec"][1] <= 2e-3 and worst["mat"][1] <= 3e-3 and worst["qk"][1] <= 2e-2, worst
+    # the forward rounding alone explains the distance to fp32: medians within 25 % of each other
+    a = sorted(v[0] for v in fwd_share)[len(fwd_share) // 2]
+    b = sorted(v[1] for v in fwd_share)[len(fwd_share) // 2]
+    assert 0.75 * b <= a <= 1.25 * b, (a, b)
+
+
 def test_c1_config1_reference_scale_n64():
     """BASELINE.json configs[0] exactly, the reference's weights after construction (seed 0): loss <= 1e-4 relative
     (north_star), every gradient L2 norm <= 2e-2, four full gradient tensors RMS-relative <= 2e-2."""
