@@ -88,7 +88,7 @@ class WgradTask(C.Structure):
 
 
 class WgradParams(C.Structure):
-    _fields_ = [("t", WgradTask * 8), ("ntasks", i32), ("M", i32), ("msplit", i32), ("det_base", vp), ("det_acc", vp), ("slab", vp)]
+    _fields_ = [("t", WgradTask * 16), ("ntasks", i32), ("M", i32), ("msplit", i32), ("det_base", vp), ("det_acc", vp), ("slab", vp)]
 
 
 class LnBwdParams(C.Structure):

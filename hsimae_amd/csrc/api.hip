@@ -344,6 +344,81 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     return HSIMAE_OK;
 }
 
+// ------------------------------------------------------------------ pair launches of the two axis stacks (round 4)
+// blocks_1.i and blocks_2.i (Models.py:556-560) are independent and have the same shapes.  Round 3 ran them on two streams; the
+// gain was 0.4 ms of the 0.8 ms that the launches' fixed costs add up to over the 18 axis blocks (a launch costs 11-36 us on top
+// of its per-row time: profiles/r03_g_where_the_time_is.txt).  Here the row-panel kernels of block i of BOTH stacks run as one
+// launch (blockIdx.y = stack): the MLP half forward / backward, the q|k|v data gradient + LayerNorm-1 backward and the 14 linears'
+// weight gradients; the two per-sample attention kernels (fixed cost ~5 us) stay two launches on the same stream.
+// Applies where every kernel involved has its fused D = 128 form.
+// MEASURED AND NOT ADOPTED (profiles/r04_p_pair_launch.txt, same box, C2): pair launches 16.51 / 16.51 / 16.53 ms per step, the
+// two-stream schedule 16.45 / 16.35 / 16.32, one stream 16.91.  A pair launch takes exactly twice a single one (enc_mlp_bwd 3.01 ms
+// per step against 2.95, wgrad_dma 2.54 against 2.54; only lnbwd_dma gains, 0.96 against 1.07): the "fixed cost" read off the
+// batch-size scaling is not a per-launch head / tail that merging removes.  Kept behind HSIMAE_PAIR_LAUNCH=1 (parity-tested: the
+// whole GPU suite passes with it on); the default is the two-stream schedule.
+static bool pair_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("HSIMAE_PAIR_LAUNCH"); on = (e && e[0] == '1'); }
+    return on != 0;
+}
+static bool pair_shapes_ok(const Geo& g, int Ts) {
+    return pair_enabled() && g.D == 128 && g.Dp == g.D && !(g.prec == HSIMAE_PREC_FP8 && fp8_unfused()) && hs_attn_block_fusable(g.D, g.H, Ts) &&
+           fused_mlp_enabled(g.D, g.h);
+}
+
+// What block_bwd launches on the fused D = 128 path, as parameter blocks (nothing is launched here)
+struct BlkBwdPlan { EncMlpPtrs mw; EncMlpBwdCall mlp; AttnParams attn; WgradTask t[7]; GemmParams ln; };
+static bool block_bwd_plan(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, const BlkBuf& b, int64_t M, int d, int heads,
+                           int h, int hp, int Ts, int nsamples, int mode, int len_l, float* G0, const Scr& w, float* dx_out,
+                           const float* rs_a, const float* rs_m, int64_t* det_acc, BlkBwdPlan& q) {
+    const int dp = rup(d, 32);
+    if (d != 128 || dp != d || P.prec == HSIMAE_PREC_FP8 || !fused_mlp_enabled(d, h)) return false;
+    float* G1 = w.G1;
+    q.mw = mlp_ptrs(P, h);
+    q.mlp = EncMlpBwdCall{b.x1, G0, G1, b.u2, w.dh13, b.g, w.g0b, w.g1b, &q.mw, grads + o.n2w, grads + o.n2b, rs_m, rs_a};
+    AttnParams& a = q.attn; std::memset(&a, 0, sizeof(a));
+    a.qkv = b.qkv; a.ld = 3 * dp; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
+    a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = dp; a.lse = b.lse; a.dout = w.g1b; a.lddo = dp; a.dqkv = w.dqkv; a.kv_off = dp;
+    if (!hs_attn_proj_fusable(a)) return false;
+    a.projT_w = P.pT;                                   // dO = dx1 Wp inside the attention backward
+    int n = 0;
+    auto task = [&](const void* dO, int ldo, const hs_bf16* A, int lda, int N, int K, int64_t dW, int64_t db) {
+        WgradTask& t = q.t[n++];
+        t.dO = dO; t.dO_f32 = 0; t.ldo = ldo; t.A = A; t.lda = lda; t.N = N; t.K = K; t.dW = grads + dW; t.ldw = K;
+        t.db = grads + db; t.dO_rowscale = nullptr;
+    };
+    task(w.dqkv, 3 * dp, b.u, dp, d, d, o.qw, o.qb);
+    task(w.dqkv + dp, 3 * dp, b.u, dp, d, d, o.kw, o.kb);
+    task(w.dqkv + 2 * dp, 3 * dp, b.u, dp, d, d, o.vw, o.vb);
+    task(w.g1b, dp, b.o, dp, d, d, o.pw, o.pb);
+    task(w.dh13, 2 * hp, b.u2, dp, h, d, o.w1w, o.w1b);
+    task(w.dh13 + hp, 2 * hp, b.u2, dp, h, d, o.w3w, o.w3b);
+    task(w.g0b, dp, b.g, hp, d, h, o.w2w, o.w2b);
+    GemmParams& p = q.ln; p = gp();
+    p.A = w.dqkv; p.lda = 3 * dp; p.M = (int)M; p.N = dp; p.K = 3 * dp; p.n_valid = d; p.W = P.qkvT;
+    p.out = dx_out; p.ldo = d; p.res = G1; p.ldr = d; p.lnx = x_in; p.gamma = P.n1w; p.accumulate = 0;
+    p.dgamma = grads + o.n1w; p.dbeta = grads + o.n1b; p.det_base = grads; p.det_acc = det_acc;
+    return hs_lnbwd_dma_supported(p);
+}
+
+// backward of blocks i of both stacks from the two plans: 5 launches instead of 8
+static int block_bwd_pair(const BlkBwdPlan q[2], float* grads, int64_t M, int d, int64_t* det_acc, float* slab, hipStream_t s) {
+    EncMlpBwdCall mc[2] = {q[0].mlp, q[1].mlp};
+    mc[0].w = &q[0].mw; mc[1].w = &q[1].mw;
+    CK(hs_enc_mlp_bwd_pair(mc, (int)M, d, s, HsDet{grads, reinterpret_cast<long long*>(det_acc)}));
+    CK(hs_attn_bwd(q[0].attn, s));
+    CK(hs_attn_bwd(q[1].attn, s));
+    WgradParams g; std::memset(&g, 0, sizeof(g));
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < 7; ++i) g.t[g.ntasks++] = q[k].t[i];
+    g.M = (int)M; g.det_base = grads; g.det_acc = det_acc; g.slab = slab;
+    int tiles = 0;
+    for (int i = 0; i < g.ntasks; ++i) tiles += ((g.t[i].N + 127) / 128) * ((g.t[i].K + 127) / 128);
+    g.msplit = wgrad_msplit(tiles, M, 1);
+    CK(hs_wgrad(g, s));
+    return hs_lnbwd_dma_pair(q[0].ln, q[1].ln, s);
+}
+
 struct Ctx {
     Geo g; PLayout L; WLayout W; Ws w;
     int N, K, len_t, len_l;
@@ -446,7 +521,36 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
     CK(hs_gemm(p, A_BF16, E_POS_F32, s));
 
     const float* x = w.x0;
-    if (g.has_axis) {
+    if (g.has_axis && pair_shapes_ok(g, c.K) && g.sdepth > 1) {
+        // pair launches (see block_bwd_pair): blocks i of both stacks — two attention-half launches, ONE MLP-half launch.  The last
+        // pair stays two launches: the spectral block's epilogue adds the spatial block's output of the same index (x1 + x2).
+        const float* xa = w.x0;
+        const float* xb = w.x0;
+        for (int i = 0; i < g.sdepth; ++i) {
+            BlkP b1 = resolve_enc(g, c.L.b1[i], c.W.b1[i], P, io->wpk, c.W);
+            BlkP b2 = resolve_enc(g, c.L.b2[i], c.W.b2[i], P, io->wpk, c.W);
+            const DropRs r1 = drop_rs(io, i, c.Me), r2d = drop_rs(io, g.sdepth + i, c.Me);
+            const bool last = (i == g.sdepth - 1);
+            if (last) {
+                CK(block_fwd(b1, xa, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, nullptr, s, r1.a, r1.m));
+                CK(block_fwd(b2, xb, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.b1[i].x2, s, r2d.a, r2d.m));
+            } else {
+                CK(hs_attn_block_fwd(xa, b1.n1w, b1.n1b, b1.qkv, b1.bqkv, b1.p, b1.pb, w.b1[i].u, w.b1[i].qkv, w.b1[i].o, w.b1[i].lse,
+                                     w.b1[i].x1, r1.a, c.K, c.N, 1, c.len_l, s));
+                CK(hs_attn_block_fwd(xb, b2.n1w, b2.n1b, b2.qkv, b2.bqkv, b2.p, b2.pb, w.b2[i].u, w.b2[i].qkv, w.b2[i].o, w.b2[i].lse,
+                                     w.b2[i].x1, r2d.a, c.K, c.N, 2, c.len_l, s));
+                const EncMlpPtrs m1 = mlp_ptrs(b1, g.h), m2 = mlp_ptrs(b2, g.h);
+                const float* const x1s[2] = {w.b1[i].x1, w.b2[i].x1};
+                const float* const res[2] = {nullptr, nullptr};
+                float* const x2s[2] = {w.b1[i].x2, w.b2[i].x2};
+                const EncMlpPtrs* const ms[2] = {&m1, &m2};
+                const float* const rsc[2] = {r1.m, r2d.m};
+                CK(hs_enc_mlp_fwd_pair(x1s, res, x2s, (int)c.Me, g.D, ms, s, rsc));
+            }
+            xa = w.b1[i].x2; xb = w.b2[i].x2;
+        }
+        x = xb;
+    } else if (g.has_axis) {
         Side& sd = side();
         const bool forked = sd.ok && g.sdepth > 1;
         if (forked) {
@@ -567,7 +671,37 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
                      rf.a, rf.m, io->det_acc));
         CK(emit(L.bf[i].n1w, L.bf[i].end, s));
     }
-    if (g.has_axis) {
+    if (g.has_axis && pair_shapes_ok(g, c.K) && g.sdepth > 1) {
+        // d(x1 + x2) feeds both stacks (Models.py:564).  Blocks i of both stacks as pair launches, everything on the caller's stream;
+        // the spectral stack's gradient lives in G0 (scratch set sc2), the spatial stack's in G2 (scratch set sc)
+        CK((int)hipMemcpyAsync(w.G2, w.G0, c.Me * g.Dp * 4, hipMemcpyDeviceToDevice, s));
+        for (int i = g.sdepth - 1; i >= 0; --i) {
+            BlkP b2 = resolve_enc(g, L.b2[i], c.W.b2[i], P, io->wpk, c.W);
+            BlkP b1 = resolve_enc(g, L.b1[i], c.W.b1[i], P, io->wpk, c.W);
+            const DropRs r1 = drop_rs(io, i, c.Me), r2d = drop_rs(io, g.sdepth + i, c.Me);
+            const float* xin2 = (i > 0) ? w.b2[i - 1].x2 : w.x0;
+            const float* xin1 = (i > 0) ? w.b1[i - 1].x2 : w.x0;
+            BlkBwdPlan q[2];
+            const bool planned = i > 0 &&           // (block 0: the spatial stack's last step ACCUMULATES onto the spectral dX: two launches)
+                block_bwd_plan(b2, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, w.sc2, w.G0,
+                               r2d.a, r2d.m, io->det_acc, q[0]) &&
+                block_bwd_plan(b1, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, w.G2,
+                               r1.a, r1.m, io->det_acc, q[1]);
+            if (planned) {
+                static int wslab = -1;
+                if (wslab < 0) { const char* e = getenv("HSIMAE_WGRAD_SLAB"); wslab = !(e && e[0] == '0'); }
+                CK(block_bwd_pair(q, grads, c.Me, g.D, io->det_acc, wslab ? w.slab : nullptr, s));
+            } else {
+                CK(block_bwd(b2, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, w.sc2, w.G0, 0, s, 1,
+                             r2d.a, r2d.m, io->det_acc));
+                float* out = (i == 0) ? w.G0 : w.G2;
+                CK(block_bwd(b1, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, out, i == 0, s, 1,
+                             r1.a, r1.m, io->det_acc));
+            }
+            CK(emit(L.b2[i].n1w, L.b2[i].end, s));
+            CK(emit(L.b1[i].n1w, L.b1[i].end, s));
+        }
+    } else if (g.has_axis) {
         // d(x1 + x2) feeds both stacks (Models.py:564); the spectral stack's backward runs on the side stream
         Side& sd = side();
         const bool forked = sd.ok && g.sdepth > 1;

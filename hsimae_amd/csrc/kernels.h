@@ -25,6 +25,7 @@ int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s);
 int hs_gemm_tiled(const GemmParams& p, int akind, int epi, int bm, int kc, hipStream_t s);   // tile sweep hook
 bool hs_lnbwd_dma_supported(const GemmParams& p);     // persistent LDS-DMA form of (A_BF16, E_LN_BWD) at N = 128, K = 384
 int hs_lnbwd_dma(const GemmParams& p, hipStream_t s);
+int hs_lnbwd_dma_pair(const GemmParams& a, const GemmParams& b, hipStream_t s);     // two problems of the same M, one launch
 bool hs_lnqkv_supported(const GemmParams& p);          // persistent form of (A_F32_LN, E_BF16) at K = 128, N = 384
 int hs_lnqkv(const GemmParams& p, hipStream_t s);
 int hs_pack(const PackDesc* descs_dev, int ndesc, int max_elems, hipStream_t s);
@@ -93,6 +94,14 @@ int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, 
 int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
                    hs_bf16* dx1b, int M, int d, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s,
                    const float* rs_mlp = nullptr, const float* rs_attn = nullptr, HsDet det = HsDet{nullptr, nullptr});
+// blocks i of the two axis stacks in one launch (blockIdx.y = stack; fused_enc.hip EncMlpFwdArgs2)
+int hs_enc_mlp_fwd_pair(const float* const x1[2], const float* const res2[2], float* const x2[2], int M, int d, const EncMlpPtrs* const b[2],
+                        hipStream_t s, const float* const rowscale[2]);
+struct EncMlpBwdCall {
+    const float* x1; const float* dy; float* dx1; hs_bf16* u2; hs_bf16* dh13; hs_bf16* g; hs_bf16* dyb; hs_bf16* dx1b;
+    const EncMlpPtrs* w; float* g_n2w; float* g_n2b; const float* rs_mlp; const float* rs_attn;
+};
+int hs_enc_mlp_bwd_pair(const EncMlpBwdCall c[2], int M, int d, hipStream_t s, HsDet det);
 
 int hs_adamw(float* p, const float* g, float* m, float* v, const unsigned char* group, int64_t n, float lr, float b1, float b2,
              float eps, float wd, int step, hipStream_t s);

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512) void wgrad_slab_reduce_kernel(WgradParams p) {
 
 int hs_wgrad(const WgradParams& p, hipStream_t s) {
     if (p.ntasks <= 0 || p.M <= 0) return HS_OK;
-    if (p.ntasks > 8 || p.msplit < 1) return HS_EDIMS;
+    if (p.ntasks > 16 || p.msplit < 1) return HS_EDIMS;
     for (int i = 0; i < p.ntasks; ++i)
         if (p.t[i].ldo % 8 || p.t[i].lda % 8) return HS_EDIMS;
     const int tiles = wg_tiles(p, 128);

@@ -301,7 +301,7 @@ int hsimae_dec_block_bwd(const hsimae_dec_block_weights* w, const hsimae_dec_blo
                          const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o, const float* lse, int32_t nsamples,
                          int32_t Ts, float* slab, void* stream);
 
-/* Weight / bias gradients of up to 8 linears in one launch (autograd of F.linear).  msplit = number of row slices the
+/* Weight / bias gradients of up to 16 linears in one launch (autograd of F.linear).  msplit = number of row slices the
    128 x 128 dW tiles are split into (partial sums meet in dW through atomics).  When every task of a launch has N >= 256 and
    K >= 256 and bf16 operands, the launch runs on 256 x 256 tiles, one workgroup per CU, and sizes its own row split (msplit is
    then only validated); the result is the same sum. */
@@ -314,7 +314,7 @@ typedef struct {
     const float* dO_rowscale;     /* optional per-row factor [M] on an fp32 dO (DropPath); NULL = 1 */
 } hsimae_wgrad_task;
 typedef struct {
-    hsimae_wgrad_task t[8]; int32_t ntasks; int32_t M; int32_t msplit;
+    hsimae_wgrad_task t[16]; int32_t ntasks; int32_t M; int32_t msplit;      /* (16 since round 4: the 2 x 7 linears of a pair of axis-stack blocks) */
     const float* det_base; int64_t* det_acc;      /* deterministic dW / db commits, as in hsimae_lnbwd_params; NULL = fp32 atomics */
     /* optional scratch of >= 64 MiB (256 workgroups x 256 x 256 floats), private to the calling stream: a launch on 256 x 256
        tiles then writes every workgroup's partial dW tile there as coalesced rows and a second launch sums the row slices in
