@@ -28,6 +28,9 @@
 #ifndef HS_W256_PF2
 #define HS_W256_PF2 0  /* q|k|v weight fragments two k-steps ahead instead of one (12 more registers) */
 #endif
+#ifndef HS_W256_LATE_X
+#define HS_W256_LATE_X 1 /* the next group's x rows are fetched after the attention (16 registers less across it) instead of before it */
+#endif
 #ifndef HS_W256_EARLY
 #define HS_W256_EARLY 0 /* projection weights (first half) and residual pieces fetched in front of the attention */
 #endif
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(NTHW, 1) void blk256_fwd_kernel(Blk256Args p) {
             }
         };
         if (HS_W256_EARLY) early();
-        fetch(first + gridDim.x * SPW);
+        if (!HS_W256_LATE_X) fetch(first + gridDim.x * SPW);
         PH(3)
         lds_barrier();                                            // B2: every wave is done with U; the staging image is complete
         PH(4)
@@ -315,6 +318,7 @@ __global__ __launch_bounds__(NTHW, 1) void blk256_fwd_kernel(Blk256Args p) {
         bf16x8 wpk[KSW / 2];                                      // second half of the projection weights (loads in front of the stores)
 #pragma unroll
         for (int ks = 0; ks < KSW / 2; ++ks) wpk[ks] = pfrag(KSW / 2 + ks);
+        if (HS_W256_LATE_X) fetch(first + gridDim.x * SPW);      // next group's rows: behind this phase's short loads, in front of its stores
         // ---- o and lse leave as whole rows
         for (int idx = tid; idx < RT * 32; idx += NTHW) {
             const int irow = idx >> 5, pc = idx & 31;

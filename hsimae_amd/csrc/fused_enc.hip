@@ -51,6 +51,9 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases_enc(un
 #ifndef HS_MLP_WPCF_64
 #define HS_MLP_WPCF_64 3
 #endif
+#ifndef HS_SWZ256
+#define HS_SWZ256 0          /* 1: the swizzled unpadded layout at D = 256 too (experiment) */
+#endif
 #ifndef HS_MLP_FWD_PERSIST
 #define HS_MLP_FWD_PERSIST 0     /* 1: the forward kernel walks panels with the next panel's rows prefetched into registers.  Measured
                                     (r04_l, same box): <128,352> 57.9 -> 62.1 us, <64,192> 88.3 -> 93.6 us — slower: gfx950 counts loads with
@@ -64,7 +67,7 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases_enc(un
 namespace {
 
 constexpr int MH = 2, NTH = 256;
-template <int D> constexpr int LCd = D <= 128 ? 64 : 64 + 8;      // 64-column chunk image row stride (D <= 128: unpadded + swizzled, see below)
+template <int D> constexpr int LCd = (D <= 128 || HS_SWZ256) ? 64 : 64 + 8;      // 64-column chunk image row stride (D <= 128: unpadded + swizzled, see below)
 
 // LDS layouts (round 4; bank model: scripts/micro/lds_banks.py, audit of the same scheme: scripts/micro/lds_audit_dec.py).  Round 3
 // padded the panel rows (D + 16 at D <= 128: conflict-free 16-byte row fragments, 4-way 8-byte tile writes; D + 8 at D = 256:
@@ -78,8 +81,8 @@ template <int D> constexpr int LCd = D <= 128 ? 64 : 64 + 8;      // 64-column c
 // 139.4 -> 139.4 us, forward 55.2 -> 55.1, <64,192> forward 83.4 -> 82.1 — and at D = 256 the extra address arithmetic costs the
 // backward kernel 6 more spilled registers (376 -> 424 us): D = 256 keeps the round-3 padded layout (no swizzle).
 __host__ __device__ constexpr int swz64(int row) { return (((row >> 1) & 3) << 1) ^ (((row >> 3) & 1) * 5); }
-template <int D> __host__ __device__ constexpr int swzp(int row) { return D == 64 ? swz64(row) : (D == 128 ? (row & 15) : 0); }
-template <int D> __host__ __device__ constexpr int swzc(int row) { return D <= 128 ? swz64(row) : 0; }
+template <int D> __host__ __device__ constexpr int swzp(int row) { return D == 64 ? swz64(row) : ((D == 128 || HS_SWZ256) ? (row & 15) : 0); }
+template <int D> __host__ __device__ constexpr int swzc(int row) { return (D <= 128 || HS_SWZ256) ? swz64(row) : 0; }
 
 // Geometry for model width D, padded hidden width HP (multiples of 64 / 32) and R_-row panels.
 //   D = 128: 48-row panels, three 4-wave workgroups per CU (2304 = 3 x 768 workgroups at M = 110,592)
@@ -91,7 +94,7 @@ struct MG {
     static constexpr int R = R_;
     static constexpr int WPC = D <= 128 ? 3 : 2;            // workgroups per CU the kernels are compiled for
     // bf16 panel row stride (elements)
-    static constexpr int LU = D <= 128 ? D : D + 8;      // (see "LDS layouts" above; was D + 16 at D <= 128)
+    static constexpr int LU = (D <= 128 || HS_SWZ256) ? D : D + 8;      // (see "LDS layouts" above; was D + 16 at D <= 128)
     static constexpr int LC = LCd<D>;
     static constexpr int LX = D + 4;            // fp32 staging row stride (floats)
     static constexpr int LG = HP + 8;           // gate image row stride
@@ -225,9 +228,11 @@ struct EncMlpFwdArgs2 { EncMlpFwdArgs v[2]; };
 // The W2 product is accumulated per 64-column hidden chunk (the gate lives in two 9-KB chunk images instead of a
 // 46-KB panel image) and the residual is added from an L2-hot re-read in the store loop, so a workgroup needs 36 KB of
 // LDS and ~150 registers: three workgroups per CU instead of two.
-template <int D, int HPE>
+// PAIR = false: a single problem (argument set 0).  The indexed form costs the single launches 3-6 % (r04_r: <128,352> backward
+// 144.0 -> 147.9 us, <256,704> 381.9 -> 403.8), so it is only instantiated for the pair launches.
+template <int D, int HPE, bool PAIR = false>
 __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(EncMlpFwdArgs2 pp) {
-    const EncMlpFwdArgs& p = pp.v[blockIdx.y];
+    const EncMlpFwdArgs& p = pp.v[PAIR ? blockIdx.y : 0];
     using G = MG<D, HPE>;
     constexpr int R = G::R;
     constexpr int LU = G::LU, LC = G::LC, LX = G::LX, NCH = G::NCH, KSD = G::KSD, LPR = G::LPR;
@@ -419,9 +424,9 @@ struct EncMlpBwdArgs {
 };
 struct EncMlpBwdArgs2 { EncMlpBwdArgs v[2]; };
 
-template <int D, int HPE>
+template <int D, int HPE, bool PAIR = false>
 __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(EncMlpBwdArgs2 pp) {
-    const EncMlpBwdArgs& p = pp.v[blockIdx.y];
+    const EncMlpBwdArgs& p = pp.v[PAIR ? blockIdx.y : 0];
     using G = MG<D, HPE>;
     constexpr int R = G::R;
     constexpr int LU = G::LU, LC = G::LC, LX = G::LX, NCH = G::NCH, KSD = G::KSD, KSH = G::KSH, LPR = G::LPR;
@@ -710,6 +715,10 @@ static void set_attrs() {
     if (done) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_fwd_kernel<D, HP>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_FWD);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel<D, HP>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_BWD);
+    if constexpr (D == 128) {                 // the pair instantiations exist at the Base width only (api.hip pair_shapes_ok)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_fwd_kernel<D, HP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_FWD);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel<D, HP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_BWD);
+    }
     done = true;
 }
 
@@ -723,15 +732,17 @@ static int fwd_grid(int M) {
 }
 
 static int launch_fwd(const EncMlpFwdArgs2& a, int M, int d, int npair, hipStream_t s) {
+    if (npair == 2 && d != 128) return HS_EUNSUPPORTED;
     if (d == 128) {
         set_attrs<128, 352>();
-        hipLaunchKernelGGL((enc_mlp_fwd_kernel<128, 352>), dim3(fwd_grid<128, 352>(M), npair), dim3(NTH), (MG<128, 352>::LDS_FWD), s, a);
+        if (npair == 2) hipLaunchKernelGGL((enc_mlp_fwd_kernel<128, 352, true>), dim3(fwd_grid<128, 352>(M), 2), dim3(NTH), (MG<128, 352>::LDS_FWD), s, a);
+        else hipLaunchKernelGGL((enc_mlp_fwd_kernel<128, 352>), dim3(fwd_grid<128, 352>(M)), dim3(NTH), (MG<128, 352>::LDS_FWD), s, a);
     } else if (d == 256) {
         set_attrs<256, 704>();
-        hipLaunchKernelGGL((enc_mlp_fwd_kernel<256, 704>), dim3(fwd_grid<256, 704>(M), npair), dim3(NTH), (MG<256, 704>::LDS_FWD), s, a);
+        hipLaunchKernelGGL((enc_mlp_fwd_kernel<256, 704>), dim3(fwd_grid<256, 704>(M)), dim3(NTH), (MG<256, 704>::LDS_FWD), s, a);
     } else if (d == 64) {
         set_attrs<64, 192>();
-        hipLaunchKernelGGL((enc_mlp_fwd_kernel<64, 192>), dim3(fwd_grid<64, 192>(M), npair), dim3(NTH), (MG<64, 192>::LDS_FWD), s, a);
+        hipLaunchKernelGGL((enc_mlp_fwd_kernel<64, 192>), dim3(fwd_grid<64, 192>(M)), dim3(NTH), (MG<64, 192>::LDS_FWD), s, a);
     } else {
         return HS_EUNSUPPORTED;
     }
@@ -759,18 +770,20 @@ int hs_enc_mlp_fwd_pair(const float* const x1[2], const float* const res2[2], fl
 }
 
 static int launch_bwd(const EncMlpBwdArgs2& a, int M, int d, int npair, hipStream_t s) {
+    if (npair == 2 && d != 128) return HS_EUNSUPPORTED;
     if (d == 128) {
         constexpr int R = MG<128, 352>::R;
         set_attrs<128, 352>();
-        hipLaunchKernelGGL((enc_mlp_bwd_kernel<128, 352>), dim3((M + R - 1) / R, npair), dim3(NTH), (MG<128, 352>::LDS_BWD), s, a);
+        if (npair == 2) hipLaunchKernelGGL((enc_mlp_bwd_kernel<128, 352, true>), dim3((M + R - 1) / R, 2), dim3(NTH), (MG<128, 352>::LDS_BWD), s, a);
+        else hipLaunchKernelGGL((enc_mlp_bwd_kernel<128, 352>), dim3((M + R - 1) / R), dim3(NTH), (MG<128, 352>::LDS_BWD), s, a);
     } else if (d == 256) {
         constexpr int R = MG<256, 704>::R;
         set_attrs<256, 704>();
-        hipLaunchKernelGGL((enc_mlp_bwd_kernel<256, 704>), dim3((M + R - 1) / R, npair), dim3(NTH), (MG<256, 704>::LDS_BWD), s, a);
+        hipLaunchKernelGGL((enc_mlp_bwd_kernel<256, 704>), dim3((M + R - 1) / R), dim3(NTH), (MG<256, 704>::LDS_BWD), s, a);
     } else if (d == 64) {
         constexpr int R = MG<64, 192>::R;
         set_attrs<64, 192>();
-        hipLaunchKernelGGL((enc_mlp_bwd_kernel<64, 192>), dim3((M + R - 1) / R, npair), dim3(NTH), (MG<64, 192>::LDS_BWD), s, a);
+        hipLaunchKernelGGL((enc_mlp_bwd_kernel<64, 192>), dim3((M + R - 1) / R), dim3(NTH), (MG<64, 192>::LDS_BWD), s, a);
     } else {
         return HS_EUNSUPPORTED;
     }

@@ -29,8 +29,9 @@ __device__ __forceinline__ int swz(int row) { return row & 15; }
 
 struct GemmParams2 { GemmParams v[2]; };      // pair launch: blockIdx.y picks the argument set (see fused_enc.hip EncMlpFwdArgs2)
 
+template <bool PAIR>
 __global__ __launch_bounds__(256, 2) void lnbwd_dma_kernel(GemmParams2 pp) {
-    const GemmParams& p = pp.v[blockIdx.y];
+    const GemmParams& p = pp.v[PAIR ? blockIdx.y : 0];
     __shared__ __attribute__((aligned(16))) bf16_t stage0[DC * KA];
     __shared__ __attribute__((aligned(16))) bf16_t stage1[DC * KA];
     __shared__ __attribute__((aligned(16))) float T1[DC * TSX];
@@ -319,7 +320,7 @@ int hs_lnbwd_dma(const GemmParams& p, hipStream_t s) {
     if (!hs_lnbwd_dma_supported(p)) return HS_EUNSUPPORTED;
     const int nchunks = (p.M + DC - 1) / DC;
     GemmParams2 pp; pp.v[0] = p; pp.v[1] = p;
-    hipLaunchKernelGGL(lnbwd_dma_kernel, dim3(nchunks < 512 ? nchunks : 512), dim3(256), 0, s, pp);
+    hipLaunchKernelGGL(lnbwd_dma_kernel<false>, dim3(nchunks < 512 ? nchunks : 512), dim3(256), 0, s, pp);
     return (int)hipGetLastError();
 }
 
@@ -329,6 +330,6 @@ int hs_lnbwd_dma_pair(const GemmParams& a, const GemmParams& b, hipStream_t s) {
     if (a.M != b.M || !hs_lnbwd_dma_supported(a) || !hs_lnbwd_dma_supported(b)) return HS_EUNSUPPORTED;
     const int nchunks = (a.M + DC - 1) / DC;
     GemmParams2 pp; pp.v[0] = a; pp.v[1] = b;
-    hipLaunchKernelGGL(lnbwd_dma_kernel, dim3(nchunks < 256 ? nchunks : 256, 2), dim3(256), 0, s, pp);
+    hipLaunchKernelGGL(lnbwd_dma_kernel<true>, dim3(nchunks < 256 ? nchunks : 256, 2), dim3(256), 0, s, pp);
     return (int)hipGetLastError();
 }
