@@ -37,6 +37,7 @@ def work(name, s):
     att_d = 2 * 2 * Md * Dd * TL
     t = {
         "blk128_fwd_kernel": (2 * Me * D * 4 * D + att_e, Me * (4 * D + 4 * D)),                       # x in, x1 out
+        "blk256_fwd_kernel": (2 * Me * D * 4 * D + att_e, Me * (4 * D + 4 * D)),                       # the same half at D = 256 (attn_wide.hip)
         "enc_mlp_fwd_kernel<128": (2 * Me * 3 * D * h, Me * 8 * D),
         "enc_mlp_fwd_kernel<256": (2 * Me * 3 * D * h, Me * 8 * D),
         "enc_mlp_fwd_kernel<64": (2 * Md * 3 * Dd * hd, Md * 8 * Dd),
