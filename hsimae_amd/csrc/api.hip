@@ -279,12 +279,52 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         CK(hs_rows_to_bf16(G0, w.g0b, M, dp, rs_m, s));
         CK(hs_rows_to_bf16(G1, w.g1b, M, dp, rs_a, s));
     }
+    // All weight / bias gradients of the block: 7 tasks for the batched weight-gradient kernel (every operand is a bf16 buffer on the
+    // fused path, so no launch below reads G0 / G1, which the LayerNorm-1 backward overwrites with dx when the caller runs in place).
+    // HSIMAE_WGRAD_SPLIT=1: two launches, each right behind the kernel that produced its operands (the MLP's three straight after
+    // the MLP-half backward, the attention's four after the attention backward), so that they are read while still cache-resident.
+    auto run_wgrad = [&](int first, int count) -> int {
+        WgradParams g; std::memset(&g, 0, sizeof(g));
+        auto task = [&](int id, const void* dO, int ldo, const hs_bf16* A, int lda, int N, int K, int64_t dW, int64_t db) {
+            if (id < first || id >= first + count) return;
+            WgradTask& t = g.t[g.ntasks++];
+            t.dO = dO; t.dO_f32 = 0; t.ldo = ldo; t.A = A; t.lda = lda; t.N = N; t.K = K; t.dW = grads + dW; t.ldw = K;
+            t.db = grads + db; t.dO_rowscale = nullptr;
+        };
+        task(0, w.dqkv, 3 * dp, b.u, dp, d, d, o.qw, o.qb);
+        task(1, w.dqkv + dp, 3 * dp, b.u, dp, d, d, o.kw, o.kb);
+        task(2, w.dqkv + 2 * dp, 3 * dp, b.u, dp, d, d, o.vw, o.vb);
+        task(3, w.g1b, dp, b.o, dp, d, d, o.pw, o.pb);              // all-bf16 operands: wgrad takes its LDS-DMA path
+        task(4, w.dh13, 2 * hp, b.u2, dp, h, d, o.w1w, o.w1b);
+        task(5, w.dh13 + hp, 2 * hp, b.u2, dp, h, d, o.w3w, o.w3b);
+        task(6, w.g0b, dp, b.g, hp, d, h, o.w2w, o.w2b);
+        g.M = (int)M; g.det_base = grads; g.det_acc = det_acc;
+        static int wslab = -1;                    // HSIMAE_WGRAD_SLAB=0: float atomics on dW also in the 256 x 256-tile launches
+        if (wslab < 0) { const char* e = getenv("HSIMAE_WGRAD_SLAB"); wslab = !(e && e[0] == '0'); }
+        g.slab = wslab ? w.slab : nullptr;        // this stream's slab
+        int tiles = 0;
+        for (int i = 0; i < g.ntasks; ++i) tiles += ((g.t[i].N + 127) / 128) * ((g.t[i].K + 127) / 128);
+        g.msplit = wgrad_msplit(tiles, M, concurrent);
+        return hs_wgrad(g, s);
+    };
+    static int wsplit_env = -1;
+    if (wsplit_env < 0) { const char* e = getenv("HSIMAE_WGRAD_SPLIT"); wsplit_env = (e && e[0] == '1'); }
+    const bool wsplit = wsplit_env && fmlp;
+    if (wsplit) CK(run_wgrad(4, 3));
     AttnParams a; std::memset(&a, 0, sizeof(a));
     a.qkv = b.qkv; a.ld = 3 * dp; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
     a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = dp; a.lse = b.lse; a.dout = w.dob; a.lddo = dp; a.dqkv = w.dqkv; a.kv_off = dp;
     static int fuse_pb = -1;                  // HSIMAE_FUSED_PROJ_BWD=0: keep the projection's data gradient a separate GEMM
     if (fuse_pb < 0) { const char* e = getenv("HSIMAE_FUSED_PROJ_BWD"); fuse_pb = !(e && e[0] == '0'); }
-    if (fuse_pb && fmlp && hs_attn_proj_fusable(a)) {    // dO = dx1 Wp inside the attention backward (dx1 = the bf16 copy from enc_mlp_bwd)
+    static int fuse_ln = -1;
+    if (fuse_ln < 0) { const char* e = getenv("HSIMAE_FUSED_LNBWD"); fuse_ln = !(e && e[0] == '0'); }
+    // round 4: dO, the attention backward, du and the LayerNorm-1 backward as ONE persistent launch (attn.hip blk128_bwd_kernel)
+    const bool blk_bwd = fuse_pb && fuse_ln && fmlp && !f8u && d == 128 && dp == d && dx_out != x_in && hs_attn_proj_fusable(a) &&
+                         hs_attn_block_bwd_fusable(d, heads, Ts);
+    if (blk_bwd) {
+        CK(hs_attn_block_bwd(b.qkv, b.o, b.lse, w.g1b, G1, x_in, P.n1w, P.pT, P.qkvT, w.dqkv, dx_out, grads + o.n1w, grads + o.n1b,
+                             grads, reinterpret_cast<long long*>(det_acc), Ts, nsamples, mode, len_l, accumulate, s));
+    } else if (fuse_pb && fmlp && hs_attn_proj_fusable(a)) {    // dO = dx1 Wp inside the attention backward (dx1 = the bf16 copy from enc_mlp_bwd)
         a.dout = w.g1b; a.projT_w = P.pT;
     } else {
         p = gp();
@@ -293,35 +333,12 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         w8(p, P.pT8);
         CK(hs_gemm(p, A_BF16, E_BF16, s));
     }
-    CK(hs_attn_bwd(a, s));
-    // Weight gradients first: the LayerNorm-backward GEMM below writes dx over G0 / G1 when the caller runs in place
-    WgradParams g; std::memset(&g, 0, sizeof(g));
-    auto task = [&](const void* dO, int f32, int ldo, const hs_bf16* A, int lda, int N, int K, int64_t dW, int64_t db,
-                    const float* rs = nullptr) {
-        WgradTask& t = g.t[g.ntasks++];
-        t.dO = dO; t.dO_f32 = f32; t.ldo = ldo; t.A = A; t.lda = lda; t.N = N; t.K = K; t.dW = grads + dW; t.ldw = K;
-        t.db = grads + db; t.dO_rowscale = f32 ? rs : nullptr;
-    };
-    task(w.dqkv, 0, 3 * dp, b.u, dp, d, d, o.qw, o.qb);
-    task(w.dqkv + dp, 0, 3 * dp, b.u, dp, d, d, o.kw, o.kb);
-    task(w.dqkv + 2 * dp, 0, 3 * dp, b.u, dp, d, d, o.vw, o.vb);
-    task(w.g1b, 0, dp, b.o, dp, d, d, o.pw, o.pb);              // all-bf16 operands: wgrad takes its LDS-DMA path
-    task(w.dh13, 0, 2 * hp, b.u2, dp, h, d, o.w1w, o.w1b);
-    task(w.dh13 + hp, 0, 2 * hp, b.u2, dp, h, d, o.w3w, o.w3b);
-    task(w.g0b, 0, dp, b.g, hp, d, h, o.w2w, o.w2b);
-    g.M = (int)M; g.det_base = grads; g.det_acc = det_acc;
-    static int wslab = -1;                    // HSIMAE_WGRAD_SLAB=0: float atomics on dW also in the 256 x 256-tile launches
-    if (wslab < 0) { const char* e = getenv("HSIMAE_WGRAD_SLAB"); wslab = !(e && e[0] == '0'); }
-    g.slab = wslab ? w.slab : nullptr;        // this stream's slab
-    int tiles = 0;
-    for (int i = 0; i < g.ntasks; ++i) tiles += ((g.t[i].N + 127) / 128) * ((g.t[i].K + 127) / 128);
-    g.msplit = wgrad_msplit(tiles, M, concurrent);
-    CK(hs_wgrad(g, s));
+    if (!blk_bwd) CK(hs_attn_bwd(a, s));
+    if (wsplit) CK(run_wgrad(0, 4)); else CK(run_wgrad(0, 7));
 
+    if (blk_bwd) return HSIMAE_OK;
     // du = dqkv * Wqkv and the LayerNorm-1 backward: one kernel at d = 128 (LN backward as the GEMM's epilogue,
     // du never goes to HBM), two otherwise.  HSIMAE_FUSED_LNBWD=0 forces the two-kernel form.
-    static int fuse_ln = -1;
-    if (fuse_ln < 0) { const char* e = getenv("HSIMAE_FUSED_LNBWD"); fuse_ln = !(e && e[0] == '0'); }
     const bool ln_fused = fuse_ln && ((d == 128 && !f8u) || wide_ln_fused(d, dp, f8));
     p = gp();
     p.A = w.dqkv; p.lda = 3 * dp; p.M = (int)M; p.N = dp; p.K = 3 * dp; p.n_valid = d; p.W = P.qkvT;

@@ -917,6 +917,26 @@ __global__ __launch_bounds__(512) void attn128_bwd_kernel(AttnParams p) {
 // its 48 columns of Wqkv and its 16 columns of Wp stay in registers for the whole launch, its q / k / v columns go
 // from the MFMA accumulators (operands swapped: a lane owns 4 consecutive columns of one token) into the LDS images
 // the attention reads, so the only workgroup barriers are LN1 -> products and attention -> projection.
+// Per-phase cycle accounting for scripts/phase_blk128_bwd.py (compiled only with -DHS_PHASE_TIMING; never in the shipped library)
+#ifdef HS_PHASE_TIMING
+}  // namespace
+__device__ unsigned long long hs_phase_cycles_b128[32];      // [0, 16): blk128_bwd_kernel, [16, 32): blk128_fwd_kernel
+extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases_b128(unsigned long long* out, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(hs_phase_cycles_b128), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(hs_phase_cycles_b128), z, sizeof(z)); }
+    return rc;
+}
+namespace {
+#define PHB_DECL unsigned long long ph_t0 = __builtin_readcyclecounter(), ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PHB(i) { const unsigned long long ph_t = __builtin_readcyclecounter(); ph_acc[i] += ph_t - ph_t0; ph_t0 = ph_t; }
+#define PHB_FLUSH() if (threadIdx.x == 64 * 5) { for (int i = 0; i < 12; ++i) atomicAdd(&hs_phase_cycles_b128[i], ph_acc[i]); }
+#define PHF_FLUSH() if (threadIdx.x == 64 * 5) { for (int i = 0; i < 12; ++i) atomicAdd(&hs_phase_cycles_b128[16 + i], ph_acc[i]); }
+#else
+#define PHB_DECL
+#define PHB(i)
+#define PHB_FLUSH()
+#define PHF_FLUSH()
+#endif
 struct Blk128Args {
     const float* x; const float* n1w; const float* n1b;
     const bf16_t* wqkv; const float* bqkv; const bf16_t* wp; const float* pb;
@@ -1005,6 +1025,7 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
                 cm[qt][kt][r] = (kc >= 0 && kc == qc) ? 0.f : -INFINITY;
             }
     }
+    PHB_DECL
     for (int first = blockIdx.x * SPW; first < p.nsamples; first += gridDim.x * SPW) {
         // global row of image row i (slot-major), or -1
         auto grow = [&](int irow) -> int64_t {
@@ -1039,8 +1060,11 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
                 if (gr >= 0) HS_NT(HS_NT_C, reinterpret_cast<bf16x8*>(p.u + gr * 128 + lc8), ub);
             }
         }
+        PHB(0)
         fetch(first + gridDim.x * SPW);                           // next group's rows fly during this one
+        PHB(1)
         lds_barrier();
+        PHB(2)
         // ---- q | k | v of this head: transposed accumulators -> 8-byte writes into the images
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
@@ -1055,6 +1079,7 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
                 *reinterpret_cast<bf16x4*>(img + (mt * 16 + c16) * FS + hc + 4 * g) = cvt4(acc);
             }
         }
+        PHB(3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // own writes before own reads (only this wave touches these columns)
         // ---- attention of this head (as attn128_fwd_kernel) slot by slot, O into its own image
 #pragma unroll
@@ -1101,7 +1126,9 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
                 if (g == 0) lse_s[query * 8 + head] = m + __builtin_amdgcn_logf(fmaxf(lsum, 1e-30f));
             }
         }
+        PHB(4)
         lds_barrier();
+        PHB(5)
         // ---- residual pieces of this wave's output tiles (L2-hot: the LayerNorm read the same rows)
         f32x4 xr[MTT];
         int64_t orow[MTT];
@@ -1111,6 +1138,8 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
             xr[mt] = orow[mt] >= 0 ? *reinterpret_cast<const f32x4*>(p.x + orow[mt] * 128 + hc + 4 * g) : z4;
         }
         // ---- saved activations leave as whole rows: q|k|v (48 pieces per row), o, lse
+        //      (round 4: moving the q|k|v stores into the next group's LayerNorm phase moved their cost with them — 727 M cycles per
+        //       step either way: the waves wait for the memory system wherever the stores are issued)
         for (int idx = threadIdx.x; idx < RT * 48; idx += 512) {
             const int irow = idx / 48, pc = idx - irow * 48;
             const int64_t gr = grow(irow);
@@ -1128,6 +1157,7 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
             const int64_t gr = grow(irow);
             if (gr >= 0) *reinterpret_cast<float4*>(p.lse + gr * 8 + (idx & 1) * 4) = *reinterpret_cast<const float4*>(lse_s + idx * 4);
         }
+        PHB(6)
         // ---- projection: this wave's 16 output columns; transposed accumulators -> x1 leaves as 16-byte pieces
         //      (rows c16, columns hc + 4 g ..: two heads complete a 128-byte line)
         const f32x4 pbias = *reinterpret_cast<const f32x4*>(vec_s + 640 + hc + 4 * g);
@@ -1145,9 +1175,11 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
                 *reinterpret_cast<f32x4*>(p.x1 + orow[mt] * 128 + hc + 4 * g) = ov;
             }
         }
+        PHB(7)
         // no barrier here: the next group's LayerNorm writes only U (its readers passed the barrier above), and its
         // q|k|v image writes come after its own first barrier, which every wave reaches after the row stores above
     }
+    PHF_FLUSH()
 }
 
 template <int NT, int SPW>
@@ -1162,6 +1194,370 @@ int launch_blk128(const Blk128Args& a, hipStream_t s) {
     if (!wgs) { const char* e = getenv("HSIMAE_BLK128_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 1) wgs = 256; }
     const int groups = (a.nsamples + SPW - 1) / SPW;
     hipLaunchKernelGGL((blk128_fwd_kernel<NT, SPW>), dim3(groups < wgs ? groups : wgs), dim3(512), (size_t)L::TOTAL, s, a);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The attention half of an encoder Block, BACKWARD, in one persistent kernel (d = 128, 8 heads, <= 32 tokens; round 4):
+//   dO = dx1 Wp;  dq|dk|dv = attention backward per head;  du = dq|dk|dv Wqkv;  dx = dx1 + LayerNorm1-backward(du; x),  dgamma / dbeta
+// (autograd of Models.py:303-304 with Attention.forward :192-219).  Replaces attn128_bwd_kernel + lnbwd_dma_kernel: dq|dk|dv
+// are written once (the q / k / v weight gradients' operand) and not read back, x and dx1 are read once.  Mirror image of
+// blk128_fwd_kernel: wave h owns head h in the attention and output columns 16 h .. 16 h + 15 of both products, whose weight
+// slices (4 + 12 packed fragments = 64 registers) stay in registers for the whole launch; two samples per iteration; the next
+// group's q|k|v / O / dx1 rows are fetched into registers while du and the LayerNorm epilogue of this one run.
+struct Blk128BwdArgs {
+    const bf16_t* qkv; const bf16_t* o; const float* lse;        // saved by the forward: [rows][384] | [rows][128] | [rows][8]
+    const bf16_t* dx1b; const float* dx1;                        // the projection's dY as bf16 (DropPath factor folded in) | the residual gradient
+    const float* x; const float* gamma;                          // block input, LayerNorm-1 weight
+    const bf16_t* wpT; const bf16_t* wqkvT;                      // packed images of Wp^T [n = 128][k = 128] and Wqkv^T [n = 128][k = 384]
+    bf16_t* dqkv; float* dx; float* dgamma; float* dbeta;
+    const float* det_base; long long* det_acc;
+    int Ts, nsamples, mode, len_l, accumulate;
+};
+
+template <int NT, int SPW>
+struct LayBB {
+    static constexpr int ROWS = NT * 16, RT = SPW * ROWS, IMG = RT * FS;
+    static constexpr int DUS = 132;                              // fp32 du tile row stride
+    static constexpr int TT = 8 * 2 * 16 * RS16;                 // per-wave P / dS transposition tiles (elements)
+    static constexpr int RED = 2 * 512 * 8 * 4;                  // final dgamma / dbeta reduction (bytes), over the du tile
+    static constexpr int DUB = RT * DUS * 4 > RED ? RT * DUS * 4 : RED;
+    // cls | Q K V dO dX | T | lse delta | du | gamma
+    static constexpr int TOTAL = RT * 4 + 5 * IMG * 2 + TT * 2 + 2 * 8 * RT * 4 + DUB + 128 * 4;
+};
+
+template <int NT, int SPW>
+__global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
+    using L = LayBB<NT, SPW>;
+    constexpr int ROWS = L::ROWS, RT = L::RT, MTT = SPW * NT, DUS = L::DUS;
+    constexpr int PASSES = (RT * 16 + 511) / 512;               // wide layout: 16 lanes per row, 32 rows per pass
+    constexpr int NQ = (RT * 48 + 511) / 512;                   // q|k|v pieces per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int* cls = reinterpret_cast<int*>(smem);
+    bf16_t* Qf = reinterpret_cast<bf16_t*>(smem + RT * 4);
+    bf16_t* Kf = Qf + L::IMG;
+    bf16_t* Vf = Kf + L::IMG;
+    bf16_t* Df = Vf + L::IMG;                                   // O, then dO (per head in place)
+    bf16_t* Xf = Df + L::IMG;                                   // dx1 rows (bf16)
+    bf16_t* Tp = Xf + L::IMG + head * (2 * 16 * RS16);          // this wave's P / dS transposition tiles
+    bf16_t* Td = Tp + 16 * RS16;
+    float* lse_s = reinterpret_cast<float*>(Xf + L::IMG + L::TT);       // [8][RT]
+    float* dlt_s = lse_s + 8 * RT;                              // [8][RT]
+    float* DU = dlt_s + 8 * RT;                                 // [RT][DUS]
+    float* gam_s = reinterpret_cast<float*>(reinterpret_cast<char*>(DU) + L::DUB);
+    const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3, hc = head * 16;
+    const float scale = 0.25f, sc = 0.25f * 1.4426950408889634f;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const int troff = (4 * g + q4) * FS + hc + 4 * p4;
+    const int ttoff = (4 * g + q4) * RS16 + 4 * p4;
+
+    // this wave's weights: n-tile `head` of Wp^T (dO columns of its head) and of Wqkv^T (its 16 du columns)
+    bf16x8 wo[4], wu[12];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wo[ks] = *reinterpret_cast<const bf16x8*>(p.wpT + ((size_t)(head * 4 + ks) * 64 + lane) * 8);
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks) wu[ks] = *reinterpret_cast<const bf16x8*>(p.wqkvT + ((size_t)(head * 12 + ks) * 64 + lane) * 8);
+    float dgam[8], dbet[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; }
+    if (threadIdx.x < 128) gam_s[threadIdx.x] = p.gamma[threadIdx.x];
+    for (int i = threadIdx.x; i < RT; i += 512) {
+        const int slot = i / ROWS, r = i - slot * ROWS;
+        int c = -1;
+        if (r < p.Ts) c = slot * 64 + ((p.mode == 1) ? r / p.len_l : (p.mode == 2) ? r % p.len_l : 0);
+        cls[i] = c;
+    }
+    auto grow = [&](int first, int irow) -> int64_t {            // global row of image row irow (slot-major) of the group, or -1
+        const int slot = irow / ROWS, r = irow - slot * ROWS;
+        return (first + slot < p.nsamples && r < p.Ts) ? (int64_t)(first + slot) * p.Ts + r : -1;
+    };
+    // a group's inputs as register pieces: q|k|v (NQ), O and dx1 (PASSES each), lse (one float per (row, head) pair)
+    struct Pre { bf16x8 q[NQ], o[PASSES], d[PASSES]; float l[(RT * 8 + 511) / 512]; };
+    // (issued in three parts spread over the group's compute phases: every CU bursting its ~200 KB per group at once runs into the
+    //  memory system's back-pressure, and a wave blocked at issue computes nothing: 26 % of the kernel in the first version)
+    auto fetch_q = [&](int first, Pre& r, int tx, int i0, int i1) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (i < i0 || i >= i1) continue;
+            const int idx = tx + 512 * i, irow = idx / 48, pc = idx - irow * 48;
+            const int64_t gr = irow < RT ? grow(first, irow) : -1;
+            r.q[i] = gr >= 0 ? *reinterpret_cast<const bf16x8*>(p.qkv + gr * 384 + pc * 8) : zero8();
+        }
+    };
+    auto fetch_rest = [&](int first, Pre& r, int tx) {
+        const int lc8 = (tx & 15) * 8;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int irow = i * 32 + (tx >> 4);
+            const int64_t gr = irow < RT ? grow(first, irow) : -1;
+            r.o[i] = gr >= 0 ? *reinterpret_cast<const bf16x8*>(p.o + gr * 128 + lc8) : zero8();
+            r.d[i] = gr >= 0 ? *reinterpret_cast<const bf16x8*>(p.dx1b + gr * 128 + lc8) : zero8();
+        }
+#pragma unroll
+        for (int i = 0; i < (RT * 8 + 511) / 512; ++i) {
+            const int idx = tx + 512 * i, irow = idx >> 3;
+            const int64_t gr = irow < RT ? grow(first, irow) : -1;
+            r.l[i] = gr >= 0 ? p.lse[gr * 8 + (idx & 7)] : 1e30f;             // padding rows: exp2(s - 1e30) = 0
+        }
+    };
+    auto commit = [&](const Pre& r, int tx) {
+        const int lc8 = (tx & 15) * 8;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int idx = tx + 512 * i, irow = idx / 48, pc = idx - irow * 48;
+            if (irow < RT) *reinterpret_cast<bf16x8*>(Qf + (pc >> 4) * L::IMG + irow * FS + (pc & 15) * 8) = r.q[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int irow = i * 32 + (tx >> 4);
+            if (irow < RT) {
+                *reinterpret_cast<bf16x8*>(Df + irow * FS + lc8) = r.o[i];
+                *reinterpret_cast<bf16x8*>(Xf + irow * FS + lc8) = r.d[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (RT * 8 + 511) / 512; ++i) {
+            const int idx = tx + 512 * i, irow = idx >> 3;
+            if (irow < RT) lse_s[(idx & 7) * RT + irow] = r.l[i];
+        }
+    };
+    {
+        Pre r0;
+        fetch_q(blockIdx.x * SPW, r0, threadIdx.x, 0, NQ);
+        fetch_rest(blockIdx.x * SPW, r0, threadIdx.x);
+        lds_barrier();                                            // cls visible
+        commit(r0, threadIdx.x);
+    }
+    PHB_DECL
+    for (int first = blockIdx.x * SPW; first < p.nsamples; first += gridDim.x * SPW) {
+        lds_barrier();                                            // the group's images are complete
+        PHB(0)
+        // (every per-thread index below derives from a copy of the thread id the compiler cannot see through: hoisted out of
+        //  the sample loop, these ~40 addresses and row numbers spill; recomputed, they cost ~100 VALU instructions per group)
+        int tx = threadIdx.x;
+        asm volatile("" : "+v"(tx));
+        const int lc8 = (tx & 15) * 8;
+        // ---- the next group's inputs start to fly (three parts spread over this group's phases)
+        Pre nx;
+        const int nfirst = first + gridDim.x * SPW;
+        const bool more = nfirst < p.nsamples;
+        if (more) fetch_q(nfirst, nx, tx, 0, NQ / 2);
+        PHB(1)
+        // ---- dO[:, this head's columns] = dx1 Wp, delta = rowsum(dO * O) of this head; dO replaces O in place (own columns)
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) {
+            f32x4 acc = z4;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc = mfma16(wo[ks], *reinterpret_cast<const bf16x8*>(Xf + (mt * 16 + c16) * FS + ks * 32 + g * 8), acc);
+            bf16_t* cell = Df + (mt * 16 + c16) * FS + hc + 4 * g;
+            const bf16x4 o4 = *reinterpret_cast<const bf16x4*>(cell), dob = cvt4(acc);
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v += bf2f(dob[r]) * bf2f(o4[r]);
+            v = rows_sum(v);
+            if (g == 0) dlt_s[head * RT + mt * 16 + c16] = v;
+            *reinterpret_cast<bf16x4*>(cell) = dob;
+        }
+        if (more) fetch_q(nfirst, nx, tx, NQ / 2, NQ);
+        PHB(2)
+        // class / padding mask of a (query tile, key tile) pair, as the accumulator the score MFMA starts from (0 or -inf): rebuilt
+        // from LDS per group — 16 registers that would otherwise live (or spill) through the product / epilogue phases
+        f32x4 cm[NT][NT];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            const int qc = cls[qt * 16 + c16];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const int4 kc4 = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
+                const int kcl[4] = {kc4.x, kc4.y, kc4.z, kc4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cm[qt][kt][r] = (kcl[r] >= 0 && kcl[r] == qc) ? 0.f : -INFINITY;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // own writes before own reads
+        // ---- attention backward of this head (as attn128_bwd_kernel), slot by slot; dq, dk, dv in place
+        const float* lse_h = lse_s + head * RT;
+        const float* dlt_h = dlt_s + head * RT;
+#pragma unroll
+        for (int slot = 0; slot < SPW; ++slot) {
+            const int r0 = slot * ROWS;
+            f32x4 dkT[NT], dvT[NT];
+            bf16x4 KT[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) { dkT[kt] = z4; dvT[kt] = z4; KT[kt] = tr4(Kf + (r0 + kt * 16) * FS + troff); }
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) {
+                if (qt * 16 >= p.Ts) break;
+                const int query = r0 + qt * 16 + c16;
+                const bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qf + query * FS + hc + 4 * g);
+                const bf16x4 bdo = *reinterpret_cast<const bf16x4*>(Df + query * FS + hc + 4 * g);
+                const float lqn = -lse_h[query], dl = dlt_h[query];
+                const bf16x4 QT = tr4(Qf + (r0 + qt * 16) * FS + troff);
+                const bf16x4 DT = tr4(Df + (r0 + qt * 16) * FS + troff);
+                f32x4 dqT = z4;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (r0 + kt * 16 + c16) * FS + hc + 4 * g);
+                    const bf16x4 av = *reinterpret_cast<const bf16x4*>(Vf + (r0 + kt * 16 + c16) * FS + hc + 4 * g);
+                    const f32x4 sv = mfma_k16(ak, bq, cm[qt][kt]);
+                    const f32x4 dp = mfma_k16(av, bdo, z4);
+                    f32x4 pv, ds;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pv[r] = __builtin_amdgcn_exp2f(fmaf(sv[r], sc, lqn));
+                        ds[r] = pv[r] * (dp[r] - dl);
+                    }
+                    const bf16x4 pb = cvt4(pv), dsb = cvt4(ds);
+                    dqT = mfma_k16(KT[kt], dsb, dqT);
+                    *reinterpret_cast<bf16x4*>(Tp + c16 * RS16 + 4 * g) = pb;
+                    *reinterpret_cast<bf16x4*>(Td + c16 * RS16 + 4 * g) = dsb;
+                    asm volatile("" ::: "memory");
+                    const bf16x4 Bp = tr4(Tp + ttoff), Bds = tr4(Td + ttoff);
+                    dkT[kt] = mfma_k16(QT, Bds, dkT[kt]);
+                    dvT[kt] = mfma_k16(DT, Bp, dvT[kt]);
+                }
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dqT[r] * scale);
+                *reinterpret_cast<bf16x4*>(Qf + query * FS + hc + 4 * g) = v;
+            }
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const int key = r0 + kt * 16 + c16;
+                bf16x4 vk, vv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { vk[r] = (bf16_t)(dkT[kt][r] * scale); vv[r] = (bf16_t)dvT[kt][r]; }
+                *reinterpret_cast<bf16x4*>(Kf + key * FS + hc + 4 * g) = vk;
+                *reinterpret_cast<bf16x4*>(Vf + key * FS + hc + 4 * g) = vv;
+            }
+            if (slot == 0 && more) fetch_rest(nfirst, nx, tx);
+        }
+        // ---- the rows the LayerNorm epilogue needs (wide layout) fly during the row stores and the du product
+        float xr[PASSES][8], rs[PASSES][8];
+        int64_t erow[PASSES];
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int irow = ps * 32 + (tx >> 4);
+            erow[ps] = irow < RT ? grow(first, irow) : -1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xr[ps][e] = 0.f; rs[ps][e] = 0.f; }
+            if (erow[ps] >= 0) {
+                const float* xp = p.x + erow[ps] * 128 + lc8;
+                const float* rp = p.dx1 + erow[ps] * 128 + lc8;
+                const float4 a0 = *reinterpret_cast<const float4*>(xp), a1 = *reinterpret_cast<const float4*>(xp + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(rp), b1 = *reinterpret_cast<const float4*>(rp + 4);
+                xr[ps][0] = a0.x; xr[ps][1] = a0.y; xr[ps][2] = a0.z; xr[ps][3] = a0.w; xr[ps][4] = a1.x; xr[ps][5] = a1.y; xr[ps][6] = a1.z; xr[ps][7] = a1.w;
+                rs[ps][0] = b0.x; rs[ps][1] = b0.y; rs[ps][2] = b0.z; rs[ps][3] = b0.w; rs[ps][4] = b1.x; rs[ps][5] = b1.y; rs[ps][6] = b1.z; rs[ps][7] = b1.w;
+                if (p.accumulate) {
+                    const float* op = p.dx + erow[ps] * 128 + lc8;
+                    const float4 c0 = *reinterpret_cast<const float4*>(op), c1 = *reinterpret_cast<const float4*>(op + 4);
+                    rs[ps][0] += c0.x; rs[ps][1] += c0.y; rs[ps][2] += c0.z; rs[ps][3] += c0.w; rs[ps][4] += c1.x; rs[ps][5] += c1.y; rs[ps][6] += c1.z; rs[ps][7] += c1.w;
+                }
+            }
+        }
+        PHB(3)
+        lds_barrier();                                            // dq | dk | dv images complete
+        PHB(4)
+        // ---- dq|dk|dv leave as whole rows (the q / k / v weight gradients' operand), a few pieces in front of every m-tile of
+        //      du[:, this wave's 16 columns] = dq|dk|dv Wqkv (contraction over the 384 image columns) -> fp32 tile
+        auto store_q = [&](int i0, int i1) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                if (i < i0 || i >= i1) continue;
+                const int idx = tx + 512 * i, irow = idx / 48, pc = idx - irow * 48;
+                const int64_t gr = irow < RT ? grow(first, irow) : -1;
+                if (gr >= 0)
+                    HS_NT(HS_NT_E, reinterpret_cast<bf16x8*>(p.dqkv + gr * 384 + pc * 8),
+                          *reinterpret_cast<const bf16x8*>(Qf + (pc >> 4) * L::IMG + irow * FS + (pc & 15) * 8));
+            }
+        };
+        PHB(5)
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) {
+            store_q(mt * NQ / MTT, (mt + 1) * NQ / MTT);
+            f32x4 acc = z4;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    acc = mfma16(wu[m * 4 + ks], *reinterpret_cast<const bf16x8*>(Qf + m * L::IMG + (mt * 16 + c16) * FS + ks * 32 + g * 8), acc);
+            *reinterpret_cast<f32x4*>(DU + (mt * 16 + c16) * DUS + hc + 4 * g) = acc;
+            asm volatile("" ::: "memory");
+        }
+        PHB(6)
+        lds_barrier();                                            // du tile complete; every read of the images is done
+        PHB(7)
+        // ---- LayerNorm-1 backward + residual gradient, wide layout (as lnbwd_dma_kernel's epilogue)
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int irow = ps * 32 + (tx >> 4);
+            if (irow < RT) {
+                const float4 t0 = *reinterpret_cast<const float4*>(DU + irow * DUS + lc8);
+                const float4 t1 = *reinterpret_cast<const float4*>(DU + irow * DUS + lc8 + 4);
+                const float du[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                float sm = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm += xr[ps][e];
+                sm = lanes_sum<16>(sm);
+                const float mean = sm * (1.f / 128.f);
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xr[ps][e] -= mean; q += xr[ps][e] * xr[ps][e]; }
+                q = lanes_sum<16>(q);
+                const float rstd = rsqrtf(q * (1.f / 128.f) + 1e-5f);
+                const float4 g0 = *reinterpret_cast<const float4*>(gam_s + lc8), g1 = *reinterpret_cast<const float4*>(gam_s + lc8 + 4);
+                const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                float a = 0.f, b = 0.f, t[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xr[ps][e] *= rstd; t[e] = du[e] * gm[e]; a += t[e]; b += t[e] * xr[ps][e]; }
+                a = lanes_sum<16>(a); b = lanes_sum<16>(b);
+                a *= (1.f / 128.f); b *= (1.f / 128.f);
+                if (erow[ps] >= 0) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[e] = rs[ps][e] + rstd * (t[e] - a - xr[ps][e] * b);
+                        dgam[e] += du[e] * xr[ps][e];
+                        dbet[e] += du[e];
+                    }
+                    float* op = p.dx + erow[ps] * 128 + lc8;
+                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+        }
+        PHB(8)
+        if (more) commit(nx, tx);                                     // images / lse of the next group (their readers are past the barrier above)
+        PHB(9)
+    }
+    PHB_FLUSH()
+    // dgamma / dbeta: 32 threads per column octet -> LDS, one commit per column and workgroup
+    lds_barrier();
+    float* red = DU;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[threadIdx.x * 8 + e] = dgam[e]; red[4096 + threadIdx.x * 8 + e] = dbet[e]; }
+    lds_barrier();
+    if (threadIdx.x < 256) {
+        const int which = threadIdx.x >> 7, c = threadIdx.x & 127, o8 = c >> 3, e = c & 7;
+        float sacc = 0.f;
+        for (int t2 = o8; t2 < 512; t2 += 16) sacc += red[which * 4096 + t2 * 8 + e];
+        hs_gadd(HsDet{p.det_base, p.det_acc}, (which ? p.dbeta : p.dgamma) + c, sacc);
+    }
+}
+
+template <int NT, int SPW>
+int launch_blk128_bwd(const Blk128BwdArgs& a, hipStream_t s) {
+    using L = LayBB<NT, SPW>;
+    static_assert(L::TOTAL <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk128_bwd_kernel<NT, SPW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::TOTAL); attr_set = true; }
+    static int wgs = 0;
+    if (!wgs) { const char* e = getenv("HSIMAE_BLK128_BWD_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 1) wgs = 256; }
+    const int groups = (a.nsamples + SPW - 1) / SPW;
+    hipLaunchKernelGGL((blk128_bwd_kernel<NT, SPW>), dim3(groups < wgs ? groups : wgs), dim3(512), (size_t)L::TOTAL, s, a);
     return (int)hipGetLastError();
 }
 
@@ -1309,3 +1705,22 @@ int hs_attn_block_fwd(const float* x, const float* n1w, const float* n1b, const 
     if (spw == 1) return Ts <= 16 ? launch_blk128<1, 1>(a, s) : launch_blk128<2, 1>(a, s);
     return Ts <= 16 ? launch_blk128<1, 2>(a, s) : launch_blk128<2, 2>(a, s);
 }
+
+// dO + attention backward + du + LayerNorm-1 backward in one launch (see blk128_bwd_kernel).  HSIMAE_FUSED_ATTN_BLOCK_BWD=0 disables.
+bool hs_attn_block_bwd_fusable(int d, int heads, int Ts) {
+    const char* e = getenv("HSIMAE_FUSED_ATTN_BLOCK_BWD");    // read per call: the parity test flips it inside one process
+    return !(e && e[0] == '0') && hs_attn_block_fusable(d, heads, Ts);
+}
+int hs_attn_block_bwd(const hs_bf16* qkv, const hs_bf16* o, const float* lse, const hs_bf16* dx1b, const float* dx1, const float* x,
+                      const float* gamma, const hs_bf16* wpT, const hs_bf16* wqkvT, hs_bf16* dqkv, float* dx, float* dgamma,
+                      float* dbeta, const float* det_base, long long* det_acc, int Ts, int nsamples, int mode, int len_l,
+                      int accumulate, hipStream_t s) {
+    if (nsamples <= 0) return HS_OK;
+    if (Ts < 1 || Ts > 32) return HS_EUNSUPPORTED;
+    Blk128BwdArgs a;
+    a.qkv = qkv; a.o = o; a.lse = lse; a.dx1b = dx1b; a.dx1 = dx1; a.x = x; a.gamma = gamma; a.wpT = wpT; a.wqkvT = wqkvT;
+    a.dqkv = dqkv; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta; a.det_base = det_base; a.det_acc = det_acc;
+    a.Ts = Ts; a.nsamples = nsamples; a.mode = mode; a.len_l = len_l; a.accumulate = accumulate;
+    return Ts <= 16 ? launch_blk128_bwd<1, 2>(a, s) : launch_blk128_bwd<2, 2>(a, s);
+}
+

@@ -447,6 +447,45 @@ def test_fused_attention_half_matches_separate_kernels(bands, grid, N):
     print(f"[fused-attn-half {bands}] worst grad rms-rel vs separate {worst}")
 
 
+@pytest.mark.parametrize("bands,grid,N,det", [(48, (2, 7), 37, False), (96, (3, 9), 24, False), (96, (9, 3), 25, False), (96, (9, 3), 1, False),
+                                              (96, (3, 9), 24, True)])
+def test_fused_attention_half_backward_matches_separate_kernels(bands, grid, N, det):
+    """blk128_bwd_kernel (dO = dx1 Wp -> attention backward -> du = dq|dk|dv Wqkv -> LayerNorm-1 backward + residual, dgamma /
+    dbeta, in one persistent launch) against attn128_bwd_kernel + lnbwd_dma_kernel after the SAME forward: every gradient (the
+    q / k / v weight gradients read the dq|dk|dv rows the kernel writes, everything upstream reads its dx), both axis-class modes
+    and the whole-sample fusion blocks, odd sample counts (pairs of samples per iteration), 14-token sequences (one key tile), the
+    block whose dx accumulates into the other stack's, and the deterministic commit path of dgamma / dbeta."""
+    cfg = O.OracleConfig(bands=bands)
+    m = build(cfg, O.init_state(cfg, seed=13, std=0.06))
+    m.deterministic = det
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand(N, 1, bands, 9, 9, generator=g).to(DEV)
+    n = (torch.rand(N, bands // 8, generator=g), torch.rand(N, 9, generator=g))
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["HSIMAE_FUSED_ATTN_BLOCK_BWD"] = mode
+        try:
+            m.zero_grad()
+            loss, pred, _ = m(x, 0.75, noise=n, grid=grid)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = (loss.item(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        finally:
+            os.environ.pop("HSIMAE_FUSED_ATTN_BLOCK_BWD", None)
+    (l0, g0), (l1, g1) = res["0"], res["1"]
+    assert l0 == l1                                     # same forward kernels
+    worst = ("", 0.0)
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        if k.endswith("attn.k.bias"):
+            continue
+        r = rms_rel(g1[k], g0[k])
+        if r > worst[1]:
+            worst = (k, r)
+        assert r < 5e-3, (k, r)
+    print(f"[fused-attn-half-bwd {bands} {grid} N={N} det={det}] worst grad rms-rel vs separate {worst}")
+
+
 @pytest.mark.parametrize("bands,grid,N", [(96, (3, 9), 21), (96, (9, 3), 21), (48, (2, 7), 9), (96, (3, 9), 1)])
 def test_fused_attention_half_d256_matches_separate_kernels(bands, grid, N):
     """blk256_fwd_kernel (attn_wide.hip: LN1 -> q|k|v -> attention -> projection + residual of a D = 256 block in one persistent
