@@ -170,6 +170,15 @@ int dec_block_fwd_fused(const BlkP& bp, const float* z, const BlkBuf& b, int N, 
     return hs_dec_block_fwd(z, b.x1, b.x2, b.o, b.lse, N, TL, dec_ptrs(bp, hdec), s);
 }
 
+// The attention half's backward as ONE launch that recomputes q|k|v from u (attn.hip blk128_bwd_kernel<RC>): decided by the same
+// predicate in the forward (which then does not store q|k|v) and in the backward.  The environment switches are read per call so
+// that a parity test can flip them around a whole forward + backward pair.
+static bool attn_bwd_recompute(int d, int dp, int heads, int h, int Ts, bool f8u) {
+    const char* e1 = getenv("HSIMAE_FUSED_PROJ_BWD"); const char* e2 = getenv("HSIMAE_FUSED_LNBWD"); const char* e3 = getenv("HSIMAE_ATTN_BWD_RECOMPUTE");
+    if ((e1 && e1[0] == '0') || (e2 && e2[0] == '0') || (e3 && e3[0] == '0')) return false;
+    return !f8u && d == 128 && dp == d && fused_mlp_enabled(d, h) && hs_attn_block_bwd_fusable(d, heads, Ts);
+}
+
 // One transformer Block forward (Models.py:303-306): 5 launches.
 // rs_a / rs_m: optional per-row DropPath factors of the attention / MLP branch (Models.py:304-305), NULL = none.
 int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int d, int heads, int h, int hp, int Ts,
@@ -182,8 +191,8 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
     auto w8 = [&](GemmParams& q, const BlkP::I8& a) { if (f8) { q.prec = HSIMAE_PREC_FP8; q.W8 = a.w; q.S8 = a.s; } };
     if (!f8u && hs_attn_block_fusable(d, heads, Ts)) {
         // LN1 + q|k|v + attention + projection + residual in one persistent kernel (attn.hip blk128_fwd_kernel)
-        CK(hs_attn_block_fwd(x_in, P.n1w, P.n1b, P.qkv, P.bqkv, P.p, P.pb, b.u, b.qkv, b.o, b.lse, b.x1, rs_a, Ts, nsamples, mode,
-                             len_l, s));
+        CK(hs_attn_block_fwd(x_in, P.n1w, P.n1b, P.qkv, P.bqkv, P.p, P.pb, b.u, attn_bwd_recompute(d, dp, heads, h, Ts, f8u) ? nullptr : b.qkv,
+                             b.o, b.lse, b.x1, rs_a, Ts, nsamples, mode, len_l, s));
         if (fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
     } else if (!f8 && dp == d && hs_attn_block256_fusable(d, heads, Ts)) {
         // the same half at D = 256 (attn_wide.hip blk256_fwd_kernel: 16 waves = 16 heads, weights streamed from L2)
@@ -318,12 +327,15 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     if (fuse_pb < 0) { const char* e = getenv("HSIMAE_FUSED_PROJ_BWD"); fuse_pb = !(e && e[0] == '0'); }
     static int fuse_ln = -1;
     if (fuse_ln < 0) { const char* e = getenv("HSIMAE_FUSED_LNBWD"); fuse_ln = !(e && e[0] == '0'); }
-    // round 4: dO, the attention backward, du and the LayerNorm-1 backward as ONE persistent launch (attn.hip blk128_bwd_kernel)
-    const bool blk_bwd = fuse_pb && fuse_ln && fmlp && !f8u && d == 128 && dp == d && dx_out != x_in && hs_attn_proj_fusable(a) &&
-                         hs_attn_block_bwd_fusable(d, heads, Ts);
+    // round 4: dO, the attention backward, du and the LayerNorm-1 backward as ONE persistent launch (attn.hip blk128_bwd_kernel);
+    // with q|k|v recomputed from u when the forward did not save them (attn_bwd_recompute: the same predicate there)
+    const bool rc = attn_bwd_recompute(d, dp, heads, h, Ts, f8u);
+    const bool blk_bwd = rc || (fuse_pb && fuse_ln && fmlp && !f8u && d == 128 && dp == d && hs_attn_proj_fusable(a) &&
+                                hs_attn_block_bwd_fusable(d, heads, Ts));
     if (blk_bwd) {
-        CK(hs_attn_block_bwd(b.qkv, b.o, b.lse, w.g1b, G1, x_in, P.n1w, P.pT, P.qkvT, w.dqkv, dx_out, grads + o.n1w, grads + o.n1b,
-                             grads, reinterpret_cast<long long*>(det_acc), Ts, nsamples, mode, len_l, accumulate, s));
+        CK(hs_attn_block_bwd(rc ? nullptr : b.qkv, b.u, P.qkv, P.bqkv, b.o, b.lse, w.g1b, G1, x_in, P.n1w, P.pT, P.qkvT, w.dqkv, dx_out,
+                             grads + o.n1w, grads + o.n1b, grads, reinterpret_cast<long long*>(det_acc), Ts, nsamples, mode, len_l,
+                             accumulate, s));
     } else if (fuse_pb && fmlp && hs_attn_proj_fusable(a)) {    // dO = dx1 Wp inside the attention backward (dx1 = the bf16 copy from enc_mlp_bwd)
         a.dout = w.g1b; a.projT_w = P.pT;
     } else {

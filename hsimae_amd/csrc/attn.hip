@@ -21,6 +21,12 @@
 #ifndef HS_NT_C
 #define HS_NT_C 1      /* u / q|k|v / o saved by blk128_fwd for the backward: read ~10 ms later (step -0.5 %) */
 #endif
+#ifndef HS_BF_XCOPY
+#define HS_BF_XCOPY 1          /* blk128_fwd_kernel: residual from an fp32 LDS copy of x (1) or re-read from L2 (0) */
+#endif
+#ifndef HS_BB_WQ_RESIDENT
+#define HS_BB_WQ_RESIDENT 1   /* blk128_bwd_kernel<RC>: forward Wqkv fragments resident (1) or streamed from L2 per group (0) */
+#endif
 #ifndef HS_NT_E
 #define HS_NT_E 0      /* dqkv of attn128_bwd */
 #endif
@@ -952,8 +958,9 @@ struct LayB {
     static constexpr int ROWS = NT * 16;                 // rows of one slot
     static constexpr int RT = SPW * ROWS;                // rows of the images
     static constexpr int IMG = RT * FS;
-    // cls | U | Q K V | O | lse | vectors (gamma | beta | bqkv | bp)
-    static constexpr int TOTAL = RT * 4 + 5 * IMG * 2 + RT * 8 * 4 + 768 * 4;
+    static constexpr int XS = 132;                       // fp32 copy of the group's x rows (the residual): row stride
+    // cls | U | Q K V | O | lse | vectors (gamma | beta | bqkv | bp) | X
+    static constexpr int TOTAL = RT * 4 + 5 * IMG * 2 + RT * 8 * 4 + 768 * 4 + HS_BF_XCOPY * RT * XS * 4;
 };
 
 template <int NT, int SPW>
@@ -984,6 +991,7 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
     for (int ks = 0; ks < 4; ++ks) wpj[ks] = *reinterpret_cast<const bf16x8*>(p.wp + ((size_t)(head * 4 + ks) * 64 + lane) * 8);
     // vectors every sample needs live in LDS, not in registers (the weights take 64)
     float* vec_s = lse_s + RT * 8;                                // gamma[128] | beta[128] | bqkv[384] | bp[128]
+    float* XR = vec_s + 768;                                      // [RT][XS] (HS_BF_XCOPY)
     for (int i = threadIdx.x; i < 768; i += 512)
         vec_s[i] = i < 128 ? p.n1w[i] : i < 256 ? p.n1b[i - 128] : i < 640 ? p.bqkv[i - 256] : p.pb[i - 640];
     for (int i = threadIdx.x; i < RT; i += 512) {                 // class of an image row: -1 = padding; slots never mix
@@ -1037,6 +1045,10 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
         for (int ps = 0; ps < PASSES; ++ps) {
             const int irow = ps * 32 + (threadIdx.x >> 4);
             if (irow < RT) {
+#if HS_BF_XCOPY
+                *reinterpret_cast<float4*>(XR + irow * L::XS + lc8) = make_float4(xn[ps][0], xn[ps][1], xn[ps][2], xn[ps][3]);
+                *reinterpret_cast<float4*>(XR + irow * L::XS + lc8 + 4) = make_float4(xn[ps][4], xn[ps][5], xn[ps][6], xn[ps][7]);
+#endif
                 float sm = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sm += xn[ps][e];
@@ -1126,20 +1138,30 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
                 if (g == 0) lse_s[query * 8 + head] = m + __builtin_amdgcn_logf(fmaxf(lsum, 1e-30f));
             }
         }
+#if HS_BF_XCOPY
+        // ---- residual pieces of this wave's output tiles, from the fp32 copy the LayerNorm phase left in LDS (read BEFORE the
+        //      barrier: the next group's LayerNorm phase, which overwrites the copy, starts only after it).  Re-read from global
+        //      memory they were L2 hits, but 22 % of this kernel's traffic through the CU's memory pipeline, which is what it waits for
+        f32x4 xr[MTT];
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) xr[mt] = *reinterpret_cast<const f32x4*>(XR + (mt * 16 + c16) * L::XS + hc + 4 * g);
+#endif
         PHB(4)
         lds_barrier();
         PHB(5)
-        // ---- residual pieces of this wave's output tiles (L2-hot: the LayerNorm read the same rows)
-        f32x4 xr[MTT];
         int64_t orow[MTT];
 #pragma unroll
-        for (int mt = 0; mt < MTT; ++mt) {
-            orow[mt] = grow(mt * 16 + c16);
-            xr[mt] = orow[mt] >= 0 ? *reinterpret_cast<const f32x4*>(p.x + orow[mt] * 128 + hc + 4 * g) : z4;
-        }
+        for (int mt = 0; mt < MTT; ++mt) orow[mt] = grow(mt * 16 + c16);
+#if !HS_BF_XCOPY
+        // ---- residual pieces of this wave's output tiles (L2-hot: the LayerNorm read the same rows)
+        f32x4 xr[MTT];
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) xr[mt] = orow[mt] >= 0 ? *reinterpret_cast<const f32x4*>(p.x + orow[mt] * 128 + hc + 4 * g) : z4;
+#endif
         // ---- saved activations leave as whole rows: q|k|v (48 pieces per row), o, lse
         //      (round 4: moving the q|k|v stores into the next group's LayerNorm phase moved their cost with them — 727 M cycles per
         //       step either way: the waves wait for the memory system wherever the stores are issued)
+        if (p.qkv)                 // nullptr: the backward recomputes q|k|v from u (blk128_bwd_kernel<RC>), nothing to save
         for (int idx = threadIdx.x; idx < RT * 48; idx += 512) {
             const int irow = idx / 48, pc = idx - irow * 48;
             const int64_t gr = grow(irow);
@@ -1204,9 +1226,14 @@ int launch_blk128(const Blk128Args& a, hipStream_t s) {
 // are written once (the q / k / v weight gradients' operand) and not read back, x and dx1 are read once.  Mirror image of
 // blk128_fwd_kernel: wave h owns head h in the attention and output columns 16 h .. 16 h + 15 of both products, whose weight
 // slices (4 + 12 packed fragments = 64 registers) stay in registers for the whole launch; two samples per iteration; the next
-// group's q|k|v / O / dx1 rows are fetched into registers while du and the LayerNorm epilogue of this one run.
+// group's inputs are fetched into registers during this one's phases.
+// RC (the default schedule): q|k|v are RECOMPUTED from the saved LayerNorm output u (bf16, kept anyway for the q / k / v weight
+// gradients) exactly as blk128_fwd_kernel computed them — same operands, same MFMA order, hence the same bf16 values — so the
+// forward does not store them (85 MB per launch at C2) and this kernel reads 128 instead of 384 columns per row; the 12 weight
+// fragments per wave come from L2 once per group.  !RC reads the q|k|v the forward saved.
 struct Blk128BwdArgs {
-    const bf16_t* qkv; const bf16_t* o; const float* lse;        // saved by the forward: [rows][384] | [rows][128] | [rows][8]
+    const bf16_t* qkv; const bf16_t* o; const float* lse;        // saved by the forward: [rows][384] (!RC) | [rows][128] | [rows][8]
+    const bf16_t* u; const bf16_t* wqkv; const float* bqkv;      // RC: LayerNorm-1 output [rows][128], packed Wqkv [n = 384][k = 128], bias
     const bf16_t* dx1b; const float* dx1;                        // the projection's dY as bf16 (DropPath factor folded in) | the residual gradient
     const float* x; const float* gamma;                          // block input, LayerNorm-1 weight
     const bf16_t* wpT; const bf16_t* wqkvT;                      // packed images of Wp^T [n = 128][k = 128] and Wqkv^T [n = 128][k = 384]
@@ -1215,23 +1242,24 @@ struct Blk128BwdArgs {
     int Ts, nsamples, mode, len_l, accumulate;
 };
 
-template <int NT, int SPW>
+template <int NT, int SPW, bool RC>
 struct LayBB {
     static constexpr int ROWS = NT * 16, RT = SPW * ROWS, IMG = RT * FS;
     static constexpr int DUS = 132;                              // fp32 du tile row stride
     static constexpr int TT = 8 * 2 * 16 * RS16;                 // per-wave P / dS transposition tiles (elements)
     static constexpr int RED = 2 * 512 * 8 * 4;                  // final dgamma / dbeta reduction (bytes), over the du tile
     static constexpr int DUB = RT * DUS * 4 > RED ? RT * DUS * 4 : RED;
-    // cls | Q K V dO dX | T | lse delta | du | gamma
-    static constexpr int TOTAL = RT * 4 + 5 * IMG * 2 + TT * 2 + 2 * 8 * RT * 4 + DUB + 128 * 4;
+    // cls | Q K V dO dX | T | lse delta | du | gamma (+ bqkv) | RC: U
+    static constexpr int TOTAL = RT * 4 + 5 * IMG * 2 + TT * 2 + 2 * 8 * RT * 4 + DUB + 512 * 4 + (RC ? IMG * 2 : 0);
 };
 
-template <int NT, int SPW>
+template <int NT, int SPW, bool RC>
 __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
-    using L = LayBB<NT, SPW>;
+    using L = LayBB<NT, SPW, RC>;
     constexpr int ROWS = L::ROWS, RT = L::RT, MTT = SPW * NT, DUS = L::DUS;
     constexpr int PASSES = (RT * 16 + 511) / 512;               // wide layout: 16 lanes per row, 32 rows per pass
-    constexpr int NQ = (RT * 48 + 511) / 512;                   // q|k|v pieces per thread
+    constexpr int NQ = RC ? 0 : (RT * 48 + 511) / 512;          // saved q|k|v pieces per thread
+    constexpr int NS = (RT * 48 + 511) / 512;                   // dq|dk|dv pieces per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int* cls = reinterpret_cast<int*>(smem);
@@ -1245,7 +1273,8 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
     float* lse_s = reinterpret_cast<float*>(Xf + L::IMG + L::TT);       // [8][RT]
     float* dlt_s = lse_s + 8 * RT;                              // [8][RT]
     float* DU = dlt_s + 8 * RT;                                 // [RT][DUS]
-    float* gam_s = reinterpret_cast<float*>(reinterpret_cast<char*>(DU) + L::DUB);
+    float* gam_s = reinterpret_cast<float*>(reinterpret_cast<char*>(DU) + L::DUB);         // gamma[128] | bqkv[384]
+    bf16_t* Uf = reinterpret_cast<bf16_t*>(gam_s + 512);        // RC: LayerNorm-1 output rows
     const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3, hc = head * 16;
     const float scale = 0.25f, sc = 0.25f * 1.4426950408889634f;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -1262,6 +1291,7 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; }
     if (threadIdx.x < 128) gam_s[threadIdx.x] = p.gamma[threadIdx.x];
+    else if (RC) gam_s[threadIdx.x] = p.bqkv[threadIdx.x - 128];
     for (int i = threadIdx.x; i < RT; i += 512) {
         const int slot = i / ROWS, r = i - slot * ROWS;
         int c = -1;
@@ -1273,7 +1303,7 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
         return (first + slot < p.nsamples && r < p.Ts) ? (int64_t)(first + slot) * p.Ts + r : -1;
     };
     // a group's inputs as register pieces: q|k|v (NQ), O and dx1 (PASSES each), lse (one float per (row, head) pair)
-    struct Pre { bf16x8 q[NQ], o[PASSES], d[PASSES]; float l[(RT * 8 + 511) / 512]; };
+    struct Pre { bf16x8 q[NQ ? NQ : 1], o[PASSES], d[PASSES], u[RC ? PASSES : 1]; float l[(RT * 8 + 511) / 512]; };
     // (issued in three parts spread over the group's compute phases: every CU bursting its ~200 KB per group at once runs into the
     //  memory system's back-pressure, and a wave blocked at issue computes nothing: 26 % of the kernel in the first version)
     auto fetch_q = [&](int first, Pre& r, int tx, int i0, int i1) {
@@ -1283,6 +1313,15 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
             const int idx = tx + 512 * i, irow = idx / 48, pc = idx - irow * 48;
             const int64_t gr = irow < RT ? grow(first, irow) : -1;
             r.q[i] = gr >= 0 ? *reinterpret_cast<const bf16x8*>(p.qkv + gr * 384 + pc * 8) : zero8();
+        }
+    };
+    auto fetch_u = [&](int first, Pre& r, int tx) {
+        const int lc8 = (tx & 15) * 8;
+#pragma unroll
+        for (int i = 0; i < (RC ? PASSES : 0); ++i) {
+            const int irow = i * 32 + (tx >> 4);
+            const int64_t gr = irow < RT ? grow(first, irow) : -1;
+            r.u[i] = gr >= 0 ? *reinterpret_cast<const bf16x8*>(p.u + gr * 128 + lc8) : zero8();
         }
     };
     auto fetch_rest = [&](int first, Pre& r, int tx) {
@@ -1314,6 +1353,7 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
             if (irow < RT) {
                 *reinterpret_cast<bf16x8*>(Df + irow * FS + lc8) = r.o[i];
                 *reinterpret_cast<bf16x8*>(Xf + irow * FS + lc8) = r.d[i];
+                if constexpr (RC) *reinterpret_cast<bf16x8*>(Uf + irow * FS + lc8) = r.u[i];
             }
         }
 #pragma unroll
@@ -1325,14 +1365,56 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
     {
         Pre r0;
         fetch_q(blockIdx.x * SPW, r0, threadIdx.x, 0, NQ);
+        fetch_u(blockIdx.x * SPW, r0, threadIdx.x);
         fetch_rest(blockIdx.x * SPW, r0, threadIdx.x);
         lds_barrier();                                            // cls visible
         commit(r0, threadIdx.x);
     }
+#if HS_BB_WQ_RESIDENT
+    // RC: the 12 fragments of Wqkv this wave's head needs (n-tiles head, 8 + head, 16 + head) stay in registers too: streamed per
+    // group they cost the kernel more memory-pipeline time (96 KB per group and CU from L2) than the q|k|v reads they replace
+    bf16x8 wq[RC ? 3 : 1][4];
+    if constexpr (RC) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wq[m][ks] = *reinterpret_cast<const bf16x8*>(p.wqkv + ((size_t)((m * 8 + head) * 4 + ks) * 64 + lane) * 8);
+    }
+#endif
     PHB_DECL
     for (int first = blockIdx.x * SPW; first < p.nsamples; first += gridDim.x * SPW) {
+#if !HS_BB_WQ_RESIDENT
+        // RC: this group's 12 fragments of Wqkv (n-tiles head, 8 + head, 16 + head), in flight across the barrier.  The image
+        // pointer goes through an opaque copy: the loads are loop-invariant, and hoisted they would hold 48 registers for the
+        // whole launch
+        bf16x8 wq[RC ? 3 : 1][4];
+        if constexpr (RC) {
+            const bf16_t* wsrc = p.wqkv;
+            asm volatile("" : "+s"(wsrc));
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wq[m][ks] = *reinterpret_cast<const bf16x8*>(wsrc + ((size_t)((m * 8 + head) * 4 + ks) * 64 + lane) * 8);
+        }
+#endif
         lds_barrier();                                            // the group's images are complete
         PHB(0)
+        if constexpr (RC) {
+            // ---- q | k | v of this head from U (as blk128_fwd_kernel): transposed accumulators -> 8-byte writes into the images
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                bf16_t* img = Qf + m * L::IMG;
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(gam_s + 128 + m * 128 + hc + 4 * g);
+#pragma unroll
+                for (int mt = 0; mt < MTT; ++mt) {
+                    f32x4 acc = bias;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        acc = mfma16(wq[m][ks], *reinterpret_cast<const bf16x8*>(Uf + (mt * 16 + c16) * FS + ks * 32 + g * 8), acc);
+                    *reinterpret_cast<bf16x4*>(img + (mt * 16 + c16) * FS + hc + 4 * g) = cvt4(acc);
+                }
+            }
+        }
         // (every per-thread index below derives from a copy of the thread id the compiler cannot see through: hoisted out of
         //  the sample loop, these ~40 addresses and row numbers spill; recomputed, they cost ~100 VALU instructions per group)
         int tx = threadIdx.x;
@@ -1342,7 +1424,7 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
         Pre nx;
         const int nfirst = first + gridDim.x * SPW;
         const bool more = nfirst < p.nsamples;
-        if (more) fetch_q(nfirst, nx, tx, 0, NQ / 2);
+        if (more) { fetch_q(nfirst, nx, tx, 0, NQ / 2); fetch_u(nfirst, nx, tx); }
         PHB(1)
         // ---- dO[:, this head's columns] = dx1 Wp, delta = rowsum(dO * O) of this head; dO replaces O in place (own columns)
 #pragma unroll
@@ -1464,7 +1546,7 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
         //      du[:, this wave's 16 columns] = dq|dk|dv Wqkv (contraction over the 384 image columns) -> fp32 tile
         auto store_q = [&](int i0, int i1) {
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) {
+            for (int i = 0; i < NS; ++i) {
                 if (i < i0 || i >= i1) continue;
                 const int idx = tx + 512 * i, irow = idx / 48, pc = idx - irow * 48;
                 const int64_t gr = irow < RT ? grow(first, irow) : -1;
@@ -1476,7 +1558,7 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
         PHB(5)
 #pragma unroll
         for (int mt = 0; mt < MTT; ++mt) {
-            store_q(mt * NQ / MTT, (mt + 1) * NQ / MTT);
+            store_q(mt * NS / MTT, (mt + 1) * NS / MTT);
             f32x4 acc = z4;
 #pragma unroll
             for (int m = 0; m < 3; ++m)
@@ -1547,17 +1629,17 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
     }
 }
 
-template <int NT, int SPW>
+template <int NT, int SPW, bool RC>
 int launch_blk128_bwd(const Blk128BwdArgs& a, hipStream_t s) {
-    using L = LayBB<NT, SPW>;
+    using L = LayBB<NT, SPW, RC>;
     static_assert(L::TOTAL <= 160 * 1024, "LDS");
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk128_bwd_kernel<NT, SPW>),
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk128_bwd_kernel<NT, SPW, RC>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::TOTAL); attr_set = true; }
     static int wgs = 0;
     if (!wgs) { const char* e = getenv("HSIMAE_BLK128_BWD_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 1) wgs = 256; }
     const int groups = (a.nsamples + SPW - 1) / SPW;
-    hipLaunchKernelGGL((blk128_bwd_kernel<NT, SPW>), dim3(groups < wgs ? groups : wgs), dim3(512), (size_t)L::TOTAL, s, a);
+    hipLaunchKernelGGL((blk128_bwd_kernel<NT, SPW, RC>), dim3(groups < wgs ? groups : wgs), dim3(512), (size_t)L::TOTAL, s, a);
     return (int)hipGetLastError();
 }
 
@@ -1711,16 +1793,18 @@ bool hs_attn_block_bwd_fusable(int d, int heads, int Ts) {
     const char* e = getenv("HSIMAE_FUSED_ATTN_BLOCK_BWD");    // read per call: the parity test flips it inside one process
     return !(e && e[0] == '0') && hs_attn_block_fusable(d, heads, Ts);
 }
-int hs_attn_block_bwd(const hs_bf16* qkv, const hs_bf16* o, const float* lse, const hs_bf16* dx1b, const float* dx1, const float* x,
-                      const float* gamma, const hs_bf16* wpT, const hs_bf16* wqkvT, hs_bf16* dqkv, float* dx, float* dgamma,
-                      float* dbeta, const float* det_base, long long* det_acc, int Ts, int nsamples, int mode, int len_l,
-                      int accumulate, hipStream_t s) {
+int hs_attn_block_bwd(const hs_bf16* qkv, const hs_bf16* u, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* o, const float* lse,
+                      const hs_bf16* dx1b, const float* dx1, const float* x, const float* gamma, const hs_bf16* wpT, const hs_bf16* wqkvT,
+                      hs_bf16* dqkv, float* dx, float* dgamma, float* dbeta, const float* det_base, long long* det_acc, int Ts,
+                      int nsamples, int mode, int len_l, int accumulate, hipStream_t s) {
     if (nsamples <= 0) return HS_OK;
     if (Ts < 1 || Ts > 32) return HS_EUNSUPPORTED;
+    const bool rc = qkv == nullptr;                  // no saved q|k|v: recompute them from u
+    if (rc && !(u && wqkv && bqkv)) return HS_EUNSUPPORTED;
     Blk128BwdArgs a;
-    a.qkv = qkv; a.o = o; a.lse = lse; a.dx1b = dx1b; a.dx1 = dx1; a.x = x; a.gamma = gamma; a.wpT = wpT; a.wqkvT = wqkvT;
-    a.dqkv = dqkv; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta; a.det_base = det_base; a.det_acc = det_acc;
+    a.qkv = qkv; a.u = u; a.wqkv = wqkv; a.bqkv = bqkv; a.o = o; a.lse = lse; a.dx1b = dx1b; a.dx1 = dx1; a.x = x; a.gamma = gamma;
+    a.wpT = wpT; a.wqkvT = wqkvT; a.dqkv = dqkv; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta; a.det_base = det_base; a.det_acc = det_acc;
     a.Ts = Ts; a.nsamples = nsamples; a.mode = mode; a.len_l = len_l; a.accumulate = accumulate;
-    return Ts <= 16 ? launch_blk128_bwd<1, 2>(a, s) : launch_blk128_bwd<2, 2>(a, s);
+    if (rc) return Ts <= 16 ? launch_blk128_bwd<1, 2, true>(a, s) : launch_blk128_bwd<2, 2, true>(a, s);
+    return Ts <= 16 ? launch_blk128_bwd<1, 2, false>(a, s) : launch_blk128_bwd<2, 2, false>(a, s);
 }
-

@@ -81,10 +81,10 @@ struct EncMlpPtrs {
 };
 bool hs_attn_block_fusable(int d, int heads, int Ts);
 bool hs_attn_block_bwd_fusable(int d, int heads, int Ts);
-int hs_attn_block_bwd(const hs_bf16* qkv, const hs_bf16* o, const float* lse, const hs_bf16* dx1b, const float* dx1, const float* x,
-                      const float* gamma, const hs_bf16* wpT, const hs_bf16* wqkvT, hs_bf16* dqkv, float* dx, float* dgamma,
-                      float* dbeta, const float* det_base, long long* det_acc, int Ts, int nsamples, int mode, int len_l,
-                      int accumulate, hipStream_t s);
+int hs_attn_block_bwd(const hs_bf16* qkv, const hs_bf16* u, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* o, const float* lse,
+                      const hs_bf16* dx1b, const float* dx1, const float* x, const float* gamma, const hs_bf16* wpT, const hs_bf16* wqkvT,
+                      hs_bf16* dqkv, float* dx, float* dgamma, float* dbeta, const float* det_base, long long* det_acc, int Ts,
+                      int nsamples, int mode, int len_l, int accumulate, hipStream_t s);
 int hs_attn_block_fwd(const float* x, const float* n1w, const float* n1b, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* wp,
                       const float* pb, hs_bf16* u, hs_bf16* qkv, hs_bf16* o, float* lse, float* x1, const float* rowscale, int Ts,
                       int nsamples, int mode, int len_l, hipStream_t s);

@@ -45,6 +45,7 @@ def work(name, s):
         "enc_mlp_bwd_kernel<256": (2 * 2 * Me * 3 * D * h / 2, Me * 12 * D),
         "enc_mlp_bwd_kernel<64": (2 * 2 * Md * 3 * Dd * hd / 2, Md * 12 * Dd),
         "wgrad_dma_kernel": (2 * Me * (4 * D * D + 3 * D * h), Me * 2 * (3 * D + 3 * D + 3 * h + D)),  # every operand once
+        "blk128_bwd_kernel": (2 * Me * D * 4 * D + 2 * att_e, Me * (4 * D + 4 * D + 4 * D)),          # x, dx1 in, dx out (attention half, backward)
         "attn128_bwd_kernel": (2 * Me * D * D + 2 * att_e, Me * (2 * 3 * D + 2 * D + 2 * D + 2 * 3 * D)),
         "lnbwd_dma_kernel": (2 * Me * 3 * D * D, Me * (2 * 3 * D + 4 * D + 4 * D + 4 * D)),
         "dec_attn_fwd_kernel": (2 * Md * 4 * Dd * Dd + att_d, Md * 8 * Dd),
