@@ -1231,6 +1231,14 @@ int launch_blk128(const Blk128Args& a, hipStream_t s) {
 // gradients) exactly as blk128_fwd_kernel computed them — same operands, same MFMA order, hence the same bf16 values — so the
 // forward does not store them (85 MB per launch at C2) and this kernel reads 128 instead of 384 columns per row; the 12 weight
 // fragments per wave come from L2 once per group.  !RC reads the q|k|v the forward saved.
+// LDS layout of blk128_bwd_kernel (round 4; bank model scripts/micro/lds_banks.py, audit scripts/micro/lds_audit_blk128.py): unpadded
+// 256-byte image rows, 16-byte chunk c of row r at chunk c ^ bsw(r).  Found by exhaustive search over the XOR-linear maps of the
+// row's low 4 bits: 16-byte row fragments (8 -> 4 cycles per wave-instruction against the 272-byte pitch of the forward kernel's
+// images), 8-byte head-row reads and the transposed reads of 8 consecutive rows are conflict-free for every head and k-step; the
+// 8-byte head-row WRITES stay 2-way (16 rows x 8 bytes meet in one 32-bank half: no layout of 256-byte rows avoids it).
+constexpr int BIR = 128;                   // image row (elements)
+constexpr int BTS = 16;                    // P / dS transposition tile row (elements), chunks rotated by the row group (fused_dec.hip TTS)
+__device__ __forceinline__ int bsw(int row) { return ((row & 1) << 1) ^ ((row & 2) << 1) ^ ((row & 4) << 1) ^ (((row >> 3) & 1) * 9); }
 struct Blk128BwdArgs {
     const bf16_t* qkv; const bf16_t* o; const float* lse;        // saved by the forward: [rows][384] (!RC) | [rows][128] | [rows][8]
     const bf16_t* u; const bf16_t* wqkv; const float* bqkv;      // RC: LayerNorm-1 output [rows][128], packed Wqkv [n = 384][k = 128], bias
@@ -1244,9 +1252,9 @@ struct Blk128BwdArgs {
 
 template <int NT, int SPW, bool RC>
 struct LayBB {
-    static constexpr int ROWS = NT * 16, RT = SPW * ROWS, IMG = RT * FS;
+    static constexpr int ROWS = NT * 16, RT = SPW * ROWS, IMG = RT * BIR;
     static constexpr int DUS = 132;                              // fp32 du tile row stride
-    static constexpr int TT = 8 * 2 * 16 * RS16;                 // per-wave P / dS transposition tiles (elements)
+    static constexpr int TT = 8 * 2 * 16 * BTS;                  // per-wave P / dS transposition tiles (elements)
     static constexpr int RED = 2 * 512 * 8 * 4;                  // final dgamma / dbeta reduction (bytes), over the du tile
     static constexpr int DUB = RT * DUS * 4 > RED ? RT * DUS * 4 : RED;
     // cls | Q K V dO dX | T | lse delta | du | gamma (+ bqkv) | RC: U
@@ -1268,8 +1276,8 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
     bf16_t* Vf = Kf + L::IMG;
     bf16_t* Df = Vf + L::IMG;                                   // O, then dO (per head in place)
     bf16_t* Xf = Df + L::IMG;                                   // dx1 rows (bf16)
-    bf16_t* Tp = Xf + L::IMG + head * (2 * 16 * RS16);          // this wave's P / dS transposition tiles
-    bf16_t* Td = Tp + 16 * RS16;
+    bf16_t* Tp = Xf + L::IMG + head * (2 * 16 * BTS);           // this wave's P / dS transposition tiles
+    bf16_t* Td = Tp + 16 * BTS;
     float* lse_s = reinterpret_cast<float*>(Xf + L::IMG + L::TT);       // [8][RT]
     float* dlt_s = lse_s + 8 * RT;                              // [8][RT]
     float* DU = dlt_s + 8 * RT;                                 // [RT][DUS]
@@ -1278,8 +1286,21 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
     const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3, hc = head * 16;
     const float scale = 0.25f, sc = 0.25f * 1.4426950408889634f;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const int troff = (4 * g + q4) * FS + hc + 4 * p4;
-    const int ttoff = (4 * g + q4) * RS16 + 4 * p4;
+    // image addressing (elements): 16-byte chunk c of row r sits at chunk c ^ bsw(r) of its unpadded 256-byte row
+    const int fr = bsw(c16), ft = bsw(4 * g + q4);
+    const int hcell = c16 * BIR + (((2 * head + (g >> 1)) ^ fr) << 3) + (g & 1) * 4;      // this head's 4 columns 4g.. of row c16 (+ 16 mt rows)
+    const int troff = (4 * g + q4) * BIR + (((2 * head + (p4 >> 1)) ^ ft) << 3) + (p4 & 1) * 4;
+    const int tw = c16 * BTS + (((g + q4) & 3) << 2);             // tile write: row c16, keys 4g.. at chunk (g + (c16 >> 2)) & 3
+    const int ttoff = (4 * g + q4) * BTS + (((p4 + g) & 3) << 2); // tile transpose read: row 4g + q4, chunk p4
+    // MFMA operand, row 16 mt + c16, columns 32 ks + 8 g ..: chunk (4 ks + g) ^ fr = 4 (ks ^ (fr >> 2)) + (g ^ (fr & 3)), i.e. the
+    // k-step only flips bits 5-6 of ONE per-lane offset.  `fa` is re-materialised (an opaque copy) in every phase that uses it:
+    // left to itself hipcc keeps the four per-k-step offsets of every image base alive across the whole group (57 spills)
+    const int fa0 = c16 * BIR + ((fr >> 2) << 5) + ((g ^ (fr & 3)) << 3);
+    auto frag = [&](const bf16_t* img, int fa, int mt, int ks) -> const bf16x8* {
+        return reinterpret_cast<const bf16x8*>(img + mt * 16 * BIR + (fa ^ (ks << 5)));
+    };
+    auto fresh = [](int v) { asm volatile("" : "+v"(v)); return v; };
+    auto wide = [&](int irow, int pc) -> int { return irow * BIR + ((pc ^ bsw(irow)) << 3); };     // 16-byte piece pc of row irow
 
     // this wave's weights: n-tile `head` of Wp^T (dO columns of its head) and of Wqkv^T (its 16 du columns)
     bf16x8 wo[4], wu[12];
@@ -1345,15 +1366,15 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int idx = tx + 512 * i, irow = idx / 48, pc = idx - irow * 48;
-            if (irow < RT) *reinterpret_cast<bf16x8*>(Qf + (pc >> 4) * L::IMG + irow * FS + (pc & 15) * 8) = r.q[i];
+            if (irow < RT) *reinterpret_cast<bf16x8*>(Qf + (pc >> 4) * L::IMG + wide(irow, pc & 15)) = r.q[i];
         }
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
             const int irow = i * 32 + (tx >> 4);
             if (irow < RT) {
-                *reinterpret_cast<bf16x8*>(Df + irow * FS + lc8) = r.o[i];
-                *reinterpret_cast<bf16x8*>(Xf + irow * FS + lc8) = r.d[i];
-                if constexpr (RC) *reinterpret_cast<bf16x8*>(Uf + irow * FS + lc8) = r.u[i];
+                *reinterpret_cast<bf16x8*>(Df + wide(irow, tx & 15)) = r.o[i];
+                *reinterpret_cast<bf16x8*>(Xf + wide(irow, tx & 15)) = r.d[i];
+                if constexpr (RC) *reinterpret_cast<bf16x8*>(Uf + wide(irow, tx & 15)) = r.u[i];
             }
         }
 #pragma unroll
@@ -1401,6 +1422,7 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
         PHB(0)
         if constexpr (RC) {
             // ---- q | k | v of this head from U (as blk128_fwd_kernel): transposed accumulators -> 8-byte writes into the images
+            const int fa = fresh(fa0);
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 bf16_t* img = Qf + m * L::IMG;
@@ -1410,8 +1432,8 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
                     f32x4 acc = bias;
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
-                        acc = mfma16(wq[m][ks], *reinterpret_cast<const bf16x8*>(Uf + (mt * 16 + c16) * FS + ks * 32 + g * 8), acc);
-                    *reinterpret_cast<bf16x4*>(img + (mt * 16 + c16) * FS + hc + 4 * g) = cvt4(acc);
+                        acc = mfma16(wq[m][ks], *frag(Uf, fa, mt, ks), acc);
+                    *reinterpret_cast<bf16x4*>(img + mt * 16 * BIR + hcell) = cvt4(acc);
                 }
             }
         }
@@ -1427,13 +1449,14 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
         if (more) { fetch_q(nfirst, nx, tx, 0, NQ / 2); fetch_u(nfirst, nx, tx); }
         PHB(1)
         // ---- dO[:, this head's columns] = dx1 Wp, delta = rowsum(dO * O) of this head; dO replaces O in place (own columns)
+        const int fa_o = fresh(fa0);
 #pragma unroll
         for (int mt = 0; mt < MTT; ++mt) {
             f32x4 acc = z4;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                acc = mfma16(wo[ks], *reinterpret_cast<const bf16x8*>(Xf + (mt * 16 + c16) * FS + ks * 32 + g * 8), acc);
-            bf16_t* cell = Df + (mt * 16 + c16) * FS + hc + 4 * g;
+                acc = mfma16(wo[ks], *frag(Xf, fa_o, mt, ks), acc);
+            bf16_t* cell = Df + mt * 16 * BIR + hcell;
             const bf16x4 o4 = *reinterpret_cast<const bf16x4*>(cell), dob = cvt4(acc);
             float v = 0.f;
 #pragma unroll
@@ -1468,21 +1491,22 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
             f32x4 dkT[NT], dvT[NT];
             bf16x4 KT[NT];
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt) { dkT[kt] = z4; dvT[kt] = z4; KT[kt] = tr4(Kf + (r0 + kt * 16) * FS + troff); }
+            for (int kt = 0; kt < NT; ++kt) { dkT[kt] = z4; dvT[kt] = z4; KT[kt] = tr4(Kf + (r0 + kt * 16) * BIR + troff); }
 #pragma unroll
             for (int qt = 0; qt < NT; ++qt) {
                 if (qt * 16 >= p.Ts) break;
                 const int query = r0 + qt * 16 + c16;
-                const bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qf + query * FS + hc + 4 * g);
-                const bf16x4 bdo = *reinterpret_cast<const bf16x4*>(Df + query * FS + hc + 4 * g);
+                const int qcell = (r0 + qt * 16) * BIR + hcell;
+                const bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qf + qcell);
+                const bf16x4 bdo = *reinterpret_cast<const bf16x4*>(Df + qcell);
                 const float lqn = -lse_h[query], dl = dlt_h[query];
-                const bf16x4 QT = tr4(Qf + (r0 + qt * 16) * FS + troff);
-                const bf16x4 DT = tr4(Df + (r0 + qt * 16) * FS + troff);
+                const bf16x4 QT = tr4(Qf + (r0 + qt * 16) * BIR + troff);
+                const bf16x4 DT = tr4(Df + (r0 + qt * 16) * BIR + troff);
                 f32x4 dqT = z4;
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) {
-                    const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (r0 + kt * 16 + c16) * FS + hc + 4 * g);
-                    const bf16x4 av = *reinterpret_cast<const bf16x4*>(Vf + (r0 + kt * 16 + c16) * FS + hc + 4 * g);
+                    const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (r0 + kt * 16) * BIR + hcell);
+                    const bf16x4 av = *reinterpret_cast<const bf16x4*>(Vf + (r0 + kt * 16) * BIR + hcell);
                     const f32x4 sv = mfma_k16(ak, bq, cm[qt][kt]);
                     const f32x4 dp = mfma_k16(av, bdo, z4);
                     f32x4 pv, ds;
@@ -1493,8 +1517,8 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
                     }
                     const bf16x4 pb = cvt4(pv), dsb = cvt4(ds);
                     dqT = mfma_k16(KT[kt], dsb, dqT);
-                    *reinterpret_cast<bf16x4*>(Tp + c16 * RS16 + 4 * g) = pb;
-                    *reinterpret_cast<bf16x4*>(Td + c16 * RS16 + 4 * g) = dsb;
+                    *reinterpret_cast<bf16x4*>(Tp + tw) = pb;
+                    *reinterpret_cast<bf16x4*>(Td + tw) = dsb;
                     asm volatile("" ::: "memory");
                     const bf16x4 Bp = tr4(Tp + ttoff), Bds = tr4(Td + ttoff);
                     dkT[kt] = mfma_k16(QT, Bds, dkT[kt]);
@@ -1503,16 +1527,16 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
                 bf16x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dqT[r] * scale);
-                *reinterpret_cast<bf16x4*>(Qf + query * FS + hc + 4 * g) = v;
+                *reinterpret_cast<bf16x4*>(Qf + qcell) = v;
             }
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
-                const int key = r0 + kt * 16 + c16;
+                const int kcell = (r0 + kt * 16) * BIR + hcell;
                 bf16x4 vk, vv;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { vk[r] = (bf16_t)(dkT[kt][r] * scale); vv[r] = (bf16_t)dvT[kt][r]; }
-                *reinterpret_cast<bf16x4*>(Kf + key * FS + hc + 4 * g) = vk;
-                *reinterpret_cast<bf16x4*>(Vf + key * FS + hc + 4 * g) = vv;
+                *reinterpret_cast<bf16x4*>(Kf + kcell) = vk;
+                *reinterpret_cast<bf16x4*>(Vf + kcell) = vv;
             }
             if (slot == 0 && more) fetch_rest(nfirst, nx, tx);
         }
@@ -1552,10 +1576,11 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
                 const int64_t gr = irow < RT ? grow(first, irow) : -1;
                 if (gr >= 0)
                     HS_NT(HS_NT_E, reinterpret_cast<bf16x8*>(p.dqkv + gr * 384 + pc * 8),
-                          *reinterpret_cast<const bf16x8*>(Qf + (pc >> 4) * L::IMG + irow * FS + (pc & 15) * 8));
+                          *reinterpret_cast<const bf16x8*>(Qf + (pc >> 4) * L::IMG + wide(irow, pc & 15)));
             }
         };
         PHB(5)
+        const int fa_u = fresh(fa0);
 #pragma unroll
         for (int mt = 0; mt < MTT; ++mt) {
             store_q(mt * NS / MTT, (mt + 1) * NS / MTT);
@@ -1564,7 +1589,7 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
             for (int m = 0; m < 3; ++m)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
-                    acc = mfma16(wu[m * 4 + ks], *reinterpret_cast<const bf16x8*>(Qf + m * L::IMG + (mt * 16 + c16) * FS + ks * 32 + g * 8), acc);
+                    acc = mfma16(wu[m * 4 + ks], *frag(Qf + m * L::IMG, fa_u, mt, ks), acc);
             *reinterpret_cast<f32x4*>(DU + (mt * 16 + c16) * DUS + hc + 4 * g) = acc;
             asm volatile("" ::: "memory");
         }
