@@ -474,6 +474,54 @@ def test_wgrad_wide_block_batch():
         assert rel_err(db + 1.0, dOr.sum(0)) < 5e-5
 
 
+@pytest.mark.parametrize("M,msplit,rect", [(3100, 8, "0"), (110592 // 8, 59, "0"), (45, 3, "0"), (3100, 8, "1"), (110592 // 8, 59, "1"), (45, 3, "1")])
+def test_wgrad_narrow_block_batch(M, msplit, rect):
+    """One d = 128 encoder block's seven linears in one launch as hsimae_backward passes them: q | k | v as three 128-column slices of
+    one dqkv slab over the same A, the projection (128 x 128), w1 | w3 as slices of one dh13 slab (352 x 128 each), w2 (128 x 352);
+    ragged row counts, a row count smaller than the row split, accumulation onto what the buffers hold.  rect = "1": the
+    rectangular-tile kernel of round 4 (q | k | v merged into ONE 384 x 128 tile with three dW targets; opt-in, HSIMAE_WGRAD_RECT=1)
+    on the same data — the switch is read once per process, so that case runs in a child process."""
+    import subprocess, sys
+    if rect == "1" and os.environ.get("HSIMAE_WGRAD_RECT") != "1":
+        code = (f"import os; os.environ['HSIMAE_WGRAD_RECT']='1'; import tests.test_gpu_kernels as t; "
+                f"t.test_wgrad_narrow_block_batch({M}, {msplit}, '1'); print('ok')")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+        return
+    torch.manual_seed(17)
+    lib = _lib.load()
+    d, h = 128, 344
+    hp = rup(h, 32)
+    dqkv = torch.randn(M, 3 * d, device=DEV).to(torch.bfloat16)
+    u = torch.randn(M, d, device=DEV).to(torch.bfloat16)
+    g1b = torch.randn(M, d, device=DEV).to(torch.bfloat16)
+    o = torch.randn(M, d, device=DEV).to(torch.bfloat16)
+    dh13 = torch.zeros(M, 2 * hp, device=DEV, dtype=torch.bfloat16)
+    dh13[:, :h] = torch.randn(M, h, device=DEV).to(torch.bfloat16)
+    dh13[:, hp:hp + h] = torch.randn(M, h, device=DEV).to(torch.bfloat16)
+    u2 = torch.randn(M, d, device=DEV).to(torch.bfloat16)
+    g0b = torch.randn(M, d, device=DEV).to(torch.bfloat16)
+    gt = torch.zeros(M, hp, device=DEV, dtype=torch.bfloat16)
+    gt[:, :h] = torch.randn(M, h, device=DEV).to(torch.bfloat16)
+    specs = [(dqkv, 0, 3 * d, u, d, d, d), (dqkv, d, 3 * d, u, d, d, d), (dqkv, 2 * d, 3 * d, u, d, d, d), (g1b, 0, d, o, d, d, d),
+             (dh13, 0, 2 * hp, u2, d, h, d), (dh13, hp, 2 * hp, u2, d, h, d), (g0b, 0, d, gt, hp, d, h)]
+    wp = _lib.WgradParams()
+    outs = []
+    for i, (dO, off, ldo, A, lda, N, K) in enumerate(specs):
+        dW = torch.full((N, K), 0.5, device=DEV)
+        db = torch.full((N,), -1.0, device=DEV)
+        outs.append((dW, db))
+        wp.t[i] = _lib.WgradTask(dO=dO.data_ptr() + 2 * off, dO_f32=0, ldo=ldo, A=A.data_ptr(), lda=lda, N=N, K=K,
+                                 dW=dW.data_ptr(), ldw=K, db=db.data_ptr())
+    wp.ntasks, wp.M, wp.msplit = len(specs), M, msplit
+    _lib.check(lib.hsimae_wgrad(C.byref(wp), stream()), "wgrad")
+    torch.cuda.synchronize()
+    for (dO, off, ldo, A, lda, N, K), (dW, db) in zip(specs, outs):
+        dOr = dO[:, off:off + N].float()
+        assert rel_err(dW - 0.5, dOr.t() @ A[:, :K].float()) < 5e-5, (N, K)
+        assert rel_err(db + 1.0, dOr.sum(0)) < 5e-5, (N, K)
+
+
 # ----------------------------------------------------------------------------------------------- LayerNorm bwd / fwd
 @pytest.mark.parametrize("M,d,acc", [(300, 128, 0), (129, 64, 1), (70, 256, 0), (65, 512, 0), (50, 32, 1)])
 def test_layernorm_backward(M, d, acc):
