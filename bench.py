@@ -521,6 +521,9 @@ def dry_run(args, world, rank):
 
 
 def main():
+    # before anything initialises HIP (hsimae_amd/__init__.py does the same on import): see the comment there
+    if not os.environ.get("HSIMAE_KEEP_HW_QUEUES"):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -532,6 +535,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the step timing (profiling runs)")
     ap.add_argument("--force-ddp", action="store_true", help="run the RCCL gradient reducer even with one rank (test)")
+    ap.add_argument("--init-pg-only", action="store_true", help="experiment: create the RCCL process group but do not use it")
     ap.add_argument("--dry-run", action="store_true", help="launcher / protocol check on CPU with gloo (no GPU work)")
     ap.add_argument("--cpu-probe", type=int, default=0, help=argparse.SUPPRESS)      # child of cpu_baseline(): threads to probe
     ap.add_argument("--probe-bands", type=int, default=96, help=argparse.SUPPRESS)
@@ -563,6 +567,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_ddp = world > 1 or args.force_ddp
+    if args.init_pg_only and not use_ddp:             # (scripts/exp_ddp_slow.sh: what creating the communicator alone costs the step)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        if os.environ.get("HSIMAE_EXP_PG_ALLREDUCE") == "1":
+            t_ = torch.ones(8, device=dev); dist.all_reduce(t_); torch.cuda.synchronize()
     if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
