@@ -170,3 +170,21 @@ def test_bucket_plan_covers_every_element_once():
     assert all(ln >= 64 for _, ln, _ in plan[:-1])
     trig = [t for _, _, t in plan]
     assert trig == sorted(trig)
+
+
+def test_import_sets_the_hardware_queue_count_unless_told_not_to():
+    """hsimae_amd/__init__.py: GPU_MAX_HW_QUEUES=8 before HIP initialises (an idle RCCL communicator on the default 4 queues costs
+    the step 0.7 ms, profiles/r04_ddp_queues.txt); a user's own setting wins, HSIMAE_KEEP_HW_QUEUES=1 opts out."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def run(env_extra):
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "HSIMAE_KEEP_HW_QUEUES")}
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", "import os, hsimae_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"],
+                           capture_output=True, text=True, cwd=root, env=env)
+        assert r.returncode == 0, r.stderr[-1500:]
+        return r.stdout.strip().splitlines()[-1]
+    assert run({}) == "8"
+    assert run({"GPU_MAX_HW_QUEUES": "2"}) == "2"
+    assert run({"HSIMAE_KEEP_HW_QUEUES": "1"}) == "None"
