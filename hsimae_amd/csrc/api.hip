@@ -173,7 +173,9 @@ int dec_block_fwd_fused(const BlkP& bp, const float* z, const BlkBuf& b, int N, 
 // The attention half's backward as ONE launch that recomputes q|k|v from u (attn.hip blk128_bwd_kernel<RC>): decided by the same
 // predicate in the forward (which then does not store q|k|v) and in the backward.  The environment switches are read per call so
 // that a parity test can flip them around a whole forward + backward pair.
+static bool pair_enabled();
 static bool attn_bwd_recompute(int d, int dp, int heads, int h, int Ts, bool f8u) {
+    if (pair_enabled()) return false;       // the pair schedule's backward (block_bwd_plan) reads the q|k|v the forward saved
     const char* e1 = getenv("HSIMAE_FUSED_PROJ_BWD"); const char* e2 = getenv("HSIMAE_FUSED_LNBWD"); const char* e3 = getenv("HSIMAE_ATTN_BWD_RECOMPUTE");
     if ((e1 && e1[0] == '0') || (e2 && e2[0] == '0') || (e3 && e3[0] == '0')) return false;
     return !f8u && d == 128 && dp == d && fused_mlp_enabled(d, h) && hs_attn_block_bwd_fusable(d, heads, Ts);

@@ -550,3 +550,20 @@ def test_model_on_a_non_default_device():
     a, b = dict(m0.named_parameters()), dict(m1.named_parameters())
     assert all(b[k].grad.device.index == 1 for k in b if b[k].grad is not None)
     assert rms_rel(b["blocks.0.mlp.w2.weight"].grad, a["blocks.0.mlp.w2.weight"].grad) <= 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["HSIMAE_PAIR_LAUNCH=1", "HSIMAE_ATTN_BWD_RECOMPUTE=0", "HSIMAE_FUSED_MLP=0"])
+def test_config1_record_under_the_schedule_switches(switch):
+    """The schedule switches are read once per process, so each runs in a child: the config-1 record of the reference (loss, 532
+    gradient norms) must hold on the pair schedule (whose backward reads the q|k|v the forward saved: the forward must then save
+    them — round 4 regression), on the fused attention-half backward fed by saved q|k|v, and on the layer-at-a-time MLP half."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    k, v = switch.split("=")
+    env = dict(os.environ)
+    env[k] = v
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_boundary.py", "-m", "gpu", "-x", "-q", "-k",
+                        "test_c1_config1_reference_scale_n64 or test_c1_base48"], capture_output=True, text=True, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
