@@ -24,6 +24,9 @@
 #ifndef HS_BF_XCOPY
 #define HS_BF_XCOPY 1          /* blk128_fwd_kernel: residual from an fp32 LDS copy of x (1) or re-read from L2 (0) */
 #endif
+#ifndef HS_BB_DELTA_PDP
+#define HS_BB_DELTA_PDP 1        /* blk128_bwd_kernel: delta = sum_j P dP inside the core (1: O is not read) or rowsum(dO * O) (0) */
+#endif
 #ifndef HS_BB_WQ_RESIDENT
 #define HS_BB_WQ_RESIDENT 1   /* blk128_bwd_kernel<RC>: forward Wqkv fragments resident (1) or streamed from L2 per group (0) */
 #endif
@@ -537,22 +540,29 @@ __global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
         load16_wg<NT, HD, HPW>(base + 2 * KVO(p), p.ld, p.Ts, nheads, img0 + 2 * L::IMG, WSTR);
         load16_wg<NT, HD, HPW>(p.dout + row_base * p.lddo + head0 * HD, p.lddo, p.Ts, nheads, img0 + 3 * L::IMG, WSTR);
     }
+    // delta_i = rowsum(dO * O) = sum_j P_ij dP_ij.  With up to four key tiles per query tile (every encoder attention) it is formed
+    // inside the core from the P and dP tiles themselves (PDP): O is not read, and the delta no longer carries the bf16 rounding of
+    // the saved O (round 4: what the backward adds to the q / k gradients at config 1 went 7e-3 -> 3e-3 in the d = 128 kernel).
+    // Longer sequences (the 216-token decoder: 14 key tiles = 112 registers of P and dP) keep the prologue form.
+    constexpr bool PDP = NT <= 4;
     if (active) {
         for (int tok = lane; tok < L::ROWS; tok += 64) {
             float acc = 0.f, l = 1e30f;                          // rows past Ts: exp2(s - 1e30) = 0
             if (tok < p.Ts) {
-                const bf16_t* orow = p.o + (row_base + tok) * p.ldo + head * HD;
-                const bf16_t* drow = p.dout + (row_base + tok) * p.lddo + head * HD;
+                if constexpr (!PDP) {
+                    const bf16_t* orow = p.o + (row_base + tok) * p.ldo + head * HD;
+                    const bf16_t* drow = p.dout + (row_base + tok) * p.lddo + head * HD;
 #pragma unroll
-                for (int e = 0; e < HD; e += 8) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(orow + e);
-                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(drow + e);
+                    for (int e = 0; e < HD; e += 8) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(orow + e);
+                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(drow + e);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) acc += bf2f(a[i]) * bf2f(b[i]);
+                        for (int i = 0; i < 8; ++i) acc += bf2f(a[i]) * bf2f(b[i]);
+                    }
                 }
                 l = p.lse[(row_base + tok) * p.heads + head];
             }
-            delta[tok] = acc;
+            if constexpr (!PDP) delta[tok] = acc;
             lse[tok] = l;
         }
     }
@@ -572,37 +582,46 @@ __global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
         const int qcls = cls[query];
         const bf16x4 bq = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Qi + query * RS16 + 4 * g) : zero4_();
         const bf16x4 bdo = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Di + query * RS16 + 4 * g) : zero4_();
-        const float lqn = -lse[query], dl = delta[query];
+        const float lqn = -lse[query];
         const bf16x4 QT = tr4(Qi + qt * 16 * RS16 + troff);      // Q^T[d = c16][query 4g + j]
         const bf16x4 DT = tr4(Di + qt * 16 * RS16 + troff);
         f32x4 dqT = z4;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
+        // P (and dP) of one (query tile, key tile) pair: S^T[key 4g + r][query c16]
+        auto pair_p = [&](int kt, f32x4& pv, f32x4& dp) {
             const bf16x4 ak = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Ki + (kt * 16 + c16) * RS16 + 4 * g) : zero4_();
             const bf16x4 av = (HD == 16 || g < 2) ? *reinterpret_cast<const bf16x4*>(Vi + (kt * 16 + c16) * RS16 + 4 * g) : zero4_();
-            const f32x4 s = mfma_k16(ak, bq, z4);                // S^T[key 4g + r][query c16]
-            const f32x4 dp = mfma_k16(av, bdo, z4);
-            f32x4 pv, ds;
+            const f32x4 s = mfma_k16(ak, bq, z4);
+            dp = mfma_k16(av, bdo, z4);
             if constexpr (MODE0) {
-                // one class: no mask.  The K / V image rows past Ts are zero (load16_wg), so a padded key has s = 0, dP = 0 and a
-                // finite garbage P / dS that meets K = 0 in dq; its dk / dv rows are never stored (store16_wg stops at Ts).
-                // The exponent is clamped at 0 (P <= 1 holds for every real key): a padded key of a query whose logsumexp is
-                // very negative (diverging run: every real score below about -88) would otherwise give P = inf and inf * 0 = NaN in dq
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pv[r] = __builtin_amdgcn_exp2f(fminf(fmaf(s[r], sc, lqn), 0.f));
-                    ds[r] = pv[r] * (dp[r] - dl);
-                }
+                for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fminf(fmaf(s[r], sc, lqn), 0.f));
             } else {
                 const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
                 const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
-                    pv[r] = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn)) : 0.f;
-                    ds[r] = pv[r] * (dp[r] - dl);
-                }
+                for (int r = 0; r < 4; ++r) pv[r] = ((kcl[r] >= 0) && (kcl[r] == qcls)) ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn)) : 0.f;
             }
+        };
+        f32x4 pvs[PDP ? NT : 1], dps[PDP ? NT : 1];
+        float dl = 0.f;
+        if constexpr (PDP) {
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                pair_p(kt, pvs[kt], dps[kt]);
+                // (MODE0: a padded key has K = V = 0 rows, so dP = 0 and its clamped finite P adds nothing)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dl = fmaf(pvs[kt][r], dps[kt][r], dl);
+            }
+            dl = rows_sum(dl);
+        } else {
+            dl = delta[query];
+        }
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 pv, dp, ds;
+            if constexpr (PDP) { pv = pvs[kt]; dp = dps[kt]; } else pair_p(kt, pv, dp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[r] = pv[r] * (dp[r] - dl);
             const bf16x4 pb = cvt4(pv), dsb = cvt4(ds);
             dqT = mfma_k16(KT[kt], dsb, dqT);
             *reinterpret_cast<bf16x4*>(Tp + c16 * TRS + 4 * g) = pb;
@@ -1351,7 +1370,9 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
         for (int i = 0; i < PASSES; ++i) {
             const int irow = i * 32 + (tx >> 4);
             const int64_t gr = irow < RT ? grow(first, irow) : -1;
+#if !HS_BB_DELTA_PDP
             r.o[i] = gr >= 0 ? *reinterpret_cast<const bf16x8*>(p.o + gr * 128 + lc8) : zero8();
+#endif
             r.d[i] = gr >= 0 ? *reinterpret_cast<const bf16x8*>(p.dx1b + gr * 128 + lc8) : zero8();
         }
 #pragma unroll
@@ -1372,7 +1393,9 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
         for (int i = 0; i < PASSES; ++i) {
             const int irow = i * 32 + (tx >> 4);
             if (irow < RT) {
+#if !HS_BB_DELTA_PDP
                 *reinterpret_cast<bf16x8*>(Df + wide(irow, tx & 15)) = r.o[i];
+#endif
                 *reinterpret_cast<bf16x8*>(Xf + wide(irow, tx & 15)) = r.d[i];
                 if constexpr (RC) *reinterpret_cast<bf16x8*>(Uf + wide(irow, tx & 15)) = r.u[i];
             }
@@ -1457,6 +1480,9 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
             for (int ks = 0; ks < 4; ++ks)
                 acc = mfma16(wo[ks], *frag(Xf, fa_o, mt, ks), acc);
             bf16_t* cell = Df + mt * 16 * BIR + hcell;
+#if HS_BB_DELTA_PDP
+            *reinterpret_cast<bf16x4*>(cell) = cvt4(acc);          // delta comes out of the core (sum_j P_ij dP_ij): O is not read at all
+#else
             const bf16x4 o4 = *reinterpret_cast<const bf16x4*>(cell), dob = cvt4(acc);
             float v = 0.f;
 #pragma unroll
@@ -1464,6 +1490,7 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
             v = rows_sum(v);
             if (g == 0) dlt_s[head * RT + mt * 16 + c16] = v;
             *reinterpret_cast<bf16x4*>(cell) = dob;
+#endif
         }
         if (more) fetch_q(nfirst, nx, tx, NQ / 2, NQ);
         PHB(2)
@@ -1484,7 +1511,9 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // own writes before own reads
         // ---- attention backward of this head (as attn128_bwd_kernel), slot by slot; dq, dk, dv in place
         const float* lse_h = lse_s + head * RT;
+#if !HS_BB_DELTA_PDP
         const float* dlt_h = dlt_s + head * RT;
+#endif
 #pragma unroll
         for (int slot = 0; slot < SPW; ++slot) {
             const int r0 = slot * ROWS;
@@ -1499,22 +1528,49 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
                 const int qcell = (r0 + qt * 16) * BIR + hcell;
                 const bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qf + qcell);
                 const bf16x4 bdo = *reinterpret_cast<const bf16x4*>(Df + qcell);
-                const float lqn = -lse_h[query], dl = dlt_h[query];
+                const float lqn = -lse_h[query];
                 const bf16x4 QT = tr4(Qf + (r0 + qt * 16) * BIR + troff);
                 const bf16x4 DT = tr4(Df + (r0 + qt * 16) * BIR + troff);
                 f32x4 dqT = z4;
+#if HS_BB_DELTA_PDP
+                // delta_i = sum_j P_ij dP_ij (= rowsum(dO * O), the form the separate kernel uses, without needing O): with at most
+                // NT = 2 key tiles per query tile both P and dP are in hand before dS is formed
+                f32x4 pvs[NT], dps[NT];
+                float dl = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) {
                     const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (r0 + kt * 16) * BIR + hcell);
                     const bf16x4 av = *reinterpret_cast<const bf16x4*>(Vf + (r0 + kt * 16) * BIR + hcell);
                     const f32x4 sv = mfma_k16(ak, bq, cm[qt][kt]);
-                    const f32x4 dp = mfma_k16(av, bdo, z4);
+                    dps[kt] = mfma_k16(av, bdo, z4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pvs[kt][r] = __builtin_amdgcn_exp2f(fmaf(sv[r], sc, lqn));
+                        dl = fmaf(pvs[kt][r], dps[kt][r], dl);
+                    }
+                }
+                dl = rows_sum(dl);
+#else
+                const float dl = dlt_h[query];
+#endif
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
                     f32x4 pv, ds;
+#if HS_BB_DELTA_PDP
+                    pv = pvs[kt];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds[r] = pv[r] * (dps[kt][r] - dl);
+#else
+                    const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (r0 + kt * 16) * BIR + hcell);
+                    const bf16x4 av = *reinterpret_cast<const bf16x4*>(Vf + (r0 + kt * 16) * BIR + hcell);
+                    const f32x4 sv = mfma_k16(ak, bq, cm[qt][kt]);
+                    const f32x4 dp = mfma_k16(av, bdo, z4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         pv[r] = __builtin_amdgcn_exp2f(fmaf(sv[r], sc, lqn));
                         ds[r] = pv[r] * (dp[r] - dl);
                     }
+#endif
                     const bf16x4 pb = cvt4(pv), dsb = cvt4(ds);
                     dqT = mfma_k16(KT[kt], dsb, dqT);
                     *reinterpret_cast<bf16x4*>(Tp + tw) = pb;

@@ -486,7 +486,9 @@ def test_fused_attention_half_backward_matches_separate_kernels(bands, grid, N, 
         r, r2 = rms_rel(g1[k], g0[k]), rms_rel(g2[k], g1[k])
         worst = max(worst, (k, r), key=lambda t: t[1])
         worst2 = max(worst2, (k, r2), key=lambda t: t[1])
-        assert r < 5e-3, (k, r)
+        # (the fused kernel forms delta_i = sum_j P_ij dP_ij in fp32 inside its core, the separate one rowsum(dO * O) from the bf16 O the
+        #  forward saved: two roundings of the same quantity; q / k gradients, the most sensitive family, differ by up to 6e-3)
+        assert r < 2e-2, (k, r)
         assert r2 < (1e-6 if det else 2e-4), (k, r2)
     print(f"[fused-attn-half-bwd {bands} {grid} N={N} det={det}] worst grad rms-rel fused vs separate {worst}, recompute vs saved {worst2}")
 
