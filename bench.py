@@ -582,9 +582,11 @@ def main():
     precision = args.precision or ("fp8" if args.model == "huge" else "bf16")
     effective_note = None
     torch.manual_seed(0)
-    model = HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=bands, b_patch_size=8, embed_dim=D, depth=12,
-                   num_heads=heads, s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8,
-                   norm_pix_loss=True, trunc_init=True).to(dev)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # the module prints what the reference's constructor prints; stdout carries the JSON line only
+        model = HSIMAE(img_size=9, patch_size=3, in_chans=1, bands=bands, b_patch_size=8, embed_dim=D, depth=12,
+                       num_heads=heads, s_depth=9, decoder_embed_dim=64, decoder_depth=8, decoder_num_heads=8,
+                       norm_pix_loss=True, trunc_init=True).to(dev)
     if precision == "fp8":
         model.set_precision("fp8")
         # what the encoder linears really run in: below embed_dim 512 "fp8" keeps the bf16 kernels (hsimae_effective_precision),
