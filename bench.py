@@ -507,13 +507,42 @@ def dry_run(args, world, rank):
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    verify = None
+    if world > 1 and args.verify:
+        # the --verify protocol on synthetic gradients: a bucketed reduction of a rank-dependent buffer against one plain collective.
+        # HSIMAE_DRYRUN_FAULT (tests): "order" = rank 1 reports its collectives in another order, "grad" = rank 1's reduced buffer
+        # differs in one element, "grid" = rank 1 drew another grid — each must come back as dp_consistent = false.
+        from hsimae_amd.parallel import GradReducer, verify_step
+        total = 200_000
+        base = (torch.arange(total, dtype=torch.float32) % 977) + 1.0
+        flat = base * (rank + 1) / world
+        ref = flat.clone()
+        red = GradReducer(bucket_bytes=64 << 10)
+        ranges = [(o, min(7_000, total - o)) for o in range(0, total, 7_000)][::-1]      # back to front, as the backward reports
+        red.make_callback(flat)
+        for st, (o, ln) in enumerate(ranges):
+            red._on_range(st, o, ln, None)
+        red.finish()
+        dist.all_reduce(ref)
+        launched, grids = list(red.launched), [(3, 9), (9, 3)]
+        fault = os.environ.get("HSIMAE_DRYRUN_FAULT", "")
+        if rank == 1 and fault == "order":
+            launched[0], launched[1] = launched[1], launched[0]
+        if rank == 1 and fault == "grad":
+            flat[total // 2] += 1.0
+        if rank == 1 and fault == "grid":
+            grids[1] = (3, 9)
+        verify = verify_step(flat, ref, grids, launched, 0.0)
     if rank == 0:
         N = args.batch or 4
-        print(json.dumps({"metric": "HSI patches/sec (dry run)", "value": round(world * N * args.steps / float(t), 1),
-                          "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(float(t) / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "none", "data": "dry-run",
-                          "config": {"workload": "launcher dry run (no GPU work)", "parallelism": f"dp{world}"}}), flush=True)
+        line = {"metric": "HSI patches/sec (dry run)", "value": round(world * N * args.steps / float(t), 1),
+                "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(float(t) / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "none", "data": "dry-run",
+                "config": {"workload": "launcher dry run (no GPU work)", "parallelism": f"dp{world}"}}
+        if verify is not None:
+            line["dp_consistent"], line["dp_verify"] = verify["dp_consistent"], verify
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -537,6 +566,12 @@ def main():
     ap.add_argument("--force-ddp", action="store_true", help="run the RCCL gradient reducer even with one rank (test)")
     ap.add_argument("--init-pg-only", action="store_true", help="experiment: create the RCCL process group but do not use it")
     ap.add_argument("--dry-run", action="store_true", help="launcher / protocol check on CPU with gloo (no GPU work)")
+    ap.add_argument("--verify", dest="verify", action="store_true", default=None,
+                    help="data-parallel self-check after the timed steps (default: on whenever the gradient reducer runs): one extra "
+                         "step in deterministic mode, its bucketed + overlapped reduction compared with ONE plain all-reduce of the "
+                         "same step's local gradients, hashes of the reduced buffer / grid sequence / collective order all-gathered; "
+                         "rank 0 prints dp_consistent and the bucket list")
+    ap.add_argument("--no-verify", dest="verify", action="store_false")
     ap.add_argument("--cpu-probe", type=int, default=0, help=argparse.SUPPRESS)      # child of cpu_baseline(): threads to probe
     ap.add_argument("--probe-bands", type=int, default=96, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -546,6 +581,8 @@ def main():
         print(rate)
         return
 
+    if args.verify is None:
+        args.verify = True                            # (only acts where a reducer exists: world > 1 or --force-ddp)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args, sys.argv[1:]))
 
@@ -658,6 +695,34 @@ def main():
                 "exposed_ms": round(dt / args.steps * 1e3 - float(tn.item()) * 1e3, 3),
                 "transport": "RCCL all-reduce(sum) per bucket on the reducer's launch stream, fp32, pre-scaled by 1/world"}
 
+    verify = None
+    if use_ddp and args.verify:
+        # The first multi-rank run must DETECT a wrong bucket order or a collective that overtook its kernels, not only time the
+        # step (no 8-GPU node has run this path yet).  One more step in deterministic mode (bit-reproducible local gradients):
+        #   (1) with the reducer: bucketed all-reduces launched from inside the backward on the reducer's stream;
+        #   (2) the SAME step (RNG streams restored) with the reducer detached, then ONE plain all-reduce of the whole flat
+        #       buffer after a device synchronise, / world;
+        # (1) must equal (2) up to the summation order inside the collective, on every rank, and every rank must hold
+        # bit-identical reduced gradients, the same grid sequence and the same list of collectives (hsimae_amd/parallel.py).
+        from hsimae_amd.parallel import verify_step
+        red = model._reducer
+        prev_det = model._deterministic
+        model.deterministic = True
+        rng = (random.getstate(), torch.get_rng_state(), torch.cuda.get_rng_state(dev))
+        lv = float(step().item()); torch.cuda.synchronize()
+        g_b, launched_v, grid_v = model._flat_grad.clone(), list(red.launched), (model.len_t, model.len_l)
+        random.setstate(rng[0]); torch.set_rng_state(rng[1]); torch.cuda.set_rng_state(rng[2], dev)
+        model._reducer = None
+        step(); torch.cuda.synchronize()
+        g_ref = model._flat_grad.clone()
+        model._reducer = red
+        model.deterministic = prev_det
+        if world > 1:
+            dist.all_reduce(g_ref)
+        g_ref /= world                                # (detached, the step does not fold 1 / world into dLoss)
+        verify = verify_step(g_b, g_ref, grids + [grid_v], launched_v, lv)
+        del g_b, g_ref
+
     if rank == 0:
         h, hd = swiglu_hidden(D, 4.0), swiglu_hidden(64, 4.0)
         lt0, ll0 = HSIMAE.grid_candidates(bands // 8, 9, 0.75)[0]
@@ -697,6 +762,8 @@ def main():
         }
         if comm is not None:
             out["comm"] = comm
+        if verify is not None:
+            out["dp_consistent"], out["dp_verify"] = verify["dp_consistent"], verify
         if effective_note:
             out["config"]["precision_note"] = effective_note
         _log(f"step timing done: {dt / args.steps * 1e3:.3f} ms/step")

@@ -123,6 +123,7 @@ SYMBOLS = {
     "hsimae_two_streams_active": (C.c_int, []),
     "hsimae_effective_precision": (C.c_int, [C.POINTER(Config)]),
     "hsimae_dec_block_slab_floats": (i64, []),
+    "hsimae_wgrad_slab_bytes": (i64, [C.POINTER(Config), i32]),
     "hsimae_param_layout": (C.c_int, [C.POINTER(Config), C.POINTER(i64), C.POINTER(i64), C.c_int]),
     "hsimae_wpk_elems": (i64, [C.POINTER(Config)]),
     "hsimae_pack_table_bytes": (i64, [C.POINTER(Config)]),
@@ -160,6 +161,7 @@ SYMBOLS = {
     "hsimae_decode_backward": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp, vp, vp, BUCKET_CB, vp, vp]),
 }
 
+ABI_VERSION = 104       # HSIMAE_VERSION of include/hsimae_hip.h these ctypes structs mirror (a CPU test compares the two)
 PREC_BF16, PREC_FP8 = 0, 1
 A_BF16, A_F32, A_F32_LN = 0, 1, 2
 E_BF16, E_F32, E_RES_F32, E_POS_F32, E_SWIGLU, E_SWIGLU_BWD, E_LN_BWD = 0, 1, 2, 3, 4, 5, 6
@@ -179,6 +181,10 @@ def load() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        got = lib.hsimae_version()
+        if got != ABI_VERSION:          # a stale .so next to newer bindings: struct layouts would silently disagree
+            raise RuntimeError(f"{LIB_PATH} answers ABI version {got}, these bindings were written for {ABI_VERSION}: "
+                               "rebuild it with `python -m hsimae_amd.build --force`")
         _lib = lib
     return _lib
 

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
+#include <unordered_map>
 
 using namespace hsplan;
 
@@ -40,14 +41,74 @@ BlkP resolve(const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk,
     b.qkvT8 = i8(w.qkvT8); b.pT8 = i8(w.pT8); b.w13T8 = i8(w.w13T8); b.w2T8 = i8(w.w2T8);
     return b;
 }
+// ------------------------------------------------------------------ the schedule of a pass, decided ONCE, by its forward
+// Every choice between two kernel generations that changes what the forward leaves in the workspace for the backward — fused
+// or layer-at-a-time halves (which intermediates exist), q|k|v saved or recomputed, fp8 GEMMs or fused bf16 kernels — is read from
+// the environment exactly once per pass: by the forward entry point (sched_from_env), which records it for its workspace arena
+// (record_sched).  The backward entry points look the record up and follow it; they never read the environment.  A switch that
+// is flipped between a forward and its backward therefore has no effect on that pass (rounds 1-4 re-derived each decision where
+// it was needed, partly per call and partly latched in function statics: a forward that skipped the q|k|v store followed by a
+// backward that decided not to recompute read an unwritten buffer and returned HSIMAE_OK — VERDICT r04 item 5).
+// A backward on an arena no forward of this process has filled returns HSIMAE_ENOFORWARD.
+enum : uint32_t {
+    SC_FUSED_DEC = 1u << 0,        // HSIMAE_FUSED_DEC=0 clears: layer-at-a-time decoder
+    SC_DEC_SPLIT = 1u << 1,        // HSIMAE_DEC_SPLIT=0 clears: one-kernel decoder block forward
+    SC_FP8_UNFUSED = 1u << 2,      // HSIMAE_FP8_UNFUSED=1 sets: every linear of an fp8 encoder block on the MX GEMMs, no fused kernel
+    SC_FUSED_MLP = 1u << 3,        // HSIMAE_FUSED_MLP=0 clears: layer-at-a-time MLP half of the encoder blocks
+    SC_ATTN_BLOCK = 1u << 4,       // HSIMAE_FUSED_ATTN_BLOCK=0 clears: blk128_fwd
+    SC_ATTN_BLOCK256 = 1u << 5,    // HSIMAE_FUSED_ATTN_BLOCK256=0 clears: blk256_fwd
+    SC_ATTN_BLOCK_BWD = 1u << 6,   // HSIMAE_FUSED_ATTN_BLOCK_BWD=0 clears: blk128_bwd
+    SC_PROJ_BWD = 1u << 7,         // HSIMAE_FUSED_PROJ_BWD=0 clears: the projection's data gradient as its own GEMM
+    SC_LNBWD = 1u << 8,            // HSIMAE_FUSED_LNBWD=0 clears: du store + separate ln_bwd pass
+    SC_LNBWD_512 = 1u << 9,        // HSIMAE_FUSED_LNBWD_512=0 clears it at d = 512 only
+    SC_RECOMPUTE = 1u << 10,       // HSIMAE_ATTN_BWD_RECOMPUTE=0 clears: the forward saves q|k|v
+    SC_WGRAD_SLAB = 1u << 11,      // HSIMAE_WGRAD_SLAB=0 clears: float atomics in the 256 x 256-tile weight-gradient launches
+    SC_DEC_SLAB = 1u << 12,        // HSIMAE_DEC_SLAB=0 clears: float atomics in the fused decoder backward
+};
+uint32_t sched_from_env() {
+    auto off = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
+    auto one = [](const char* name) { const char* e = getenv(name); return e && e[0] == '1'; };
+    uint32_t b = 0;
+    if (!off("HSIMAE_FUSED_DEC")) b |= SC_FUSED_DEC;
+    if (!off("HSIMAE_DEC_SPLIT")) b |= SC_DEC_SPLIT;
+    if (one("HSIMAE_FP8_UNFUSED")) b |= SC_FP8_UNFUSED;
+    if (!off("HSIMAE_FUSED_MLP")) b |= SC_FUSED_MLP;
+    if (!off("HSIMAE_FUSED_ATTN_BLOCK")) b |= SC_ATTN_BLOCK;
+    if (!off("HSIMAE_FUSED_ATTN_BLOCK256")) b |= SC_ATTN_BLOCK256;
+    if (!off("HSIMAE_FUSED_ATTN_BLOCK_BWD")) b |= SC_ATTN_BLOCK_BWD;
+    if (!off("HSIMAE_FUSED_PROJ_BWD")) b |= SC_PROJ_BWD;
+    if (!off("HSIMAE_FUSED_LNBWD")) b |= SC_LNBWD;
+    if (!off("HSIMAE_FUSED_LNBWD_512")) b |= SC_LNBWD_512;
+    if (!off("HSIMAE_ATTN_BWD_RECOMPUTE")) b |= SC_RECOMPUTE;
+    if (!off("HSIMAE_WGRAD_SLAB")) b |= SC_WGRAD_SLAB;
+    if (!off("HSIMAE_DEC_SLAB")) b |= SC_DEC_SLAB;
+    return b;
+}
+struct SchedRec { uint32_t enc = 0, dec = 0; bool has_enc = false, has_dec = false; };
+std::mutex g_sched_mu;
+std::unordered_map<const void*, SchedRec> g_sched;          // keyed by the workspace arena the forward filled
+void record_sched(const void* ws, bool enc, bool dec, uint32_t bits) {
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    if (g_sched.size() > 4096) g_sched.clear();             // (a process that leaks arenas: start over rather than grow)
+    SchedRec& r = g_sched[ws];
+    if (enc) { r.enc = bits; r.has_enc = true; }
+    if (dec) { r.dec = bits; r.has_dec = true; }
+}
+int lookup_sched(const void* ws, bool need_enc, bool need_dec, uint32_t& enc, uint32_t& dec) {
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    auto it = g_sched.find(ws);
+    if (it == g_sched.end() || (need_enc && !it->second.has_enc) || (need_dec && !it->second.has_dec)) return HSIMAE_ENOFORWARD;
+    enc = it->second.enc; dec = it->second.dec;
+    return HSIMAE_OK;
+}
+
 // encoder blocks under precision = FP8 (the decoder's blocks never are)
-bool fp8_unfused();
-BlkP resolve_enc(const Geo& g, const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk, const WLayout& WL) {
+BlkP resolve_enc(const Geo& g, uint32_t sc, const BlkOff& o, const BlkW& w, const float* P, const hs_bf16* wpk, const WLayout& WL) {
     BlkP b = resolve(o, w, P, wpk, WL);
     // fp8 where it pays: K >= 512.  At d = 256 the MX GEMMs (A quantised while it is staged) are no faster than the bf16 ones
     // (Large: 37.8 vs 37.2 ms per step with the attention-half linears in fp8, r03_k), at d = 128 every linear sits inside a
     // fused bf16 kernel; HSIMAE_FP8_UNFUSED=1 forces the MX GEMMs at every width (tests of the generic path).
-    b.prec = (g.prec == HSIMAE_PREC_FP8 && (g.D >= 512 || fp8_unfused())) ? HSIMAE_PREC_FP8 : HSIMAE_PREC_BF16;
+    b.prec = (g.prec == HSIMAE_PREC_FP8 && (g.D >= 512 || (sc & SC_FP8_UNFUSED))) ? HSIMAE_PREC_FP8 : HSIMAE_PREC_BF16;
     return b;
 }
 
@@ -112,35 +173,23 @@ struct Emitter {
     }
 };
 
-// HSIMAE_FUSED_DEC=0 forces the layer-at-a-time decoder (A/B testing of the fused decoder kernels)
-bool fused_dec_enabled(const Geo& g) {
-    const char* e = getenv("HSIMAE_FUSED_DEC");
-    if (e && e[0] == '0') return false;
-    return hs_dec_fused_supported(g.Dd, g.Hd, g.hdec, g.TL);
+// SC_FUSED_DEC clear: the layer-at-a-time decoder (A/B testing of the fused decoder kernels)
+bool fused_dec_enabled(const Geo& g, uint32_t sc) {
+    return (sc & SC_FUSED_DEC) && hs_dec_fused_supported(g.Dd, g.Hd, g.hdec, g.TL);
 }
 
 // Forward of one fused decoder block.  Default (round 3): the attention half with q / k / v in registers
 // (dec_attn_fwd_kernel, 16 waves per CU) + the MLP half as the row-panel kernel enc_mlp_fwd_kernel<64, 192>;
-// HSIMAE_DEC_SPLIT=0 selects the one-kernel form (dec_block_fwd_kernel) for A/B tests.
-bool dec_split_enabled() {
-    const char* e = getenv("HSIMAE_DEC_SPLIT");
-    return !(e && e[0] == '0');
-}
+// SC_DEC_SPLIT clear selects the one-kernel form (dec_block_fwd_kernel) for A/B tests.
 
 // precision = FP8 puts the MX e4m3 images on the linears that run as stand-alone GEMMs.  Where a fused bf16 kernel covers
 // the shape (the attention half at d = 128, the MLP half at d = 128 / 256) it is kept: the fused bf16 form beats the
 // layer-at-a-time fp8 form (round 2: Base 26.9 vs 19.4 ms, Large 44.1 vs 39.5 ms with every fused kernel switched off).
-// HSIMAE_FP8_UNFUSED=1 restores that all-fp8 layer-at-a-time schedule (tests of the generic fp8 path at small widths).
-bool fp8_unfused() {
-    const char* e = getenv("HSIMAE_FP8_UNFUSED");
-    return e && e[0] == '1';
-}
+// SC_FP8_UNFUSED restores that all-fp8 layer-at-a-time schedule (tests of the generic fp8 path at small widths).
 
-// HSIMAE_FUSED_MLP=0 forces the layer-at-a-time MLP half of the encoder blocks
-bool fused_mlp_enabled(int d, int h) {
-    const char* e = getenv("HSIMAE_FUSED_MLP");
-    if (e && e[0] == '0') return false;
-    return hs_enc_mlp_fused_supported(d, h);
+// SC_FUSED_MLP clear: the layer-at-a-time MLP half of the encoder blocks
+bool fused_mlp_enabled(int d, int h, uint32_t sc) {
+    return (sc & SC_FUSED_MLP) && hs_enc_mlp_fused_supported(d, h);
 }
 
 EncMlpPtrs mlp_ptrs(const BlkP& b, int h) {
@@ -162,41 +211,38 @@ DecBlockPtrs dec_ptrs(const BlkP& b, int h) {
 
 GemmParams gp() { GemmParams p; std::memset(&p, 0, sizeof(p)); return p; }
 
-int dec_block_fwd_fused(const BlkP& bp, const float* z, const BlkBuf& b, int N, int64_t Md, int TL, int Dd, int hdec, hipStream_t s) {
-    if (dec_split_enabled() && hs_enc_mlp_fused_supported(Dd, hdec)) {
+int dec_block_fwd_fused(const BlkP& bp, const float* z, const BlkBuf& b, int N, int64_t Md, int TL, int Dd, int hdec, uint32_t sc, hipStream_t s) {
+    if ((sc & SC_DEC_SPLIT) && hs_enc_mlp_fused_supported(Dd, hdec)) {
         CK(hs_dec_attn_fwd(z, b.x1, b.o, b.lse, N, TL, dec_ptrs(bp, hdec), s));
         return hs_enc_mlp_fwd(b.x1, nullptr, b.x2, (int)Md, Dd, mlp_ptrs(bp, hdec), s);
     }
     return hs_dec_block_fwd(z, b.x1, b.x2, b.o, b.lse, N, TL, dec_ptrs(bp, hdec), s);
 }
 
-// The attention half's backward as ONE launch that recomputes q|k|v from u (attn.hip blk128_bwd_kernel<RC>): decided by the same
-// predicate in the forward (which then does not store q|k|v) and in the backward.  The environment switches are read per call so
-// that a parity test can flip them around a whole forward + backward pair.
-static bool pair_enabled();
-static bool attn_bwd_recompute(int d, int dp, int heads, int h, int Ts, bool f8u) {
-    if (pair_enabled()) return false;       // the pair schedule's backward (block_bwd_plan) reads the q|k|v the forward saved
-    const char* e1 = getenv("HSIMAE_FUSED_PROJ_BWD"); const char* e2 = getenv("HSIMAE_FUSED_LNBWD"); const char* e3 = getenv("HSIMAE_ATTN_BWD_RECOMPUTE");
-    if ((e1 && e1[0] == '0') || (e2 && e2[0] == '0') || (e3 && e3[0] == '0')) return false;
-    return !f8u && d == 128 && dp == d && fused_mlp_enabled(d, h) && hs_attn_block_bwd_fusable(d, heads, Ts);
+// The attention half's backward as ONE launch that recomputes q|k|v from u (attn.hip blk128_bwd_kernel<RC>): the same predicate
+// of the same recorded schedule word in the forward (which then does not store q|k|v) and in the backward.
+static bool attn_bwd_recompute(int d, int dp, int heads, int h, int Ts, bool f8u, uint32_t sc) {
+    if (!(sc & SC_PROJ_BWD) || !(sc & SC_LNBWD) || !(sc & SC_RECOMPUTE)) return false;
+    return !f8u && d == 128 && dp == d && fused_mlp_enabled(d, h, sc) && (sc & SC_ATTN_BLOCK) && (sc & SC_ATTN_BLOCK_BWD) &&
+           hs_attn_block_bwd_fusable(d, heads, Ts);
 }
 
 // One transformer Block forward (Models.py:303-306): 5 launches.
 // rs_a / rs_m: optional per-row DropPath factors of the attention / MLP branch (Models.py:304-305), NULL = none.
-int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int d, int heads, int h, int hp, int Ts,
+int block_fwd(const BlkP& P, uint32_t sc, const float* x_in, const BlkBuf& b, int64_t M, int d, int heads, int h, int hp, int Ts,
               int nsamples, int mode, int len_l, const float* res2, hipStream_t s, const float* rs_a = nullptr,
               const float* rs_m = nullptr) {
     GemmParams p = gp();
     const int dp = rup(d, 32);                        // storage width of the rows (plan.h Geo::Dp); the fused kernels need dp == d
     const bool f8 = P.prec == HSIMAE_PREC_FP8;        // the stand-alone linears on MX e4m3 images
-    const bool f8u = f8 && fp8_unfused();             // ... and no fused kernel at all (HSIMAE_FP8_UNFUSED=1)
+    const bool f8u = f8 && (sc & SC_FP8_UNFUSED);     // ... and no fused kernel at all (HSIMAE_FP8_UNFUSED=1)
     auto w8 = [&](GemmParams& q, const BlkP::I8& a) { if (f8) { q.prec = HSIMAE_PREC_FP8; q.W8 = a.w; q.S8 = a.s; } };
-    if (!f8u && hs_attn_block_fusable(d, heads, Ts)) {
+    if (!f8u && (sc & SC_ATTN_BLOCK) && hs_attn_block_fusable(d, heads, Ts)) {
         // LN1 + q|k|v + attention + projection + residual in one persistent kernel (attn.hip blk128_fwd_kernel)
-        CK(hs_attn_block_fwd(x_in, P.n1w, P.n1b, P.qkv, P.bqkv, P.p, P.pb, b.u, attn_bwd_recompute(d, dp, heads, h, Ts, f8u) ? nullptr : b.qkv,
+        CK(hs_attn_block_fwd(x_in, P.n1w, P.n1b, P.qkv, P.bqkv, P.p, P.pb, b.u, attn_bwd_recompute(d, dp, heads, h, Ts, f8u, sc) ? nullptr : b.qkv,
                              b.o, b.lse, b.x1, rs_a, Ts, nsamples, mode, len_l, s));
-        if (fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
-    } else if (!f8 && dp == d && hs_attn_block256_fusable(d, heads, Ts)) {
+        if (fused_mlp_enabled(d, h, sc)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
+    } else if (!f8 && dp == d && (sc & SC_ATTN_BLOCK256) && hs_attn_block256_fusable(d, heads, Ts, nsamples)) {
         // the same half at D = 256 (attn_wide.hip blk256_fwd_kernel: 16 waves = 16 heads, weights streamed from L2)
         CK(hs_attn_block256_fwd(x_in, P.n1w, P.n1b, P.qkv, P.bqkv, P.p, P.pb, b.u, b.qkv, b.o, b.lse, b.x1, rs_a, Ts, nsamples, mode,
                                 len_l, s));
@@ -220,7 +266,7 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
         CK(hs_gemm(p, A_BF16, E_RES_F32, s));
     }
     }
-    if (!f8u && fused_mlp_enabled(d, h)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
+    if (!f8u && fused_mlp_enabled(d, h, sc)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
     p = gp();
     p.A = b.x1; p.lda = dp; p.M = (int)M; p.N = hp; p.K = dp; p.n_valid = h; p.W = P.w1; p.W2 = P.w3; p.bias = P.w1b;
     p.bias2 = P.w3b; p.gamma = P.n2w; p.beta = P.n2b; p.u_out = b.u2; p.ldu = dp; p.out = b.g; p.ldo = hp;
@@ -238,18 +284,13 @@ int block_fwd(const BlkP& P, const float* x_in, const BlkBuf& b, int64_t M, int 
 
 // d = 256 / 512 (rows of exactly two / four 128-column chunks): LayerNorm backward as the epilogue of the k-outer GEMM
 // (gemm.hip epilogue_ln_ko; d = 512 on 32-row panels, fp8 only: Huge fp8 49.9 -> 48.9 ms per step, but bf16 60.2 -> 61.5).
-// HSIMAE_FUSED_LNBWD=0 keeps the separate du store + ln_bwd pass, HSIMAE_FUSED_LNBWD_512=0 keeps it at d = 512 only.
-static bool wide_ln_fused(int d, int dp, bool f8) {
-    static int on = -1, on512 = -1;
-    if (on < 0) {
-        const char* e = getenv("HSIMAE_FUSED_LNBWD"); on = !(e && e[0] == '0');
-        e = getenv("HSIMAE_FUSED_LNBWD_512"); on512 = !(e && e[0] == '0');
-    }
-    return on && dp == d && (d == 256 || (d == 512 && f8 && on512));
+// SC_LNBWD clear keeps the separate du store + ln_bwd pass, SC_LNBWD_512 clear keeps it at d = 512 only.
+static bool wide_ln_fused(int d, int dp, bool f8, uint32_t sc) {
+    return (sc & SC_LNBWD) && dp == d && (d == 256 || (d == 512 && f8 && (sc & SC_LNBWD_512)));
 }
 
 // One Block backward: data grads (7 launches) + all weight/bias grads of the block (1 launch).
-int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, const BlkBuf& b, int64_t M, int d,
+int block_bwd(const BlkP& P, uint32_t sc, const BlkOff& o, float* grads, const float* x_in, const BlkBuf& b, int64_t M, int d,
               int heads, int h, int hp, int Ts, int nsamples, int mode, int len_l, float* G0, const Scr& w,
               float* dx_out, int accumulate, hipStream_t s, int concurrent = 1, const float* rs_a = nullptr,
               const float* rs_m = nullptr, int64_t* det_acc = nullptr) {
@@ -259,9 +300,9 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
     l.M = (int)M; l.d = d; l.ld = dp; l.det_base = grads; l.det_acc = det_acc;
     const bool f8 = P.prec == HSIMAE_PREC_FP8;
-    const bool f8u = f8 && fp8_unfused();
+    const bool f8u = f8 && (sc & SC_FP8_UNFUSED);
     auto w8 = [&](GemmParams& q, const BlkP::I8& a) { if (f8) { q.prec = HSIMAE_PREC_FP8; q.W8 = a.w; q.S8 = a.s; } };
-    const bool fmlp = !f8u && fused_mlp_enabled(d, h);
+    const bool fmlp = !f8u && fused_mlp_enabled(d, h, sc);
     if (fmlp) {
         // recompute u2 / h1 / h3 / g inside the tile; emits dx1 and the wgrad operands u2, dh1|dh3, g, bf16 dY and dx1
         CK(hs_enc_mlp_bwd(b.x1, G0, G1, b.u2, w.dh13, b.g, w.g0b, w.g1b, (int)M, d, mlp_ptrs(P, h), grads + o.n2w,
@@ -274,7 +315,7 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         p = gp();
         p.A = w.dh13; p.lda = 2 * hp; p.M = (int)M; p.N = dp; p.K = 2 * hp; p.n_valid = d; p.W = P.w13T;
         w8(p, P.w13T8);
-        if (wide_ln_fused(d, dp, f8)) {       // LayerNorm-2 backward as the epilogue of the k-outer GEMM (the whole row is on chip)
+        if (wide_ln_fused(d, dp, f8, sc)) {   // LayerNorm-2 backward as the epilogue of the k-outer GEMM (the whole row is on chip)
             p.out = G1; p.ldo = dp; p.res = G0; p.ldr = dp; p.lnx = b.x1; p.gamma = P.n2w; p.accumulate = 0;
             p.dgamma = grads + o.n2w; p.dbeta = grads + o.n2b; p.det_base = grads; p.det_acc = det_acc;
             CK(hs_gemm(p, A_BF16, E_LN_BWD, s));
@@ -292,12 +333,11 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
     }
     // All weight / bias gradients of the block: 7 tasks for the batched weight-gradient kernel (every operand is a bf16 buffer on the
     // fused path, so no launch below reads G0 / G1, which the LayerNorm-1 backward overwrites with dx when the caller runs in place).
-    // HSIMAE_WGRAD_SPLIT=1: two launches, each right behind the kernel that produced its operands (the MLP's three straight after
-    // the MLP-half backward, the attention's four after the attention backward), so that they are read while still cache-resident.
-    auto run_wgrad = [&](int first, int count) -> int {
+    // (Round 4 measured the same work as two launches, each right behind the kernel that produced its operands: + 0.3 ms per step,
+    //  removed in round 5.)
+    auto run_wgrad = [&]() -> int {
         WgradParams g; std::memset(&g, 0, sizeof(g));
-        auto task = [&](int id, const void* dO, int ldo, const hs_bf16* A, int lda, int N, int K, int64_t dW, int64_t db) {
-            if (id < first || id >= first + count) return;
+        auto task = [&](int, const void* dO, int ldo, const hs_bf16* A, int lda, int N, int K, int64_t dW, int64_t db) {
             WgradTask& t = g.t[g.ntasks++];
             t.dO = dO; t.dO_f32 = 0; t.ldo = ldo; t.A = A; t.lda = lda; t.N = N; t.K = K; t.dW = grads + dW; t.ldw = K;
             t.db = grads + db; t.dO_rowscale = nullptr;
@@ -310,30 +350,22 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         task(5, w.dh13 + hp, 2 * hp, b.u2, dp, h, d, o.w3w, o.w3b);
         task(6, w.g0b, dp, b.g, hp, d, h, o.w2w, o.w2b);
         g.M = (int)M; g.det_base = grads; g.det_acc = det_acc;
-        static int wslab = -1;                    // HSIMAE_WGRAD_SLAB=0: float atomics on dW also in the 256 x 256-tile launches
-        if (wslab < 0) { const char* e = getenv("HSIMAE_WGRAD_SLAB"); wslab = !(e && e[0] == '0'); }
-        g.slab = wslab ? w.slab : nullptr;        // this stream's slab
+        g.slab = (sc & SC_WGRAD_SLAB) ? w.slab : nullptr;        // this stream's slab (clear: float atomics on dW also in the 256 x 256-tile launches)
         int tiles = 0;
         for (int i = 0; i < g.ntasks; ++i) tiles += ((g.t[i].N + 127) / 128) * ((g.t[i].K + 127) / 128);
         g.msplit = wgrad_msplit(tiles, M, concurrent);
         return hs_wgrad(g, s);
     };
-    static int wsplit_env = -1;
-    if (wsplit_env < 0) { const char* e = getenv("HSIMAE_WGRAD_SPLIT"); wsplit_env = (e && e[0] == '1'); }
-    const bool wsplit = wsplit_env && fmlp;
-    if (wsplit) CK(run_wgrad(4, 3));
     AttnParams a; std::memset(&a, 0, sizeof(a));
     a.qkv = b.qkv; a.ld = 3 * dp; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
     a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = dp; a.lse = b.lse; a.dout = w.dob; a.lddo = dp; a.dqkv = w.dqkv; a.kv_off = dp;
-    static int fuse_pb = -1;                  // HSIMAE_FUSED_PROJ_BWD=0: keep the projection's data gradient a separate GEMM
-    if (fuse_pb < 0) { const char* e = getenv("HSIMAE_FUSED_PROJ_BWD"); fuse_pb = !(e && e[0] == '0'); }
-    static int fuse_ln = -1;
-    if (fuse_ln < 0) { const char* e = getenv("HSIMAE_FUSED_LNBWD"); fuse_ln = !(e && e[0] == '0'); }
+    const bool fuse_pb = (sc & SC_PROJ_BWD) != 0;   // clear: keep the projection's data gradient a separate GEMM
+    const bool fuse_ln = (sc & SC_LNBWD) != 0;
     // round 4: dO, the attention backward, du and the LayerNorm-1 backward as ONE persistent launch (attn.hip blk128_bwd_kernel);
-    // with q|k|v recomputed from u when the forward did not save them (attn_bwd_recompute: the same predicate there)
-    const bool rc = attn_bwd_recompute(d, dp, heads, h, Ts, f8u);
+    // with q|k|v recomputed from u when the forward did not save them (attn_bwd_recompute: the same predicate of the same word)
+    const bool rc = attn_bwd_recompute(d, dp, heads, h, Ts, f8u, sc);
     const bool blk_bwd = rc || (fuse_pb && fuse_ln && fmlp && !f8u && d == 128 && dp == d && hs_attn_proj_fusable(a) &&
-                                hs_attn_block_bwd_fusable(d, heads, Ts));
+                                (sc & SC_ATTN_BLOCK_BWD) && hs_attn_block_bwd_fusable(d, heads, Ts));
     if (blk_bwd) {
         CK(hs_attn_block_bwd(rc ? nullptr : b.qkv, b.u, P.qkv, P.bqkv, b.o, b.lse, w.g1b, G1, x_in, P.n1w, P.pT, P.qkvT, w.dqkv, dx_out,
                              grads + o.n1w, grads + o.n1b, grads, reinterpret_cast<long long*>(det_acc), Ts, nsamples, mode, len_l,
@@ -348,12 +380,12 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         CK(hs_gemm(p, A_BF16, E_BF16, s));
     }
     if (!blk_bwd) CK(hs_attn_bwd(a, s));
-    if (wsplit) CK(run_wgrad(0, 4)); else CK(run_wgrad(0, 7));
+    CK(run_wgrad());
 
     if (blk_bwd) return HSIMAE_OK;
     // du = dqkv * Wqkv and the LayerNorm-1 backward: one kernel at d = 128 (LN backward as the GEMM's epilogue,
     // du never goes to HBM), two otherwise.  HSIMAE_FUSED_LNBWD=0 forces the two-kernel form.
-    const bool ln_fused = fuse_ln && ((d == 128 && !f8u) || wide_ln_fused(d, dp, f8));
+    const bool ln_fused = fuse_ln && ((d == 128 && !f8u) || wide_ln_fused(d, dp, f8, sc));
     p = gp();
     p.A = w.dqkv; p.lda = 3 * dp; p.M = (int)M; p.N = dp; p.K = 3 * dp; p.n_valid = d; p.W = P.qkvT;
     if (ln_fused) {
@@ -373,81 +405,6 @@ int block_bwd(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, c
         CK(hs_ln_bwd(l, s));
     }
     return HSIMAE_OK;
-}
-
-// ------------------------------------------------------------------ pair launches of the two axis stacks (round 4)
-// blocks_1.i and blocks_2.i (Models.py:556-560) are independent and have the same shapes.  Round 3 ran them on two streams; the
-// gain was 0.4 ms of the 0.8 ms that the launches' fixed costs add up to over the 18 axis blocks (a launch costs 11-36 us on top
-// of its per-row time: profiles/r03_g_where_the_time_is.txt).  Here the row-panel kernels of block i of BOTH stacks run as one
-// launch (blockIdx.y = stack): the MLP half forward / backward, the q|k|v data gradient + LayerNorm-1 backward and the 14 linears'
-// weight gradients; the two per-sample attention kernels (fixed cost ~5 us) stay two launches on the same stream.
-// Applies where every kernel involved has its fused D = 128 form.
-// MEASURED AND NOT ADOPTED (profiles/r04_p_pair_launch.txt, same box, C2): pair launches 16.51 / 16.51 / 16.53 ms per step, the
-// two-stream schedule 16.45 / 16.35 / 16.32, one stream 16.91.  A pair launch takes exactly twice a single one (enc_mlp_bwd 3.01 ms
-// per step against 2.95, wgrad_dma 2.54 against 2.54; only lnbwd_dma gains, 0.96 against 1.07): the "fixed cost" read off the
-// batch-size scaling is not a per-launch head / tail that merging removes.  Kept behind HSIMAE_PAIR_LAUNCH=1 (parity-tested: the
-// whole GPU suite passes with it on); the default is the two-stream schedule.
-static bool pair_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("HSIMAE_PAIR_LAUNCH"); on = (e && e[0] == '1'); }
-    return on != 0;
-}
-static bool pair_shapes_ok(const Geo& g, int Ts) {
-    return pair_enabled() && g.D == 128 && g.Dp == g.D && !(g.prec == HSIMAE_PREC_FP8 && fp8_unfused()) && hs_attn_block_fusable(g.D, g.H, Ts) &&
-           fused_mlp_enabled(g.D, g.h);
-}
-
-// What block_bwd launches on the fused D = 128 path, as parameter blocks (nothing is launched here)
-struct BlkBwdPlan { EncMlpPtrs mw; EncMlpBwdCall mlp; AttnParams attn; WgradTask t[7]; GemmParams ln; };
-static bool block_bwd_plan(const BlkP& P, const BlkOff& o, float* grads, const float* x_in, const BlkBuf& b, int64_t M, int d, int heads,
-                           int h, int hp, int Ts, int nsamples, int mode, int len_l, float* G0, const Scr& w, float* dx_out,
-                           const float* rs_a, const float* rs_m, int64_t* det_acc, BlkBwdPlan& q) {
-    const int dp = rup(d, 32);
-    if (d != 128 || dp != d || P.prec == HSIMAE_PREC_FP8 || !fused_mlp_enabled(d, h)) return false;
-    float* G1 = w.G1;
-    q.mw = mlp_ptrs(P, h);
-    q.mlp = EncMlpBwdCall{b.x1, G0, G1, b.u2, w.dh13, b.g, w.g0b, w.g1b, &q.mw, grads + o.n2w, grads + o.n2b, rs_m, rs_a};
-    AttnParams& a = q.attn; std::memset(&a, 0, sizeof(a));
-    a.qkv = b.qkv; a.ld = 3 * dp; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
-    a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = dp; a.lse = b.lse; a.dout = w.g1b; a.lddo = dp; a.dqkv = w.dqkv; a.kv_off = dp;
-    if (!hs_attn_proj_fusable(a)) return false;
-    a.projT_w = P.pT;                                   // dO = dx1 Wp inside the attention backward
-    int n = 0;
-    auto task = [&](const void* dO, int ldo, const hs_bf16* A, int lda, int N, int K, int64_t dW, int64_t db) {
-        WgradTask& t = q.t[n++];
-        t.dO = dO; t.dO_f32 = 0; t.ldo = ldo; t.A = A; t.lda = lda; t.N = N; t.K = K; t.dW = grads + dW; t.ldw = K;
-        t.db = grads + db; t.dO_rowscale = nullptr;
-    };
-    task(w.dqkv, 3 * dp, b.u, dp, d, d, o.qw, o.qb);
-    task(w.dqkv + dp, 3 * dp, b.u, dp, d, d, o.kw, o.kb);
-    task(w.dqkv + 2 * dp, 3 * dp, b.u, dp, d, d, o.vw, o.vb);
-    task(w.g1b, dp, b.o, dp, d, d, o.pw, o.pb);
-    task(w.dh13, 2 * hp, b.u2, dp, h, d, o.w1w, o.w1b);
-    task(w.dh13 + hp, 2 * hp, b.u2, dp, h, d, o.w3w, o.w3b);
-    task(w.g0b, dp, b.g, hp, d, h, o.w2w, o.w2b);
-    GemmParams& p = q.ln; p = gp();
-    p.A = w.dqkv; p.lda = 3 * dp; p.M = (int)M; p.N = dp; p.K = 3 * dp; p.n_valid = d; p.W = P.qkvT;
-    p.out = dx_out; p.ldo = d; p.res = G1; p.ldr = d; p.lnx = x_in; p.gamma = P.n1w; p.accumulate = 0;
-    p.dgamma = grads + o.n1w; p.dbeta = grads + o.n1b; p.det_base = grads; p.det_acc = det_acc;
-    return hs_lnbwd_dma_supported(p);
-}
-
-// backward of blocks i of both stacks from the two plans: 5 launches instead of 8
-static int block_bwd_pair(const BlkBwdPlan q[2], float* grads, int64_t M, int d, int64_t* det_acc, float* slab, hipStream_t s) {
-    EncMlpBwdCall mc[2] = {q[0].mlp, q[1].mlp};
-    mc[0].w = &q[0].mw; mc[1].w = &q[1].mw;
-    CK(hs_enc_mlp_bwd_pair(mc, (int)M, d, s, HsDet{grads, reinterpret_cast<long long*>(det_acc)}));
-    CK(hs_attn_bwd(q[0].attn, s));
-    CK(hs_attn_bwd(q[1].attn, s));
-    WgradParams g; std::memset(&g, 0, sizeof(g));
-    for (int k = 0; k < 2; ++k)
-        for (int i = 0; i < 7; ++i) g.t[g.ntasks++] = q[k].t[i];
-    g.M = (int)M; g.det_base = grads; g.det_acc = det_acc; g.slab = slab;
-    int tiles = 0;
-    for (int i = 0; i < g.ntasks; ++i) tiles += ((g.t[i].N + 127) / 128) * ((g.t[i].K + 127) / 128);
-    g.msplit = wgrad_msplit(tiles, M, 1);
-    CK(hs_wgrad(g, s));
-    return hs_lnbwd_dma_pair(q[0].ln, q[1].ln, s);
 }
 
 struct Ctx {
@@ -480,13 +437,13 @@ int make_ctx(const hsimae_config* cfg, const hsimae_io* io, Ctx& c, bool need_ws
 // ====================================================================== C ABI
 extern "C" {
 
-int hsimae_version(void) { return 103; }
+int hsimae_version(void) { return HSIMAE_VERSION; }
 
 int hsimae_two_streams_active(void) { return side().ok ? 1 : 0; }
 int hsimae_effective_precision(const hsimae_config* cfg) {
     if (!cfg) return HSIMAE_ENULL;
     Geo g; CK(make_geo(cfg, g));
-    return (g.prec == HSIMAE_PREC_FP8 && (g.D >= 512 || fp8_unfused())) ? HSIMAE_PREC_FP8 : HSIMAE_PREC_BF16;
+    return (g.prec == HSIMAE_PREC_FP8 && (g.D >= 512 || (sched_from_env() & SC_FP8_UNFUSED))) ? HSIMAE_PREC_FP8 : HSIMAE_PREC_BF16;
 }
 
 const char* hsimae_strerror(int code) {
@@ -496,6 +453,7 @@ const char* hsimae_strerror(int code) {
         case HSIMAE_EUNSUPPORTED: return "configuration not supported by the gfx950 kernels";
         case HSIMAE_EALIGN: return "misaligned pointer";
         case HSIMAE_ENULL: return "required pointer is NULL";
+        case HSIMAE_ENOFORWARD: return "no forward pass of this process has filled this workspace (the backward follows the forward's recorded schedule)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
@@ -539,6 +497,8 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
     if (!encoder_only && io->want_recons && (!io->pred_img || !io->mask_img)) return HSIMAE_ENULL;
     hipStream_t s = S(stream);
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w;
+    const uint32_t sc = sched_from_env();             // the pass's schedule: read here, recorded for the backward (see SC_*)
+    record_sched(io->workspace, true, !encoder_only, sc);
 
     MaskParams m; m.noise1 = io->noise1; m.noise2 = io->noise2; m.N = c.N; m.T = g.T; m.L = 9; m.len_t = c.len_t;
     m.len_l = c.len_l; m.ids_keep = io->ids_keep; m.ids_restore = io->ids_restore; m.mask = io->mask;
@@ -552,36 +512,7 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
     CK(hs_gemm(p, A_BF16, E_POS_F32, s));
 
     const float* x = w.x0;
-    if (g.has_axis && pair_shapes_ok(g, c.K) && g.sdepth > 1) {
-        // pair launches (see block_bwd_pair): blocks i of both stacks — two attention-half launches, ONE MLP-half launch.  The last
-        // pair stays two launches: the spectral block's epilogue adds the spatial block's output of the same index (x1 + x2).
-        const float* xa = w.x0;
-        const float* xb = w.x0;
-        for (int i = 0; i < g.sdepth; ++i) {
-            BlkP b1 = resolve_enc(g, c.L.b1[i], c.W.b1[i], P, io->wpk, c.W);
-            BlkP b2 = resolve_enc(g, c.L.b2[i], c.W.b2[i], P, io->wpk, c.W);
-            const DropRs r1 = drop_rs(io, i, c.Me), r2d = drop_rs(io, g.sdepth + i, c.Me);
-            const bool last = (i == g.sdepth - 1);
-            if (last) {
-                CK(block_fwd(b1, xa, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, nullptr, s, r1.a, r1.m));
-                CK(block_fwd(b2, xb, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.b1[i].x2, s, r2d.a, r2d.m));
-            } else {
-                CK(hs_attn_block_fwd(xa, b1.n1w, b1.n1b, b1.qkv, b1.bqkv, b1.p, b1.pb, w.b1[i].u, w.b1[i].qkv, w.b1[i].o, w.b1[i].lse,
-                                     w.b1[i].x1, r1.a, c.K, c.N, 1, c.len_l, s));
-                CK(hs_attn_block_fwd(xb, b2.n1w, b2.n1b, b2.qkv, b2.bqkv, b2.p, b2.pb, w.b2[i].u, w.b2[i].qkv, w.b2[i].o, w.b2[i].lse,
-                                     w.b2[i].x1, r2d.a, c.K, c.N, 2, c.len_l, s));
-                const EncMlpPtrs m1 = mlp_ptrs(b1, g.h), m2 = mlp_ptrs(b2, g.h);
-                const float* const x1s[2] = {w.b1[i].x1, w.b2[i].x1};
-                const float* const res[2] = {nullptr, nullptr};
-                float* const x2s[2] = {w.b1[i].x2, w.b2[i].x2};
-                const EncMlpPtrs* const ms[2] = {&m1, &m2};
-                const float* const rsc[2] = {r1.m, r2d.m};
-                CK(hs_enc_mlp_fwd_pair(x1s, res, x2s, (int)c.Me, g.D, ms, s, rsc));
-            }
-            xa = w.b1[i].x2; xb = w.b2[i].x2;
-        }
-        x = xb;
-    } else if (g.has_axis) {
+    if (g.has_axis) {
         Side& sd = side();
         const bool forked = sd.ok && g.sdepth > 1;
         if (forked) {
@@ -592,28 +523,28 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
         const float* xb = w.x0;
         for (int i = 0; i < g.sdepth; ++i) {
             // spatial stack: attend within one kept band group (Models.py:553,556)
-            BlkP b1 = resolve_enc(g, c.L.b1[i], c.W.b1[i], P, io->wpk, c.W);
+            BlkP b1 = resolve_enc(g, sc, c.L.b1[i], c.W.b1[i], P, io->wpk, c.W);
             const DropRs r1 = drop_rs(io, i, c.Me), r2d = drop_rs(io, g.sdepth + i, c.Me);
-            CK(block_fwd(b1, xa, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, nullptr, s, r1.a, r1.m));
+            CK(block_fwd(b1, sc, xa, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, nullptr, s, r1.a, r1.m));
             xa = w.b1[i].x2;
             // spectral stack: attend within one kept position (Models.py:554,559)
-            BlkP b2 = resolve_enc(g, c.L.b2[i], c.W.b2[i], P, io->wpk, c.W);
+            BlkP b2 = resolve_enc(g, sc, c.L.b2[i], c.W.b2[i], P, io->wpk, c.W);
             const bool last = (i == g.sdepth - 1);
             const float* r2 = last ? xa : nullptr;                      // x1 + x2 fused into the last epilogue (Models.py:564)
             if (last && forked) {                                       // needs the spatial stack's result: rejoin first
                 CK((int)hipEventRecord(sd.join, sd.s));
                 CK((int)hipStreamWaitEvent(s, sd.join, 0));
             }
-            CK(block_fwd(b2, xb, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, r2, (forked && !last) ? sd.s : s,
+            CK(block_fwd(b2, sc, xb, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, r2, (forked && !last) ? sd.s : s,
                          r2d.a, r2d.m));
             xb = w.b2[i].x2;
         }
         x = xb;
     }
     for (int i = 0; i < g.nfus; ++i) {
-        BlkP bp = resolve_enc(g, c.L.bf[i], c.W.bf[i], P, io->wpk, c.W);
+        BlkP bp = resolve_enc(g, sc, c.L.bf[i], c.W.bf[i], P, io->wpk, c.W);
         const DropRs rf = drop_rs(io, (g.has_axis ? 2 * g.sdepth : 0) + i, c.Me);
-        CK(block_fwd(bp, x, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, nullptr, s, rf.a, rf.m));
+        CK(block_fwd(bp, sc, x, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, nullptr, s, rf.a, rf.m));
         x = w.bf[i].x2;
     }
     if (encoder_only) {                       // `norm` only (Models.py:570 / 892): the latent the fine-tuning head reads
@@ -630,11 +561,11 @@ static int forward_impl(const hsimae_config* cfg, const hsimae_io* io, void* str
     as.yfull = w.yfull;
     CK(hs_assemble_fwd(as, s));
     const float* z = w.yfull;
-    const bool fdec = fused_dec_enabled(g);
+    const bool fdec = fused_dec_enabled(g, sc);
     for (int i = 0; i < g.ddepth; ++i) {
         BlkP bp = resolve(c.L.bd[i], c.W.bd[i], P, io->wpk, c.W);
-        if (fdec) CK(dec_block_fwd_fused(bp, z, w.bd[i], c.N, c.Md, g.TL, g.Dd, g.hdec, s));
-        else CK(block_fwd(bp, z, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, nullptr, s));
+        if (fdec) CK(dec_block_fwd_fused(bp, z, w.bd[i], c.N, c.Md, g.TL, g.Dd, g.hdec, sc, s));
+        else CK(block_fwd(bp, sc, z, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, nullptr, s));
         z = w.bd[i].x2;
     }
     // decoder_norm + decoder_pred (Models.py:597-600)
@@ -662,6 +593,8 @@ int hsimae_decode(const hsimae_config* cfg, const hsimae_io* io, const float* la
     if (!latent || !pred || !io->ids_restore) return HSIMAE_ENULL;
     hipStream_t s = S(stream);
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w;
+    const uint32_t sc = sched_from_env();
+    record_sched(io->workspace, false, true, sc);     // (the decoder's part only: an encoder pass in the same arena keeps its own record)
     GemmParams p = gp();                      // decoder_embed (Models.py:579)
     const float* lat_in = latent;
     if (g.Dp != g.D) {      // rows stored wider than the model: stage the caller's [Me][D] latent into a padded buffer (pad columns are zeros)
@@ -677,11 +610,11 @@ int hsimae_decode(const hsimae_config* cfg, const hsimae_io* io, const float* la
     as.yfull = w.yfull;
     CK(hs_assemble_fwd(as, s));
     const float* z = w.yfull;
-    const bool fdec = fused_dec_enabled(g);
+    const bool fdec = fused_dec_enabled(g, sc);
     for (int i = 0; i < g.ddepth; ++i) {
         BlkP bp = resolve(c.L.bd[i], c.W.bd[i], P, io->wpk, c.W);
-        if (fdec) CK(dec_block_fwd_fused(bp, z, w.bd[i], c.N, c.Md, g.TL, g.Dd, g.hdec, s));
-        else CK(block_fwd(bp, z, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, nullptr, s));
+        if (fdec) CK(dec_block_fwd_fused(bp, z, w.bd[i], c.N, c.Md, g.TL, g.Dd, g.hdec, sc, s));
+        else CK(block_fwd(bp, sc, z, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, nullptr, s));
         z = w.bd[i].x2;
     }
     p = gp();                                 // decoder_norm + decoder_pred (Models.py:597-600)
@@ -692,47 +625,17 @@ int hsimae_decode(const hsimae_config* cfg, const hsimae_io* io, const float* la
 
 // Backward of the encoder stacks + patch embedding, from d(x of the last encoder block) in w.G0.  Shared by
 // hsimae_backward (after the decoder) and hsimae_encode_backward (after `norm`).
-static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hipStream_t s, Emitter& emit) {
+static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hipStream_t s, Emitter& emit, uint32_t sc) {
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
     for (int i = g.nfus - 1; i >= 0; --i) {
-        BlkP bp = resolve_enc(g, L.bf[i], c.W.bf[i], P, io->wpk, c.W);
+        BlkP bp = resolve_enc(g, sc, L.bf[i], c.W.bf[i], P, io->wpk, c.W);
         const float* xin = (i > 0) ? w.bf[i - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
         const DropRs rf = drop_rs(io, (g.has_axis ? 2 * g.sdepth : 0) + i, c.Me);
-        CK(block_bwd(bp, L.bf[i], grads, xin, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, w.G0, w.sc, w.G0, 0, s, 1,
+        CK(block_bwd(bp, sc, L.bf[i], grads, xin, w.bf[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 0, c.len_l, w.G0, w.sc, w.G0, 0, s, 1,
                      rf.a, rf.m, io->det_acc));
         CK(emit(L.bf[i].n1w, L.bf[i].end, s));
     }
-    if (g.has_axis && pair_shapes_ok(g, c.K) && g.sdepth > 1) {
-        // d(x1 + x2) feeds both stacks (Models.py:564).  Blocks i of both stacks as pair launches, everything on the caller's stream;
-        // the spectral stack's gradient lives in G0 (scratch set sc2), the spatial stack's in G2 (scratch set sc)
-        CK((int)hipMemcpyAsync(w.G2, w.G0, c.Me * g.Dp * 4, hipMemcpyDeviceToDevice, s));
-        for (int i = g.sdepth - 1; i >= 0; --i) {
-            BlkP b2 = resolve_enc(g, L.b2[i], c.W.b2[i], P, io->wpk, c.W);
-            BlkP b1 = resolve_enc(g, L.b1[i], c.W.b1[i], P, io->wpk, c.W);
-            const DropRs r1 = drop_rs(io, i, c.Me), r2d = drop_rs(io, g.sdepth + i, c.Me);
-            const float* xin2 = (i > 0) ? w.b2[i - 1].x2 : w.x0;
-            const float* xin1 = (i > 0) ? w.b1[i - 1].x2 : w.x0;
-            BlkBwdPlan q[2];
-            const bool planned = i > 0 &&           // (block 0: the spatial stack's last step ACCUMULATES onto the spectral dX: two launches)
-                block_bwd_plan(b2, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, w.sc2, w.G0,
-                               r2d.a, r2d.m, io->det_acc, q[0]) &&
-                block_bwd_plan(b1, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, w.G2,
-                               r1.a, r1.m, io->det_acc, q[1]);
-            if (planned) {
-                static int wslab = -1;
-                if (wslab < 0) { const char* e = getenv("HSIMAE_WGRAD_SLAB"); wslab = !(e && e[0] == '0'); }
-                CK(block_bwd_pair(q, grads, c.Me, g.D, io->det_acc, wslab ? w.slab : nullptr, s));
-            } else {
-                CK(block_bwd(b2, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, w.sc2, w.G0, 0, s, 1,
-                             r2d.a, r2d.m, io->det_acc));
-                float* out = (i == 0) ? w.G0 : w.G2;
-                CK(block_bwd(b1, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, out, i == 0, s, 1,
-                             r1.a, r1.m, io->det_acc));
-            }
-            CK(emit(L.b2[i].n1w, L.b2[i].end, s));
-            CK(emit(L.b1[i].n1w, L.b1[i].end, s));
-        }
-    } else if (g.has_axis) {
+    if (g.has_axis) {
         // d(x1 + x2) feeds both stacks (Models.py:564); the spectral stack's backward runs on the side stream
         Side& sd = side();
         const bool forked = sd.ok && g.sdepth > 1;
@@ -747,20 +650,20 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
         // for the right stream through an event); without one the side stream's ranges wait for the join
         const bool per_block = emit.bucket != nullptr || !forked;
         for (int i = g.sdepth - 1; i >= 0; --i) {
-            BlkP b2 = resolve_enc(g, L.b2[i], c.W.b2[i], P, io->wpk, c.W);
+            BlkP b2 = resolve_enc(g, sc, L.b2[i], c.W.b2[i], P, io->wpk, c.W);
             const DropRs r1 = drop_rs(io, i, c.Me), r2d = drop_rs(io, g.sdepth + i, c.Me);
             const float* xin2 = (i > 0) ? w.b2[i - 1].x2 : w.x0;
-            CK(block_bwd(b2, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, scr2, w.G0, 0, s2, forked ? 2 : 1,
+            CK(block_bwd(b2, sc, L.b2[i], grads, xin2, w.b2[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 2, c.len_l, w.G0, scr2, w.G0, 0, s2, forked ? 2 : 1,
                          r2d.a, r2d.m, io->det_acc));
             if (per_block) CK(emit(L.b2[i].n1w, L.b2[i].end, s2));
             if (i == 0 && forked) {                 // the spatial stack's last step accumulates onto the spectral dX
                 CK((int)hipEventRecord(sd.join, sd.s));
                 CK((int)hipStreamWaitEvent(s, sd.join, 0));
             }
-            BlkP b1 = resolve_enc(g, L.b1[i], c.W.b1[i], P, io->wpk, c.W);
+            BlkP b1 = resolve_enc(g, sc, L.b1[i], c.W.b1[i], P, io->wpk, c.W);
             const float* xin1 = (i > 0) ? w.b1[i - 1].x2 : w.x0;
             float* out = (i == 0) ? w.G0 : w.G2;
-            CK(block_bwd(b1, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, out, i == 0, s, forked ? 2 : 1,
+            CK(block_bwd(b1, sc, L.b1[i], grads, xin1, w.b1[i], c.Me, g.D, g.H, g.h, g.hp, c.K, c.N, 1, c.len_l, w.G2, w.sc, out, i == 0, s, forked ? 2 : 1,
                          r1.a, r1.m, io->det_acc));
             if (per_block) CK(emit(L.b1[i].n1w, L.b1[i].end, s));
         }
@@ -784,7 +687,7 @@ static int encoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
 // Backward of the decoder from dL/dpred (bf16 [Md][96] in w.dpred) down to dL/d(latent) in w.du [Me][D]
 // (autograd of Models.py:573-601): decoder_pred / decoder_norm, the decoder blocks, the sequence assembly and
 // decoder_embed (its weight gradient included).  Shared by hsimae_backward and hsimae_decode_backward.
-static int decoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hipStream_t s, Emitter& emit) {
+static int decoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hipStream_t s, Emitter& emit, uint32_t sc) {
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
     const float* zlast = w.bd[g.ddepth - 1].x2;
     GemmParams p = gp();
@@ -804,7 +707,7 @@ static int decoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
     CK(hs_ln_bwd(l, s));
     CK(emit(L.dnw, L.total, s));
 
-    const bool fdec = fused_dec_enabled(g);
+    const bool fdec = fused_dec_enabled(g, sc);
     for (int i = g.ddepth - 1; i >= 0; --i) {
         BlkP bp = resolve(L.bd[i], c.W.bd[i], P, io->wpk, c.W);
         const float* xin = (i == 0) ? w.yfull : w.bd[i - 1].x2;
@@ -819,13 +722,11 @@ static int decoder_backward(const Ctx& c, const hsimae_io* io, float* grads, hip
             dg.det = HsDet{grads, reinterpret_cast<long long*>(io->det_acc)};
             // MLP half then attention half, both persistent with the block's weight gradients held in registers
             // (measured equal to "row-tile kernel + wgrad operands through HBM" at d = 64, with 0.7 GB less traffic)
-            // HSIMAE_DEC_SLAB=0: commit the in-register weight gradients with float atomics (rounds 1-2) instead of slab + reduce
-            static int use_slab = -1;
-            if (use_slab < 0) { const char* e = getenv("HSIMAE_DEC_SLAB"); use_slab = !(e && e[0] == '0'); }
+            // SC_DEC_SLAB clear: commit the in-register weight gradients with float atomics (rounds 1-2) instead of slab + reduce
             CK(hs_dec_block_bwd(xin, w.bd[i].x1, w.G0, w.G1, w.G0, w.bd[i].o, w.bd[i].lse, c.N, g.TL, dec_ptrs(bp, g.hdec), dg, s,
-                                use_slab ? w.slab : nullptr));
+                                (sc & SC_DEC_SLAB) ? w.slab : nullptr));
         } else {
-            CK(block_bwd(bp, L.bd[i], grads, xin, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, w.G0, w.sc, w.G0, 0, s, 1, nullptr, nullptr,
+            CK(block_bwd(bp, sc, L.bd[i], grads, xin, w.bd[i], c.Md, g.Dd, g.Hd, g.hdec, g.hpd, g.TL, c.N, 0, 9, w.G0, w.sc, w.G0, 0, s, 1, nullptr, nullptr,
                          io->det_acc));
         }
         CK(emit(L.bd[i].n1w, L.bd[i].end, s));
@@ -852,11 +753,13 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
                     void* stream) {
     Ctx c; CK(make_ctx(cfg, io, c, true));
     if (!grads || !io->ids_restore) return HSIMAE_ENULL;
+    uint32_t sc_enc = 0, sc_dec = 0;                  // what the forward that filled this arena ran (never the environment's word now)
+    CK(lookup_sched(io->workspace, true, true, sc_enc, sc_dec));
     hipStream_t s = S(stream);
     if (io->det_acc) CK((int)hipMemsetAsync(io->det_acc, 0, (size_t)c.L.total * 8, s));     // deterministic mode: fixed-point shadow sums
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
     Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0, grads, io->det_acc};
-    CK(decoder_backward(c, io, grads, s, emit));
+    CK(decoder_backward(c, io, grads, s, emit, sc_dec));
     // norm (Models.py:570)
     const float* xf = g.nfus ? w.bf[g.nfus - 1].x2 : (g.has_axis ? w.b2[g.sdepth - 1].x2 : w.x0);
     LnBwdParams l; std::memset(&l, 0, sizeof(l));
@@ -864,19 +767,21 @@ int hsimae_backward(const hsimae_config* cfg, const hsimae_io* io, float* grads,
     l.M = (int)c.Me; l.d = g.D; l.ld = g.Dp; l.det_base = grads; l.det_acc = io->det_acc;
     CK(hs_ln_bwd(l, s));
     CK(emit(L.nw, L.deb + g.Dd, s));
-    return encoder_backward(c, io, grads, s, emit);
+    return encoder_backward(c, io, grads, s, emit, sc_enc);
 }
 
 int hsimae_decode_backward(const hsimae_config* cfg, const hsimae_io* io, const float* dpred, float* dlatent, float* grads,
                            hsimae_bucket_cb cb, void* user, void* stream) {
     Ctx c; CK(make_ctx(cfg, io, c, true));
     if (!grads || !dpred || !dlatent || !io->ids_restore) return HSIMAE_ENULL;
+    uint32_t sc_enc = 0, sc_dec = 0;
+    CK(lookup_sched(io->workspace, false, true, sc_enc, sc_dec));
     hipStream_t s = S(stream);
     if (io->det_acc) CK((int)hipMemsetAsync(io->det_acc, 0, (size_t)c.L.total * 8, s));     // deterministic mode: fixed-point shadow sums
     const Geo& g = c.g; const Ws& w = c.w; const PLayout& L = c.L;
     CK(hs_rows_pad_bf16(dpred, w.dpred, c.Md, 72, 96, s));
     Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0, grads, io->det_acc};
-    CK(decoder_backward(c, io, grads, s, emit));
+    CK(decoder_backward(c, io, grads, s, emit, sc_dec));
     CK(emit(L.dew, L.deb + g.Dd, s));
     return (int)hipMemcpy2DAsync(dlatent, (size_t)g.D * 4, w.du, (size_t)g.Dp * 4, (size_t)g.D * 4, (size_t)c.Me, hipMemcpyDeviceToDevice, s);
 }
@@ -885,6 +790,8 @@ int hsimae_encode_backward(const hsimae_config* cfg, const hsimae_io* io, const 
                            hsimae_bucket_cb cb, void* user, void* stream) {
     Ctx c; CK(make_ctx(cfg, io, c, true));
     if (!grads || !dlatent) return HSIMAE_ENULL;
+    uint32_t sc_enc = 0, sc_dec = 0;
+    CK(lookup_sched(io->workspace, true, false, sc_enc, sc_dec));
     hipStream_t s = S(stream);
     if (io->det_acc) CK((int)hipMemsetAsync(io->det_acc, 0, (size_t)c.L.total * 8, s));     // deterministic mode: fixed-point shadow sums
     const Geo& g = c.g; const float* P = io->params; const Ws& w = c.w; const PLayout& L = c.L;
@@ -901,7 +808,7 @@ int hsimae_encode_backward(const hsimae_config* cfg, const hsimae_io* io, const 
     CK(hs_ln_bwd(l, s));
     Emitter emit{cb, user, cb ? S(io->bucket_stream) : nullptr, 0, grads, io->det_acc};
     CK(emit(L.nw, L.nb + g.D, s));
-    return encoder_backward(c, io, grads, s, emit);
+    return encoder_backward(c, io, grads, s, emit, sc_enc);
 }
 
 // ---------------------------------------------------------------------- per-kernel entry points
@@ -963,6 +870,7 @@ int hsimae_dec_block_fwd(const hsimae_dec_block_weights* w, const float* x, floa
     return hs_dec_block_fwd(x, x1, x2, o, lse, nsamples, Ts, d, S(stream));
 }
 int64_t hsimae_dec_block_slab_floats(void) { return kDecSlabFloats; }
+int64_t hsimae_wgrad_slab_bytes(const hsimae_config* cfg, int32_t side_stream) { return wgrad_slab_bytes(cfg, side_stream); }
 int hsimae_dec_block_bwd(const hsimae_dec_block_weights* w, const hsimae_dec_block_grads* g, const float* x, const float* x1,
                          const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o, const float* lse, int32_t nsamples,
                          int32_t Ts, float* slab, void* stream) {

@@ -1847,13 +1847,12 @@ bool hs_attn_proj_fusable(const AttnParams& p) {
 }
 int hs_attn_bwd(const AttnParams& p, hipStream_t s) { return dispatch<true>(p, s); }
 
-// LN1 + q|k|v + attention + projection + residual in one launch (see blk128_fwd_kernel).  HSIMAE_FUSED_ATTN_BLOCK=0 disables.
+// LN1 + q|k|v + attention + projection + residual in one launch (see blk128_fwd_kernel).  Shape predicate only: whether a pass
+// uses it is part of the schedule word its forward records (api.hip SC_ATTN_BLOCK, HSIMAE_FUSED_ATTN_BLOCK=0 clears it).
 bool hs_attn_block_fusable(int d, int heads, int Ts) {
-    const char* e = getenv("HSIMAE_FUSED_ATTN_BLOCK");        // read per call: the parity test flips it inside one process
-    const bool on = !(e && e[0] == '0');
     AttnParams q = AttnParams();
     q.d = d; q.heads = heads; q.hd = heads ? d / heads : 0; q.Ts = Ts; q.ld = 384; q.ldo = 128; q.lse = reinterpret_cast<float*>(1);
-    return on && hs_attn_proj_fusable(q);
+    return hs_attn_proj_fusable(q);
 }
 int hs_attn_block_fwd(const float* x, const float* n1w, const float* n1b, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* wp,
                       const float* pb, hs_bf16* u, hs_bf16* qkv, hs_bf16* o, float* lse, float* x1, const float* rowscale, int Ts,
@@ -1869,11 +1868,9 @@ int hs_attn_block_fwd(const float* x, const float* n1w, const float* n1b, const 
     return Ts <= 16 ? launch_blk128<1, 2>(a, s) : launch_blk128<2, 2>(a, s);
 }
 
-// dO + attention backward + du + LayerNorm-1 backward in one launch (see blk128_bwd_kernel).  HSIMAE_FUSED_ATTN_BLOCK_BWD=0 disables.
-bool hs_attn_block_bwd_fusable(int d, int heads, int Ts) {
-    const char* e = getenv("HSIMAE_FUSED_ATTN_BLOCK_BWD");    // read per call: the parity test flips it inside one process
-    return !(e && e[0] == '0') && hs_attn_block_fusable(d, heads, Ts);
-}
+// dO + attention backward + du + LayerNorm-1 backward in one launch (see blk128_bwd_kernel).  Shape predicate only (api.hip
+// SC_ATTN_BLOCK_BWD, HSIMAE_FUSED_ATTN_BLOCK_BWD=0 clears it in the forward's schedule word).
+bool hs_attn_block_bwd_fusable(int d, int heads, int Ts) { return hs_attn_block_fusable(d, heads, Ts); }
 int hs_attn_block_bwd(const hs_bf16* qkv, const hs_bf16* u, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* o, const float* lse,
                       const hs_bf16* dx1b, const float* dx1, const float* x, const float* gamma, const hs_bf16* wpT, const hs_bf16* wqkvT,
                       hs_bf16* dqkv, float* dx, float* dgamma, float* dbeta, const float* det_base, long long* det_acc, int Ts,

@@ -378,9 +378,10 @@ int launch_blk256(const Blk256Args& a, hipStream_t s) {
 
 }  // namespace
 
-bool hs_attn_block256_fusable(int d, int heads, int Ts) {
-    const char* e = getenv("HSIMAE_FUSED_ATTN_BLOCK256");     // =0: the layer-at-a-time kernels (A/B runs; read per call like HSIMAE_FUSED_ATTN_BLOCK)
-    return !(e && e[0] == '0') && d == DW && heads == HW && Ts >= 1 && Ts <= 32;
+// Shape predicate (api.hip SC_ATTN_BLOCK256 is the A/B switch).  The kernel's 32-bit element offsets bound the launch size: a
+// larger launch answers false here and takes the layer-at-a-time kernels instead of failing in hs_attn_block256_fwd.
+bool hs_attn_block256_fusable(int d, int heads, int Ts, int nsamples) {
+    return d == DW && heads == HW && Ts >= 1 && Ts <= 32 && (int64_t)nsamples * Ts * 3 * DW < (1ll << 31);
 }
 
 int hs_attn_block256_fwd(const float* x, const float* n1w, const float* n1b, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* wp,

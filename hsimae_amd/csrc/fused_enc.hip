@@ -218,21 +218,16 @@ struct EncMlpW {
 };
 
 struct EncMlpFwdArgs { const float* x1; const float* res2; float* x2; int M; EncMlpW w; const float* rowscale; };
-// Pair launches (round 4): the two axis stacks of the encoder (blocks_1.i / blocks_2.i, Models.py:556-560) are independent and
-// have the same shapes, so block i of both runs as ONE launch of twice the workgroups: blockIdx.y picks the argument set.  A
-// launch costs a fixed 11-36 us on top of its per-row time (head: every resident workgroup waits for its first rows together;
-// tail: the last round drains; profiles/r03_g_where_the_time_is.txt) — paid once per pair instead of twice.
-struct EncMlpFwdArgs2 { EncMlpFwdArgs v[2]; };
+// (Round 4 also had a "pair launch" form — blocks i of the two axis stacks as one launch of twice the workgroups, blockIdx.y
+//  picking the argument set.  Measured and rejected: a pair launch takes exactly twice a single one, profiles/r04_p_pair_launch.txt;
+//  removed from the library in round 5, the code is in the git history at e1f4f12.)
 
 // x2 = x1 + rs * (b2 + (silu(u2 W1^T + b1) * (u2 W3^T + b3)) W2^T)  (+ res2), u2 = LN2(x1), one 64-row panel per workgroup.
 // The W2 product is accumulated per 64-column hidden chunk (the gate lives in two 9-KB chunk images instead of a
 // 46-KB panel image) and the residual is added from an L2-hot re-read in the store loop, so a workgroup needs 36 KB of
 // LDS and ~150 registers: three workgroups per CU instead of two.
-// PAIR = false: a single problem (argument set 0).  The indexed form costs the single launches 3-6 % (r04_r: <128,352> backward
-// 144.0 -> 147.9 us, <256,704> 381.9 -> 403.8), so it is only instantiated for the pair launches.
-template <int D, int HPE, bool PAIR = false>
-__global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(EncMlpFwdArgs2 pp) {
-    const EncMlpFwdArgs& p = pp.v[PAIR ? blockIdx.y : 0];
+template <int D, int HPE>
+__global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(EncMlpFwdArgs p) {
     using G = MG<D, HPE>;
     constexpr int R = G::R;
     constexpr int LU = G::LU, LC = G::LC, LX = G::LX, NCH = G::NCH, KSD = G::KSD, LPR = G::LPR;
@@ -422,11 +417,9 @@ struct EncMlpBwdArgs {
     const float* rs_mlp; const float* rs_attn;
     HsDet det;
 };
-struct EncMlpBwdArgs2 { EncMlpBwdArgs v[2]; };
 
-template <int D, int HPE, bool PAIR = false>
-__global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(EncMlpBwdArgs2 pp) {
-    const EncMlpBwdArgs& p = pp.v[PAIR ? blockIdx.y : 0];
+template <int D, int HPE>
+__global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     using G = MG<D, HPE>;
     constexpr int R = G::R;
     constexpr int LU = G::LU, LC = G::LC, LX = G::LX, NCH = G::NCH, KSD = G::KSD, KSH = G::KSH, LPR = G::LPR;
@@ -715,10 +708,6 @@ static void set_attrs() {
     if (done) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_fwd_kernel<D, HP>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_FWD);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel<D, HP>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_BWD);
-    if constexpr (D == 128) {                 // the pair instantiations exist at the Base width only (api.hip pair_shapes_ok)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_fwd_kernel<D, HP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_FWD);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel<D, HP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_BWD);
-    }
     done = true;
 }
 
@@ -731,12 +720,10 @@ static int fwd_grid(int M) {
     return panels < slots ? panels : slots;
 }
 
-static int launch_fwd(const EncMlpFwdArgs2& a, int M, int d, int npair, hipStream_t s) {
-    if (npair == 2 && d != 128) return HS_EUNSUPPORTED;
+static int launch_fwd(const EncMlpFwdArgs& a, int M, int d, hipStream_t s) {
     if (d == 128) {
         set_attrs<128, 352>();
-        if (npair == 2) hipLaunchKernelGGL((enc_mlp_fwd_kernel<128, 352, true>), dim3(fwd_grid<128, 352>(M), 2), dim3(NTH), (MG<128, 352>::LDS_FWD), s, a);
-        else hipLaunchKernelGGL((enc_mlp_fwd_kernel<128, 352>), dim3(fwd_grid<128, 352>(M)), dim3(NTH), (MG<128, 352>::LDS_FWD), s, a);
+        hipLaunchKernelGGL((enc_mlp_fwd_kernel<128, 352>), dim3(fwd_grid<128, 352>(M)), dim3(NTH), (MG<128, 352>::LDS_FWD), s, a);
     } else if (d == 256) {
         set_attrs<256, 704>();
         hipLaunchKernelGGL((enc_mlp_fwd_kernel<256, 704>), dim3(fwd_grid<256, 704>(M)), dim3(NTH), (MG<256, 704>::LDS_FWD), s, a);
@@ -752,30 +739,16 @@ static int launch_fwd(const EncMlpFwdArgs2& a, int M, int d, int npair, hipStrea
 int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, const EncMlpPtrs& b, hipStream_t s,
                    const float* rowscale) {
     if (M <= 0) return HS_OK;
-    EncMlpFwdArgs2 a;
-    a.v[0].x1 = x1; a.v[0].res2 = res2; a.v[0].x2 = x2; a.v[0].M = M; a.v[0].w = mkw(b); a.v[0].rowscale = rowscale;
-    a.v[1] = a.v[0];
-    return launch_fwd(a, M, d, 1, s);
+    EncMlpFwdArgs a;
+    a.x1 = x1; a.res2 = res2; a.x2 = x2; a.M = M; a.w = mkw(b); a.rowscale = rowscale;
+    return launch_fwd(a, M, d, s);
 }
 
-// blocks i of the two axis stacks in one launch (see EncMlpFwdArgs2)
-int hs_enc_mlp_fwd_pair(const float* const x1[2], const float* const res2[2], float* const x2[2], int M, int d, const EncMlpPtrs* const b[2],
-                        hipStream_t s, const float* const rowscale[2]) {
-    if (M <= 0) return HS_OK;
-    EncMlpFwdArgs2 a;
-    for (int i = 0; i < 2; ++i) {
-        a.v[i].x1 = x1[i]; a.v[i].res2 = res2[i]; a.v[i].x2 = x2[i]; a.v[i].M = M; a.v[i].w = mkw(*b[i]); a.v[i].rowscale = rowscale[i];
-    }
-    return launch_fwd(a, M, d, 2, s);
-}
-
-static int launch_bwd(const EncMlpBwdArgs2& a, int M, int d, int npair, hipStream_t s) {
-    if (npair == 2 && d != 128) return HS_EUNSUPPORTED;
+static int launch_bwd(const EncMlpBwdArgs& a, int M, int d, hipStream_t s) {
     if (d == 128) {
         constexpr int R = MG<128, 352>::R;
         set_attrs<128, 352>();
-        if (npair == 2) hipLaunchKernelGGL((enc_mlp_bwd_kernel<128, 352, true>), dim3((M + R - 1) / R, 2), dim3(NTH), (MG<128, 352>::LDS_BWD), s, a);
-        else hipLaunchKernelGGL((enc_mlp_bwd_kernel<128, 352>), dim3((M + R - 1) / R), dim3(NTH), (MG<128, 352>::LDS_BWD), s, a);
+        hipLaunchKernelGGL((enc_mlp_bwd_kernel<128, 352>), dim3((M + R - 1) / R), dim3(NTH), (MG<128, 352>::LDS_BWD), s, a);
     } else if (d == 256) {
         constexpr int R = MG<256, 704>::R;
         set_attrs<256, 704>();
@@ -802,17 +775,5 @@ int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs
                    hs_bf16* dx1b, int M, int d, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s,
                    const float* rs_mlp, const float* rs_attn, HsDet det) {
     if (M <= 0) return HS_OK;
-    EncMlpBwdArgs2 a;
-    a.v[0] = mk_bwd(x1, dy, dx1, u2, dh13, g, dyb, dx1b, M, b, g_n2w, g_n2b, rs_mlp, rs_attn, det);
-    a.v[1] = a.v[0];
-    return launch_bwd(a, M, d, 1, s);
-}
-
-int hs_enc_mlp_bwd_pair(const EncMlpBwdCall c[2], int M, int d, hipStream_t s, HsDet det) {
-    if (M <= 0) return HS_OK;
-    EncMlpBwdArgs2 a;
-    for (int i = 0; i < 2; ++i)
-        a.v[i] = mk_bwd(c[i].x1, c[i].dy, c[i].dx1, c[i].u2, c[i].dh13, c[i].g, c[i].dyb, c[i].dx1b, M, *c[i].w, c[i].g_n2w, c[i].g_n2b,
-                        c[i].rs_mlp, c[i].rs_attn, det);
-    return launch_bwd(a, M, d, 2, s);
+    return launch_bwd(mk_bwd(x1, dy, dx1, u2, dh13, g, dyb, dx1b, M, b, g_n2w, g_n2b, rs_mlp, rs_attn, det), M, d, s);
 }

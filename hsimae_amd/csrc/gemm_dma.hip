@@ -27,11 +27,7 @@ typedef __attribute__((address_space(3))) void* lds_vptr;
 // bank groups when a wave reads one k-group of all of them (row pitch 768 B = 0 mod 256 B)
 __device__ __forceinline__ int swz(int row) { return row & 15; }
 
-struct GemmParams2 { GemmParams v[2]; };      // pair launch: blockIdx.y picks the argument set (see fused_enc.hip EncMlpFwdArgs2)
-
-template <bool PAIR>
-__global__ __launch_bounds__(256, 2) void lnbwd_dma_kernel(GemmParams2 pp) {
-    const GemmParams& p = pp.v[PAIR ? blockIdx.y : 0];
+__global__ __launch_bounds__(256, 2) void lnbwd_dma_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) bf16_t stage0[DC * KA];
     __shared__ __attribute__((aligned(16))) bf16_t stage1[DC * KA];
     __shared__ __attribute__((aligned(16))) float T1[DC * TSX];
@@ -319,17 +315,6 @@ int hs_lnbwd_dma(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0) return HS_OK;
     if (!hs_lnbwd_dma_supported(p)) return HS_EUNSUPPORTED;
     const int nchunks = (p.M + DC - 1) / DC;
-    GemmParams2 pp; pp.v[0] = p; pp.v[1] = p;
-    hipLaunchKernelGGL(lnbwd_dma_kernel<false>, dim3(nchunks < 512 ? nchunks : 512), dim3(256), 0, s, pp);
-    return (int)hipGetLastError();
-}
-
-// two independent problems of the same M in one launch (blocks i of the two axis stacks); each half walks its rows with half the workgroups
-int hs_lnbwd_dma_pair(const GemmParams& a, const GemmParams& b, hipStream_t s) {
-    if (a.M <= 0) return HS_OK;
-    if (a.M != b.M || !hs_lnbwd_dma_supported(a) || !hs_lnbwd_dma_supported(b)) return HS_EUNSUPPORTED;
-    const int nchunks = (a.M + DC - 1) / DC;
-    GemmParams2 pp; pp.v[0] = a; pp.v[1] = b;
-    hipLaunchKernelGGL(lnbwd_dma_kernel<true>, dim3(nchunks < 256 ? nchunks : 256, 2), dim3(256), 0, s, pp);
+    hipLaunchKernelGGL(lnbwd_dma_kernel, dim3(nchunks < 512 ? nchunks : 512), dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }

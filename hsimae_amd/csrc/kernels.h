@@ -25,7 +25,6 @@ int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s);
 int hs_gemm_tiled(const GemmParams& p, int akind, int epi, int bm, int kc, hipStream_t s);   // tile sweep hook
 bool hs_lnbwd_dma_supported(const GemmParams& p);     // persistent LDS-DMA form of (A_BF16, E_LN_BWD) at N = 128, K = 384
 int hs_lnbwd_dma(const GemmParams& p, hipStream_t s);
-int hs_lnbwd_dma_pair(const GemmParams& a, const GemmParams& b, hipStream_t s);     // two problems of the same M, one launch
 bool hs_lnqkv_supported(const GemmParams& p);          // persistent form of (A_F32_LN, E_BF16) at K = 128, N = 384
 int hs_lnqkv(const GemmParams& p, hipStream_t s);
 int hs_pack(const PackDesc* descs_dev, int ndesc, int max_elems, hipStream_t s);
@@ -88,8 +87,8 @@ int hs_attn_block_bwd(const hs_bf16* qkv, const hs_bf16* u, const hs_bf16* wqkv,
 int hs_attn_block_fwd(const float* x, const float* n1w, const float* n1b, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* wp,
                       const float* pb, hs_bf16* u, hs_bf16* qkv, hs_bf16* o, float* lse, float* x1, const float* rowscale, int Ts,
                       int nsamples, int mode, int len_l, hipStream_t s);
-// the same half at D = 256 (16 heads of 16, <= 32 tokens): attn_wide.hip.  HSIMAE_FUSED_ATTN_BLOCK256=0 disables.
-bool hs_attn_block256_fusable(int d, int heads, int Ts);
+// the same half at D = 256 (16 heads of 16, <= 32 tokens): attn_wide.hip.  HSIMAE_FUSED_ATTN_BLOCK256=0 disables (api.hip SC_*).
+bool hs_attn_block256_fusable(int d, int heads, int Ts, int nsamples);
 int hs_attn_block256_fwd(const float* x, const float* n1w, const float* n1b, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* wp,
                          const float* pb, hs_bf16* u, hs_bf16* qkv, hs_bf16* o, float* lse, float* x1, const float* rowscale, int Ts,
                          int nsamples, int mode, int len_l, hipStream_t s);
@@ -99,14 +98,6 @@ int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, 
 int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
                    hs_bf16* dx1b, int M, int d, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s,
                    const float* rs_mlp = nullptr, const float* rs_attn = nullptr, HsDet det = HsDet{nullptr, nullptr});
-// blocks i of the two axis stacks in one launch (blockIdx.y = stack; fused_enc.hip EncMlpFwdArgs2)
-int hs_enc_mlp_fwd_pair(const float* const x1[2], const float* const res2[2], float* const x2[2], int M, int d, const EncMlpPtrs* const b[2],
-                        hipStream_t s, const float* const rowscale[2]);
-struct EncMlpBwdCall {
-    const float* x1; const float* dy; float* dx1; hs_bf16* u2; hs_bf16* dh13; hs_bf16* g; hs_bf16* dyb; hs_bf16* dx1b;
-    const EncMlpPtrs* w; float* g_n2w; float* g_n2b; const float* rs_mlp; const float* rs_attn;
-};
-int hs_enc_mlp_bwd_pair(const EncMlpBwdCall c[2], int M, int d, hipStream_t s, HsDet det);
 
 int hs_adamw(float* p, const float* g, float* m, float* v, const unsigned char* group, int64_t n, float lr, float b1, float b2,
              float eps, float wd, int step, hipStream_t s);

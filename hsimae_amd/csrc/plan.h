@@ -218,10 +218,14 @@ struct Ws {
 //   * the 256 x 256-tile weight-gradient launch (wgrad.hip, all matrices >= 256 wide: Large / Huge): 256 workgroups x 256 KB,
 //     one slab per stream — the caller's and, for the forked spectral stack, the side stream's;
 //   * the fused decoder's backward: HSIMAE_DEC_BLOCK_SLAB_FLOATS (checked against fused_dec.hip's own constants there), caller's stream.
+//   The caller's stream also runs the DECODER's weight-gradient launches when the decoder goes layer at a time (block_bwd with
+//   w.sc): a decoder of width >= 256 takes the 256 x 256-tile path whatever the encoder's width is (embed_dim 128 +
+//   decoder_embed_dim 256 wrote 247 x 256 KB into a 56.7 MB slab), so the caller's slab is sized from BOTH widths; the side
+//   stream only ever runs encoder blocks.
 constexpr int64_t kSlabBytes = 256ll * 256 * 256 * 4;
 inline int64_t slab_bytes(const Geo& g, bool side_stream) {
-    const int64_t wg = g.Dp >= 256 ? kSlabBytes : 0;
-    if (side_stream) return g.has_axis ? wg : 0;
+    if (side_stream) return (g.has_axis && g.Dp >= 256) ? kSlabBytes : 0;
+    const int64_t wg = std::max(g.Dp, g.Ddp) >= 256 ? kSlabBytes : 0;
     return std::max<int64_t>(wg, HSIMAE_DEC_BLOCK_SLAB_FLOATS * 4);
 }
 
@@ -314,6 +318,10 @@ inline int build_pack_table(const hsimae_config* cfg, const float* params_dev, h
     std::vector<PackDesc> d; pack_descs(g, L, W, params_dev, wpk_dev, d);
     std::memcpy(table_host, d.data(), d.size() * sizeof(PackDesc));
     return HSIMAE_OK;
+}
+inline int64_t wgrad_slab_bytes(const hsimae_config* cfg, int32_t side_stream) {
+    Geo g; if (make_geo(cfg, g)) return -1;
+    return slab_bytes(g, side_stream != 0);
 }
 inline int64_t workspace_bytes(const hsimae_config* cfg, int32_t N, int32_t len_t, int32_t len_l) {
     Geo g; if (make_geo(cfg, g)) return -1;

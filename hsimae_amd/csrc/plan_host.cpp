@@ -18,4 +18,5 @@ int64_t hsimae_workspace_bytes(const hsimae_config* cfg, int32_t N, int32_t len_
     return workspace_bytes(cfg, N, len_t, len_l);
 }
 int32_t hsimae_wgrad_msplit(int32_t tiles, int64_t M) { return wgrad_msplit(tiles, M); }
+int64_t hsimae_wgrad_slab_bytes(const hsimae_config* cfg, int32_t side_stream) { return wgrad_slab_bytes(cfg, side_stream); }
 }

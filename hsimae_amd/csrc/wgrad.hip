@@ -456,229 +456,10 @@ __global__ __launch_bounds__(512) void wgrad_slab_reduce_kernel(WgradParams p) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Rectangular tiles for the narrow layers (round 4; d = 128: every linear of an encoder block is 128 x 128, 352 x 128 or
-// 128 x 352).  A workgroup of wgrad_dma_kernel<DS, false> streams 128 + 128 operand columns per row for a 128 x 128 tile: the 13
-// tiles of a block fetch 3,328 columns per row — 736 MB per launch through the CUs' memory pipelines for 474 MB of HBM reads
-// (the A operand of q | k | v and of w1 | w3 is pulled once per tile), and the bytes a CU pulls, L2 hits included, are what
-// these kernels wait for.  Here a workgroup owns a WHOLE linear (q | k | v as one 384 x 128
-// tile with three dW targets): 5 tiles, 2,304 columns per row, 509 MB.  8 waves as 4 (n) x 2 (k), 96 accumulator registers per
-// wave in every shape; stage = 32 rows x (TN + TK) columns (32 KB; 16 KB for the 128 x 128 projection), 3-stage ring, one
-// workgroup per CU; per-tile row splits in proportion to the tile's bytes; workgroup -> (tile, row slice) from a host-built table
-// ordered by row range, cut into 8 contiguous parts (one per XCD) so that the tiles of a row range share an L2.
-// MEASURED AND NOT ADOPTED (profiles/r04_x_wgrad_rect.txt; HSIMAE_WGRAD_RECT=1 enables it, the kernel test covers it): 135-140 us per
-// launch against 122 for the 128 x 128 tiles, step + 0.25 ms.  The loop alone (commits compiled out) takes 124 us against ~108,
-// with 3 or 4 ring stages, with 128, 192 or 252 workgroups alike: it moves its 509 MB at 4.1 TB/s where the 128-tiles move their
-// 736 MB at 6.8 — three independent 4-wave workgroups per CU keep the memory system busier than one 8-wave workgroup in
-// barrier lock-step does, and that is worth more than a third of the bytes.
-struct RectTile {
-    const bf16_t* dO; const bf16_t* A;
-    float* dW[3]; float* db[3];           // n-slab s (128 rows) commits to dW[s] / db[s] (merged q | k | v); nsub = 1: dW[0] holds all N rows
-    int ldo, lda, ldw, N, K, nsub, kind;  // kind 0: 384 (n) x 128 (k), 1: 128 x 384, 2: 128 x 128
-    int msplit;
-};
-struct RectParams {
-    RectTile t[8];
-    unsigned short wg[256];               // flat workgroup index -> tile | row slice << 3
-    int ntiles, total, M;
-    const float* det_base; long long* det_acc;
-};
-
-template <int ROWB>
-__device__ __forceinline__ uint32_t rect_frag_addr(uint32_t tile_bytes, int col0, int lane) {
-    const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
-    const int row = 8 * g + q;
-    const int chunk = ((col0 >> 3) + (pq >> 1)) ^ swz(row);
-    return tile_bytes + (uint32_t)(row * ROWB + chunk * 16 + (pq & 1) * 8);
-}
-template <int ROWB>
-__device__ __forceinline__ void rect_tr_read2(uint32_t addr, Frag2& f) {
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3"
-                 : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr), "n"(4 * ROWB) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void rect_wait_lds(Frag2 (&x)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(x[i].lo), "+v"(x[i].hi));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(x[i].lo), "+v"(x[i].hi));
-}
-
-// one tile shape: TN / TK operand columns, NF n-fragments and KF k-fragments of 16 per wave
-template <int DS, int TN, int TK>
-__device__ __forceinline__ void rect_body(const RectParams& p, const RectTile& t, int ms, char* smem_raw) {
-    constexpr int NF = TN / 64, KF = TK / 32;                       // 4 waves along n, 2 along k
-    constexpr int RBN = TN * 2, RBK = TK * 2;                       // LDS row bytes of the two operands
-    constexpr int STAGE_B = DC * (RBN + RBK);
-    constexpr int IN_ = DC * TN / 8 / 64 / 8, IK_ = DC * TK / 8 / 64 / 8;      // DMA instructions per wave and chunk (3 | 1)
-    static_assert(IN_ * 8 * 64 * 8 == DC * TN && IK_ * 8 * 64 * 8 == DC * TK, "stage must be whole wave-instructions");
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wk = wave & 1;
-    const HsDet det{p.det_base, p.det_acc};
-    const int nchunks = (p.M + DC - 1) / DC;
-    const int cpw = (nchunks + t.msplit - 1) / t.msplit;
-    const int cbeg = ms * cpw, cend = min(nchunks, cbeg + cpw);
-    const int nch = cend - cbeg;
-    const uint32_t bytes_d = (uint32_t)min((int64_t)p.M * t.ldo * 2, (int64_t)0xffffffffu);
-    const uint32_t bytes_a = (uint32_t)min((int64_t)p.M * t.lda * 2, (int64_t)0xffffffffu);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(t.dO), 0, bytes_d, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(t.A), 0, bytes_a, 0x00020000);
-    // DMA slot s (16 bytes, linear in the stage) = (row s / CPR, column chunk (s % CPR) with its low 4 bits ^ swz(row))
-    uint32_t vd[IN_], va[IK_];
-#pragma unroll
-    for (int i = 0; i < IN_; ++i) {
-        constexpr int CPR = TN / 8;
-        const int slot = (wave * IN_ + i) * 64 + lane, row = slot / CPR, ch = slot % CPR;
-        vd[i] = (uint32_t)(row * t.ldo + 8 * ((ch & ~15) | ((ch & 15) ^ swz(row)))) * 2u;
-    }
-#pragma unroll
-    for (int i = 0; i < IK_; ++i) {
-        constexpr int CPR = TK / 8;
-        const int slot = (wave * IK_ + i) * 64 + lane, row = slot / CPR, ch = slot % CPR;
-        va[i] = (uint32_t)(row * t.lda + 8 * ((ch & ~15) | ((ch & 15) ^ swz(row)))) * 2u;
-    }
-    auto issue = [&](int c, int stage) {
-        char* st = smem_raw + stage * STAGE_B;
-        const uint32_t od = (uint32_t)c * DC * t.ldo * 2u, oa = (uint32_t)c * DC * t.lda * 2u;
-#pragma unroll
-        for (int i = 0; i < IN_; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_vptr)(st + (wave * IN_ + i) * 1024), 16, vd[i], od, 0, HS_NT_W);
-#pragma unroll
-        for (int i = 0; i < IK_; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_vptr)(st + DC * RBN + (wave * IK_ + i) * 1024), 16, va[i], oa, 0, HS_NT_W);
-    };
-    f32x4 acc[NF][KF], accb[NF];
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < KF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
-#pragma unroll
-    for (int i = 0; i < DS - 1; ++i)
-        if (i < nch) issue(cbeg + i, i);
-    int stage = 0;
-    for (int i = 0; i < nch; ++i) {
-        if (i + DS - 2 < nch) wait_vm<(DS - 2) * (IN_ + IK_)>(); else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
-        if (i + DS - 1 < nch) issue(cbeg + i + DS - 1, stage == 0 ? DS - 1 : stage - 1);
-        const uint32_t dOt = lds_base + (uint32_t)stage * STAGE_B, At = dOt + DC * RBN;
-        Frag2 fa[NF];
-#pragma unroll
-        for (int ii = 0; ii < NF; ++ii) rect_tr_read2<RBN>(rect_frag_addr<RBN>(dOt, (wn * NF + ii) * 16, lane), fa[ii]);
-        rect_wait_lds<NF>(fa);
-        bf16x8 a[NF];
-#pragma unroll
-        for (int ii = 0; ii < NF; ++ii) { a[ii] = join(fa[ii]); accb[ii] = mfma16(a[ii], ones, accb[ii]); }
-#pragma unroll
-        for (int j0 = 0; j0 < KF; j0 += 4) {
-            Frag2 fb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rect_tr_read2<RBK>(rect_frag_addr<RBK>(At, wk * (TK / 2) + (j0 + j) * 16, lane), fb[j]);
-            rect_wait_lds<4>(fb);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bf16x8 b = join(fb[j]);
-#pragma unroll
-                for (int ii = 0; ii < NF; ++ii) acc[ii][j0 + j] = mfma16(a[ii], b, acc[ii][j0 + j]);
-            }
-        }
-        stage = stage == DS - 1 ? 0 : stage + 1;
-    }
-    const int c16 = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < NF; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = (wn * NF + i) * 16 + g * 4 + r;
-            if (n >= t.N) continue;
-            const int sub = t.nsub > 1 ? n >> 7 : 0, nl = t.nsub > 1 ? n & 127 : n;
-            float* dw = t.dW[sub] + (size_t)nl * t.ldw;
-#pragma unroll
-            for (int j = 0; j < KF; ++j) {
-                const int k = wk * (TK / 2) + j * 16 + c16;
-                if (k < t.K) hs_gadd(det, dw + k, acc[i][j][r]);
-            }
-            if (wk == 0 && c16 == 0 && t.db[sub]) hs_gadd(det, t.db[sub] + nl, accb[i][r]);
-        }
-}
-
-template <int DS>
-__global__ __launch_bounds__(512) void wgrad_rect_kernel(RectParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int per = (p.total + 7) >> 3, li = blockIdx.x >> 3;
-    const int f = (blockIdx.x & 7) * per + li;
-    if (li >= per || f >= p.total) return;
-    const int code = p.wg[f], ti = code & 7, ms = code >> 3;
-    const RectTile& t = p.t[ti];
-    if (t.kind == 0) rect_body<DS, 384, 128>(p, t, ms, smem_raw);
-    else if (t.kind == 1) rect_body<DS, 128, 384>(p, t, ms, smem_raw);
-    else rect_body<DS, 128, 128>(p, t, ms, smem_raw);
-}
-
-// Builds the rectangular-tile plan for a launch, or returns false when its shapes do not fit (then the 128 x 128 tiles run)
-static bool rect_plan(const WgradParams& p, RectParams& q) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("HSIMAE_WGRAD_RECT"); on = (e && e[0] == '1'); }     // opt-in: measured slower, see the header comment
-    if (!on) return false;
-    q.ntiles = 0; q.M = p.M; q.det_base = p.det_base; q.det_acc = reinterpret_cast<long long*>(p.det_acc);
-    const int nchunks = (p.M + DC - 1) / DC;
-    for (int i = 0; i < p.ntasks;) {
-        const WgradTask& a = p.t[i];
-        if (q.ntiles >= 8 || a.dO_f32 || a.N < 128 || a.K < 128 || a.N > 384 || a.K > 384 || (a.N > 128 && a.K > 128)) return false;
-        if ((int64_t)(p.M + DC) * a.ldo * 2 >= (1ll << 32) || (int64_t)(p.M + DC) * a.lda * 2 >= (1ll << 32)) return false;
-        if ((reinterpret_cast<uintptr_t>(a.dO) | reinterpret_cast<uintptr_t>(a.A)) & 15) return false;
-        RectTile& t = q.t[q.ntiles];
-        t.dO = reinterpret_cast<const bf16_t*>(a.dO); t.A = reinterpret_cast<const bf16_t*>(a.A); t.ldo = a.ldo; t.lda = a.lda; t.ldw = a.ldw;
-        t.N = a.N; t.K = a.K; t.nsub = 1; t.dW[0] = a.dW; t.db[0] = a.db; t.dW[1] = t.dW[2] = nullptr; t.db[1] = t.db[2] = nullptr;
-        int used = 1;
-        if (a.N == 128 && a.K == 128) {                  // q | k | v: consecutive 128-column slices of one dO over the same A
-            while (used < 3 && i + used < p.ntasks) {
-                const WgradTask& b = p.t[i + used];
-                if (b.dO_f32 || b.N != 128 || b.K != 128 || b.A != a.A || b.lda != a.lda || b.ldo != a.ldo || b.ldw != a.ldw ||
-                    reinterpret_cast<const bf16_t*>(b.dO) != reinterpret_cast<const bf16_t*>(a.dO) + 128 * used || a.ldo < 128 * (used + 1)) break;
-                t.dW[used] = b.dW; t.db[used] = b.db; ++used;
-            }
-            if (used == 2) used = 1;                      // pairs stay single tiles (keeps the n-slab arithmetic to 1 | 3)
-            if (used == 3) { t.nsub = 3; t.N = 384; } else { t.dW[1] = t.dW[2] = nullptr; t.db[1] = t.db[2] = nullptr; }
-        }
-        t.kind = t.N > 128 ? 0 : (t.K > 128 ? 1 : 2);
-        ++q.ntiles; i += used;
-    }
-    // row splits in proportion to the operand bytes of a tile; one workgroup per CU (a share of the chip when the caller's msplit
-    // says that another launch runs next to this one)
-    static int wgs_env = -1;
-    if (wgs_env < 0) { const char* e = getenv("HSIMAE_WGRAD_RECT_WGS"); wgs_env = e ? atoi(e) : 0; }
-    const int tiles128 = wg_tiles(p, 128);
-    int slots = wgs_env > 0 ? wgs_env : std::max(8, std::min(256, (p.msplit * tiles128 + 2) / 3));
-    slots = std::min(slots, 256);
-    int cost = 0;
-    for (int i = 0; i < q.ntiles; ++i) cost += q.t[i].kind == 2 ? 256 : 512;
-    int total = 0;
-    for (int i = 0; i < q.ntiles; ++i) {
-        const int c = q.t[i].kind == 2 ? 256 : 512;
-        static int eq = -1;                           // HSIMAE_WGRAD_RECT_EQ=1: the same row split for every tile (experiment)
-        if (eq < 0) { const char* e = getenv("HSIMAE_WGRAD_RECT_EQ"); eq = (e && e[0] == '1'); }
-        q.t[i].msplit = std::max(1, std::min(nchunks, eq ? slots / q.ntiles : slots * c / cost));
-        total += q.t[i].msplit;
-    }
-    if (total > 256) return false;
-    q.total = total;
-    // workgroup order: by the start of the row range (ties: tile order), so that a contiguous eighth of the list (one XCD) holds
-    // the tiles of one row range
-    struct E { float start; int tile, ms; };
-    E e[256]; int n = 0;
-    for (int i = 0; i < q.ntiles; ++i)
-        for (int m = 0; m < q.t[i].msplit; ++m) e[n++] = E{(float)m / (float)q.t[i].msplit, i, m};
-    std::stable_sort(e, e + n, [](const E& x, const E& y) { return x.start < y.start; });
-    for (int i = 0; i < n; ++i) q.wg[i] = (unsigned short)(e[i].tile | (e[i].ms << 3));
-    return true;
-}
+// (Round 4 also built rectangular one-workgroup-per-linear tiles here — q | k | v as one 384 x 128 tile, 8 waves, one workgroup per
+//  CU: a third fewer bytes through the CUs, measured 135-140 us per launch against 122 for the 128 x 128 tiles below, step + 0.25 ms,
+//  profiles/r04_x_wgrad_rect.txt: three independent 4-wave workgroups per CU keep the memory system busier than one 8-wave
+//  workgroup in barrier lock-step.  Rejected; removed from the library in round 5, the code is in the git history at e1f4f12.)
 
 }  // namespace
 
@@ -726,22 +507,6 @@ int hs_wgrad(const WgradParams& p, hipStream_t s) {
         else hipLaunchKernelGGL((wgrad_dma_kernel<4, true>), grid, dim3(512), 4 * WT<true>::STAGE_ELEMS * 2, s, q);
         if (q.slab) hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(t256 * 128), dim3(512), 0, s, q);
         return (int)hipGetLastError();
-    }
-    if (dma) {
-        RectParams q;
-        if (rect_plan(p, q)) {
-            static int rds = 0;                         // ring depth: HSIMAE_WGRAD_RECT_DS = 3 | 4 (default 4: 96 KB in flight per CU)
-            constexpr int SBR = DC * (384 + 128) * 2;
-            if (!rds) {
-                const char* e = getenv("HSIMAE_WGRAD_RECT_DS"); rds = (e && e[0] == '3') ? 3 : 4;
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_rect_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SBR);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_rect_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SBR);
-            }
-            const dim3 rgrid(8 * ((q.total + 7) / 8));
-            if (rds == 3) hipLaunchKernelGGL((wgrad_rect_kernel<3>), rgrid, dim3(512), 3 * SBR, s, q);
-            else hipLaunchKernelGGL((wgrad_rect_kernel<4>), rgrid, dim3(512), 4 * SBR, s, q);
-            return (int)hipGetLastError();
-        }
     }
     const dim3 grid((p.msplit & 7) == 0 ? 8 * tiles * (p.msplit / 8) : 8 * ((tiles + 7) / 8) * p.msplit);      // decode_wg
     if (dma) {

@@ -13,7 +13,7 @@ from . import _lib
 
 
 class FusedAdamW:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, no_decay=("bias", "norm"), strict=False):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, no_decay=("bias", "norm"), strict=True):
         self.model = model
         self.strict = bool(strict)                   # see _sync_grads
         self._mask_cache = {}
@@ -88,10 +88,13 @@ class FusedAdamW:
 
         Cost: the model keeps track of which of its two parameter ranges (encoder, decoder) had their `.grad` attached by a
         backward since the last `zero_grad` (`HSIMAE._grads_home`).  When both were — every step of the reference's loop —
-        the check is four identity comparisons (first / last parameter of each range) and the step is ONE launch.  `strict=True`
-        compares every `.grad` with its flat view instead (532 attribute reads, ~50 us).  Only when something is missing or
-        foreign is the per-parameter walk done, and its mask is built on the host and uploaded once (cached per pattern) —
-        no per-parameter device writes."""
+        the default (`strict=True`) compares every `.grad` with its flat view (532 attribute reads, ~50 us of host time that
+        overlaps the device's backward) and the step is ONE launch: a `.grad` set to None or replaced by another tensor after
+        the backward (clipping by assignment, masking, a hook) is seen, exactly as `torch.optim.AdamW` would see it.
+        `strict=False` is the opt-in fast path for loops that never touch `.grad` between backward and step: four identity
+        comparisons (first / last parameter of each range); a middle parameter's replaced `.grad` is then NOT noticed.  Only when
+        something is missing or foreign is the per-parameter walk done, and its mask is built on the host and uploaded once
+        (cached per pattern) — no per-parameter device writes."""
         m = self.model
         params, views = m._params_cache, m._grad_views
         home = getattr(m, "_grads_home", None)

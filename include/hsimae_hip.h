@@ -44,7 +44,15 @@ extern "C" {
 #define HSIMAE_EUNSUPPORTED (-2) /* configuration outside what the kernels are built for */
 #define HSIMAE_EALIGN (-3)       /* misaligned pointer */
 #define HSIMAE_ENULL (-4)        /* required pointer is NULL */
+#define HSIMAE_ENOFORWARD (-5)   /* a backward entry point was given a workspace that no forward entry point of this process has
+                                    filled: the backward follows the schedule its forward recorded (which intermediates exist,
+                                    q|k|v saved or recomputed, ...) and never re-derives it from the environment */
 
+/* ABI version of this header; hsimae_version() returns the value the loaded library was built with, and a binder must
+ * refuse a library that answers differently (hsimae_amd/_lib.py does).  104 (round 5): HSIMAE_ENOFORWARD, schedule recorded
+ * by the forward; 103 -> 104 also covers round 4's incompatible change of the weight-gradient parameter block (t[8] -> t[16]), which had
+ * shipped without a bump. */
+#define HSIMAE_VERSION 104
 int hsimae_version(void);
 const char* hsimae_strerror(int code);
 /* 1 if the library runs the two axis stacks of the encoder on two streams on the CURRENT device (the side stream is created
@@ -297,6 +305,11 @@ int hsimae_dec_block_fwd(const hsimae_dec_block_weights* w, const float* x, floa
                          int32_t nsamples, int32_t Ts, int32_t split, void* stream);
 #define HSIMAE_DEC_BLOCK_SLAB_FLOATS (256ll * (104 * 512 + 2112))   /* workgroups x (in-register dW values x threads + bias / LayerNorm sums) */
 int64_t hsimae_dec_block_slab_floats(void);     /* = HSIMAE_DEC_BLOCK_SLAB_FLOATS of the library that is loaded: size of `slab` above */
+/* Bytes of weight-gradient slab that hsimae_workspace_bytes() reserves for the caller's stream (side_stream = 0) or for the
+   side stream of the forked spectral stack (1; 0 bytes = that stream commits with float atomics).  Whenever a stream can run
+   a 256 x 256-tile weight-gradient launch (an encoder OR — caller's stream, layer-at-a-time decoder — a decoder of storage
+   width >= 256) the answer is >= 64 MiB = 256 workgroups x 256 KB, what such a launch may write (csrc/plan.h slab_bytes). */
+int64_t hsimae_wgrad_slab_bytes(const hsimae_config* cfg, int32_t side_stream);
 int hsimae_dec_block_bwd(const hsimae_dec_block_weights* w, const hsimae_dec_block_grads* g, const float* x, const float* x1,
                          const float* dy, float* dx1_tmp, float* dx, const hs_bf16* o, const float* lse, int32_t nsamples,
                          int32_t Ts, float* slab, void* stream);

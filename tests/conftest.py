@@ -11,6 +11,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of host time next to the GPU work (full-size oracle comparisons); still part of -m gpu")
 
 
 @pytest.fixture(scope="session")

@@ -450,6 +450,30 @@ def test_fused_adamw_common_path_is_one_launch_and_no_torch_ops():
     assert counts[0] <= 4 and counts[1] == 0 and counts[2] == 0, counts
 
 
+def test_fused_adamw_default_sees_a_middle_gradient_replaced_after_backward():
+    """the default FusedAdamW must treat `.grad` as torch.optim.AdamW does — a MIDDLE parameter whose
+    `.grad` is set to None after the backward is skipped, one whose `.grad` is replaced by a new tensor is stepped with the new
+    values (the 4-probe fast path, `strict=False`, is opt-in because it cannot see either)."""
+    from hsimae_amd import FusedAdamW
+    m = base48(5)
+    opt = FusedAdamW(m, lr=1e-2, weight_decay=0.0)
+    assert opt.strict
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(8, 1, 48, 9, 9, generator=g).to(DEV)
+    noise = (torch.rand(8, 6, generator=g), torch.rand(8, 9, generator=g))
+    opt.zero_grad()
+    m(x, 0.75, noise=noise, grid=(2, 7))[0].backward()
+    named = dict(m.named_parameters())
+    skipped, replaced = named["blocks_2.4.mlp.w1.weight"], named["decoder_blocks.3.attn.proj.weight"]
+    s0, r0 = skipped.detach().clone(), replaced.detach().clone()
+    skipped.grad = None
+    replaced.grad = torch.ones_like(replaced)               # first Adam step with fresh moments: -lr * sign(g) = -1e-2 everywhere
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(skipped.detach(), s0)
+    assert torch.allclose(replaced.detach(), r0 - 1e-2, atol=1e-5)
+
+
 @pytest.mark.parametrize("dim,dec_dim,bands", [(64, 48, 32), (144, 72, 32)])
 def test_reference_default_widths_construct_and_match_oracle(dim, dec_dim, bands):
     """Model_Pretraining.py:57-58 (dim 64, dec_dim 48) and Model_Finetuning.py:66-67 (144 / 72): widths that are
@@ -553,11 +577,10 @@ def test_model_on_a_non_default_device():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["HSIMAE_PAIR_LAUNCH=1", "HSIMAE_ATTN_BWD_RECOMPUTE=0", "HSIMAE_FUSED_MLP=0"])
+@pytest.mark.parametrize("switch", ["HSIMAE_ATTN_BWD_RECOMPUTE=0", "HSIMAE_FUSED_MLP=0"])
 def test_config1_record_under_the_schedule_switches(switch):
-    """The schedule switches are read once per process, so each runs in a child: the config-1 record of the reference (loss, 532
-    gradient norms) must hold on the pair schedule (whose backward reads the q|k|v the forward saved: the forward must then save
-    them — round 4 regression), on the fused attention-half backward fed by saved q|k|v, and on the layer-at-a-time MLP half."""
+    """The config-1 record of the reference (loss, 532 gradient norms) must hold on the fused attention-half backward fed by
+    saved q|k|v and on the layer-at-a-time MLP half (each in a child process with the switch set for the whole run)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -598,21 +598,24 @@ def test_large_and_huge_full_size_properties(name, bands, dim, N, prec):
     torch.manual_seed(7)
     x = torch.rand(N, 1, bands, 9, 9, device=DEV)
     n1, n2 = torch.rand(N, T), torch.rand(N, 9)
-    grid = HSIMAE.grid_candidates(T, 9, 0.75)[0]
-    K = grid[0] * grid[1]
-    loss, pred, mask = m(x, 0.75, noise=(n1, n2), grid=grid)
-    loss.backward()
-    torch.cuda.synchronize()
-    assert torch.isfinite(loss) and torch.isfinite(pred).all() and 0.5 < loss.item() < 2.0
-    assert float(mask.sum()) == N * (T * 9 - K) * 72
-    k2, r2, m2 = O.mask_from_noise(n1.numpy(), n2.numpy(), *grid)
-    assert torch.equal(mask.cpu(), O.unpatchify(torch.from_numpy(m2).unsqueeze(2).repeat(1, 1, 72), cfg))
-    for pname, p in m.named_parameters():
-        if p.requires_grad and pname != "mask_token":
-            assert p.grad is not None and torch.isfinite(p.grad).all(), pname
-    with torch.no_grad():
-        small = m(x[:32], 0.75, noise=(n1[:32], n2[:32]), grid=grid)[1]
-    assert rms_rel(small, pred[:32]) < (1e-6 if prec == "bf16" else 1e-6)
+    cands = HSIMAE.grid_candidates(T, 9, 0.75)            # every grid bench.py draws (round 4 ran the first one only)
+    assert len(cands) >= 2
+    for grid in cands:
+        K = grid[0] * grid[1]
+        m.zero_grad(set_to_none=True)
+        loss, pred, mask = m(x, 0.75, noise=(n1, n2), grid=grid)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss) and torch.isfinite(pred).all() and 0.5 < loss.item() < 2.0, grid
+        assert float(mask.sum()) == N * (T * 9 - K) * 72
+        k2, r2, m2 = O.mask_from_noise(n1.numpy(), n2.numpy(), *grid)
+        assert torch.equal(mask.cpu(), O.unpatchify(torch.from_numpy(m2).unsqueeze(2).repeat(1, 1, 72), cfg))
+        for pname, p in m.named_parameters():
+            if p.requires_grad and pname != "mask_token":
+                assert p.grad is not None and torch.isfinite(p.grad).all(), (grid, pname)
+        with torch.no_grad():
+            small = m(x[:32], 0.75, noise=(n1[:32], n2[:32]), grid=grid)[1]
+        assert rms_rel(small, pred[:32]) < 1e-6, grid
 
 
 def test_fused_adamw_matches_torch_adamw_and_training_step():

@@ -474,20 +474,11 @@ def test_wgrad_wide_block_batch():
         assert rel_err(db + 1.0, dOr.sum(0)) < 5e-5
 
 
-@pytest.mark.parametrize("M,msplit,rect", [(3100, 8, "0"), (110592 // 8, 59, "0"), (45, 3, "0"), (3100, 8, "1"), (110592 // 8, 59, "1"), (45, 3, "1")])
-def test_wgrad_narrow_block_batch(M, msplit, rect):
+@pytest.mark.parametrize("M,msplit", [(3100, 8), (110592 // 8, 59), (45, 3)])
+def test_wgrad_narrow_block_batch(M, msplit):
     """One d = 128 encoder block's seven linears in one launch as hsimae_backward passes them: q | k | v as three 128-column slices of
     one dqkv slab over the same A, the projection (128 x 128), w1 | w3 as slices of one dh13 slab (352 x 128 each), w2 (128 x 352);
-    ragged row counts, a row count smaller than the row split, accumulation onto what the buffers hold.  rect = "1": the
-    rectangular-tile kernel of round 4 (q | k | v merged into ONE 384 x 128 tile with three dW targets; opt-in, HSIMAE_WGRAD_RECT=1)
-    on the same data — the switch is read once per process, so that case runs in a child process."""
-    import subprocess, sys
-    if rect == "1" and os.environ.get("HSIMAE_WGRAD_RECT") != "1":
-        code = (f"import os; os.environ['HSIMAE_WGRAD_RECT']='1'; import tests.test_gpu_kernels as t; "
-                f"t.test_wgrad_narrow_block_batch({M}, {msplit}, '1'); print('ok')")
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
-        return
+    ragged row counts, a row count smaller than the row split, accumulation onto what the buffers hold."""
     torch.manual_seed(17)
     lib = _lib.load()
     d, h = 128, 344

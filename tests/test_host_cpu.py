@@ -114,8 +114,36 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS.keys())
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.hsimae_version() >= 100
+    # the bindings refuse a library built from another header version (the ABI had changed without a bump)
+    assert lib.hsimae_version() == _lib.ABI_VERSION == int(re.search(r"#define HSIMAE_VERSION (\d+)", hdr).group(1))
     assert b"dimension" in lib.hsimae_strerror(-1)
+    assert b"forward" in lib.hsimae_strerror(-5)                  # HSIMAE_ENOFORWARD
+
+
+def test_weight_gradient_slab_is_sized_from_both_widths():
+    """the caller's stream also runs the DECODER's weight-gradient launches when the decoder goes layer at a
+    time; with embed_dim 128 and decoder_embed_dim 256 those take the 256 x 256-tile path (13 tiles x 19 row slices = 247
+    workgroups x 256 KB = 64.7 MB) and the slab — the LAST carve of the arena — was sized from the encoder width only (56.7 MB):
+    8 MB of device writes past the end of the workspace.  Whatever stream can run such a launch gets >= 64 MiB."""
+    lib = _lib.load()
+    from hsimae_amd import swiglu_hidden
+    def cfg(D, heads, Dd, dheads):
+        return _lib.Config(bands=96, embed_dim=D, depth=12, s_depth=9, num_heads=heads, dec_dim=Dd, dec_depth=8, dec_heads=dheads,
+                           hidden=swiglu_hidden(D, 4.0), dec_hidden=swiglu_hidden(Dd, 4.0), norm_pix_loss=1)
+    MiB64 = 256 * 256 * 256 * 4
+    dec = lib.hsimae_dec_block_slab_floats() * 4
+    for D, H, Dd, Hd in [(128, 8, 64, 8), (128, 8, 256, 16), (128, 8, 512, 32), (256, 16, 64, 8), (256, 16, 256, 16), (144, 9, 72, 9),
+                         (512, 32, 64, 8), (64, 4, 288, 18)]:
+        c = cfg(D, H, Dd, Hd)
+        main, side = lib.hsimae_wgrad_slab_bytes(C.byref(c), 0), lib.hsimae_wgrad_slab_bytes(C.byref(c), 1)
+        Dp, Ddp = (D + 31) // 32 * 32, (Dd + 31) // 32 * 32
+        assert main >= dec
+        assert main >= MiB64 if max(Dp, Ddp) >= 256 else main == dec, (D, Dd, main)
+        assert side == (MiB64 if Dp >= 256 else 0), (D, Dd, side)
+        # the arena grows by what the slabs take (they are its last carves)
+        small = cfg(128, 8, 64, 8)
+        assert lib.hsimae_workspace_bytes(C.byref(c), 8, 3, 9) > main + side
+    assert lib.hsimae_wgrad_slab_bytes(None, 0) == -1
 
 
 def test_layout_helpers_agree_with_module_tree():

@@ -169,3 +169,42 @@ def test_loader_shards_cover_the_global_batches_with_a_ragged_tail(world):
         got = [i for r in range(world) for i in shards[r][bi]]
         assert got == glob[:per * world], (bi, len(glob))
         assert all(len(shards[r][bi]) == per for r in range(world))
+
+
+@pytest.mark.parametrize("world,fault,field", [(2, "", None), (8, "", None), (2, "order", "same_collective_order"),
+                                               (8, "grad", "same_reduced_gradients"), (2, "grid", "same_grid_sequence")])
+def test_bench_verify_detects_divergent_ranks(world, fault, field):
+    """`bench.py --verify`: the self-check a multi-rank run carries in its JSON line.  On gloo ranks with
+    synthetic gradients: consistent ranks answer dp_consistent = true with the bucket list; a rank that reports another
+    collective order, holds a different reduced gradient, or drew another grid turns it false and names what differed."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    env["OMP_NUM_THREADS"] = "1"
+    env["HSIMAE_DRYRUN_FAULT"] = fault
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dry-run", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    v = out["dp_verify"]
+    assert v["ranks"] == world and len(v["buckets"]) >= 2
+    assert v["matches_single_collective"] is (fault != "grad")      # (the perturbed rank also disagrees with the plain collective)
+    if not fault:
+        assert out["dp_consistent"] is True and all(v[k] for k in ("same_reduced_gradients", "same_grid_sequence", "same_collective_order"))
+    else:
+        assert out["dp_consistent"] is False and v[field] is False
+        assert all(v[k] for k in ("same_reduced_gradients", "same_grid_sequence", "same_collective_order") if k != field)
+
+
+def test_verify_step_flags_a_bucketed_result_that_differs_from_the_plain_collective():
+    """The other leg of the check, single process: a bucket that was reduced before its kernels had written it shows up as a
+    mismatch against the one-collective reference even when every rank agrees with every other."""
+    from hsimae_amd.parallel import flat_hash, verify_step
+    g = torch.Generator().manual_seed(0)
+    ref = torch.randn(50_000, generator=g)
+    good = ref + 1e-8 * ref.abs().max() * torch.randn(50_000, generator=g)        # summation-order noise
+    assert verify_step(good, ref, [(3, 9)], [(0, 50_000)], 1.0)["dp_consistent"] is True
+    bad = good.clone(); bad[1234] = 0.0
+    v = verify_step(bad, ref, [(3, 9)], [(0, 50_000)], 1.0)
+    assert v["dp_consistent"] is False and v["matches_single_collective"] is False
+    a = torch.arange(1000, dtype=torch.float32); b = a.clone(); b[[3, 7]] = b[[7, 3]]
+    assert flat_hash(a) == flat_hash(a.clone()) and flat_hash(a) != flat_hash(b)
