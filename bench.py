@@ -151,7 +151,9 @@ def mlp_bwd_launch(model, M):
     x1, dy = torch.randn(M, d, **f32), torch.randn(M, d, **f32) * 1e-3
     dx1 = torch.empty(M, d, **f32)
     u2, dyb, dx1b = (torch.empty(M, d, **bf) for _ in range(3))
-    dh13, g = torch.empty(M, 2 * hp, **bf), torch.empty(M, hp, **bf)
+    hp64 = (hp + 63) // 64 * 64                              # the schedule's operand layout: 64-column planes of M + 48 rows when M % 32 == 0
+    planar = M + 48 if M % 32 == 0 else 0
+    dh13, g = torch.empty(M + 48, 2 * hp64, **bf), torch.empty(M + 48, hp64, **bf)
     # packed weight images: any bf16 content of the right size is a valid image (timing only)
     w1, w3, w2T = (torch.randn(hp * d, **bf) * 0.05 for _ in range(3))
     w2, w13T = torch.randn(d * hp, **bf) * 0.05, torch.randn(d * 2 * hp, **bf) * 0.05
@@ -165,7 +167,7 @@ def mlp_bwd_launch(model, M):
     def launch():
         _lib.check(lib.hsimae_enc_mlp_bwd(x1.data_ptr(), dy.data_ptr(), dx1.data_ptr(), u2.data_ptr(), dh13.data_ptr(),
                                           g.data_ptr(), dyb.data_ptr(), dx1b.data_ptr(), M, d, C.byref(w), gw.data_ptr(),
-                                          gb.data_ptr(), None, None, s), "hsimae_enc_mlp_bwd")
+                                          gb.data_ptr(), None, None, planar, s), "hsimae_enc_mlp_bwd")
     launch.keep = (x1, dy, dx1, u2, dyb, dx1b, dh13, g, w1, w3, w2T, w2, w13T, n2w, n2b, b2, b1, b3, gw, gb, w)
     launch.flops = float(M) * 3 * 2 * d * h                 # dg = dY W2, du2 = dh1 W1 + dh3 W3 (the h1 / h3 recompute is not credited)
     launch.design_bytes = float(M) * (4 * d + 4 * d + 4 * d + 2 * d + 2 * d + 2 * d + 2 * 2 * hp + 2 * hp)

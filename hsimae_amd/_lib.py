@@ -84,7 +84,7 @@ class DecBlockGrads(C.Structure):
 
 class WgradTask(C.Structure):
     _fields_ = [("dO", vp), ("dO_f32", i32), ("ldo", i32), ("A", vp), ("lda", i32), ("N", i32), ("K", i32),
-                ("dW", vp), ("ldw", i32), ("db", vp), ("dO_rowscale", vp)]
+                ("dW", vp), ("ldw", i32), ("db", vp), ("dO_rowscale", vp), ("dO_plane_rows", i32), ("A_plane_rows", i32)]
 
 
 class WgradParams(C.Structure):
@@ -138,7 +138,7 @@ SYMBOLS = {
     "hsimae_gemm_tiled": (C.c_int, [C.POINTER(GemmParams), i32, i32, i32, i32, vp]),
     "hsimae_pack_matrix": (C.c_int, [vp, i32, i32, vp]),
     "hsimae_enc_mlp_fwd": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(MlpWeights), vp, vp]),
-    "hsimae_enc_mlp_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(MlpWeights), vp, vp, vp, vp, vp]),
+    "hsimae_enc_mlp_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(MlpWeights), vp, vp, vp, vp, i32, vp]),
     "hsimae_dec_block_fwd": (C.c_int, [C.POINTER(DecBlockWeights), vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "hsimae_dec_block_bwd": (C.c_int, [C.POINTER(DecBlockWeights), C.POINTER(DecBlockGrads), vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     "hsimae_attn_fwd": (C.c_int, [C.POINTER(AttnParams), vp]),

@@ -64,6 +64,7 @@ enum : uint32_t {
     SC_RECOMPUTE = 1u << 10,       // HSIMAE_ATTN_BWD_RECOMPUTE=0 clears: the forward saves q|k|v
     SC_WGRAD_SLAB = 1u << 11,      // HSIMAE_WGRAD_SLAB=0 clears: float atomics in the 256 x 256-tile weight-gradient launches
     SC_DEC_SLAB = 1u << 12,        // HSIMAE_DEC_SLAB=0 clears: float atomics in the fused decoder backward
+    SC_PLANAR = 1u << 13,          // HSIMAE_WGRAD_PLANAR=0 clears: g / dh1|dh3 of the fused MLP backward row-major instead of 64-column planes
 };
 uint32_t sched_from_env() {
     auto off = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
@@ -82,6 +83,7 @@ uint32_t sched_from_env() {
     if (!off("HSIMAE_ATTN_BWD_RECOMPUTE")) b |= SC_RECOMPUTE;
     if (!off("HSIMAE_WGRAD_SLAB")) b |= SC_WGRAD_SLAB;
     if (!off("HSIMAE_DEC_SLAB")) b |= SC_DEC_SLAB;
+    if (!off("HSIMAE_WGRAD_PLANAR") && hs_wgrad_dma_enabled()) b |= SC_PLANAR;
     return b;
 }
 struct SchedRec { uint32_t enc = 0, dec = 0; bool has_enc = false, has_dec = false; };
@@ -303,10 +305,14 @@ int block_bwd(const BlkP& P, uint32_t sc, const BlkOff& o, float* grads, const f
     const bool f8u = f8 && (sc & SC_FP8_UNFUSED);
     auto w8 = [&](GemmParams& q, const BlkP::I8& a) { if (f8) { q.prec = HSIMAE_PREC_FP8; q.W8 = a.w; q.S8 = a.s; } };
     const bool fmlp = !f8u && fused_mlp_enabled(d, h, sc);
+    // g / dh1 / dh3 as 64-column planes (include/hsimae_hip.h, hsimae_wgrad_task): needs whole 32-row DMA chunks and 32-bit offsets
+    const int hp64 = rup(hp, 64);
+    const bool planar = fmlp && (sc & SC_PLANAR) && M % 32 == 0 && (M + 64) * 2 * (int64_t)hp64 * 2 < (1ll << 32);
+    const int prow = planar ? (int)M + HS_PLANE_PAD_ROWS : 0;       // rows per plane (plan.h: the arena reserves kPlanePadRows)
     if (fmlp) {
         // recompute u2 / h1 / h3 / g inside the tile; emits dx1 and the wgrad operands u2, dh1|dh3, g, bf16 dY and dx1
         CK(hs_enc_mlp_bwd(b.x1, G0, G1, b.u2, w.dh13, b.g, w.g0b, w.g1b, (int)M, d, mlp_ptrs(P, h), grads + o.n2w,
-                          grads + o.n2b, s, rs_m, rs_a, HsDet{grads, reinterpret_cast<long long*>(det_acc)}));
+                          grads + o.n2b, s, rs_m, rs_a, HsDet{grads, reinterpret_cast<long long*>(det_acc)}, prow));
     } else {
         p.A = G0; p.lda = dp; p.M = (int)M; p.N = hp; p.K = dp; p.n_valid = hp; p.W = P.w2T; p.out = w.dh13; p.ldo = 2 * hp;
         p.h13 = b.h13; p.ldh = 2 * hp; p.hoff = hp; p.a_rowscale = rs_m;        // DropPath: the branch saw rs_m * dY
@@ -346,9 +352,17 @@ int block_bwd(const BlkP& P, uint32_t sc, const BlkOff& o, float* grads, const f
         task(1, w.dqkv + dp, 3 * dp, b.u, dp, d, d, o.kw, o.kb);
         task(2, w.dqkv + 2 * dp, 3 * dp, b.u, dp, d, d, o.vw, o.vb);
         task(3, w.g1b, dp, b.o, dp, d, d, o.pw, o.pb);              // all-bf16 operands: wgrad takes its LDS-DMA path
-        task(4, w.dh13, 2 * hp, b.u2, dp, h, d, o.w1w, o.w1b);
-        task(5, w.dh13 + hp, 2 * hp, b.u2, dp, h, d, o.w3w, o.w3b);
-        task(6, w.g0b, dp, b.g, hp, d, h, o.w2w, o.w2b);
+        if (planar) {
+            task(4, w.dh13, hp64, b.u2, dp, h, d, o.w1w, o.w1b); g.t[g.ntasks - 1].dO_plane_rows = prow;
+            task(5, w.dh13 + (int64_t)hp64 * prow, hp64, b.u2, dp, h, d, o.w3w, o.w3b); g.t[g.ntasks - 1].dO_plane_rows = prow;
+        } else {
+            task(4, w.dh13, 2 * hp, b.u2, dp, h, d, o.w1w, o.w1b);
+            task(5, w.dh13 + hp, 2 * hp, b.u2, dp, h, d, o.w3w, o.w3b);
+        }
+#ifdef HS_ABL_DW2           /* timing ablation (variant builds only, see fused_enc.hip): the W2 task leaves the launch on the fused path */
+        if (!fmlp)
+#endif
+        { task(6, w.g0b, dp, b.g, planar ? hp64 : hp, d, h, o.w2w, o.w2b); g.t[g.ntasks - 1].A_plane_rows = prow; }
         g.M = (int)M; g.det_base = grads; g.det_acc = det_acc;
         g.slab = (sc & SC_WGRAD_SLAB) ? w.slab : nullptr;        // this stream's slab (clear: float atomics on dW also in the 256 x 256-tile launches)
         int tiles = 0;
@@ -838,13 +852,15 @@ int hsimae_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int32_t M,
 }
 int hsimae_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
                        hs_bf16* dx1b, int32_t M, int32_t d, const hsimae_mlp_weights* w, float* g_n2w, float* g_n2b,
-                       const float* rs_mlp, const float* rs_attn, void* stream) {
+                       const float* rs_mlp, const float* rs_attn, int32_t plane_rows, void* stream) {
+    if (plane_rows && plane_rows < M) return HSIMAE_EDIMS;
     if (M <= 0) return HSIMAE_OK;
     if (!x1 || !dy || !dx1 || !w || !g_n2w || !g_n2b) return HSIMAE_ENULL;
     // operand outputs are optional as groups: {u2, dyb} and {dh13, g} (NULL = not written: the data path alone), dx1b on its own
     if ((!u2) != (!dyb) || (!dh13) != (!g)) return HSIMAE_ENULL;
     if (!hs_enc_mlp_fused_supported(d, w->hidden)) return HSIMAE_EUNSUPPORTED;
-    return hs_enc_mlp_bwd(x1, dy, dx1, u2, dh13, g, dyb, dx1b, M, d, mlp_from_abi(w), g_n2w, g_n2b, S(stream), rs_mlp, rs_attn);
+    return hs_enc_mlp_bwd(x1, dy, dx1, u2, dh13, g, dyb, dx1b, M, d, mlp_from_abi(w), g_n2w, g_n2b, S(stream), rs_mlp, rs_attn,
+                          HsDet{nullptr, nullptr}, plane_rows);
 }
 static DecBlockPtrs dec_from_abi(const hsimae_dec_block_weights* w) {
     DecBlockPtrs d; std::memset(&d, 0, sizeof(d));

@@ -962,6 +962,12 @@ namespace {
 #define PHB_FLUSH()
 #define PHF_FLUSH()
 #endif
+// XOR swizzle of the 16-byte chunks of an unpadded 256-byte image row (found for blk128_bwd_kernel in round 4 by exhaustive search
+// over the XOR-linear maps of the row's low 4 bits; scripts/micro/lds_audit_blk128.py): chunk c of row r sits at chunk c ^ bsw(r).
+__device__ __forceinline__ int bsw(int row) { return ((row & 1) << 1) ^ ((row & 2) << 1) ^ ((row & 4) << 1) ^ (((row >> 3) & 1) * 9); }
+#ifndef HS_BF_SWZ
+#define HS_BF_SWZ 1          /* blk128_fwd_kernel: images as unpadded swizzled 256-byte rows (round 5; 0 = 272-byte pitch of rounds 3-4) */
+#endif
 struct Blk128Args {
     const float* x; const float* n1w; const float* n1b;
     const bf16_t* wqkv; const float* bqkv; const bf16_t* wp; const float* pb;
@@ -976,7 +982,8 @@ template <int NT, int SPW>
 struct LayB {
     static constexpr int ROWS = NT * 16;                 // rows of one slot
     static constexpr int RT = SPW * ROWS;                // rows of the images
-    static constexpr int IMG = RT * FS;
+    static constexpr int PITCH = HS_BF_SWZ ? 128 : FS;   // image row (elements)
+    static constexpr int IMG = RT * PITCH;
     static constexpr int XS = 132;                       // fp32 copy of the group's x rows (the residual): row stride
     // cls | U | Q K V | O | lse | vectors (gamma | beta | bqkv | bp) | X
     static constexpr int TOTAL = RT * 4 + 5 * IMG * 2 + RT * 8 * 4 + 768 * 4 + HS_BF_XCOPY * RT * XS * 4;
@@ -999,6 +1006,20 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
     const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3, hc = head * 16;
     const float sc = 0.25f * 1.4426950408889634f;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    // Image addressing (elements).  Round 5 (3.4 bank-conflict cycles per LDS instruction at the counters, against
+    // 0.5-1.1 in the backward kernels): the layout of blk128_bwd_kernel — unpadded 256-byte rows, 16-byte chunk c of row r at
+    // c ^ bsw(r) — under which the 16-byte row fragments (8 -> 4 LDS cycles per wave-instruction against the 272-byte pitch), the
+    // 8-byte head-row reads and the transposed reads are conflict-free (scripts/micro/lds_audit_blk128.py lists every pattern of
+    // both kernels under both layouts); the 8-byte head-row writes stay 2-way.
+    constexpr int PITCH = L::PITCH;
+    const int fr = bsw(c16), ft = bsw(4 * g + q4);
+    auto wide = [&](int irow, int pc) -> int { return HS_BF_SWZ ? irow * 128 + ((pc ^ bsw(irow)) << 3) : irow * FS + pc * 8; };          // 16-byte piece pc of row irow
+    auto fragoff = [&](int mt, int ks) -> int {                      // MFMA operand: row 16 mt + c16, columns 32 ks + 8 g ..
+        return HS_BF_SWZ ? (mt * 16 + c16) * 128 + (((4 * ks + g) ^ fr) << 3) : (mt * 16 + c16) * FS + ks * 32 + g * 8; };
+    auto cell = [&](int row0) -> int {                               // this head's columns 4 g .. of row row0 + c16 (row0 % 16 == 0)
+        return HS_BF_SWZ ? (row0 + c16) * 128 + (((2 * head + (g >> 1)) ^ fr) << 3) + (g & 1) * 4 : (row0 + c16) * FS + hc + 4 * g; };
+    auto trof = [&](int row0) -> int {                               // transposed read: rows row0 + 4 g + q4, this head's columns 4 p4 ..
+        return HS_BF_SWZ ? (row0 + 4 * g + q4) * 128 + (((2 * head + (p4 >> 1)) ^ ft) << 3) + (p4 & 1) * 4 : (row0 + 4 * g + q4) * FS + hc + 4 * p4; };
 
     // this wave's weights: n-tiles head (q), 8 + head (k), 16 + head (v) of the packed [384][128] image, n-tile head of Wp
     bf16x8 wq[3][4], wpj[4];
@@ -1087,7 +1108,7 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
                 }
                 const int64_t gr = grow(irow);
                 const bf16x8 ub = gr >= 0 ? cvt8(f) : zero8();
-                *reinterpret_cast<bf16x8*>(Uf + irow * FS + lc8) = ub;
+                *reinterpret_cast<bf16x8*>(Uf + wide(irow, threadIdx.x & 15)) = ub;
                 if (gr >= 0) HS_NT(HS_NT_C, reinterpret_cast<bf16x8*>(p.u + gr * 128 + lc8), ub);
             }
         }
@@ -1106,8 +1127,8 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
                 f32x4 acc = bias;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
-                    acc = mfma16(wq[m][ks], *reinterpret_cast<const bf16x8*>(Uf + (mt * 16 + c16) * FS + ks * 32 + g * 8), acc);
-                *reinterpret_cast<bf16x4*>(img + (mt * 16 + c16) * FS + hc + 4 * g) = cvt4(acc);
+                    acc = mfma16(wq[m][ks], *reinterpret_cast<const bf16x8*>(Uf + fragoff(mt, ks)), acc);
+                *reinterpret_cast<bf16x4*>(img + cell(mt * 16)) = cvt4(acc);
             }
         }
         PHB(3)
@@ -1120,12 +1141,12 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
             for (int qt = 0; qt < NT; ++qt) {
                 if (qt * 16 >= p.Ts) break;
                 const int query = r0 + qt * 16 + c16;
-                const bf16x4 bqf = *reinterpret_cast<const bf16x4*>(Qf + query * FS + hc + 4 * g);
+                const bf16x4 bqf = *reinterpret_cast<const bf16x4*>(Qf + cell(r0 + qt * 16));
                 f32x4 sv[NT];
                 float m = -INFINITY;
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) {
-                    const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (r0 + kt * 16 + c16) * FS + hc + 4 * g);
+                    const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + cell(r0 + kt * 16));
                     sv[kt] = mfma_k16(ak, bqf, cm[qt][kt]);           // masked pairs start (and stay) at -inf
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -1149,11 +1170,11 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
                 f32x4 o = z4;
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt)
-                    o = mfma_k16(tr4(Vf + (r0 + kt * 16 + 4 * g + q4) * FS + hc + 4 * p4), cvt4(sv[kt]), o);
+                    o = mfma_k16(tr4(Vf + trof(r0 + kt * 16)), cvt4(sv[kt]), o);
                 bf16x4 ov;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
-                *reinterpret_cast<bf16x4*>(Of + query * FS + hc + 4 * g) = ov;
+                *reinterpret_cast<bf16x4*>(Of + cell(r0 + qt * 16)) = ov;
                 if (g == 0) lse_s[query * 8 + head] = m + __builtin_amdgcn_logf(fmaxf(lsum, 1e-30f));
             }
         }
@@ -1186,12 +1207,12 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
             const int64_t gr = grow(irow);
             if (gr >= 0)
                 HS_NT(HS_NT_C, reinterpret_cast<bf16x8*>(p.qkv + gr * 384 + pc * 8),
-                      *reinterpret_cast<const bf16x8*>(Qf + (pc >> 4) * L::IMG + irow * FS + (pc & 15) * 8));
+                      *reinterpret_cast<const bf16x8*>(Qf + (pc >> 4) * L::IMG + wide(irow, pc & 15)));
         }
         for (int idx = threadIdx.x; idx < RT * 16; idx += 512) {
             const int irow = idx >> 4, pc = idx & 15;
             const int64_t gr = grow(irow);
-            if (gr >= 0) HS_NT(HS_NT_C, reinterpret_cast<bf16x8*>(p.o + gr * 128 + pc * 8), *reinterpret_cast<const bf16x8*>(Of + irow * FS + pc * 8));
+            if (gr >= 0) HS_NT(HS_NT_C, reinterpret_cast<bf16x8*>(p.o + gr * 128 + pc * 8), *reinterpret_cast<const bf16x8*>(Of + wide(irow, pc)));
         }
         for (int idx = threadIdx.x; idx < RT * 2; idx += 512) {
             const int irow = idx >> 1;
@@ -1207,7 +1228,7 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
             f32x4 pa = pbias;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                pa = mfma16(wpj[ks], *reinterpret_cast<const bf16x8*>(Of + (mt * 16 + c16) * FS + ks * 32 + g * 8), pa);
+                pa = mfma16(wpj[ks], *reinterpret_cast<const bf16x8*>(Of + fragoff(mt, ks)), pa);
             if (orow[mt] >= 0) {
                 const float rs = p.rowscale ? p.rowscale[orow[mt]] : 1.f;        // DropPath: x + scale * attn(x)
                 f32x4 ov;
@@ -1257,7 +1278,6 @@ int launch_blk128(const Blk128Args& a, hipStream_t s) {
 // 8-byte head-row WRITES stay 2-way (16 rows x 8 bytes meet in one 32-bank half: no layout of 256-byte rows avoids it).
 constexpr int BIR = 128;                   // image row (elements)
 constexpr int BTS = 16;                    // P / dS transposition tile row (elements), chunks rotated by the row group (fused_dec.hip TTS)
-__device__ __forceinline__ int bsw(int row) { return ((row & 1) << 1) ^ ((row & 2) << 1) ^ ((row & 4) << 1) ^ (((row >> 3) & 1) * 9); }
 struct Blk128BwdArgs {
     const bf16_t* qkv; const bf16_t* o; const float* lse;        // saved by the forward: [rows][384] (!RC) | [rows][128] | [rows][8]
     const bf16_t* u; const bf16_t* wqkv; const float* bqkv;      // RC: LayerNorm-1 output [rows][128], packed Wqkv [n = 384][k = 128], bias

@@ -26,10 +26,19 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases(unsign
 #define PH_DECL unsigned long long ph_t0 = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PH(i) { const unsigned long long ph_t = __builtin_readcyclecounter(); ph_acc[i] += ph_t - ph_t0; ph_t0 = ph_t; }
 #define PH_FLUSH(base) if (threadIdx.x == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&hs_phase_cycles[(base) + i], ph_acc[i]); }
+// a second set of stamps inside one phase (round 5: the du + dWqkv phase of dec_bwd_attn), slots 24..31
+#define PH2_DECL unsigned long long ph_t1 = 0, ph_acc2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PH2_START ph_t1 = __builtin_readcyclecounter();
+#define PH2(i) { const unsigned long long ph_t = __builtin_readcyclecounter(); ph_acc2[i] += ph_t - ph_t1; ph_t1 = ph_t; }
+#define PH2_FLUSH if (threadIdx.x == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&hs_phase_cycles[24 + i], ph_acc2[i]); }
 #else
 #define PH_DECL
 #define PH(i)
 #define PH_FLUSH(base)
+#define PH2_DECL
+#define PH2_START
+#define PH2(i)
+#define PH2_FLUSH
 #endif
 
 #ifndef HS_NT_D
@@ -41,6 +50,9 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases(unsign
 #endif
 #ifndef HS_TOUCH_M
 #define HS_TOUCH_M 0
+#endif
+#ifndef HS_DEC_MLP_PREFETCH
+#define HS_DEC_MLP_PREFETCH 0      /* dec_bwd_mlp: 1 = x1 / dY rows one sample ahead (round-5 experiment, measured SLOWER: see the kernel) */
 #endif
 #ifndef HS_TOUCH_A
 #define HS_TOUCH_A 0
@@ -947,6 +959,26 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
     const bool bias_wave = (q.wave & 1) == 0;
 
     PH_DECL
+    // Round-5 experiment (HS_DEC_MLP_PREFETCH=1, not the default): the sample's x1 / dY rows fetched one sample AHEAD, behind the
+    // epilogue's own re-reads in the in-order memory counter, as dec_bwd_attn_kernel has done since round 4.  The phase stamps
+    // (profiles/r05_c_phase_timing.txt) have this kernel's prologue — 8 loads per thread at the top of the iteration, then
+    // everything waits — at 20.7 % of its time (46 us per launch) against 5.7 % in dec_bwd_attn.  Measured on one box, same
+    // spill count (8 B/lane): 214.2 us without, 220.3 us WITH (step 15.51 / 15.61 vs 15.55 / 15.64 ms,
+    // profiles/r05_d_prefetch_stagger_ab.txt): 32 more live registers through the epilogue cost more than the round trip
+    // they hide — the hardware's own answer (the other wave of the SIMD runs while this one waits) is not worse.
+    float fa[NPW][8], dya[NPW][8];                    // the sample's loads all in flight at once
+    auto fetch_sample = [&](int smp) {
+        const bool valid = smp < p.nsamples;
+        const size_t nb = (size_t)smp * p.Ts;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int row = (threadIdx.x + NT_ * i) >> 3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { fa[i][e] = 0.f; dya[i][e] = 0.f; }
+            if (valid && row < p.Ts) { ld8(p.x1 + (nb + row) * D + c8, fa[i]); ld8(p.dy + (nb + row) * D + c8, dya[i]); }
+        }
+    };
+    if (HS_DEC_MLP_PREFETCH) fetch_sample(blockIdx.x);
     for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
         const size_t rb = (size_t)sample * p.Ts;
         const int wl = launder_i(0);                   // keeps the LDS weight reads inside the sample loop (no LICM + spill)
@@ -957,14 +989,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
         f2.load(w2T, 2, q.wn * 2, 0, q);
         const float* n2w = launder(p.w.n2w);
         const float* n2b = launder(p.w.n2b);
-        float fa[NPW][8], dya[NPW][8];                // the sample's loads all in flight at once
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) {
-            const int row = (threadIdx.x + NT_ * i) >> 3;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { fa[i][e] = 0.f; dya[i][e] = 0.f; }
-            if (row < p.Ts) { ld8(p.x1 + (rb + row) * D + c8, fa[i]); ld8(p.dy + (rb + row) * D + c8, dya[i]); }
-        }
+        if (!HS_DEC_MLP_PREFETCH) fetch_sample(sample);
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pc = threadIdx.x + NT_ * i;
@@ -1117,6 +1142,11 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             for (int e = 0; e < 8; ++e) { xe[i][e] = 0.f; dye[i][e] = 0.f; }
             if (row < p.Ts) { ld8(p.x1 + (rb + row) * D + c8, xe[i]); ld8(p.dy + (rb + row) * D + c8, dye[i]); }
         }
+        if (HS_DEC_MLP_PREFETCH) {                    // next sample's rows: younger than the re-reads above, so the epilogue does not wait for them
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_sample(sample + (int)gridDim.x);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         lds_barrier();
         PH(3)
 #pragma unroll
@@ -1240,6 +1270,9 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
     // exponent is clamped at 0 — P <= 1 holds for every real key anyway, and a padded key (K row = 0 => s = 0) of a query whose
     // logsumexp is very negative (diverging run) would otherwise produce P = inf and poison dq through inf * 0
     constexpr int KCL = MT > 4 ? 4 : 1;
+    // (round 5: of those tiles only the ones that really hold a padded key are clamped — a wave-uniform test per tile instead of
+    //  4 v_min on the loop's longest unit; at 108 tokens that is the last tile of 7 instead of the last three)
+    const int clamp_from = Ts >> 4;                        // first key tile with a row >= Ts
     f32x4 dkT[MT], dvT[MT];
     bf16x4 KT[MT];
 #pragma unroll
@@ -1254,6 +1287,9 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
         bf16x4 bdo = *reinterpret_cast<const bf16x4*>(dOb + qt * 16 * IR + rcol2);
         if (q.g >= 2) { bq = zero4(); bdo = zero4(); }
         const float lqn = -lse_h[query], dl = dlt_h[query];
+        // (Round 5 tried to take dP - delta out of the VALU — this loop's longest unit — by starting the dP product's accumulator at
+        //  -delta, a per-lane splat: 320.2 us against 315.5 with the 4 v_sub per tile, profiles/r05_e_planar_delta_ab.txt.  A zero
+        //  accumulator is an inline constant of the MFMA; a splat has to be copied into four accumulator registers per tile.)
         const bf16x4 QT = tr4(Qb + qt * 16 * IR + troff);
         const bf16x4 dOT = tr4(dOb + qt * 16 * IR + troff);
         f32x4 dqT = z4;
@@ -1280,7 +1316,7 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
 #else
             for (int r = 0; r < 4; ++r) {
                 const float e = fmaf(s[r], sc, lqn);
-                pv[r] = __builtin_amdgcn_exp2f(kt >= KCL ? fminf(e, 0.f) : e);
+                pv[r] = __builtin_amdgcn_exp2f((kt >= KCL && clamp_from <= kt) ? fminf(e, 0.f) : e);
             }
 #endif
             // No key mask in here (rounds 1-2 masked the last tile only — wrong for 65..96-token sequences, found in round 3 by the
@@ -1414,6 +1450,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     };
     fetch_sample(blockIdx.x);
     PH_DECL
+    PH2_DECL
     for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
         const size_t rb = (size_t)sample * p.Ts;
         const int wl = launder_i(0);                  // keeps the LDS weight reads inside the sample loop
@@ -1554,9 +1591,11 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         attn_head_bwd<MT>(Qb, Kb, Vb, Ob, lse + q.wave * R, dlt + q.wave * R, TT + q.wave * TT_WAVE, q.wave, p.Ts, q);
         lds_barrier();
         PH(5)
+        PH2_START
         __builtin_amdgcn_sched_barrier(0);
         fetch_sample(sample + (int)gridDim.x);          // ~4 us (du + dWqkv + epilogue) ahead of its use
         __builtin_amdgcn_sched_barrier(0);
+        PH2(0)
         // du = dq Wq + dk Wk + dv Wv ; dWq|dWk|dWv += d{q,k,v}^T u
         f32x4 du[L::MH][2];
 #pragma unroll
@@ -1565,6 +1604,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         mm_cols<L::MH>(Qb, WQl, mt0, q, du);
         mm_cols<L::MH>(Kb, WQl + D * LW, mt0, q, du);
         mm_cols<L::MH>(Vb, WQl + 2 * D * LW, mt0, q, du);
+        PH2(1)
         f32x4 accqb[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) accqb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1599,6 +1639,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t) dbqw[t] += r4 == 0 ? accqb[t][0] : (r4 == 1 ? accqb[t][1] : (r4 == 2 ? accqb[t][2] : accqb[t][3]));
+        PH2(2)
         acc_to_xs<L::MH, true>(XS, mt0, MT, q, du);
         float xe[NPW][8], d1e[NPW][8];                // L2-hot re-reads for the LayerNorm backward, in flight over the barrier
 #pragma unroll
@@ -1606,9 +1647,13 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             const int row = (threadIdx.x + NT_ * i) >> 3;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { xe[i][e] = 0.f; d1e[i][e] = 0.f; }
+#ifndef HS_ABL_DEC_REREAD   /* timing ablation (variant builds only): what the epilogue's second read of x and dx1 costs */
             if (row < p.Ts) { ld8(p.x + (rb + row) * D + c8, xe[i]); ld8(p.dx1 + (rb + row) * D + c8, d1e[i]); }
+#endif
         }
+        PH2(3)
         lds_barrier();
+        PH2(4)
         PH(6)
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
@@ -1644,6 +1689,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     }
 
     PH_FLUSH(0)
+    PH2_FLUSH
     // ---- commit
     float* red = XS;
     float* vec = p.slab ? p.slab + kSlabTileFloats + (size_t)blockIdx.x * kVec : nullptr;

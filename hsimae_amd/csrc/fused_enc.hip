@@ -64,6 +64,11 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases_enc(un
                                     overlaps better than the loop.  Not the default. */
 #endif
 
+// (Round 5 measured a start stagger of the first round of workgroups — blockIdx.x / 256 = 1, 2 sleeping 3.4 / 6.8 us (and 10 / 20 us)
+//  so that the three workgroups of a CU run a third of a panel apart, on the theory that a launch of exactly three rounds keeps the
+//  whole chip in one phase at a time: step 15.55 / 15.64 ms without, 15.54 / 15.64 and 15.63 / 15.71 with, enc_mlp_bwd 142.2 -> 144.1 us;
+//  profiles/r05_d_prefetch_stagger_ab.txt.  Neutral to negative: not kept.)
+
 namespace {
 
 constexpr int MH = 2, NTH = 256;
@@ -416,6 +421,7 @@ struct EncMlpBwdArgs {
     // dx1b is what the attention branch sees, rs_attn * dx1.  dx1 itself (the residual path) is unscaled.
     const float* rs_mlp; const float* rs_attn;
     HsDet det;
+    int plane_rows;                  // > 0: g / dh1 / dh3 as 64-column planes [plane][plane_rows][64] (include/hsimae_hip.h, hsimae_wgrad_task)
 };
 
 template <int D, int HPE>
@@ -487,7 +493,9 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
             *reinterpret_cast<bf16x8*>(DYb + row * LU + (((c8 >> 3) ^ swzp<D>(row)) << 3)) = dyb8;
             if (ok && p.u2) {                     // (NULL operands: data path only — the caller takes its weight gradients elsewhere)
                 HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.u2 + (size_t)(row0 + row) * D + c8), ub);     // wgrad operands
+#ifndef HS_ABL_DW2          /* timing ablation (variant builds only): what "dW2 kept on chip" could save at most — see DESIGN 7.2 */
                 HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.dyb + (size_t)(row0 + row) * D + c8), dyb8);
+#endif
             }
         }
     }
@@ -582,7 +590,19 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                 const int row = pc >> 3, k8 = (pc & 7) * 8;
                 if (row0 + row < p.M && k8 < ncol) {
                     const size_t gr = (size_t)(row0 + row);
+                    if (p.plane_rows) {
+                        // 64-column planes (round 5): this chunk IS plane c, so the panel's three pieces are row-contiguous blocks
+                        // of 48 x 128 B instead of 128-byte pieces at pitches of 704 / 1408 B: enc_mlp_bwd 149.4 -> 138.7 us
+                        // (profiles/r05_c_ablation_ab.txt), the same bytes at 5.2 instead of 4.1 TB/s in scripts/micro/hbm_stride.hip
+                        const size_t po = ((size_t)c * p.plane_rows + gr) * 64 + k8;
+                        HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.g + po), *reinterpret_cast<const bf16x8*>(Gc + row * LC + (((k8 >> 3) ^ swzc<D>(row)) << 3)));
+                        HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.dh13 + po), *reinterpret_cast<const bf16x8*>(DH1 + row * LC + (((k8 >> 3) ^ swzc<D>(row)) << 3)));
+                        HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.dh13 + (size_t)NCH * 64 * p.plane_rows + po), *reinterpret_cast<const bf16x8*>(DH3 + row * LC + (((k8 >> 3) ^ swzc<D>(row)) << 3)));
+                        continue;
+                    }
+#ifndef HS_ABL_DW2
                     HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.g + gr * HPE + c * 64 + k8), *reinterpret_cast<const bf16x8*>(Gc + row * LC + (((k8 >> 3) ^ swzc<D>(row)) << 3)));
+#endif
                     HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.dh13 + gr * 2 * HPE + c * 64 + k8), *reinterpret_cast<const bf16x8*>(DH1 + row * LC + (((k8 >> 3) ^ swzc<D>(row)) << 3)));
                     HS_NT(HS_NT_A, reinterpret_cast<bf16x8*>(p.dh13 + gr * 2 * HPE + HPE + c * 64 + k8), *reinterpret_cast<const bf16x8*>(DH3 + row * LC + (((k8 >> 3) ^ swzc<D>(row)) << 3)));
                 }
@@ -765,15 +785,16 @@ static int launch_bwd(const EncMlpBwdArgs& a, int M, int d, hipStream_t s) {
 
 static EncMlpBwdArgs mk_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
                             hs_bf16* dx1b, int M, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, const float* rs_mlp,
-                            const float* rs_attn, HsDet det) {
+                            const float* rs_attn, HsDet det, int plane_rows) {
     EncMlpBwdArgs a; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.u2 = u2; a.dh13 = dh13; a.g = g; a.M = M; a.w = mkw(b);
     a.g_n2w = g_n2w; a.g_n2b = g_n2b; a.dyb = dyb; a.dx1b = dx1b; a.rs_mlp = rs_mlp; a.rs_attn = rs_attn; a.det = det;
+    a.plane_rows = plane_rows;
     return a;
 }
 
 int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
                    hs_bf16* dx1b, int M, int d, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s,
-                   const float* rs_mlp, const float* rs_attn, HsDet det) {
+                   const float* rs_mlp, const float* rs_attn, HsDet det, int plane_rows) {
     if (M <= 0) return HS_OK;
-    return launch_bwd(mk_bwd(x1, dy, dx1, u2, dh13, g, dyb, dx1b, M, b, g_n2w, g_n2b, rs_mlp, rs_attn, det), M, d, s);
+    return launch_bwd(mk_bwd(x1, dy, dx1, u2, dh13, g, dyb, dx1b, M, b, g_n2w, g_n2b, rs_mlp, rs_attn, det, plane_rows), M, d, s);
 }

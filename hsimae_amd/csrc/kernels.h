@@ -97,7 +97,8 @@ int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, 
                    const float* rowscale = nullptr);
 int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
                    hs_bf16* dx1b, int M, int d, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s,
-                   const float* rs_mlp = nullptr, const float* rs_attn = nullptr, HsDet det = HsDet{nullptr, nullptr});
+                   const float* rs_mlp = nullptr, const float* rs_attn = nullptr, HsDet det = HsDet{nullptr, nullptr}, int plane_rows = 0);
+bool hs_wgrad_dma_enabled();      // the LDS-DMA weight-gradient kernel is not switched off (HSIMAE_WGRAD_DMA=0): planar operands need it
 
 int hs_adamw(float* p, const float* g, float* m, float* v, const unsigned char* group, int64_t n, float lr, float b1, float b2,
              float eps, float wd, int step, hipStream_t s);

@@ -201,6 +201,12 @@ inline void pack_descs(const Geo& g, const PLayout& L, const WLayout& W, const f
 }
 
 // ------------------------------------------------------------------ workspace
+// rows between the planes of a planar weight-gradient operand beyond M (round 5): with exactly M rows the planes of C2 start
+// 27 x 2^19 bytes apart and the two streams of a dW tile's operand slice meet in the same HBM channels (wgrad_dma 118.8 -> 123.5 us)
+#ifndef HS_PLANE_PAD_ROWS
+#define HS_PLANE_PAD_ROWS 48
+#endif
+constexpr int kPlanePadRows = 64;          // what the arena reserves per plane (>= HS_PLANE_PAD_ROWS)
 struct BlkBuf { hs_bf16* u; hs_bf16* qkv; float* lse; hs_bf16* o; float* x1; hs_bf16* u2; hs_bf16* h13; hs_bf16* g; float* x2; };
 
 struct Scr { float* G1; float* du; hs_bf16* dh13; hs_bf16* dob; hs_bf16* dqkv; hs_bf16* g0b; hs_bf16* g1b; float* slab; };   // per-stream backward scratch (g0b/g1b: bf16 dY / dx1; slab: weight-gradient partials)
@@ -233,11 +239,13 @@ inline void carve(const Geo& g, int N, int K, char* base, Ws& w) {
     int64_t cur = 0;
     auto take = [&](int64_t bytes) { char* p = base ? base + cur : nullptr; cur += (bytes + 255) & ~255ll; return p; };
     const int64_t Me = (int64_t)N * K, Md = (int64_t)N * g.TL;
+    // (g and dh1|dh3 are sized for the planar operand layout of round 5 — 64-column planes of M + kPlanePadRows rows,
+    //  hsimae_wgrad_task — whose padded width is hp rounded up to 64)
     auto blk = [&](int64_t M, int d, int heads, int hp) {
         BlkBuf b;
         b.u = (hs_bf16*)take(M * d * 2); b.qkv = (hs_bf16*)take(M * 3 * d * 2); b.lse = (float*)take(M * heads * 4);
         b.o = (hs_bf16*)take(M * d * 2); b.x1 = (float*)take(M * d * 4); b.u2 = (hs_bf16*)take(M * d * 2);
-        b.h13 = (hs_bf16*)take(M * 2 * hp * 2); b.g = (hs_bf16*)take(M * hp * 2); b.x2 = (float*)take(M * d * 4);
+        b.h13 = (hs_bf16*)take(M * 2 * hp * 2); b.g = (hs_bf16*)take((M + kPlanePadRows) * rup(hp, 64) * 2); b.x2 = (float*)take(M * d * 4);
         return b;
     };
     w.a_pe = (hs_bf16*)take(Me * 96 * 2);
@@ -258,13 +266,13 @@ inline void carve(const Geo& g, int N, int K, char* base, Ws& w) {
     w.partial = (float*)take((int64_t)loss_partials(N, g.T) * 4);
     const int64_t gmax = std::max(Me * g.Dp, Md * g.Ddp);
     w.G0 = (float*)take(gmax * 4); w.G1 = (float*)take(gmax * 4); w.G2 = (float*)take(gmax * 4); w.du = (float*)take(gmax * 4);
-    w.dh13 = (hs_bf16*)take(std::max(Me * 2 * g.hp, Md * 2 * g.hpd) * 2);
+    w.dh13 = (hs_bf16*)take(std::max((Me + kPlanePadRows) * 2 * rup(g.hp, 64), (Md + kPlanePadRows) * 2 * rup(g.hpd, 64)) * 2);
     w.dob = (hs_bf16*)take(gmax * 2);
     w.dqkv = (hs_bf16*)take(gmax * 3 * 2);
     w.dyb = (hs_bf16*)take(Me * g.Ddp * 2);
     w.sc.G1 = w.G1; w.sc.du = w.du; w.sc.dh13 = w.dh13; w.sc.dob = w.dob; w.sc.dqkv = w.dqkv;
     w.sc2.G1 = (float*)take(Me * g.Dp * 4); w.sc2.du = (float*)take(Me * g.Dp * 4);
-    w.sc2.dh13 = (hs_bf16*)take(Me * 2 * g.hp * 2); w.sc2.dob = (hs_bf16*)take(Me * g.Dp * 2);
+    w.sc2.dh13 = (hs_bf16*)take((Me + kPlanePadRows) * 2 * rup(g.hp, 64) * 2); w.sc2.dob = (hs_bf16*)take(Me * g.Dp * 2);
     w.sc2.dqkv = (hs_bf16*)take(Me * g.Dp * 3 * 2);
     w.sc.g0b = (hs_bf16*)take(gmax * 2); w.sc.g1b = (hs_bf16*)take(gmax * 2);     // (also decoder rows on the layer-at-a-time path)
     w.sc2.g0b = (hs_bf16*)take(Me * g.Dp * 2); w.sc2.g1b = (hs_bf16*)take(Me * g.Dp * 2);

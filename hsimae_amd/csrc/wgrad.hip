@@ -310,24 +310,30 @@ __global__ __launch_bounds__(WT<BIG>::NTHR) void wgrad_dma_kernel(WgradParams p)
 
     // Out-of-range rows (last chunk) come back as zeros from the buffer bounds check.  Columns past N / K of a slab
     // are whatever follows in the row: they only reach dW rows / columns that are never committed.
-    const uint32_t bytes_d = (uint32_t)min((int64_t)p.M * t.ldo * 2, (int64_t)0xffffffffu);
-    const uint32_t bytes_a = (uint32_t)min((int64_t)p.M * t.lda * 2, (int64_t)0xffffffffu);
+    const uint32_t bytes_d = (uint32_t)min((int64_t)(t.dO_plane_rows ? t.dO_plane_rows : p.M) * t.ldo * 2, (int64_t)0xffffffffu);
+    const uint32_t bytes_a = (uint32_t)min((int64_t)(t.A_plane_rows ? t.A_plane_rows : p.M) * t.lda * 2, (int64_t)0xffffffffu);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(t.dO), 0, bytes_d, 0x00020000);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)t.A, 0, bytes_a, 0x00020000);
     // this wave's two DMA instructions per operand and chunk (1 KB = RPI rows each): rows RPI (2 wave + i) + lane / (64 / RPI),
     // 16-byte slot lane % (64 / RPI)
+    // Planar operands (hsimae_wgrad_task: [ld / 64][M][64]): the lane's 16-byte piece of row r is at plane (col / 64), row pitch 64
+    // elements — a per-lane constant plus the same per-chunk scalar offset for every lane, as in the row-major form.
     uint32_t vd[2], va[2];
+    const int pd = t.dO_plane_rows ? 64 : t.ldo, pa = t.A_plane_rows ? 64 : t.lda;      // row pitch in elements
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         constexpr int LPR = 64 / G::RPI;                     // lanes per row
         const int row = G::RPI * (2 * wave + i) + lane / LPR;
         const int chunk = (lane % LPR) ^ swz(row);
-        vd[i] = (uint32_t)(row * t.ldo + n0 + 8 * chunk) * 2u;
-        va[i] = (uint32_t)(row * t.lda + k0 + 8 * chunk) * 2u;
+        const int cd = n0 + 8 * chunk, ca = k0 + 8 * chunk;
+        vd[i] = t.dO_plane_rows ? ((uint32_t)(cd >> 6) * (uint32_t)t.dO_plane_rows * 64u + (uint32_t)(row * 64 + (cd & 63))) * 2u
+                                : (uint32_t)(row * t.ldo + cd) * 2u;
+        va[i] = t.A_plane_rows ? ((uint32_t)(ca >> 6) * (uint32_t)t.A_plane_rows * 64u + (uint32_t)(row * 64 + (ca & 63))) * 2u
+                               : (uint32_t)(row * t.lda + ca) * 2u;
     }
     auto issue = [&](int c, int stage) {
         bf16_t* st = smem + stage * STAGE_ELEMS;
-        const uint32_t od = (uint32_t)c * DC * t.ldo * 2u, oa = (uint32_t)c * DC * t.lda * 2u;
+        const uint32_t od = (uint32_t)c * DC * pd * 2u, oa = (uint32_t)c * DC * pa * 2u;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_vptr)(st + (2 * wave + i) * 512), 16, vd[i], od, 0, HS_NT_W);
@@ -463,11 +469,24 @@ __global__ __launch_bounds__(512) void wgrad_slab_reduce_kernel(WgradParams p) {
 
 }  // namespace
 
+bool hs_wgrad_dma_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("HSIMAE_WGRAD_DMA"); on = !(e && e[0] == '0'); }
+    return on != 0;
+}
+
 int hs_wgrad(const WgradParams& p, hipStream_t s) {
     if (p.ntasks <= 0 || p.M <= 0) return HS_OK;
     if (p.ntasks > 16 || p.msplit < 1) return HS_EDIMS;
-    for (int i = 0; i < p.ntasks; ++i)
+    bool any_planar = false;
+    for (int i = 0; i < p.ntasks; ++i) {
         if (p.t[i].ldo % 8 || p.t[i].lda % 8) return HS_EDIMS;
+        // planar operands: padded width a multiple of 64, whole 32-row DMA chunks (a row past M would be the next plane's row 0)
+        if (p.t[i].dO_plane_rows && (p.t[i].ldo % 64 || p.t[i].dO_f32 || p.M % DC || p.t[i].dO_plane_rows < p.M)) return HS_EDIMS;
+        if (p.t[i].A_plane_rows && (p.t[i].lda % 64 || p.M % DC || p.t[i].A_plane_rows < p.M)) return HS_EDIMS;
+        if ((int64_t)std::max(p.t[i].dO_plane_rows, p.t[i].A_plane_rows) * std::max(p.t[i].ldo, p.t[i].lda) * 2 >= (1ll << 32)) return HS_EDIMS;
+        any_planar = any_planar || p.t[i].dO_plane_rows || p.t[i].A_plane_rows;
+    }
     const int tiles = wg_tiles(p, 128);
     // all operands bf16 and addressable with 32-bit buffer offsets -> LDS-DMA kernel (HSIMAE_WGRAD_DMA=0 disables it)
     static int dma_ok = -1, big_ok = -1, ds_env = -1;
@@ -490,6 +509,7 @@ int hs_wgrad(const WgradParams& p, hipStream_t s) {
         if ((reinterpret_cast<uintptr_t>(t.dO) | reinterpret_cast<uintptr_t>(t.A)) & 15) dma = false;
         if (t.N < 256 || t.K < 256) big = false;            // wide layers only: a 256-tile of a 128-wide matrix is half padding
     }
+    if (any_planar && !dma) return HS_EUNSUPPORTED;     // only the LDS-DMA kernels address planes
     if (dma && big) {
         // 256 x 256 tiles, one workgroup per CU: the row split that fills the chip once (p.msplit is sized for 128-tiles)
         WgradParams q = p;

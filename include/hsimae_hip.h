@@ -250,9 +250,12 @@ typedef struct {
 } hsimae_mlp_weights;
 int hsimae_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int32_t M, int32_t d, const hsimae_mlp_weights* w,
                        const float* rowscale, void* stream);
+/* plane_rows = 0: dh13 [M][2 * hp], g [M][hp] row-major (hp = hidden rounded up to 32).  plane_rows = R >= M: 64-column planes
+ * (see hsimae_wgrad_task): g = [P][R][64], dh13 = dh1 [P][R][64] followed by dh3 [P][R][64], P = ceil(hp / 64); rows past M
+ * and the columns past hp of the last plane are not written. */
 int hsimae_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
                        hs_bf16* dx1b, int32_t M, int32_t d, const hsimae_mlp_weights* w, float* g_n2w, float* g_n2b,
-                       const float* rs_mlp, const float* rs_attn, void* stream);
+                       const float* rs_mlp, const float* rs_attn, int32_t plane_rows, void* stream);
 
 /* Masked multi-head attention over one sample's tokens (Models.py:192-215) and its backward. */
 typedef struct {
@@ -325,6 +328,14 @@ typedef struct {
     float* dW; int32_t ldw;
     float* db;
     const float* dO_rowscale;     /* optional per-row factor [M] on an fp32 dO (DropPath); NULL = 1 */
+    /* Operand layout (round 5).  0 = row-major [M][ldo] / [M][lda].  R > 0 = 64-column PLANES of R >= M rows each: the operand
+       is [ldo / 64][R][64] (lda likewise), i.e. column c of row r lives at (c / 64) * R * 64 + r * 64 + c % 64 and ldo / lda is
+       the padded width, a multiple of 64.  A producer that emits its operand 64 columns at a time (hsimae_enc_mlp_bwd: one
+       hidden chunk per step) then writes row-contiguous blocks instead of 128-byte pieces at the row pitch — 5.2 against
+       4.1 TB/s for the same bytes (scripts/micro/hbm_stride.hip) — and a dW tile's operand slice is two sequential streams.
+       R > M (hsimae_backward uses M + 48) keeps the planes from starting a large power of two apart.  Planar operands need
+       bf16, M % 32 == 0 and the LDS-DMA kernel (any launch with bf16 operands below 4 GB); else HSIMAE_EDIMS / _EUNSUPPORTED. */
+    int32_t dO_plane_rows, A_plane_rows;
 } hsimae_wgrad_task;
 typedef struct {
     hsimae_wgrad_task t[16]; int32_t ntasks; int32_t M; int32_t msplit;      /* (16 since round 4: the 2 x 7 linears of a pair of axis-stack blocks) */

@@ -87,7 +87,8 @@ float timeit(F f) {
 int main() {
     const size_t M = (size_t)110592 * 8;            // 8 x the C2 encoder rows: g = 623 MB, dh1|dh3 = 1.25 GB
     char *g, *dh13, *A; uint4* sink;
-    hipMalloc(&g, M * NCH * 128 + 4096); hipMalloc(&dh13, M * 2 * NCH * 128 + 4096);      // sized for the planar form (6 planes of 128 B per row) hipMalloc(&A, M * 256); hipMalloc(&sink, 8192 * 256 * 16);
+    // (sized for the planar form: 6 planes of 128 B per row)
+    hipMalloc(&g, M * NCH * 128 + 4096); hipMalloc(&dh13, M * 2 * NCH * 128 + 4096); hipMalloc(&A, M * 256); hipMalloc(&sink, 8192 * 256 * 16);
     hipMemset(g, 1, M * NCH * 128); hipMemset(dh13, 2, M * 2 * NCH * 128); hipMemset(A, 3, M * 256);
     const int panels = (int)((M + R - 1) / R);
     const double wbytes = (double)M * HPB * 3;

@@ -79,6 +79,8 @@ def main():
                              "du mm + dWqkv", "epilogue LN bwd"]),
         "dec_bwd_mlp": (8, ["prologue LN", "gate mm + silu", "wgrad", "du2 stage", "epilogue LN bwd", "du2 mm", "-", "-"]),
         "dec_fwd": (16, ["LN1 + residual", "qkv", "attention", "o store + proj", "LN2", "gate chunks", "w2 mm", "store"]),
+        "dec_bwd_attn, inside 'du mm + dWqkv'": (24, ["next sample's loads issued", "du = dq Wq + dk Wk + dv Wv", "dWq|dWk|dWv + biases",
+                                                      "du -> fp32 tile, re-reads issued", "barrier", "-", "-", "-"]),
         "enc_mlp_bwd": (32, ["prologue LN", "gate mm + silu", "operand stores", "du2 mm", "epilogue LN bwd", "LN grads", "-", "-"]),
         "enc_mlp_fwd": (40, ["prologue LN", "bias init", "gate + W2 chunks", "(barrier)", "store", "-", "-", "-"]),
     }

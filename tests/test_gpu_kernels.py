@@ -260,7 +260,7 @@ def test_fused_encoder_mlp_half_forward_backward(M, drop):
     gw, gb = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
     _lib.check(lib.hsimae_enc_mlp_bwd(x1.data_ptr(), dy.data_ptr(), dx1.data_ptr(), u2.data_ptr(), dh13.data_ptr(), g.data_ptr(),
                                       dyb.data_ptr(), dx1b.data_ptr(), M, d, C.byref(w), gw.data_ptr(), gb.data_ptr(),
-                                      _lib.ptr(rs_m), _lib.ptr(rs_a), stream()))
+                                      _lib.ptr(rs_m), _lib.ptr(rs_a), 0, stream()))
     torch.cuda.synchronize()
     assert rel_err(dx1, xr.grad) < 1.5e-2
     assert rel_err(u2.float(), u.detach()) < 2 ** -7
@@ -281,6 +281,91 @@ def test_fused_encoder_mlp_half_forward_backward(M, drop):
     xh = (x1 - x1.mean(1, keepdim=True)) / torch.sqrt(x1.var(1, unbiased=False, keepdim=True) + 1e-5)
     dgate_u = (dgate * h3.detach() * s * (1 + h1.detach() * (1 - s))) @ bf(W1) + (dgate * h1.detach() * s) @ bf(W3)
     assert rel_err(gw, (dgate_u * xh).sum(0)) < 2e-2 and rel_err(gb, dgate_u.sum(0)) < 2e-2
+
+
+@pytest.mark.parametrize("M,pad", [(96, 0), (4128, 48), (110592 // 8, 48), (4128, 16)])
+def test_planar_weight_gradient_operands(M, pad):
+    """Round 5: g / dh1 / dh3 of the fused MLP backward as 64-column planes [plane][R][64], R = M + pad rows per plane
+    (hsimae_wgrad_task.dO_plane_rows / A_plane_rows; enc_mlp_bwd then writes row-contiguous blocks instead of 128-byte pieces
+    at the row pitch).  (1) the planar buffers hold exactly the row-major values, plane by plane, and nothing else of the
+    buffer is written; (2) the weight-gradient launch on planar operands returns the dW / db of the row-major launch; (3) a
+    planar launch whose row count is not a multiple of 32, or whose planes are shorter than M, is refused."""
+    torch.manual_seed(8)
+    d, h = 128, 344
+    hp, hp64 = rup(h, 32), rup(h, 64)
+    P, R = hp64 // 64, M + pad
+    lib = _lib.load()
+    x1 = torch.randn(M, d, device=DEV)
+    dy = torch.randn(M, d, device=DEV) * 0.1
+    gamma, beta = 1 + 0.1 * torch.randn(d, device=DEV), 0.1 * torch.randn(d, device=DEV)
+    W1, W3, W2 = (torch.randn(h, d, device=DEV) * 0.1, torch.randn(h, d, device=DEV) * 0.1, torch.randn(d, h, device=DEV) * 0.1)
+    b2 = torch.randn(d, device=DEV) * 0.1
+    b1p, b3p = torch.zeros(hp, device=DEV), torch.zeros(hp, device=DEV)
+    b1p[:h], b3p[:h] = torch.randn(h, device=DEV) * 0.1, torch.randn(h, device=DEV) * 0.1
+    imgs = [pack([(W1, 0, 0, 0)], hp, d), pack([(W3, 0, 0, 0)], hp, d), pack([(W2, 0, 0, 0)], d, hp), pack([(W2, 1, 0, 0)], hp, d),
+            pack([(W1, 1, 0, 0), (W3, 1, 0, hp)], d, 2 * hp)]
+    w = _lib.MlpWeights(n2w=gamma.data_ptr(), n2b=beta.data_ptr(), w1b=b1p.data_ptr(), w3b=b3p.data_ptr(), w2b=b2.data_ptr(),
+                        w1=imgs[0].data_ptr(), w3=imgs[1].data_ptr(), w2=imgs[2].data_ptr(), w2T=imgs[3].data_ptr(),
+                        w13T=imgs[4].data_ptr(), hidden=h)
+
+    def run(plane_rows):
+        dx1 = torch.empty(M, d, device=DEV)
+        u2, dyb, dx1b = (torch.empty(M, d, dtype=torch.bfloat16, device=DEV) for _ in range(3))
+        n13, ng = (2 * P * plane_rows * 64, P * plane_rows * 64) if plane_rows else (M * 2 * hp, M * hp)
+        dh13 = torch.full((n13,), 7.0, dtype=torch.bfloat16, device=DEV)        # sentinel: unwritten elements stay 7
+        g = torch.full((ng,), 7.0, dtype=torch.bfloat16, device=DEV)
+        gw, gb = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+        _lib.check(lib.hsimae_enc_mlp_bwd(x1.data_ptr(), dy.data_ptr(), dx1.data_ptr(), u2.data_ptr(), dh13.data_ptr(), g.data_ptr(),
+                                          dyb.data_ptr(), dx1b.data_ptr(), M, d, C.byref(w), gw.data_ptr(), gb.data_ptr(),
+                                          None, None, plane_rows, stream()))
+        torch.cuda.synchronize()
+        return dx1, u2, dyb, dh13, g
+
+    dx1_r, u2, dyb, dh13_r, g_r = run(0)
+    dx1_p, _, _, dh13_p, g_p = run(R)
+    assert torch.equal(dx1_r, dx1_p)
+    g_r, dh13_r = g_r.view(M, hp), dh13_r.view(M, 2 * hp)
+    gp, d1p, d3p = g_p.view(P, R, 64), dh13_p[:P * R * 64].view(P, R, 64), dh13_p[P * R * 64:].view(P, R, 64)
+    for c in range(P):
+        ncol = min(64, hp - 64 * c)
+        assert torch.equal(gp[c, :M, :ncol], g_r[:, 64 * c:64 * c + ncol])
+        assert torch.equal(d1p[c, :M, :ncol], dh13_r[:, 64 * c:64 * c + ncol])
+        assert torch.equal(d3p[c, :M, :ncol], dh13_r[:, hp + 64 * c:hp + 64 * c + ncol])
+        if ncol < 64:                                         # the columns past hp of the last plane are not written ...
+            assert float((gp[c, :, ncol:].float() - 7.0).abs().max()) == 0
+        if pad:                                               # ... nor are the rows past M of any plane
+            assert float((gp[c, M:].float() - 7.0).abs().max()) == 0 and float((d3p[c, M:].float() - 7.0).abs().max()) == 0
+
+    def wgrad(planar, Mrows=M, rows=R):
+        wp = _lib.WgradParams()
+        outs = []
+        for i in range(3):
+            N, K = (h, d) if i < 2 else (d, h)
+            dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+            outs.append((dW, db))
+            if i < 2:       # dW1 / dW3: dO = dh1 / dh3, A = u2
+                if planar:
+                    t = _lib.WgradTask(dO=dh13_p.data_ptr() + 2 * i * P * R * 64, dO_f32=0, ldo=hp64, A=u2.data_ptr(), lda=d, N=N, K=K,
+                                       dW=dW.data_ptr(), ldw=K, db=db.data_ptr(), dO_plane_rows=rows)
+                else:
+                    t = _lib.WgradTask(dO=dh13_r.data_ptr() + 2 * i * hp, dO_f32=0, ldo=2 * hp, A=u2.data_ptr(), lda=d, N=N, K=K,
+                                       dW=dW.data_ptr(), ldw=K, db=db.data_ptr())
+            else:           # dW2: dO = dY (bf16), A = g
+                t = _lib.WgradTask(dO=dyb.data_ptr(), dO_f32=0, ldo=d, A=(g_p if planar else g_r).data_ptr(), lda=hp64 if planar else hp,
+                                   N=N, K=K, dW=dW.data_ptr(), ldw=K, db=db.data_ptr(), A_plane_rows=rows if planar else 0)
+            wp.t[i] = t
+        wp.ntasks, wp.M, wp.msplit = 3, Mrows, max(1, min(16, Mrows // 64))
+        rc = lib.hsimae_wgrad(C.byref(wp), stream())
+        torch.cuda.synchronize()
+        return rc, outs
+
+    rc_r, o_r = wgrad(False)
+    rc_p, o_p = wgrad(True)
+    assert rc_r == 0 and rc_p == 0
+    for (a_, ab), (b_, bb) in zip(o_r, o_p):
+        assert rel_err(b_, a_) < 1e-5 and rel_err(bb, ab) < 1e-5        # same products, fp32 atomics in another order
+    assert wgrad(True, Mrows=M - 8)[0] == -1                            # planes need whole 32-row chunks
+    assert wgrad(True, rows=M - 32)[0] == -1                            # ... and at least M rows each
 
 
 # ----------------------------------------------------------------------------------------------- fused decoder Block

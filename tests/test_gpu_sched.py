@@ -28,7 +28,7 @@ SWITCHES = [
     ("HSIMAE_FUSED_DEC", "0", "base"), ("HSIMAE_DEC_SPLIT", "0", "base"), ("HSIMAE_DEC_SLAB", "0", "base"),
     ("HSIMAE_FUSED_MLP", "0", "base"), ("HSIMAE_FUSED_ATTN_BLOCK", "0", "base"), ("HSIMAE_FUSED_ATTN_BLOCK_BWD", "0", "base"),
     ("HSIMAE_FUSED_PROJ_BWD", "0", "base"), ("HSIMAE_FUSED_LNBWD", "0", "base"), ("HSIMAE_ATTN_BWD_RECOMPUTE", "0", "base"),
-    ("HSIMAE_FP8_UNFUSED", "1", "base_fp8"),
+    ("HSIMAE_WGRAD_PLANAR", "0", "base"), ("HSIMAE_FP8_UNFUSED", "1", "base_fp8"),
     ("HSIMAE_FUSED_ATTN_BLOCK256", "0", "large"), ("HSIMAE_FUSED_LNBWD", "0", "large"), ("HSIMAE_WGRAD_SLAB", "0", "large"),
     ("HSIMAE_FUSED_MLP", "0", "large"),
 ]
@@ -76,7 +76,7 @@ def one_pass(m, x, noise, grid, k, v_fwd, v_bwd):
 @pytest.mark.parametrize("switch,value,kind", SWITCHES)
 def test_switch_flipped_between_forward_and_backward(switch, value, kind):
     m, bands = make(kind)
-    N = 12
+    N = 32                                             # encoder rows N * 27: a multiple of 32, so the planar operand layout is live
     g = torch.Generator().manual_seed(21)
     x = torch.rand(N, 1, bands, 9, 9, generator=g).to(DEV)
     T = bands // 8
