@@ -51,6 +51,25 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases(unsign
 #ifndef HS_TOUCH_M
 #define HS_TOUCH_M 0
 #endif
+// Start stagger of the persistent decoder backward kernels (round 5).  All 256 workgroups start together and walk 16 samples of
+// identical work each, so the whole chip is in one phase at a time: every sample's rows (73 KB per workgroup in dec_bwd_attn)
+// are requested by all CUs at once — at the CU's 1/256 share of HBM, ~10 B/clk, that burst takes ~3 us during which the issuing
+// waves are blocked (phase stamps, profiles/r05_f_phase_timing.txt: ISSUING the next sample's loads is 55 % of the du + dWqkv
+// phase of dec_bwd_attn, 33 us per launch; the prologue wait of dec_bwd_mlp is 21 % of that kernel) while HBM idles for the rest
+// of the sample.  With HS_DEC_STG_N = n classes, workgroup b sleeps ((b >> 3) % n) x HS_DEC_STG_ATTN / _MLP x 0.85 us once, before
+// its first sample, so that the classes' bursts interleave for the whole launch.  Measured (profiles/r05_g_*, r05_h_*, r05_i_*,
+// kernel statistics of three boxes): dec_bwd_attn with 2 classes 3.4-5.1 us apart 322 -> 305, 323 -> 309 / 310 us (- 4 %; 1.7 us:
+// 321, 6.8 us: 312, 10 us: 310 / 301, 15 us: 328; 3 classes 312, 4 classes 305-308, 8 classes 307); dec_bwd_mlp LOSES with every
+// offset tried (213 -> 217-220 us at 3.4-6.8 us, 213 at 1.7 us): its stagger stays off.  The same on blk128_fwd / blk128_bwd: neutral.
+#ifndef HS_DEC_STG_N
+#define HS_DEC_STG_N 2
+#endif
+#ifndef HS_DEC_STG_ATTN
+#define HS_DEC_STG_ATTN 5
+#endif
+#ifndef HS_DEC_STG_MLP
+#define HS_DEC_STG_MLP 0
+#endif
 #ifndef HS_DEC_MLP_PREFETCH
 #define HS_DEC_MLP_PREFETCH 0      /* dec_bwd_mlp: 1 = x1 / dY rows one sample ahead (round-5 experiment, measured SLOWER: see the kernel) */
 #endif
@@ -938,6 +957,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
         BL[i] = o < p.w.h ? (m == 0 ? p.w.w1b[o] : p.w.w3b[o]) : 0.f;
     }
 
+    if (HS_DEC_STG_N > 1) {
+        const int n = (int)((blockIdx.x >> 3) % (HS_DEC_STG_N > 1 ? HS_DEC_STG_N : 1)) * HS_DEC_STG_MLP;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     f32x4 accW[3][3][2];                 // [hidden chunk][this wave's n-tile][this wave's k-tile]
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -1409,6 +1432,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     // one decoder block's q / k / v gradients in ~3 % of the runs at batch 64, where every sample is a workgroup's first.
     lds_barrier();
 
+    if (HS_DEC_STG_N > 1) {
+        const int n = (int)((blockIdx.x >> 3) % (HS_DEC_STG_N > 1 ? HS_DEC_STG_N : 1)) * HS_DEC_STG_ATTN;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     f32x4 accP[2], accQ[3][2];         // dWp: n-tile = wave>>1; dWq|dWk|dWv: 12 n-tiles x 4 k-tiles, 3 x 2 per wave
 #pragma unroll
     for (int a = 0; a < 2; ++a) accP[a] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1431,22 +1458,33 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     f32x4 l4a;
     bf16x8 ova[NPW];
     // (unconditional with a validity flag: under an `if` the old values would stay live through the whole iteration)
-    auto fetch_sample = [&](int smp) {               // every load of a sample in flight before the first use
+    // part 0: the x rows, 1: the dx1 rows, 2: O and logsumexp; -1: everything (the first sample)
+    auto fetch_sample = [&](int smp, int part = -1) {               // every load of a sample in flight before the first use
         const bool valid = smp < p.nsamples;
         const size_t nb = (size_t)smp * p.Ts;
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int row = (threadIdx.x + NT_ * i) >> 3;
-            ova[i] = zero8();
+            const bool ok = valid && row < p.Ts;
+            if (part < 0 || part == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { fa[i][e] = 0.f; d1a[i][e] = 0.f; }
-            if (valid && row < p.Ts) {
-                ld8(p.x + (nb + row) * D + c8, fa[i]); ld8(p.dx1 + (nb + row) * D + c8, d1a[i]);
-                ova[i] = *reinterpret_cast<const bf16x8*>(p.o + (nb + row) * D + c8);
+                for (int e = 0; e < 8; ++e) fa[i][e] = 0.f;
+                if (ok) ld8(p.x + (nb + row) * D + c8, fa[i]);
+            }
+            if (part < 0 || part == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d1a[i][e] = 0.f;
+                if (ok) ld8(p.dx1 + (nb + row) * D + c8, d1a[i]);
+            }
+            if (part < 0 || part == 2) {
+                ova[i] = zero8();
+                if (ok) ova[i] = *reinterpret_cast<const bf16x8*>(p.o + (nb + row) * D + c8);
             }
         }
-        l4a = f32x4{1e30f, 1e30f, 1e30f, 1e30f};      // rows past Ts: exp2(s - 1e30) = 0
-        if (valid && (threadIdx.x >> 1) < p.Ts) l4a = *reinterpret_cast<const f32x4*>(p.lse_g + (nb + (threadIdx.x >> 1)) * 8 + (threadIdx.x & 1) * 4);
+        if (part < 0 || part == 2) {
+            l4a = f32x4{1e30f, 1e30f, 1e30f, 1e30f};      // rows past Ts: exp2(s - 1e30) = 0
+            if (valid && (threadIdx.x >> 1) < p.Ts) l4a = *reinterpret_cast<const f32x4*>(p.lse_g + (nb + (threadIdx.x >> 1)) * 8 + (threadIdx.x & 1) * 4);
+        }
     };
     fetch_sample(blockIdx.x);
     PH_DECL
@@ -1593,6 +1631,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         PH(5)
         PH2_START
         __builtin_amdgcn_sched_barrier(0);
+        // (issuing this burst is 55 % of this phase, profiles/r05_f_phase_timing.txt: the waves sit at the issue while every CU of
+        //  the chip asks for its sample at once.  Issued in three parts between the products below instead: 323.4 -> 318.3 us alone,
+        //  nothing on top of the start stagger (309.0 vs 310.0 us, profiles/r05_i_stagger_sweep2.txt): one burst kept.)
         fetch_sample(sample + (int)gridDim.x);          // ~4 us (du + dWqkv + epilogue) ahead of its use
         __builtin_amdgcn_sched_barrier(0);
         PH2(0)

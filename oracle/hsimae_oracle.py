@@ -227,6 +227,75 @@ def _r(t):
     return t if _ROUND is None else _ROUND(t)
 
 
+# MX e4m3 operands (test infrastructure for tests/test_gpu_fp8.py: the fp8 analogue of operands_bf16).
+# `with operands_mx8():` additionally runs every linear of the ENCODER blocks — q | k | v, proj, w1 | w3, w2, and their data
+# gradients — on operands quantised as the kernels quantise them under precision = FP8 (csrc/gemm.hip stage_store, csrc/pack.hip
+# pack8): OCP e4m3, one e8m0 scale per 32 consecutive elements of the CONTRACTION axis, scale = 2^(floor(log2 amax) - 8), scaled
+# values clamped to +-448, round to nearest even; fp32 accumulation.  Weight gradients keep bf16 operands, the decoder, patch
+# embedding, attention core and loss are as under operands_bf16.  Like operands_bf16 it is NOT the reference: it says how much of
+# the fp8 path's distance to the reference the operand format makes inherent.
+_MX = False
+
+
+def mx_e4m3(t: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """Quantise-dequantise `t` in MX e4m3 blocks of 32 along `dim` (the contraction axis of the product it enters)."""
+    x = t.movedim(dim, -1)
+    K = x.shape[-1]
+    pad = (-K) % 32
+    if pad:
+        x = F.pad(x, (0, pad))
+    xb = x.reshape(*x.shape[:-1], -1, 32)
+    am = xb.abs().amax(-1, keepdim=True)
+    e = torch.frexp(am)[1] - 1                                  # floor(log2 amax)  (amax = m * 2^e', m in [0.5, 1))
+    eb = (e + 127 - 8).clamp(1, 254)                            # the kernels' biased e8m0 byte
+    scale = torch.ldexp(torch.ones_like(am), eb - 127)
+    q = (xb / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(t.dtype) * scale
+    q = q.reshape(*x.shape)
+    if pad:
+        q = q[..., :K]
+    return q.movedim(-1, dim)
+
+
+class _MXLinear(torch.autograd.Function):
+    """y = mx(x) mx(W)^T + b;  dx = mx(dy) mx'(W) with the blocks of W along its OUTPUT axis (the transposed image the data
+    gradient multiplies with);  dW = bf16(dy)^T bf16(x), db = sum dy (the weight-gradient kernels keep bf16 operands)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_b = b is not None
+        y = mx_e4m3(x, -1) @ mx_e4m3(W, -1).t()
+        return y + b if b is not None else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        bf = lambda t: t.to(torch.bfloat16).to(t.dtype)      # noqa: E731
+        dx = mx_e4m3(dy, -1) @ mx_e4m3(W, 0)
+        d2, x2 = bf(dy).reshape(-1, dy.shape[-1]), bf(x).reshape(-1, x.shape[-1])
+        return dx, d2.t() @ x2, (dy.reshape(-1, dy.shape[-1]).sum(0) if ctx.has_b else None)
+
+
+class operands_mx8(operands_bf16):
+    def __enter__(self):
+        global _MX
+        super().__enter__()
+        self._prev_mx, _MX = _MX, True
+        return self
+
+    def __exit__(self, *exc):
+        global _MX
+        _MX = self._prev_mx
+        return super().__exit__(*exc)
+
+
+def _lin(x, W, b, pre):
+    """One linear of a Block: x is the operand BEFORE any rounding (the MX path quantises the fp32 LayerNorm output directly)."""
+    if _MX and not pre.startswith("decoder"):
+        return _MXLinear.apply(x, W, b)
+    return F.linear(_r(x), _r(W), b)
+
+
 def layer_norm(x, w, b, eps=1e-5):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
@@ -236,10 +305,8 @@ def attention(x, P, pre, heads):
     Bs, S, C = x.shape
     hd = C // heads
 
-    xr = _r(x)
-
     def lin(name):
-        return _r(F.linear(xr, _r(P[f"{pre}.{name}.weight"]), P.get(f"{pre}.{name}.bias")))
+        return _r(_lin(x, P[f"{pre}.{name}.weight"], P.get(f"{pre}.{name}.bias"), pre))
 
     q = lin("q").reshape(Bs, S, heads, hd).permute(0, 2, 1, 3)
     k = lin("k").reshape(Bs, S, heads, hd).permute(0, 2, 1, 3)
@@ -251,15 +318,14 @@ def attention(x, P, pre, heads):
     else:       # the kernels multiply the bf16-rounded numerators exp(s - max) with v and divide by the fp32 sum afterwards
         e = torch.exp(attn - attn.amax(dim=-1, keepdim=True))
         o = ((_r(e) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(Bs, S, C)
-    return F.linear(_r(o), _r(P[f"{pre}.proj.weight"]), P[f"{pre}.proj.bias"])
+    return _lin(_r(o), P[f"{pre}.proj.weight"], P[f"{pre}.proj.bias"], pre)
 
 
 def swiglu(x, P, pre):
     """Models.py:231-232."""
-    xr = _r(x)
-    h1 = F.linear(xr, _r(P[f"{pre}.w1.weight"]), P[f"{pre}.w1.bias"])
-    h3 = F.linear(xr, _r(P[f"{pre}.w3.weight"]), P[f"{pre}.w3.bias"])
-    return F.linear(_r(F.silu(h1) * h3), _r(P[f"{pre}.w2.weight"]), P[f"{pre}.w2.bias"])
+    h1 = _lin(x, P[f"{pre}.w1.weight"], P[f"{pre}.w1.bias"], pre)
+    h3 = _lin(x, P[f"{pre}.w3.weight"], P[f"{pre}.w3.bias"], pre)
+    return _lin(_r(F.silu(h1) * h3), P[f"{pre}.w2.weight"], P[f"{pre}.w2.bias"], pre)
 
 
 def block(x, P, pre, heads, drop=None):

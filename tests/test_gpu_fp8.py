@@ -186,6 +186,47 @@ def test_huge_fp8_against_oracle(grid):
     assert res["fp8"][1] <= 0.12
 
 
+@pytest.mark.parametrize("grid", [(6, 9), (9, 6)])
+def test_huge_fp8_error_is_the_mx_operand_rounding(grid):
+    """VERDICT r04 weak spot 3 / "Next round" 6: the fp8 gates against the fp32 oracle are loose (6 % on gradient norms, 12-15 %
+    RMS on elements) because that is what e4m3 operands cost — this test shows it.  The oracle re-run with the encoder linears'
+    operands quantised as the kernels quantise them (`oracle.operands_mx8`: MX e4m3 blocks of 32 along the contraction axis in
+    the forward AND the data-gradient products, bf16 weight-gradient operands, bf16 everywhere operands_bf16 rounds) lands on
+    the HIP fp8 gradients several times closer than the fp32 oracle does: the gap to the reference is the operand format, what
+    remains (quantisation decisions that flip on the last bf16 bit, accumulation order) is gated tightly."""
+    cfg = O.OracleConfig(bands=192, embed_dim=512, num_heads=32)
+    state = O.init_state(cfg, seed=0, std=0.02)
+    N = 6
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(N, 1, 192, 9, 9, generator=g)
+    n1, n2 = torch.rand(N, 24, generator=g), torch.rand(N, 9, generator=g)
+    l32, _, _, g32 = O.forward_backward(state, cfg, x, n1.numpy(), n2.numpy(), *grid)
+    with O.operands_mx8():
+        l8, _, _, g8 = O.forward_backward(state, cfg, x, n1.numpy(), n2.numpy(), *grid)
+    m = huge()
+    m.load_state_dict(state)
+    m = m.to(DEV).set_precision("fp8")
+    loss, _, _ = m(x.to(DEV), 0.75, noise=(n1, n2), grid=grid)
+    loss.backward()
+    named = dict(m.named_parameters())
+    keys = [k for k in g32 if not k.endswith("attn.k.bias")]
+    e32 = {k: rms_rel(named[k].grad, g32[k]) for k in keys}           # HIP fp8 vs the reference arithmetic
+    e8 = {k: rms_rel(named[k].grad, g8[k]) for k in keys}             # HIP fp8 vs the same operand format on the CPU
+    gap = {k: rms_rel(g8[k], g32[k]) for k in keys}                   # what the format itself moves
+    enc = [k for k in keys if k.startswith("blocks")]
+    w32, w8, wg = max(e32.values()), max(e8.values()), max(gap.values())
+    med = lambda d, ks: sorted(d[k] for k in ks)[len(ks) // 2]       # noqa: E731
+    rl32, rl8 = abs(loss.item() - l32.item()) / l32.item(), abs(loss.item() - l8.item()) / l8.item()
+    print(f"[mx operand oracle] Huge@512 grid {grid}: loss rel vs fp32 {rl32:.2e}, vs mx oracle {rl8:.2e}; encoder gradients RMS-rel "
+          f"median / worst: HIP vs fp32 {med(e32, enc):.3f} / {w32:.3f} ({max(e32, key=e32.get)}), HIP vs mx oracle {med(e8, enc):.3f} / {w8:.3f} "
+          f"({max(e8, key=e8.get)}), mx oracle vs fp32 {med(gap, enc):.3f} / {wg:.3f}")
+    # measured (profiles/r05_g_mx_operand_oracle.txt): HIP vs fp32 median 0.046 / worst 0.074, mx oracle vs fp32 0.046 / 0.073,
+    # HIP vs mx oracle median 0.002 / worst 0.022-0.036 (a decoder q bias: bf16 noise on a near-zero gradient), loss 1e-6
+    assert wg >= 0.03                                  # the format alone moves gradients by several per cent ...
+    assert med(e8, enc) <= 0.2 * med(e32, enc)         # ... and explains the HIP path's distance to the reference
+    assert med(e8, enc) <= 6e-3 and w8 <= 0.05 and rl8 <= 2e-5      # what is left, gated at ~2x what was measured
+
+
 def test_fp8_training_steps_track_bf16(monkeypatch):
     """Five AdamW steps in fp8 stay on the bf16 trajectory (loss within 2e-3 at every step), Base width (the path is generic).
     HSIMAE_FP8_UNFUSED=1: every encoder linear on the MX GEMMs, layer at a time — by default the d = 128 blocks keep their fused
