@@ -65,6 +65,7 @@ enum : uint32_t {
     SC_WGRAD_SLAB = 1u << 11,      // HSIMAE_WGRAD_SLAB=0 clears: float atomics in the 256 x 256-tile weight-gradient launches
     SC_DEC_SLAB = 1u << 12,        // HSIMAE_DEC_SLAB=0 clears: float atomics in the fused decoder backward
     SC_PLANAR = 1u << 13,          // HSIMAE_WGRAD_PLANAR=0 clears: g / dh1|dh3 of the fused MLP backward row-major instead of 64-column planes
+    SC_ATTN_BLOCK256_BWD = 1u << 14,   // HSIMAE_FUSED_ATTN_BLOCK256_BWD=0 clears: blk256_bwd (three launches instead)
 };
 uint32_t sched_from_env() {
     auto off = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
@@ -84,6 +85,7 @@ uint32_t sched_from_env() {
     if (!off("HSIMAE_WGRAD_SLAB")) b |= SC_WGRAD_SLAB;
     if (!off("HSIMAE_DEC_SLAB")) b |= SC_DEC_SLAB;
     if (!off("HSIMAE_WGRAD_PLANAR") && hs_wgrad_dma_enabled()) b |= SC_PLANAR;
+    if (!off("HSIMAE_FUSED_ATTN_BLOCK256_BWD")) b |= SC_ATTN_BLOCK256_BWD;
     return b;
 }
 struct SchedRec { uint32_t enc = 0, dec = 0; bool has_enc = false, has_dec = false; };
@@ -380,6 +382,15 @@ int block_bwd(const BlkP& P, uint32_t sc, const BlkOff& o, float* grads, const f
     const bool rc = attn_bwd_recompute(d, dp, heads, h, Ts, f8u, sc);
     const bool blk_bwd = rc || (fuse_pb && fuse_ln && fmlp && !f8u && d == 128 && dp == d && hs_attn_proj_fusable(a) &&
                                 (sc & SC_ATTN_BLOCK_BWD) && hs_attn_block_bwd_fusable(d, heads, Ts));
+    // round 5, D = 256 (Large): the same four steps as one launch (attn_wide.hip blk256_bwd_kernel), from the saved q|k|v
+    const bool blk256_bwd = !blk_bwd && !f8 && dp == d && (sc & SC_ATTN_BLOCK256_BWD) && (sc & SC_LNBWD) && (sc & SC_PROJ_BWD) &&
+                            hs_attn_block256_bwd_fusable(d, heads, Ts, nsamples);
+    if (blk256_bwd) {
+        CK(hs_attn_block256_bwd(b.qkv, b.lse, w.g1b, G1, x_in, P.n1w, P.pT, P.qkvT, w.dqkv, dx_out, grads + o.n1w, grads + o.n1b, grads,
+                                reinterpret_cast<long long*>(det_acc), Ts, nsamples, mode, len_l, accumulate, s));
+        CK(run_wgrad());
+        return HSIMAE_OK;
+    }
     if (blk_bwd) {
         CK(hs_attn_block_bwd(rc ? nullptr : b.qkv, b.u, P.qkv, P.bqkv, b.o, b.lse, w.g1b, G1, x_in, P.n1w, P.pT, P.qkvT, w.dqkv, dx_out,
                              grads + o.n1w, grads + o.n1b, grads, reinterpret_cast<long long*>(det_acc), Ts, nsamples, mode, len_l,

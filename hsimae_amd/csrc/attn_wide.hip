@@ -363,6 +363,366 @@ __global__ __launch_bounds__(NTHW, 1) void blk256_fwd_kernel(Blk256Args p) {
     PH_FLUSH()
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The attention half of an encoder Block at D = 256, BACKWARD, in one persistent kernel (round 5; VERDICT r02-r04 "Large: the
+// attention half's backward at D = 256") — the wide counterpart of blk128_bwd_kernel (attn.hip):
+//   dO = dx1 Wp  ->  attention backward per head (delta = sum_j P dP inside the core, O is not read)  ->  du = dq|dk|dv Wqkv
+//   ->  LayerNorm-1 backward + residual gradient, dgamma / dbeta.
+// It replaces three launches of round 4 — gemm<A_BF16, E_BF16> (dO, 40 us), attn16_bwd (96 us), gemm<A_BF16, E_LN_BWD> (du +
+// LayerNorm backward, 146 us) = 282 us per block with dO and dq|dk|dv making a round trip through HBM between them (1.1 GB per
+// block; this kernel: q|k|v, dx1 (bf16 + fp32), x, lse in, dq|dk|dv (the weight gradients' operand) and dx out = 0.74 GB).
+//   * one workgroup = 16 waves = 16 heads, groups of SPW = 2 samples (64 image rows, 4 m-tiles), as blk256_fwd_kernel;
+//   * wave h owns head h in the attention core and output columns 16 h .. 16 h + 15 of both products; its slices of Wp^T
+//     (8 fragments) and Wqkv^T (24) are STREAMED from L2 one k-step ahead (512 KB per group and CU, as the forward);
+//   * the forward's saved q|k|v are read (recomputing them from u would stream another 384 KB of weights per group);
+//   * LDS: Q | K | V images (dq | dk | dv in place), the dx1 image (dO in place after a barrier), per-wave P / dS transposition
+//     tiles, lse, and an fp32 du tile that aliases the Q | K images once their last reader is past: 153 KB, one workgroup per CU.
+#ifndef HS_W256B_EARLY_X
+#define HS_W256B_EARLY_X 0   /* blk256_bwd: the LayerNorm epilogue's x / dx1 rows requested in front of the du product instead of behind it */
+#endif
+#ifndef HS_W256B_STG
+#define HS_W256B_STG 0       /* blk256_bwd: start stagger, workgroups (b >> 3) & 1 sleep HS_W256B_STG x 0.85 us (fused_dec.hip HS_DEC_STG_*) */
+#endif
+constexpr int PB = DW + 8;                          // image row pitch of the backward kernel (elements)
+constexpr int BTSW = 16;                            // P / dS transposition tile row (elements), chunks rotated by the row group (attn.hip BTS)
+constexpr int DUSW = DW + 4;                        // fp32 du tile row stride
+
+struct Blk256BwdArgs {
+    const bf16_t* qkv; const float* lse;            // saved by the forward: [rows][768], [rows][16]
+    const bf16_t* dx1b; const float* dx1;           // the projection's dY as bf16 (DropPath factor folded in) | the residual gradient
+    const float* x; const float* gamma;             // block input, LayerNorm-1 weight
+    const bf16_t* wpT; const bf16_t* wqkvT;         // packed images of Wp^T [n = 256][k = 256] and Wqkv^T [n = 256][k = 768]
+    bf16_t* dqkv; float* dx; float* dgamma; float* dbeta;
+    const float* det_base; long long* det_acc;
+    int Ts, nsamples, mode, len_l, accumulate;
+};
+
+template <int NT, int SPW>
+struct LayWB {
+    static constexpr int ROWS = NT * 16, RT = SPW * ROWS, IMG = RT * PB;
+    static constexpr int OFF_Q = RT * 4;                                   // after cls
+    static constexpr int OFF_X = OFF_Q + 3 * IMG * 2;                      // dx1 image, then dO
+    static constexpr int OFF_T = OFF_X + IMG * 2;                          // per-wave transposition tiles
+    static constexpr int OFF_LSE = OFF_T + HW * 2 * 16 * BTSW * 2;         // [16][RT]
+    static constexpr int OFF_G = OFF_LSE + HW * RT * 4;                    // gamma[256]
+    static constexpr int TOTAL = OFF_G + DW * 4;
+    static_assert(RT * DUSW * 4 <= 2 * IMG * 2, "the fp32 du tile must fit in the Q | K images");
+    static_assert(2 * NTHW * 8 * 4 <= 4 * IMG * 2, "the final dgamma / dbeta reduction must fit in the four images");
+    static_assert(TOTAL <= 160 * 1024, "LDS");
+};
+
+template <int NT, int SPW>
+__global__ __launch_bounds__(NTHW, 1) void blk256_bwd_kernel(Blk256BwdArgs p) {
+    using L = LayWB<NT, SPW>;
+    constexpr int ROWS = L::ROWS, RT = L::RT, MTT = SPW * NT;
+    constexpr int PASSES = (RT * 32 + NTHW - 1) / NTHW;           // wide layout: 32 lanes per row, 32 rows per pass
+    constexpr int NQ = (RT * 96 + NTHW - 1) / NTHW;               // q|k|v / dq|dk|dv 16-byte pieces per thread (96 per row)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int* cls = reinterpret_cast<int*>(smem);
+    bf16_t* Qf = reinterpret_cast<bf16_t*>(smem + L::OFF_Q);
+    bf16_t* Kf = Qf + L::IMG;
+    bf16_t* Vf = Kf + L::IMG;
+    bf16_t* Xf = reinterpret_cast<bf16_t*>(smem + L::OFF_X);      // dx1 rows (bf16), then dO (per head in place)
+    bf16_t* Tp = reinterpret_cast<bf16_t*>(smem + L::OFF_T) + head * (2 * 16 * BTSW);
+    bf16_t* Td = Tp + 16 * BTSW;
+    float* lse_s = reinterpret_cast<float*>(smem + L::OFF_LSE);   // [16][RT]
+    float* gam_s = reinterpret_cast<float*>(smem + L::OFF_G);
+    float* DU = reinterpret_cast<float*>(Qf);                     // [RT][DUSW], over Q | K once nothing reads them any more
+    const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3, hc = head * HDW;
+    const float scale = 0.25f, sc = 0.25f * 1.4426950408889634f;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+    if (threadIdx.x < DW) gam_s[threadIdx.x] = p.gamma[threadIdx.x];
+    for (int i = threadIdx.x; i < RT; i += NTHW) {                // class of an image row: -1 = padding; slots never mix
+        const int slot = i / ROWS, r = i - slot * ROWS;
+        int c = -1;
+        if (r < p.Ts) c = slot * 64 + ((p.mode == 1) ? r / p.len_l : (p.mode == 2) ? r % p.len_l : 0);
+        cls[i] = c;
+    }
+    float dgam[8], dbet[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dgam[e] = 0.f; dbet[e] = 0.f; }
+    const int tw = c16 * BTSW + (((g + q4) & 3) << 2);             // tile write: row c16, keys 4g.. at chunk (g + (c16 >> 2)) & 3
+    const int ttoff = (4 * g + q4) * BTSW + (((p4 + g) & 3) << 2); // tile transpose read: row 4g + q4, chunk p4
+    auto wpfrag = [&](int ks) { return *reinterpret_cast<const bf16x8*>(p.wpT + ((size_t)(head * KSW + ks) * 64 + lane) * 8); };
+    auto wufrag = [&](int ks) { return *reinterpret_cast<const bf16x8*>(p.wqkvT + ((size_t)(head * 3 * KSW + ks) * 64 + lane) * 8); };
+    if (HS_W256B_STG > 0 && ((blockIdx.x >> 3) & 1)) {
+        for (int i = 0; i < HS_W256B_STG; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+
+    for (int first = blockIdx.x * SPW; first < p.nsamples; first += gridDim.x * SPW) {
+        // (per-lane address pieces laundered once per group, as in blk256_fwd_kernel: hoisted out of the loop they spill)
+        int lz = 0;
+        asm volatile("" : "+v"(lz));
+        const int tid = (int)threadIdx.x + lz;
+        const int hcell = c16 * PB + hc + 4 * g + lz;              // this head's columns 4 g .. of row c16 (+ 16 mt rows)
+        const int troff = (4 * g + q4) * PB + hc + 4 * p4 + lz;    // transposed read: rows 4 g + q4, this head's columns 4 p4 ..
+        const int fa = c16 * PB + g * 8 + lz;                      // MFMA operand: row c16 (+ 16 mt), columns 8 g .. (+ 32 ks)
+        auto grow = [&](int irow) -> int {                         // global row of image row irow (slot-major), or -1
+            const int slot = irow / ROWS, r = irow - slot * ROWS;
+            return (first + slot < p.nsamples && r < p.Ts) ? (first + slot) * p.Ts + r : -1;
+        };
+        // ---- the group's q | k | v, dx1 (bf16) and logsumexp rows -> LDS.  The first k-step of Wp^T flies with them.
+        bf16x8 wc = wpfrag(0);
+        {
+            bf16x8 rq[NQ], rd[PASSES];
+            float rl;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int idx = tid + NTHW * i, irow = idx / 96, pc = idx - irow * 96;
+                const int gr = irow < RT ? grow(irow) : -1;
+                rq[i] = gr >= 0 ? *reinterpret_cast<const bf16x8*>(p.qkv + ((unsigned)gr * (3 * DW) + pc * 8)) : zero8();
+            }
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int irow = ps * 32 + (tid >> 5);
+                const int gr = irow < RT ? grow(irow) : -1;
+                rd[ps] = gr >= 0 ? *reinterpret_cast<const bf16x8*>(p.dx1b + ((unsigned)gr * DW + (tid & 31) * 8)) : zero8();
+            }
+            {
+                const int irow = tid >> 4;                         // RT * 16 = 1024 (row, head) pairs: one per thread
+                const int gr = irow < RT ? grow(irow) : -1;
+                rl = gr >= 0 ? p.lse[(unsigned)gr * HW + (tid & 15)] : 1e30f;      // padding rows: exp2(s - 1e30) = 0
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int idx = tid + NTHW * i, irow = idx / 96, pc = idx - irow * 96;
+                if (irow < RT) *reinterpret_cast<bf16x8*>(Qf + (pc >> 5) * L::IMG + irow * PB + (pc & 31) * 8) = rq[i];
+            }
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int irow = ps * 32 + (tid >> 5);
+                if (irow < RT) *reinterpret_cast<bf16x8*>(Xf + irow * PB + (tid & 31) * 8) = rd[ps];
+            }
+            if ((tid >> 4) < RT) lse_s[(tid & 15) * RT + (tid >> 4)] = rl;
+        }
+        lds_barrier();                                             // B1: the group's images are complete
+        // ---- dO[:, this head's 16 columns] = dx1 Wp  (K = 256, Wp^T fragments one k-step ahead), held as bf16 until every wave
+        //      has read the dx1 image, then written over it (own columns)
+        bf16x4 dob[MTT];
+        {
+            f32x4 acc[MTT];
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) acc[mt] = z4;
+#pragma unroll 1
+            for (int ks = 0; ks < KSW; ++ks) {
+                bf16x8 wn = wc;
+                if (ks + 1 < KSW) wn = wpfrag(ks + 1);
+#pragma unroll
+                for (int mt = 0; mt < MTT; ++mt)
+                    acc[mt] = mfma16(wc, *reinterpret_cast<const bf16x8*>(Xf + mt * 16 * PB + fa + ks * 32), acc[mt]);
+                wc = wn;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) dob[mt] = cvt4w(acc[mt]);
+        }
+        // class / padding mask of a (query tile, key tile) pair, as the accumulator the score MFMA starts from (0 or -inf)
+        f32x4 cm[NT][NT];
+#pragma unroll
+        for (int qt = 0; qt < NT; ++qt) {
+            const int qc = cls[qt * 16 + c16];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const int4 kc4 = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
+                const int kcl[4] = {kc4.x, kc4.y, kc4.z, kc4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cm[qt][kt][r] = (kcl[r] >= 0 && kcl[r] == qc) ? 0.f : -INFINITY;
+            }
+        }
+        lds_barrier();                                             // B2: every wave is done with the dx1 image
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) *reinterpret_cast<bf16x4*>(Xf + mt * 16 * PB + hcell) = dob[mt];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // own writes before own reads (only this wave touches these columns)
+        // ---- attention backward of this head (as blk128_bwd_kernel), slot by slot; dq, dk, dv in place
+        const float* lse_h = lse_s + head * RT;
+#pragma unroll
+        for (int slot = 0; slot < SPW; ++slot) {
+            const int r0 = slot * ROWS;
+            f32x4 dkT[NT], dvT[NT];
+            bf16x4 KT[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) { dkT[kt] = z4; dvT[kt] = z4; KT[kt] = tr4w(Kf + (r0 + kt * 16) * PB + troff); }
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) {
+                if (qt * 16 >= p.Ts) break;
+                const int query = r0 + qt * 16 + c16;
+                const int qcell = (r0 + qt * 16) * PB + hcell;
+                const bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qf + qcell);
+                const bf16x4 bdo = *reinterpret_cast<const bf16x4*>(Xf + qcell);
+                const float lqn = -lse_h[query];
+                const bf16x4 QT = tr4w(Qf + (r0 + qt * 16) * PB + troff);
+                const bf16x4 DT = tr4w(Xf + (r0 + qt * 16) * PB + troff);
+                f32x4 dqT = z4;
+                // delta_i = sum_j P_ij dP_ij: with at most NT = 2 key tiles per query tile both P and dP are in hand before dS
+                f32x4 pvs[NT], dps[NT];
+                float dl = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (r0 + kt * 16) * PB + hcell);
+                    const bf16x4 av = *reinterpret_cast<const bf16x4*>(Vf + (r0 + kt * 16) * PB + hcell);
+                    const f32x4 sv = mfma_k16w(ak, bq, cm[qt][kt]);
+                    dps[kt] = mfma_k16w(av, bdo, z4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pvs[kt][r] = __builtin_amdgcn_exp2f(fmaf(sv[r], sc, lqn));
+                        dl = fmaf(pvs[kt][r], dps[kt][r], dl);
+                    }
+                }
+                dl = rows_sum(dl);
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    f32x4 ds;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ds[r] = pvs[kt][r] * (dps[kt][r] - dl);
+                    const bf16x4 pb = cvt4w(pvs[kt]), dsb = cvt4w(ds);
+                    dqT = mfma_k16w(KT[kt], dsb, dqT);
+                    *reinterpret_cast<bf16x4*>(Tp + tw) = pb;
+                    *reinterpret_cast<bf16x4*>(Td + tw) = dsb;
+                    asm volatile("" ::: "memory");
+                    const bf16x4 Bp = tr4w(Tp + ttoff), Bds = tr4w(Td + ttoff);
+                    dkT[kt] = mfma_k16w(QT, Bds, dkT[kt]);
+                    dvT[kt] = mfma_k16w(DT, Bp, dvT[kt]);
+                }
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dqT[r] * scale);
+                *reinterpret_cast<bf16x4*>(Qf + qcell) = v;
+            }
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                const int kcell = (r0 + kt * 16) * PB + hcell;
+                bf16x4 vk, vv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { vk[r] = (bf16_t)(dkT[kt][r] * scale); vv[r] = (bf16_t)dvT[kt][r]; }
+                *reinterpret_cast<bf16x4*>(Kf + kcell) = vk;
+                *reinterpret_cast<bf16x4*>(Vf + kcell) = vv;
+            }
+        }
+        // first k-step of this wave's Wqkv^T slice: in flight over the barrier
+        bf16x8 uc = wufrag(0);
+        lds_barrier();                                             // B3: dq | dk | dv images complete
+        // ---- dq|dk|dv leave as whole rows (the q / k / v weight gradients' operand); du[:, this wave's 16 columns] = dq|dk|dv Wqkv
+        //      (contraction over the 768 image columns, Wqkv^T fragments streamed one k-step ahead)
+        for (int idx = tid; idx < RT * 96; idx += NTHW) {
+            const int irow = idx / 96, pc = idx - irow * 96;
+            const int gr = grow(irow);
+            if (gr >= 0)
+                HS_NT(HS_NT_C, reinterpret_cast<bf16x8*>(p.dqkv + ((unsigned)gr * (3 * DW) + pc * 8)),
+                      *reinterpret_cast<const bf16x8*>(Qf + (pc >> 5) * L::IMG + irow * PB + (pc & 31) * 8));
+        }
+        const int lc8 = (tid & 31) * 8;
+        float xr[PASSES][8], rs[PASSES][8];
+        int erow[PASSES];
+        auto fetch_epi = [&]() {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int irow = ps * 32 + (tid >> 5);
+                erow[ps] = irow < RT ? grow(irow) : -1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xr[ps][e] = 0.f; rs[ps][e] = 0.f; }
+                if (erow[ps] >= 0) {
+                    const float* xp = p.x + ((unsigned)erow[ps] * DW + lc8);
+                    const float* rp = p.dx1 + ((unsigned)erow[ps] * DW + lc8);
+                    const float4 a0 = *reinterpret_cast<const float4*>(xp), a1 = *reinterpret_cast<const float4*>(xp + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(rp), b1 = *reinterpret_cast<const float4*>(rp + 4);
+                    xr[ps][0] = a0.x; xr[ps][1] = a0.y; xr[ps][2] = a0.z; xr[ps][3] = a0.w; xr[ps][4] = a1.x; xr[ps][5] = a1.y; xr[ps][6] = a1.z; xr[ps][7] = a1.w;
+                    rs[ps][0] = b0.x; rs[ps][1] = b0.y; rs[ps][2] = b0.z; rs[ps][3] = b0.w; rs[ps][4] = b1.x; rs[ps][5] = b1.y; rs[ps][6] = b1.z; rs[ps][7] = b1.w;
+                    if (p.accumulate) {
+                        const float* op = p.dx + ((unsigned)erow[ps] * DW + lc8);
+                        const float4 c0 = *reinterpret_cast<const float4*>(op), c1 = *reinterpret_cast<const float4*>(op + 4);
+                        rs[ps][0] += c0.x; rs[ps][1] += c0.y; rs[ps][2] += c0.z; rs[ps][3] += c0.w; rs[ps][4] += c1.x; rs[ps][5] += c1.y; rs[ps][6] += c1.z; rs[ps][7] += c1.w;
+                    }
+                }
+            }
+        };
+        if (HS_W256B_EARLY_X) fetch_epi();
+        f32x4 du[MTT];
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) du[mt] = z4;
+#pragma unroll 1
+        for (int ks = 0; ks < 3 * KSW; ++ks) {
+            bf16x8 un = uc;
+            if (ks + 1 < 3 * KSW) un = wufrag(ks + 1);
+            const bf16_t* img = Qf + (ks / KSW) * L::IMG + (ks % KSW) * 32;
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt)
+                du[mt] = mfma16(uc, *reinterpret_cast<const bf16x8*>(img + mt * 16 * PB + fa), du[mt]);
+            uc = un;
+        }
+        // ---- the rows the LayerNorm epilogue needs (wide layout, 32 lanes per row): in flight over the two barriers
+        if (!HS_W256B_EARLY_X) fetch_epi();
+        lds_barrier();                                             // B4: every read of the images (row stores, du product) is done
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) *reinterpret_cast<f32x4*>(DU + (mt * 16 + c16) * DUSW + hc + 4 * g) = du[mt];
+        lds_barrier();                                             // B5: du tile complete
+        // ---- LayerNorm-1 backward + residual gradient, wide layout
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int irow = ps * 32 + (tid >> 5);
+            if (irow < RT) {
+                const float4 t0 = *reinterpret_cast<const float4*>(DU + irow * DUSW + lc8);
+                const float4 t1 = *reinterpret_cast<const float4*>(DU + irow * DUSW + lc8 + 4);
+                const float duv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                float sm = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm += xr[ps][e];
+                sm = lanes_sum<32>(sm);
+                const float mean = sm * (1.f / DW);
+                float qv = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xr[ps][e] -= mean; qv += xr[ps][e] * xr[ps][e]; }
+                qv = lanes_sum<32>(qv);
+                const float rstd = rsqrtf(qv * (1.f / DW) + 1e-5f);
+                const float4 g0 = *reinterpret_cast<const float4*>(gam_s + lc8), g1 = *reinterpret_cast<const float4*>(gam_s + lc8 + 4);
+                const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                float a = 0.f, b = 0.f, t[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xr[ps][e] *= rstd; t[e] = duv[e] * gm[e]; a += t[e]; b += t[e] * xr[ps][e]; }
+                a = lanes_sum<32>(a); b = lanes_sum<32>(b);
+                a *= (1.f / DW); b *= (1.f / DW);
+                if (erow[ps] >= 0) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[e] = rs[ps][e] + rstd * (t[e] - a - xr[ps][e] * b);
+                        dgam[e] += duv[e] * xr[ps][e];
+                        dbet[e] += duv[e];
+                    }
+                    float* op = p.dx + ((unsigned)erow[ps] * DW + lc8);
+                    *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+        }
+        lds_barrier();                                             // B6: the du tile is read; the next group's images may overwrite it
+    }
+    // dgamma / dbeta: 32 threads per column octet -> LDS, one commit per column and workgroup
+    float* red = DU;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[threadIdx.x * 8 + e] = dgam[e]; red[NTHW * 8 + threadIdx.x * 8 + e] = dbet[e]; }
+    lds_barrier();
+    if (threadIdx.x < 2 * DW) {
+        const int which = threadIdx.x >> 8, c = threadIdx.x & 255, o8 = c >> 3, e = c & 7;
+        float sacc = 0.f;
+        for (int t2 = o8; t2 < NTHW; t2 += 32) sacc += red[which * NTHW * 8 + t2 * 8 + e];
+        hs_gadd(HsDet{p.det_base, p.det_acc}, (which ? p.dbeta : p.dgamma) + c, sacc);
+    }
+}
+
+template <int NT, int SPW>
+int launch_blk256_bwd(const Blk256BwdArgs& a, hipStream_t s) {
+    using L = LayWB<NT, SPW>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk256_bwd_kernel<NT, SPW>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::TOTAL); attr_set = true; }
+    static int wgs = 0;                       // persistent, one 16-wave workgroup per CU (HSIMAE_BLK256_BWD_WGS overrides)
+    if (!wgs) { const char* e = getenv("HSIMAE_BLK256_BWD_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 1) wgs = 256; }
+    const int groups = (a.nsamples + SPW - 1) / SPW;
+    hipLaunchKernelGGL((blk256_bwd_kernel<NT, SPW>), dim3(groups < wgs ? groups : wgs), dim3(NTHW), (size_t)L::TOTAL, s, a);
+    return (int)hipGetLastError();
+}
+
 template <int NT, int SPW>
 int launch_blk256(const Blk256Args& a, hipStream_t s) {
     using L = LayW<NT, SPW>;
@@ -382,6 +742,24 @@ int launch_blk256(const Blk256Args& a, hipStream_t s) {
 // larger launch answers false here and takes the layer-at-a-time kernels instead of failing in hs_attn_block256_fwd.
 bool hs_attn_block256_fusable(int d, int heads, int Ts, int nsamples) {
     return d == DW && heads == HW && Ts >= 1 && Ts <= 32 && (int64_t)nsamples * Ts * 3 * DW < (1ll << 31);
+}
+
+// dO + attention backward + du + LayerNorm-1 backward at D = 256 in one launch (blk256_bwd_kernel).  Shape predicate (api.hip
+// SC_ATTN_BLOCK256_BWD is the A/B switch); the same 32-bit offset bound as the forward.
+bool hs_attn_block256_bwd_fusable(int d, int heads, int Ts, int nsamples) { return hs_attn_block256_fusable(d, heads, Ts, nsamples); }
+
+int hs_attn_block256_bwd(const hs_bf16* qkv, const float* lse, const hs_bf16* dx1b, const float* dx1, const float* x, const float* gamma,
+                         const hs_bf16* wpT, const hs_bf16* wqkvT, hs_bf16* dqkv, float* dx, float* dgamma, float* dbeta,
+                         const float* det_base, long long* det_acc, int Ts, int nsamples, int mode, int len_l, int accumulate,
+                         hipStream_t s) {
+    if (nsamples <= 0) return HS_OK;
+    if (Ts < 1 || Ts > 32) return HS_EUNSUPPORTED;
+    if ((int64_t)nsamples * Ts * 3 * DW >= (1ll << 31)) return HS_EUNSUPPORTED;      // 32-bit element offsets inside the kernel
+    Blk256BwdArgs a;
+    a.qkv = qkv; a.lse = lse; a.dx1b = dx1b; a.dx1 = dx1; a.x = x; a.gamma = gamma; a.wpT = wpT; a.wqkvT = wqkvT; a.dqkv = dqkv; a.dx = dx;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.det_base = det_base; a.det_acc = det_acc;
+    a.Ts = Ts; a.nsamples = nsamples; a.mode = mode; a.len_l = len_l; a.accumulate = accumulate;
+    return Ts <= 16 ? launch_blk256_bwd<1, 2>(a, s) : launch_blk256_bwd<2, 2>(a, s);
 }
 
 int hs_attn_block256_fwd(const float* x, const float* n1w, const float* n1b, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* wp,

@@ -92,6 +92,12 @@ bool hs_attn_block256_fusable(int d, int heads, int Ts, int nsamples);
 int hs_attn_block256_fwd(const float* x, const float* n1w, const float* n1b, const hs_bf16* wqkv, const float* bqkv, const hs_bf16* wp,
                          const float* pb, hs_bf16* u, hs_bf16* qkv, hs_bf16* o, float* lse, float* x1, const float* rowscale, int Ts,
                          int nsamples, int mode, int len_l, hipStream_t s);
+// ... and its backward (dO + attention backward + du + LayerNorm-1 backward, round 5).  HSIMAE_FUSED_ATTN_BLOCK256_BWD=0 disables.
+bool hs_attn_block256_bwd_fusable(int d, int heads, int Ts, int nsamples);
+int hs_attn_block256_bwd(const hs_bf16* qkv, const float* lse, const hs_bf16* dx1b, const float* dx1, const float* x, const float* gamma,
+                         const hs_bf16* wpT, const hs_bf16* wqkvT, hs_bf16* dqkv, float* dx, float* dgamma, float* dbeta,
+                         const float* det_base, long long* det_acc, int Ts, int nsamples, int mode, int len_l, int accumulate,
+                         hipStream_t s);
 bool hs_enc_mlp_fused_supported(int d, int hidden);
 int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, const EncMlpPtrs& b, hipStream_t s,
                    const float* rowscale = nullptr);

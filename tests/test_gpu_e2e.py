@@ -532,6 +532,45 @@ def test_fused_attention_half_d256_matches_separate_kernels(bands, grid, N):
     print(f"[fused-attn-half-256 {bands}] worst grad rms-rel vs separate {worst}")
 
 
+@pytest.mark.parametrize("bands,grid,N,det", [(96, (3, 9), 21, False), (96, (9, 3), 22, False), (48, (2, 7), 9, False), (96, (3, 9), 1, False),
+                                              (96, (9, 3), 7, True)])
+def test_fused_attention_half_backward_d256_matches_separate_kernels(bands, grid, N, det):
+    """blk256_bwd_kernel (attn_wide.hip, round 5: dO = dx1 Wp -> attention backward with delta = sum P dP -> du = dq|dk|dv Wqkv ->
+    LayerNorm-1 backward + residual gradient, 16 waves = 16 heads, weights streamed) against the three launches it replaces
+    (projection data-gradient GEMM, attn16_bwd, q|k|v data-gradient GEMM with the LayerNorm-backward epilogue) on the same
+    forward: both axis-class modes and the fusion blocks, odd sample counts (the kernel walks pairs), 14-token sequences (one
+    key tile), a single sample, and deterministic mode (where the dgamma / dbeta commits go through the fixed-point path)."""
+    cfg = O.OracleConfig(bands=bands, embed_dim=256, num_heads=16)
+    m = build(cfg, O.init_state(cfg, seed=13, std=0.05))
+    m.deterministic = det
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(N, 1, bands, 9, 9, generator=g).to(DEV)
+    n = (torch.rand(N, bands // 8, generator=g), torch.rand(N, 9, generator=g))
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["HSIMAE_FUSED_ATTN_BLOCK256_BWD"] = mode
+        try:
+            m.zero_grad()
+            loss, pred, _ = m(x, 0.75, noise=n, grid=grid)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = (loss.item(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        finally:
+            os.environ.pop("HSIMAE_FUSED_ATTN_BLOCK256_BWD", None)
+    (l0, g0), (l1, g1) = res["0"], res["1"]
+    assert l0 == l1 or abs(l0 - l1) <= 1e-6 * abs(l0)            # the same forward
+    worst = ("", 0.0)
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        if k.endswith("attn.k.bias"):
+            continue
+        r = rms_rel(g1[k], g0[k])
+        if r > worst[1]:
+            worst = (k, r)
+        assert r < 2e-2, (k, r)
+    print(f"[fused-attn-half-256 bwd {bands} {grid} N={N}] worst grad rms-rel vs separate {worst}")
+
+
 @pytest.mark.parametrize("name,bands,dim,grid,N", [("C3-Large", 96, 256, (3, 9), 12), ("C3-Large", 96, 256, (9, 3), 12),
                                                    ("C5-Huge@512", 192, 512, (6, 9), 6), ("C5-Huge@512", 192, 512, (9, 6), 6),
                                                    ("C5-Huge@512", 192, 512, (18, 3), 6)])

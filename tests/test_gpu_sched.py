@@ -30,7 +30,7 @@ SWITCHES = [
     ("HSIMAE_FUSED_PROJ_BWD", "0", "base"), ("HSIMAE_FUSED_LNBWD", "0", "base"), ("HSIMAE_ATTN_BWD_RECOMPUTE", "0", "base"),
     ("HSIMAE_WGRAD_PLANAR", "0", "base"), ("HSIMAE_FP8_UNFUSED", "1", "base_fp8"),
     ("HSIMAE_FUSED_ATTN_BLOCK256", "0", "large"), ("HSIMAE_FUSED_LNBWD", "0", "large"), ("HSIMAE_WGRAD_SLAB", "0", "large"),
-    ("HSIMAE_FUSED_MLP", "0", "large"),
+    ("HSIMAE_FUSED_MLP", "0", "large"), ("HSIMAE_FUSED_ATTN_BLOCK256_BWD", "0", "large"),
 ]
 
 
