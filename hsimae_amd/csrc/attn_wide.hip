@@ -31,6 +31,8 @@
 #ifndef HS_W256_LATE_X
 #define HS_W256_LATE_X 1 /* the next group's x rows are fetched after the attention (16 registers less across it) instead of before it */
 #endif
+// (start stagger of every second workgroup, as blk256_bwd_kernel below: 8.5 us 177.0 vs 176.5, 17 us 181.6 us — neutral to worse,
+//  profiles/r05_m_large_stagger.txt; removed)
 #ifndef HS_W256_EARLY
 #define HS_W256_EARLY 0 /* projection weights (first half) and residual pieces fetched in front of the attention */
 #endif
@@ -377,11 +379,16 @@ __global__ __launch_bounds__(NTHW, 1) void blk256_fwd_kernel(Blk256Args p) {
 //   * the forward's saved q|k|v are read (recomputing them from u would stream another 384 KB of weights per group);
 //   * LDS: Q | K | V images (dq | dk | dv in place), the dx1 image (dO in place after a barrier), per-wave P / dS transposition
 //     tiles, lse, and an fp32 du tile that aliases the Q | K images once their last reader is past: 153 KB, one workgroup per CU.
+// Measured on the first version (profiles/r05_l_blk256_bwd_knobs.txt, same box): the LayerNorm epilogue's x / dx1 rows requested in
+// FRONT of the du product instead of behind it: 244.0 -> 265.8 us (the du product's weight-fragment waits then sit behind 128 KB of
+// HBM loads in the in-order counter) — not kept.  Start stagger (fused_dec.hip HS_DEC_STG_*: every second workgroup, (b >> 3) & 1,
+// sleeps HS_W256B_STG x 0.85 us before its first group): 5 us 243.3, 10 us 235.0, 17 us 230.6 / 229.4 (against 239.6 on that box),
+// 24 us 246, 31 us 255 us (profiles/r05_m_large_stagger.txt) — kept at 17 us.
 #ifndef HS_W256B_EARLY_X
-#define HS_W256B_EARLY_X 0   /* blk256_bwd: the LayerNorm epilogue's x / dx1 rows requested in front of the du product instead of behind it */
+#define HS_W256B_EARLY_X 0
 #endif
 #ifndef HS_W256B_STG
-#define HS_W256B_STG 0       /* blk256_bwd: start stagger, workgroups (b >> 3) & 1 sleep HS_W256B_STG x 0.85 us (fused_dec.hip HS_DEC_STG_*) */
+#define HS_W256B_STG 20
 #endif
 constexpr int PB = DW + 8;                          // image row pitch of the backward kernel (elements)
 constexpr int BTSW = 16;                            // P / dS transposition tile row (elements), chunks rotated by the row group (attn.hip BTS)

@@ -186,7 +186,7 @@ def test_huge_fp8_against_oracle(grid):
     assert res["fp8"][1] <= 0.12
 
 
-@pytest.mark.parametrize("grid", [(6, 9), (9, 6)])
+@pytest.mark.parametrize("grid", [(6, 9)])            # ((9, 6) measured the same: profiles/r05_g_mx_operand_oracle.txt)
 def test_huge_fp8_error_is_the_mx_operand_rounding(grid):
     """VERDICT r04 weak spot 3 / "Next round" 6: the fp8 gates against the fp32 oracle are loose (6 % on gradient norms, 12-15 %
     RMS on elements) because that is what e4m3 operands cost — this test shows it.  The oracle re-run with the encoder linears'
