@@ -187,19 +187,23 @@ def wgrad_launch(model, M):
     hp = (h + 31) // 32 * 32
     bf = dict(dtype=torch.bfloat16, device=dev)
     dqkv, u, o, u2 = (torch.randn(M, w, **bf) for w in (3 * d, d, d, d))
-    dh13, g = torch.randn(M, 2 * hp, **bf), torch.randn(M, hp, **bf)
+    # the schedule's operand layout: dh1 | dh3 and g as 64-column planes of M + 48 rows when M % 32 == 0, row-major otherwise
+    hp64, R = (hp + 63) // 64 * 64, (M + 48 if M % 32 == 0 else 0)
+    dh13 = torch.randn((R or M) * 2 * (hp64 if R else hp), **bf)
+    g = torch.randn((R or M) * (hp64 if R else hp), **bf)
     G0, G1 = torch.randn(M, d, **bf), torch.randn(M, d, **bf)      # bf16 copies of dY / dx1 (emitted by enc_mlp_bwd)
     dW = [torch.zeros(n, k, device=dev) for n, k in ((d, d),) * 4 + ((h, d),) * 2 + ((d, h),)]
     db = [torch.zeros(w.shape[0], device=dev) for w in dW]
     wp = _lib.WgradParams()
     spec = [(dqkv.data_ptr(), 0, 3 * d, u, d, d, d), (dqkv.data_ptr() + 2 * d, 0, 3 * d, u, d, d, d),
             (dqkv.data_ptr() + 4 * d, 0, 3 * d, u, d, d, d), (G1.data_ptr(), 0, d, o, d, d, d),
-            (dh13.data_ptr(), 0, 2 * hp, u2, d, h, d), (dh13.data_ptr() + 2 * hp, 0, 2 * hp, u2, d, h, d),
-            (G0.data_ptr(), 0, d, g, hp, d, h)]
+            (dh13.data_ptr(), 0, hp64 if R else 2 * hp, u2, d, h, d),
+            (dh13.data_ptr() + (2 * hp64 * R if R else 2 * hp), 0, hp64 if R else 2 * hp, u2, d, h, d),
+            (G0.data_ptr(), 0, d, g, hp64 if R else hp, d, h)]
     tiles = 0
     for i, (dO, f32, ldo, A, lda, n, k) in enumerate(spec):
         wp.t[i] = _lib.WgradTask(dO=dO, dO_f32=f32, ldo=ldo, A=A.data_ptr(), lda=lda, N=n, K=k, dW=dW[i].data_ptr(),
-                                 ldw=k, db=db[i].data_ptr())
+                                 ldw=k, db=db[i].data_ptr(), dO_plane_rows=R if i in (4, 5) else 0, A_plane_rows=R if i == 6 else 0)
         tiles += ((n + 127) // 128) * ((k + 127) // 128)
     wp.ntasks, wp.M, wp.msplit = len(spec), M, lib.hsimae_wgrad_msplit(tiles, M)    # what hsimae_backward launches
     s = torch.cuda.current_stream().cuda_stream
