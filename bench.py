@@ -279,12 +279,16 @@ def kernel_rooflines(model, M, peak_tflops, iters=20):
     except RuntimeError:
         pass
     ms = _timed_interleaved(launches, iters)
+    nblk = 2 * model.s_depth + (max(0, model.depth - model.s_depth) if model.s_depth < 12 else 0)
+    per_step = {id(la): (nblk if la is not launches[-1] else nblk + 2) for la in launches}   # the batched launch also serves embed / head
+    order = sorted(zip(launches, ms), key=lambda lt: -lt[1] * per_step[id(lt[0])])           # largest share of the step first
     out = []
-    for la, t in zip(launches, ms):
+    for la, t in order:
         tf = la.flops / (t * 1e-3) / 1e12
         gb = la.design_bytes / (t * 1e-3) / 1e9
         out.append(({"bound": "mfma", "kernel": la.name, "achieved": round(tf, 1), "peak": peak_tflops, "unit": "TFLOP/s",
-                     "frac": round(tf / peak_tflops, 4), "flops_per_launch": la.flops, "launch_ms": round(t, 4)},
+                     "frac": round(tf / peak_tflops, 4), "flops_per_launch": la.flops, "launch_ms": round(t, 4),
+                     "launches_per_step": per_step[id(la)]},
                     {"bound": "hbm", "kernel": la.name, "achieved": round(gb, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": round(gb / PEAK_HBM_GBS, 4), "bytes_per_launch": la.design_bytes,
                      "compulsory_bytes_per_launch": la.compulsory_bytes, "launch_ms": round(t, 4)}))

@@ -30,3 +30,18 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in d, k
     blk = d["roofline_decoder_block"]
     assert 50 < blk["fwd_us"] < 1000 and 100 < blk["bwd_us"] < 3000 and 0 < blk["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_bench_data_parallel_line_carries_the_self_check():
+    """`bench.py --verify` (on whenever the reducer runs): the 1-rank RCCL path (`--force-ddp`: real all-reduces of every bucket)
+    must report a consistent step — the bucketed, backward-overlapped reduction equals one plain all-reduce of the same step's
+    local gradients — and list the buckets it issued."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--force-ddp", "--no-extras"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.lstrip().startswith("{")][-1])
+    assert d["dp_consistent"] is True, d.get("dp_verify")
+    v = d["dp_verify"]
+    assert v["ranks"] == 1 and v["matches_single_collective"] is True and len(v["buckets"]) >= 3
+    assert sum(hi - lo for lo, hi in v["buckets"]) * 4 == d["comm"]["bytes"]
