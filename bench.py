@@ -267,6 +267,43 @@ def decoder_block_replay(model, N, Ts, peak_tflops, iters=10):
             "compulsory_bytes": {"fwd": float(M) * (4 * 4 * d + 2 * 2 * d + 2 * 32), "bwd": float(M) * (6 * 4 * d + 2 * d + 32)}}
 
 
+class _Watchdog:
+    """Rank 0's guarantee of ONE JSON line: `finish()` prints the complete line; if it has not been called `seconds` after the timed
+    region ended, a timer thread prints what the line holds by then (the contract fields are all there) and ends the process."""
+
+    def __init__(self, seconds, line):
+        import threading
+        self.line, self.lock, self.done = line, threading.Lock(), False
+        self.timer = None
+        if seconds and seconds > 0:
+            self.timer = threading.Timer(seconds, self._expired, args=(seconds,))
+            self.timer.daemon = True
+            self.timer.start()
+
+    def _emit(self):
+        C.CDLL(None).fflush(None)          # RCCL's banner sits in the C stdio buffer: flush it so the JSON is the LAST line
+        print(json.dumps(self.line), flush=True)
+
+    def _expired(self, seconds):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            self.line["watchdog"] = (f"the legs after the timed region did not finish within {seconds:g} s: line printed without them "
+                                     f"(have: {sorted(k for k in self.line if k.startswith(('comm', 'dp_', 'roofline_', 'cpu_')))})")
+            self._emit()
+        os._exit(0)
+
+    def finish(self):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.timer is not None:
+                self.timer.cancel()
+            self._emit()
+
+
 def kernel_rooflines(model, M, peak_tflops, iters=20):
     """The two kernels with the largest share of the step, replayed interleaved; MFMA and HBM pricing of each."""
     from hsimae_amd import _lib
@@ -582,6 +619,8 @@ def main():
                          "same step's local gradients, hashes of the reduced buffer / grid sequence / collective order all-gathered; "
                          "rank 0 prints dp_consistent and the bucket list")
     ap.add_argument("--no-verify", dest="verify", action="store_false")
+    ap.add_argument("--watchdog", type=float, default=420.0,
+                    help="seconds the legs after the timed region may take before rank 0 prints the line without them (0 = off)")
     ap.add_argument("--cpu-probe", type=int, default=0, help=argparse.SUPPRESS)      # child of cpu_baseline(): threads to probe
     ap.add_argument("--probe-bands", type=int, default=96, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -679,6 +718,47 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     last_loss = float(loss.item())
+    if rank == 0:
+        h, hd = swiglu_hidden(D, 4.0), swiglu_hidden(64, 4.0)
+        lt0, ll0 = HSIMAE.grid_candidates(bands // 8, 9, 0.75)[0]
+        fl, fl_enc = flops_per_sample(bands, D, 12, 9, 64, 8, lt0, ll0, h, hd, parts=True)
+        peak = PEAK_FP8_TFLOPS if precision == "fp8" else PEAK_BF16_TFLOPS
+        value = world * N * args.steps / dt
+        step_tflops = value * fl / 1e12 / world
+        ev = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        evs = sorted(ev)
+        per_grid = {}
+        for g, e in zip(grids, ev):
+            per_grid.setdefault(f"{g[0]}x{g[1]}", []).append(e)
+        traffic = profile_traffic(args.model if precision == "bf16" else f"{args.model}_{precision}")
+        opdesc = ("bf16 MFMA operands" if precision == "bf16" else
+                  "e4m3 MX-scaled MFMA operands in the encoder linears (bf16 elsewhere)") + " / fp32 accumulate + residual"
+        out = {
+            "metric": f"HSI patches/sec (9x9x{bands}, mask 75%) pretrain fwd+bwd", "value": round(value, 1),
+            "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": precision, "data": "synthetic",
+            "config": {"workload": f"HSIMAE-{args.model.capitalize()} pretrain fwd+bwd, 9x9x{bands} cubes, per-GPU batch {N}, "
+                                   f"mask 0.75, {opdesc}",
+                       "per_gpu_batch": N, "global_batch": N * world, "parallelism": f"dp{world}"},
+            "per_gpu": round(value / world, 1), "loss": round(last_loss, 6),
+            "gflop_per_patch": round(fl / 1e9, 4),
+            "roofline": {"bound": "mfma", "achieved": round(step_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(step_tflops / peak, 4),
+                         "traffic": traffic["hbm_bytes_per_step"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None,
+                         # the PMC passes are a separate run (rocprofv3 --pmc cannot ride along with the timed steps): the file
+                         # records the hash of the kernel sources it was measured on; stale = the kernels have changed since
+                         "traffic_stale": (traffic.get("kernel_source_sha") != kernel_source_hash()) if traffic else None,
+                         "what": "whole step, algorithmic fwd+bwd FLOPs per GPU (SURVEY 8d), wall-clock bracket"},
+            "step_ms": {"median": round(pct(evs, 0.5), 3), "p10": round(pct(evs, 0.1), 3), "p90": round(pct(evs, 0.9), 3),
+                        "per_grid": {k: {"n": len(v), "median": round(pct(sorted(v), 0.5), 3)} for k, v in per_grid.items()},
+                        "clock": "HIP events between consecutive steps on the launch stream"},
+        }
+        # The legs below (reducer detached, self-check, replays, CPU baseline) run AFTER the timed region.  If one of them does not come
+        # back — a collective that another rank never entered on a node this code has not run on yet — the measurement must not
+        # be lost with it: after --watchdog seconds rank 0 prints the line as it stands and leaves.
+        watchdog = _Watchdog(args.watchdog, out)
     comm = None
     if use_ddp:
         # what the gradient exchange costs this configuration: the same step with the reducer detached (no collectives,
@@ -734,42 +814,6 @@ def main():
         del g_b, g_ref
 
     if rank == 0:
-        h, hd = swiglu_hidden(D, 4.0), swiglu_hidden(64, 4.0)
-        lt0, ll0 = HSIMAE.grid_candidates(bands // 8, 9, 0.75)[0]
-        fl, fl_enc = flops_per_sample(bands, D, 12, 9, 64, 8, lt0, ll0, h, hd, parts=True)
-        peak = PEAK_FP8_TFLOPS if precision == "fp8" else PEAK_BF16_TFLOPS
-        value = world * N * args.steps / dt
-        step_tflops = value * fl / 1e12 / world
-        ev = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
-        evs = sorted(ev)
-        per_grid = {}
-        for g, e in zip(grids, ev):
-            per_grid.setdefault(f"{g[0]}x{g[1]}", []).append(e)
-        traffic = profile_traffic(args.model if precision == "bf16" else f"{args.model}_{precision}")
-        opdesc = ("bf16 MFMA operands" if precision == "bf16" else
-                  "e4m3 MX-scaled MFMA operands in the encoder linears (bf16 elsewhere)") + " / fp32 accumulate + residual"
-        out = {
-            "metric": f"HSI patches/sec (9x9x{bands}, mask 75%) pretrain fwd+bwd", "value": round(value, 1),
-            "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": precision, "data": "synthetic",
-            "config": {"workload": f"HSIMAE-{args.model.capitalize()} pretrain fwd+bwd, 9x9x{bands} cubes, per-GPU batch {N}, "
-                                   f"mask 0.75, {opdesc}",
-                       "per_gpu_batch": N, "global_batch": N * world, "parallelism": f"dp{world}"},
-            "per_gpu": round(value / world, 1), "loss": round(last_loss, 6),
-            "gflop_per_patch": round(fl / 1e9, 4),
-            "roofline": {"bound": "mfma", "achieved": round(step_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(step_tflops / peak, 4),
-                         "traffic": traffic["hbm_bytes_per_step"] if traffic else None,
-                         "traffic_source": traffic["source"] if traffic else None,
-                         # the PMC passes are a separate run (rocprofv3 --pmc cannot ride along with the timed steps): the file
-                         # records the hash of the kernel sources it was measured on; stale = the kernels have changed since
-                         "traffic_stale": (traffic.get("kernel_source_sha") != kernel_source_hash()) if traffic else None,
-                         "what": "whole step, algorithmic fwd+bwd FLOPs per GPU (SURVEY 8d), wall-clock bracket"},
-            "step_ms": {"median": round(pct(evs, 0.5), 3), "p10": round(pct(evs, 0.1), 3), "p90": round(pct(evs, 0.9), 3),
-                        "per_grid": {k: {"n": len(v), "median": round(pct(sorted(v), 0.5), 3)} for k, v in per_grid.items()},
-                        "clock": "HIP events between consecutive steps on the launch stream"},
-        }
         if comm is not None:
             out["comm"] = comm
         if verify is not None:
@@ -809,8 +853,7 @@ def main():
             out["input_pipeline"] = input_pipeline_ms(bands, N)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(bands)
-        C.CDLL(None).fflush(None)          # RCCL's banner sits in the C stdio buffer: flush it so the JSON is the LAST line
-        print(json.dumps(out), flush=True)
+        watchdog.finish()                  # prints the line (once: the timer cannot fire any more)
     if use_ddp:
         dist.barrier()
         dist.destroy_process_group()

@@ -1319,6 +1319,9 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
         // Software pipeline over the key tiles: the transposed operands of tile kt-1 (LDS write -> transpose read, ~200
         // cycles of latency) are consumed after the score MFMAs of tile kt have been issued, and those MFMAs' own
         // latency is covered by the dk/dv MFMAs of tile kt-1.
+        // (Round 5 measured two deeper orders — the dk/dv products pinned behind this tile's softmax arithmetic, and the score / dP
+        //  products issued one tile ahead: 325.2 -> 325.3 / 321.5 / 322.1 us, profiles/r05_n_core_order_ab.txt.  The loop is not
+        //  waiting for the transposition round trip.)
         bf16x4 Bp = zero4(), Bds = zero4();
         // K / V row fragments one tile ahead as well: their LDS latency is off the per-tile dependency chain
         bf16x4 Kn = *reinterpret_cast<const bf16x4*>(Kb + rcol);

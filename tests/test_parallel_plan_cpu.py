@@ -208,3 +208,25 @@ def test_verify_step_flags_a_bucketed_result_that_differs_from_the_plain_collect
     assert v["dp_consistent"] is False and v["matches_single_collective"] is False
     a = torch.arange(1000, dtype=torch.float32); b = a.clone(); b[[3, 7]] = b[[7, 3]]
     assert flat_hash(a) == flat_hash(a.clone()) and flat_hash(a) != flat_hash(b)
+
+
+def test_bench_watchdog_prints_the_line_when_the_legs_after_the_timed_region_hang():
+    """`bench.py`'s rank 0 owes the driver ONE JSON line.  The comm / self-check / replay legs run after the timed region; if one
+    hangs (a collective another rank never entered), the watchdog prints the line with what it holds and ends the process."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "line = {'metric': 'm', 'value': 1.0, 'comm': {'buckets': 5}}\n"
+            "w = bench._Watchdog(0.3, line)\n"
+            "time.sleep(30)\n"                      # the hung leg
+            "print('never')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-400:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out) == 1 and "never" not in r.stdout
+    d = json.loads(out[0])
+    assert d["value"] == 1.0 and "did not finish" in d["watchdog"] and "comm" in d["watchdog"]
+    # the normal end: finish() prints once, the timer is cancelled, nothing follows
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "w = bench._Watchdog(0.3, {'metric': 'm'}); w.line['extra'] = 1; w.finish(); w.finish(); time.sleep(0.8)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert r.returncode == 0 and len(out) == 1 and json.loads(out[0]) == {"metric": "m", "extra": 1}
