@@ -51,6 +51,9 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases_enc(un
 #ifndef HS_MLP_WPCF_64
 #define HS_MLP_WPCF_64 3
 #endif
+#ifndef HS_MLP_FWD_RES
+#define HS_MLP_FWD_RES 0         /* D = 128 forward: 1 = the weights-resident persistent kernel (enc_mlp_fwd_res_kernel); HSIMAE_MLP_FWD_RES overrides */
+#endif
 #ifndef HS_SWZ256
 #define HS_SWZ256 0          /* 1: the swizzled unpadded layout at D = 256 too (experiment) */
 #endif
@@ -264,7 +267,9 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
             const int row = (threadIdx.x + NTH * i) / LPR;
 #pragma unroll
             for (int e = 0; e < 8; ++e) fa[i][e] = 0.f;
+#ifndef HS_ABL_FWD_NOLOAD   /* timing ablation (variant builds only): the panel's rows are not fetched = the kernel without its exposed HBM round trip */
             if (panel < npanels && r0 + row < p.M) ld8(p.x1 + (size_t)(r0 + row) * D + c8_0, fa[i]);
+#endif
         }
     };
     fetch_panel(blockIdx.x);
@@ -343,6 +348,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifndef HS_ABL_WSTREAM      /* timing ablation (variant builds only): every chunk computes with chunk 0's weight fragments = the L2 -> CU weight stream / NCH */
         if (c + 1 < NCH) {
             if ((c + 1) * 4 + 3 < nt_h) {
                 f1.template load<false>(w.w1, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
@@ -353,6 +359,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
             }
             bn.load(w.w1b, w.w3b, ((c + 1) * 4 + q.wave) * 16 + q.g * 4, w.h);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT4; ++mt) {
@@ -366,7 +373,11 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
         // x2 += g_c W2_c^T : this wave's NJO output n-tiles, all 4 m-tiles; the last chunk of 352 is half full
         constexpr bool kHalfLast = (HPE % 64) != 0;
         FrN<2, NJO> f2n;
+#ifdef HS_ABL_WSTREAM
+        f2n = f2;
+#else
         if (c + 1 < NCH) f2n.template load<false>(w.w2, G::KSH, q.wave * NJO, 2 * (c + 1), D / 16, q.lane);
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (kHalfLast && c == NCH - 1 && ks == 1) continue;
@@ -404,6 +415,9 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] += t[e];
             }
+#ifdef HS_ABL_FWD_NOSTORE
+            if (f[0] == 123.456f)
+#endif
             st8(p.x2 + (size_t)(row0 + row) * D + c8, f);
         }
     }
@@ -411,6 +425,130 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
     if constexpr (PERSIST) lds_barrier();               // XS / XR are read: the next panel's LayerNorm may overwrite them
   } while (PERSIST && (panel += (int)gridDim.x) < npanels);
     PH_FLUSH(8)
+}
+
+// ---- weights-resident persistent form of the forward kernel at D = 128 (round 5) ------------------------------------------------------
+// enc_mlp_fwd_kernel<128, 352> streams its 270 KB of weight fragments from L2 for every 48-row panel (622 MB per launch) and waits
+// for its rows at the top of every panel; with the weight fetches and the rows in the same in-order vmcnt queue a row prefetch
+// cannot get ahead (HS_MLP_FWD_PERSIST above).  Timing ablations (profiles/r05_p_mlp_fwd_ablations.txt): 54.8 us as shipped,
+// 45.6 without the weight stream, 45.4 without the row fetch, 36.5 without both, 32.6 without the stores as well.
+// Here ONE 8-wave workgroup per CU keeps all of W1 | W3 | W2 in registers for the whole launch — wave w owns hidden n-tiles
+// {3w, 3w+1, 3w+2} (waves 6, 7: two each: 22 tiles) of the gate products and output n-tile w of the W2 product: 96 + 44 registers —,
+// walks 32-row panels (one row piece per thread), and the only global loads inside the loop are the NEXT panel's rows, fetched a
+// whole panel ahead into 8 registers (ping-pong, no copies).  Same MFMA operand order and accumulation order as the panel kernel:
+// bit-identical x2.
+constexpr int RES_R = 32, RES_NT = 512, RES_LX = 128 + 4;
+constexpr int RES_LDS = RES_R * 128 * 2 + 6 * RES_R * 64 * 2 + RES_R * RES_LX * 4 + (3 * 128 + 2 * 384) * 4;
+__global__ __launch_bounds__(RES_NT, 2) void enc_mlp_fwd_res_kernel(EncMlpFwdArgs p) {
+    constexpr int D = 128, R = RES_R, LU = 128, LC = 64, LX = RES_LX, KSD = 4, KSH = 11, NTH1 = 22;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);                   // LayerNorm-2 output, [32][128] swizzled (pfrag)
+    bf16_t* Gc = U2 + R * LU;                                       // the gate: six 64-column chunk images [32][64] (cfrag)
+    float* XS = reinterpret_cast<float*>(Gc + 6 * R * LC);          // fp32 result tile [32][LX]
+    float* CB = XS + R * LX;                                        // gamma | beta | b2 | b1 (384) | b3 (384)
+    const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fp = swzp<D>(c16), fc = swzc<D>(c16);
+    const EncMlpW& w = p.w;
+    for (int i = tid; i < 128; i += RES_NT) { CB[i] = w.n2w[i]; CB[128 + i] = w.n2b[i]; CB[256 + i] = w.w2b[i]; }
+    for (int i = tid; i < 384; i += RES_NT) { CB[384 + i] = i < w.h ? w.w1b[i] : 0.f; CB[768 + i] = i < w.h ? w.w3b[i] : 0.f; }
+    const int nt0 = wave < 6 ? wave * 3 : 18 + (wave - 6) * 2;
+    const int cnt = wave < 6 ? 3 : 2;
+    bf16x8 W1f[3][KSD], W3f[3][KSD], W2f[KSH];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {
+            const int nt = j < cnt ? nt0 + j : nt0;                 // (waves 6, 7: slot 2 is never used)
+            W1f[j][ks] = *reinterpret_cast<const bf16x8*>(w.w1 + (((size_t)nt * KSD + ks) * 64 + lane) * 8);
+            W3f[j][ks] = *reinterpret_cast<const bf16x8*>(w.w3 + (((size_t)nt * KSD + ks) * 64 + lane) * 8);
+        }
+#pragma unroll
+    for (int ks = 0; ks < KSH; ++ks) W2f[ks] = *reinterpret_cast<const bf16x8*>(w.w2 + (((size_t)wave * KSH + ks) * 64 + lane) * 8);
+    const int npanels = (p.M + R - 1) / R;
+    const int row = tid >> 4, c8 = (tid & 15) * 8;                  // this thread's 8 floats of a panel
+    auto fetch = [&](int panel, float (&f)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        if (panel < npanels && panel * R + row < p.M) ld8(p.x1 + (size_t)(panel * R + row) * D + c8, f);
+    };
+    auto body = [&](int panel, float (&cur)[8], float (&nxt)[8]) {
+        const int row0 = panel * R;
+        fetch(panel + (int)gridDim.x, nxt);                         // a whole panel ahead; nothing else is fetched in here
+        {   // LayerNorm-2 (16 lanes per row)
+            float gm[8], bt[8], f[8];
+            ld8(CB + c8, gm); ld8(CB + 128 + c8, bt);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = cur[e];
+            const float mean = redrow<16>(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
+            float v = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[e] -= mean; v += f[e] * f[e]; }
+            const float rstd = rsqrtf(redrow<16>(v) * (1.f / D) + 1e-5f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
+            *reinterpret_cast<bf16x8*>(U2 + row * LU + (((c8 >> 3) ^ swzp<D>(row)) << 3)) = cvt8(f);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j < cnt) {
+                const int nt = nt0 + j;
+                f32x4 h1[2], h3[2];
+                h1[0] = *reinterpret_cast<const f32x4*>(CB + 384 + nt * 16 + g * 4); h1[1] = h1[0];
+                h3[0] = *reinterpret_cast<const f32x4*>(CB + 768 + nt * 16 + g * 4); h3[1] = h3[0];
+#pragma unroll
+                for (int ks = 0; ks < KSD; ++ks)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(U2 + (mt * 16 + c16) * LU + (((ks * 4 + g) ^ fp) << 3));
+                        h1[mt] = mfma16(W1f[j][ks], a, h1[mt]);
+                        h3[mt] = mfma16(W3f[j][ks], a, h3[mt]);
+                    }
+                bf16_t* Gi = Gc + (nt >> 2) * R * LC;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    f32x4 gv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gv[r] = silu_nr(h1[mt][r]) * h3[mt][r];
+                    *reinterpret_cast<bf16x4*>(Gi + (mt * 16 + c16) * LC + (((2 * (nt & 3) + (g >> 1)) ^ fc) << 3) + (g & 1) * 4) = cvt4(gv);
+                }
+            }
+        }
+        lds_barrier();
+        f32x4 xr[2];
+        xr[0] = *reinterpret_cast<const f32x4*>(CB + 256 + wave * 16 + g * 4); xr[1] = xr[0];
+#pragma unroll
+        for (int ks = 0; ks < KSH; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Gc + (ks >> 1) * R * LC + (mt * 16 + c16) * LC + ((((ks & 1) * 4 + g) ^ fc) << 3));
+                xr[mt] = mfma16(W2f[ks], a, xr[mt]);
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f32x4*>(XS + (mt * 16 + c16) * LX + wave * 16 + g * 4) = xr[mt];
+        lds_barrier();
+        if (row0 + row < p.M) {
+            float f[8], t[8];
+            ld8(XS + row * LX + c8, f);
+            const float rs = p.rowscale ? p.rowscale[row0 + row] : 1.f;      // DropPath: x1 + scale * mlp(x1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], rs, cur[e]);
+            if (p.res2) {
+                ld8(p.res2 + (size_t)(row0 + row) * D + c8, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += t[e];
+            }
+            st8(p.x2 + (size_t)(row0 + row) * D + c8, f);
+        }
+    };
+    float xa[8], xb[8];
+    lds_barrier();                                                  // the staged constants
+    fetch(blockIdx.x, xa);
+    for (int panel = blockIdx.x; panel < npanels; panel += 2 * (int)gridDim.x) {
+        body(panel, xa, xb);
+        if (panel + (int)gridDim.x < npanels) body(panel + (int)gridDim.x, xb, xa);
+    }
 }
 
 struct EncMlpBwdArgs {
@@ -538,6 +676,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                         dg[mt] = mfma16(f2.b[ks][0], ad, dg[mt]);
                     }
             }
+#ifndef HS_ABL_WSTREAM
             if (c + 1 < NCH) {
                 if ((c + 1) * 4 + 3 < nt_h) {
                     f1.template load<false>(w.w1, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
@@ -550,6 +689,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                 }
                 if constexpr (BPF) bn.load(w.w1b, w.w3b, ((c + 1) * 4 + q.wave) * 16 + q.g * 4, w.h);
             }
+#endif
 #pragma unroll
             for (int mt = 0; mt < MT4; ++mt) {
                 f32x4 gv, d1, d3;
@@ -580,9 +720,14 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
         constexpr bool LATE = D >= 256;
         FrN<2, NJO> wa;
         FrN<1, NJO> wb0, wb1;
-        wa.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, 2 * c, D / 16, q.lane);
-        wb0.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * c, D / 16, q.lane);
-        if constexpr (!LATE) wb1.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * c + 1, D / 16, q.lane);
+#ifdef HS_ABL_WSTREAM
+        constexpr int cw = 0;
+#else
+        const int cw = c;
+#endif
+        wa.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, 2 * cw, D / 16, q.lane);
+        wb0.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * cw, D / 16, q.lane);
+        if constexpr (!LATE) wb1.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * cw + 1, D / 16, q.lane);
         // weight-gradient operands of this chunk to HBM (row-contiguous 16-B stores), columns < 352 only
         if (p.dh13) {
             const int ncol = (c * 64 + 64 <= HPE) ? 64 : HPE - c * 64;       // 64 or 32
@@ -616,7 +761,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
         for (int ks = 0; ks < 2; ++ks) {
             if (kHalfLast && c == NCH - 1 && ks == 1) continue;
             if constexpr (LATE) {
-                if (ks == 0 && !(kHalfLast && c == NCH - 1)) wb1.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * c + 1, D / 16, q.lane);
+                if (ks == 0 && !(kHalfLast && c == NCH - 1)) wb1.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * cw + 1, D / 16, q.lane);
             }
 #pragma unroll
             for (int mt = 0; mt < MT4; ++mt) {
@@ -742,6 +887,18 @@ static int fwd_grid(int M) {
 
 static int launch_fwd(const EncMlpFwdArgs& a, int M, int d, hipStream_t s) {
     if (d == 128) {
+        // (read per call: which forward kernel runs is not coupled to the backward, which recomputes from x1 — an A/B switch, not a schedule bit)
+        static int res_wgs = 0;
+        if (!res_wgs) {
+            const char* e = getenv("HSIMAE_MLP_FWD_RES_WGS"); res_wgs = (e && atoi(e) > 0) ? atoi(e) : 256;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_fwd_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS);
+        }
+        const char* e = getenv("HSIMAE_MLP_FWD_RES");
+        if (e ? (e[0] != '0') : HS_MLP_FWD_RES) {
+            const int panels = (M + RES_R - 1) / RES_R;
+            hipLaunchKernelGGL(enc_mlp_fwd_res_kernel, dim3(panels < res_wgs ? panels : res_wgs), dim3(RES_NT), RES_LDS, s, a);
+            return (int)hipGetLastError();
+        }
         set_attrs<128, 352>();
         hipLaunchKernelGGL((enc_mlp_fwd_kernel<128, 352>), dim3(fwd_grid<128, 352>(M)), dim3(NTH), (MG<128, 352>::LDS_FWD), s, a);
     } else if (d == 256) {
