@@ -51,9 +51,6 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases_enc(un
 #ifndef HS_MLP_WPCF_64
 #define HS_MLP_WPCF_64 3
 #endif
-#ifndef HS_MLP_FWD_RES
-#define HS_MLP_FWD_RES 0         /* D = 128 forward: 1 = the weights-resident persistent kernel (enc_mlp_fwd_res_kernel); HSIMAE_MLP_FWD_RES overrides */
-#endif
 #ifndef HS_SWZ256
 #define HS_SWZ256 0          /* 1: the swizzled unpadded layout at D = 256 too (experiment) */
 #endif
@@ -427,129 +424,14 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPCF)) void enc_mlp_fwd_kernel(En
     PH_FLUSH(8)
 }
 
-// ---- weights-resident persistent form of the forward kernel at D = 128 (round 5) ------------------------------------------------------
-// enc_mlp_fwd_kernel<128, 352> streams its 270 KB of weight fragments from L2 for every 48-row panel (622 MB per launch) and waits
-// for its rows at the top of every panel; with the weight fetches and the rows in the same in-order vmcnt queue a row prefetch
-// cannot get ahead (HS_MLP_FWD_PERSIST above).  Timing ablations (profiles/r05_p_mlp_fwd_ablations.txt): 54.8 us as shipped,
-// 45.6 without the weight stream, 45.4 without the row fetch, 36.5 without both, 32.6 without the stores as well.
-// Here ONE 8-wave workgroup per CU keeps all of W1 | W3 | W2 in registers for the whole launch — wave w owns hidden n-tiles
-// {3w, 3w+1, 3w+2} (waves 6, 7: two each: 22 tiles) of the gate products and output n-tile w of the W2 product: 96 + 44 registers —,
-// walks 32-row panels (one row piece per thread), and the only global loads inside the loop are the NEXT panel's rows, fetched a
-// whole panel ahead into 8 registers (ping-pong, no copies).  Same MFMA operand order and accumulation order as the panel kernel:
-// bit-identical x2.
-constexpr int RES_R = 32, RES_NT = 512, RES_LX = 128 + 4;
-constexpr int RES_LDS = RES_R * 128 * 2 + 6 * RES_R * 64 * 2 + RES_R * RES_LX * 4 + (3 * 128 + 2 * 384) * 4;
-__global__ __launch_bounds__(RES_NT, 2) void enc_mlp_fwd_res_kernel(EncMlpFwdArgs p) {
-    constexpr int D = 128, R = RES_R, LU = 128, LC = 64, LX = RES_LX, KSD = 4, KSH = 11, NTH1 = 22;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* U2 = reinterpret_cast<bf16_t*>(smem);                   // LayerNorm-2 output, [32][128] swizzled (pfrag)
-    bf16_t* Gc = U2 + R * LU;                                       // the gate: six 64-column chunk images [32][64] (cfrag)
-    float* XS = reinterpret_cast<float*>(Gc + 6 * R * LC);          // fp32 result tile [32][LX]
-    float* CB = XS + R * LX;                                        // gamma | beta | b2 | b1 (384) | b3 (384)
-    const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fp = swzp<D>(c16), fc = swzc<D>(c16);
-    const EncMlpW& w = p.w;
-    for (int i = tid; i < 128; i += RES_NT) { CB[i] = w.n2w[i]; CB[128 + i] = w.n2b[i]; CB[256 + i] = w.w2b[i]; }
-    for (int i = tid; i < 384; i += RES_NT) { CB[384 + i] = i < w.h ? w.w1b[i] : 0.f; CB[768 + i] = i < w.h ? w.w3b[i] : 0.f; }
-    const int nt0 = wave < 6 ? wave * 3 : 18 + (wave - 6) * 2;
-    const int cnt = wave < 6 ? 3 : 2;
-    bf16x8 W1f[3][KSD], W3f[3][KSD], W2f[KSH];
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int ks = 0; ks < KSD; ++ks) {
-            const int nt = j < cnt ? nt0 + j : nt0;                 // (waves 6, 7: slot 2 is never used)
-            W1f[j][ks] = *reinterpret_cast<const bf16x8*>(w.w1 + (((size_t)nt * KSD + ks) * 64 + lane) * 8);
-            W3f[j][ks] = *reinterpret_cast<const bf16x8*>(w.w3 + (((size_t)nt * KSD + ks) * 64 + lane) * 8);
-        }
-#pragma unroll
-    for (int ks = 0; ks < KSH; ++ks) W2f[ks] = *reinterpret_cast<const bf16x8*>(w.w2 + (((size_t)wave * KSH + ks) * 64 + lane) * 8);
-    const int npanels = (p.M + R - 1) / R;
-    const int row = tid >> 4, c8 = (tid & 15) * 8;                  // this thread's 8 floats of a panel
-    auto fetch = [&](int panel, float (&f)[8]) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = 0.f;
-        if (panel < npanels && panel * R + row < p.M) ld8(p.x1 + (size_t)(panel * R + row) * D + c8, f);
-    };
-    auto body = [&](int panel, float (&cur)[8], float (&nxt)[8]) {
-        const int row0 = panel * R;
-        fetch(panel + (int)gridDim.x, nxt);                         // a whole panel ahead; nothing else is fetched in here
-        {   // LayerNorm-2 (16 lanes per row)
-            float gm[8], bt[8], f[8];
-            ld8(CB + c8, gm); ld8(CB + 128 + c8, bt);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = cur[e];
-            const float mean = redrow<16>(f[0] + f[1] + f[2] + f[3] + f[4] + f[5] + f[6] + f[7]) * (1.f / D);
-            float v = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { f[e] -= mean; v += f[e] * f[e]; }
-            const float rstd = rsqrtf(redrow<16>(v) * (1.f / D) + 1e-5f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
-            *reinterpret_cast<bf16x8*>(U2 + row * LU + (((c8 >> 3) ^ swzp<D>(row)) << 3)) = cvt8(f);
-        }
-        lds_barrier();
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (j < cnt) {
-                const int nt = nt0 + j;
-                f32x4 h1[2], h3[2];
-                h1[0] = *reinterpret_cast<const f32x4*>(CB + 384 + nt * 16 + g * 4); h1[1] = h1[0];
-                h3[0] = *reinterpret_cast<const f32x4*>(CB + 768 + nt * 16 + g * 4); h3[1] = h3[0];
-#pragma unroll
-                for (int ks = 0; ks < KSD; ++ks)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(U2 + (mt * 16 + c16) * LU + (((ks * 4 + g) ^ fp) << 3));
-                        h1[mt] = mfma16(W1f[j][ks], a, h1[mt]);
-                        h3[mt] = mfma16(W3f[j][ks], a, h3[mt]);
-                    }
-                bf16_t* Gi = Gc + (nt >> 2) * R * LC;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    f32x4 gv;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) gv[r] = silu_nr(h1[mt][r]) * h3[mt][r];
-                    *reinterpret_cast<bf16x4*>(Gi + (mt * 16 + c16) * LC + (((2 * (nt & 3) + (g >> 1)) ^ fc) << 3) + (g & 1) * 4) = cvt4(gv);
-                }
-            }
-        }
-        lds_barrier();
-        f32x4 xr[2];
-        xr[0] = *reinterpret_cast<const f32x4*>(CB + 256 + wave * 16 + g * 4); xr[1] = xr[0];
-#pragma unroll
-        for (int ks = 0; ks < KSH; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(Gc + (ks >> 1) * R * LC + (mt * 16 + c16) * LC + ((((ks & 1) * 4 + g) ^ fc) << 3));
-                xr[mt] = mfma16(W2f[ks], a, xr[mt]);
-            }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f32x4*>(XS + (mt * 16 + c16) * LX + wave * 16 + g * 4) = xr[mt];
-        lds_barrier();
-        if (row0 + row < p.M) {
-            float f[8], t[8];
-            ld8(XS + row * LX + c8, f);
-            const float rs = p.rowscale ? p.rowscale[row0 + row] : 1.f;      // DropPath: x1 + scale * mlp(x1)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], rs, cur[e]);
-            if (p.res2) {
-                ld8(p.res2 + (size_t)(row0 + row) * D + c8, t);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] += t[e];
-            }
-            st8(p.x2 + (size_t)(row0 + row) * D + c8, f);
-        }
-    };
-    float xa[8], xb[8];
-    lds_barrier();                                                  // the staged constants
-    fetch(blockIdx.x, xa);
-    for (int panel = blockIdx.x; panel < npanels; panel += 2 * (int)gridDim.x) {
-        body(panel, xa, xb);
-        if (panel + (int)gridDim.x < npanels) body(panel + (int)gridDim.x, xb, xa);
-    }
-}
+// (Round 5 built a weights-resident persistent form of the D = 128 forward kernel — ONE 8-wave workgroup per CU holding all of
+//  W1 | W3 | W2 in registers (96 + 44 per lane, 236 VGPRs, no scratch), 32-row panels, the next panel's rows fetched a whole panel
+//  ahead as the only global loads of the loop; bit-identical x2.  Timing ablations had put the panel kernel at 54.8 us as shipped,
+//  45.6 without its L2 weight stream, 45.4 without the row fetch, 36.5 without both (profiles/r05_p_mlp_fwd_ablations.txt).  The
+//  resident kernel measured 53.0 us against 54.5, and the two-stream step 15.82-16.04 against 15.85-15.88 ms
+//  (profiles/r05_q_mlp_fwd_resident_ab.txt): with every wave of the CU in the same phase the gate products re-read the panel from
+//  LDS once per n-tile (400 KB of LDS reads per 32-row panel) and nothing overlaps the barriers.  Rejected; the code is in the git
+//  history at 1e9414a.)
 
 struct EncMlpBwdArgs {
     const float* x1; const float* dy; float* dx1; bf16_t* u2; bf16_t* dh13; bf16_t* g; int M; EncMlpW w;
@@ -887,18 +769,6 @@ static int fwd_grid(int M) {
 
 static int launch_fwd(const EncMlpFwdArgs& a, int M, int d, hipStream_t s) {
     if (d == 128) {
-        // (read per call: which forward kernel runs is not coupled to the backward, which recomputes from x1 — an A/B switch, not a schedule bit)
-        static int res_wgs = 0;
-        if (!res_wgs) {
-            const char* e = getenv("HSIMAE_MLP_FWD_RES_WGS"); res_wgs = (e && atoi(e) > 0) ? atoi(e) : 256;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_fwd_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS);
-        }
-        const char* e = getenv("HSIMAE_MLP_FWD_RES");
-        if (e ? (e[0] != '0') : HS_MLP_FWD_RES) {
-            const int panels = (M + RES_R - 1) / RES_R;
-            hipLaunchKernelGGL(enc_mlp_fwd_res_kernel, dim3(panels < res_wgs ? panels : res_wgs), dim3(RES_NT), RES_LDS, s, a);
-            return (int)hipGetLastError();
-        }
         set_attrs<128, 352>();
         hipLaunchKernelGGL((enc_mlp_fwd_kernel<128, 352>), dim3(fwd_grid<128, 352>(M)), dim3(NTH), (MG<128, 352>::LDS_FWD), s, a);
     } else if (d == 256) {

@@ -277,28 +277,12 @@ def test_fused_encoder_mlp_half_forward_backward(M, drop):
     r3 = (dgate * h1.detach() * s).t() @ u.detach()
     assert rel_err(dW1, r1) < 2e-2 and rel_err(dW3, r3) < 2e-2
     assert float(dh13[:, h:hp].float().abs().max()) == 0
-    # The weights-resident persistent forward kernel (HSIMAE_MLP_FWD_RES=1: one 8-wave workgroup per CU, 32-row panels, next panel's
-    # rows fetched a panel ahead) forms the same products in the same order as the panel kernel: bit-identical x2, with a
-    # second residual operand as well
-    import os
+    # second residual operand (the last spectral block adds the other axis stack's output)
     res2 = torch.randn(M, d, device=DEV)
-    outs = {}
-    old = os.environ.get("HSIMAE_MLP_FWD_RES")
-    try:
-        for flag in ("0", "1"):
-            os.environ["HSIMAE_MLP_FWD_RES"] = flag
-            a, b = torch.full((M, d), 7.0, device=DEV), torch.full((M, d), 7.0, device=DEV)
-            _lib.check(lib.hsimae_enc_mlp_fwd(x1.data_ptr(), None, a.data_ptr(), M, d, C.byref(w), _lib.ptr(rs_m), stream()))
-            _lib.check(lib.hsimae_enc_mlp_fwd(x1.data_ptr(), res2.data_ptr(), b.data_ptr(), M, d, C.byref(w), _lib.ptr(rs_m), stream()))
-            torch.cuda.synchronize()
-            outs[flag] = (a, b)
-    finally:
-        if old is None:
-            os.environ.pop("HSIMAE_MLP_FWD_RES", None)
-        else:
-            os.environ["HSIMAE_MLP_FWD_RES"] = old
-    assert torch.equal(outs["0"][0], x2) and torch.equal(outs["1"][0], x2)
-    assert torch.equal(outs["0"][1], outs["1"][1]) and rel_err(outs["1"][1], y.detach() + res2) < 6e-3
+    x2r = torch.full((M, d), 7.0, device=DEV)
+    _lib.check(lib.hsimae_enc_mlp_fwd(x1.data_ptr(), res2.data_ptr(), x2r.data_ptr(), M, d, C.byref(w), _lib.ptr(rs_m), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(x2r, x2 + res2) or rel_err(x2r, y.detach() + res2) < 6e-3
     # LayerNorm-2 parameter gradients (accumulated with atomics)
     xh = (x1 - x1.mean(1, keepdim=True)) / torch.sqrt(x1.var(1, unbiased=False, keepdim=True) + 1e-5)
     dgate_u = (dgate * h3.detach() * s * (1 + h1.detach() * (1 - s))) @ bf(W1) + (dgate * h1.detach() * s) @ bf(W3)
