@@ -989,6 +989,11 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
     // spill count (8 B/lane): 214.2 us without, 220.3 us WITH (step 15.51 / 15.61 vs 15.55 / 15.64 ms,
     // profiles/r05_d_prefetch_stagger_ab.txt): 32 more live registers through the epilogue cost more than the round trip
     // they hide — the hardware's own answer (the other wave of the SIMD runs while this one waits) is not worse.
+    // Second attempt, same round: the next sample's rows by LDS-DMA (`buffer_load ... lds`: no registers at all) — x1 a whole sample
+    // ahead into the 28 KB the arena has left, dY into U2 | DYb once the chunk loop is done — 214.6 -> 251.0 us
+    // (profiles/r05_r_dec_mlp_dma_ab.txt).  gfx950 counts every load in ONE in-order counter: a DMA in flight is caught by the
+    // next wait for ANY younger load (the W2^T fragments of the chunk loop, the epilogue's L2-hot re-reads), and hipcc puts a
+    // full vmcnt(0) in front of the first LDS read that follows an LDS-DMA (it may alias).  Not kept.
     float fa[NPW][8], dya[NPW][8];                    // the sample's loads all in flight at once
     auto fetch_sample = [&](int smp) {
         const bool valid = smp < p.nsamples;
