@@ -310,6 +310,10 @@ __global__ __launch_bounds__(WT<BIG>::NTHR) void wgrad_dma_kernel(WgradParams p)
 
     // Out-of-range rows (last chunk) come back as zeros from the buffer bounds check.  Columns past N / K of a slab
     // are whatever follows in the row: they only reach dW rows / columns that are never committed.
+    // (Round 5 masked those lanes off instead of fetching them — a quarter of the last tile of dh1 / dh3 / g at hidden width 344,
+    //  192 B of the 6.6 KB a row costs this launch: 126.4 -> 127.5 us at D = 128, 195.4 -> 203.1 us with the 256-tiles
+    //  (profiles/r05_s_wgrad_edge_skip_ab.txt): the exec-mask bookkeeping around four DMA instructions per chunk costs more than the
+    //  3 % of bytes it saves.  Not kept.)
     const uint32_t bytes_d = (uint32_t)min((int64_t)(t.dO_plane_rows ? t.dO_plane_rows : p.M) * t.ldo * 2, (int64_t)0xffffffffu);
     const uint32_t bytes_a = (uint32_t)min((int64_t)(t.A_plane_rows ? t.A_plane_rows : p.M) * t.lda * 2, (int64_t)0xffffffffu);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(t.dO), 0, bytes_d, 0x00020000);
