@@ -13,6 +13,9 @@
 // recomputes the scores in both orientations instead of transposing dS through LDS.
 #include "common.h"
 #include "kernels.h"
+#ifndef HS_BLK_PRIO
+#define HS_BLK_PRIO 0      /* s_setprio level of waves 4-7 in blk128_fwd / blk128_bwd (round 6) */
+#endif
 
 // column offset of k inside a q|k|v row (v: twice that): the storage width when rows are stored wider than d
 #define KVO(p) ((p).kv_off ? (p).kv_off : (p).d)
@@ -1021,6 +1024,7 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
     auto trof = [&](int row0) -> int {                               // transposed read: rows row0 + 4 g + q4, this head's columns 4 p4 ..
         return HS_BF_SWZ ? (row0 + 4 * g + q4) * 128 + (((2 * head + (p4 >> 1)) ^ ft) << 3) + (p4 & 1) * 4 : (row0 + 4 * g + q4) * FS + hc + 4 * p4; };
 
+    if (HS_BLK_PRIO > 0 && head >= 4) __builtin_amdgcn_s_setprio(HS_BLK_PRIO);      // static priority for the younger half (round 6, see fused_dec.hip HS_DEC_PRIO)
     // this wave's weights: n-tiles head (q), 8 + head (k), 16 + head (v) of the packed [384][128] image, n-tile head of Wp
     bf16x8 wq[3][4], wpj[4];
 #pragma unroll
@@ -1341,6 +1345,7 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
     auto fresh = [](int v) { asm volatile("" : "+v"(v)); return v; };
     auto wide = [&](int irow, int pc) -> int { return irow * BIR + ((pc ^ bsw(irow)) << 3); };     // 16-byte piece pc of row irow
 
+    if (HS_BLK_PRIO > 0 && head >= 4) __builtin_amdgcn_s_setprio(HS_BLK_PRIO);
     // this wave's weights: n-tile `head` of Wp^T (dO columns of its head) and of Wqkv^T (its 16 du columns)
     bf16x8 wo[4], wu[12];
 #pragma unroll

@@ -76,6 +76,20 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases(unsign
 #ifndef HS_TOUCH_A
 #define HS_TOUCH_A 0
 #endif
+// Round 6: de-phasing the two waves of a SIMD inside the persistent 8-wave backward kernels.
+//   HS_DEC_PRIO      s_setprio level of waves 4-7 (the second-dispatched half: MI355X_MICROARCH.md "Two waves per SIMD" item 4),
+//                    set once before the sample loop; 0 = off
+//   HS_DEC_CORE_NQ   query tiles a wave of dec_bwd_attn's attention core keeps in hand (1 = rounds 2-5; 2 = two independent
+//                    score -> softmax -> dS -> transposition chains per wave, the K / V row fragments read once for both)
+#ifndef HS_DEC_PRIO
+#define HS_DEC_PRIO 0
+#endif
+#ifndef HS_DEC_CORE_NQ
+#define HS_DEC_CORE_NQ 1
+#endif
+#ifndef HS_DEC_CORE_STG
+#define HS_DEC_CORE_STG 0   /* waves 4-7 enter the attention core this many x 64 clocks late (half a tile period = 4) */
+#endif
 
 namespace {
 
@@ -109,7 +123,7 @@ struct DL {
     static constexpr int IMGB = R * 64 * 2;
     // attention backward: 6 images, logsumexp + delta [8][R] fp32, 8 per-wave transposition tile pairs, Wq|Wk|Wv|Wp at pitch
     // D + 16, bq|bk|bv + LayerNorm-1 gamma / beta
-    static constexpr int BWD_ATTN_LDS = 6 * IMGB + 2 * 8 * R * 4 + 8 * 2 * 16 * 16 * 2 + 4 * D * (D + 16) * 2 + 5 * D * 4;
+    static constexpr int BWD_ATTN_LDS = 6 * IMGB + 2 * 8 * R * 4 + 8 * HS_DEC_CORE_NQ * 2 * 16 * 16 * 2 + 4 * D * (D + 16) * 2 + 5 * D * 4;
     // the fp32 staging tile of du goes over Ob | DXb and the first bytes of the logsumexp table (all dead by then)
     static_assert(2 * IMGB + 8 * R * 4 >= R * LX * 4, "fp32 staging tile must fit over Ob|DXb|lse");
     // the unguarded m-tile products (CHK = false) read one m-tile (16 rows) past an image: every image of the
@@ -117,7 +131,8 @@ struct DL {
     static_assert(BWD_ATTN_LDS - 6 * IMGB >= 16 * 64 * 2, "image overrun of the unguarded products must stay inside the allocation");
 };
 constexpr int TTS = 16;                    // transposition tile row stride (elements): 32-B rows, rotation-swizzled 8-B chunks
-constexpr int TT_WAVE = 2 * 16 * TTS;      // per wave: [P | dS][16 queries][TTS]
+constexpr int TT_PAIR = 2 * 16 * TTS;      // one tile pair: [P | dS][16 queries][TTS]
+constexpr int TT_WAVE = HS_DEC_CORE_NQ * TT_PAIR;      // per wave: one pair per query tile in hand
 
 struct Geo4 { int lane, c16, g, wave, wm, wn; };
 
@@ -961,6 +976,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
         const int n = (int)((blockIdx.x >> 3) % (HS_DEC_STG_N > 1 ? HS_DEC_STG_N : 1)) * HS_DEC_STG_MLP;
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
     }
+    if (HS_DEC_PRIO > 0 && q.wave >= 4) __builtin_amdgcn_s_setprio(HS_DEC_PRIO);      // static priority for the younger half (round 6)
     f32x4 accW[3][3][2];                 // [hidden chunk][this wave's n-tile][this wave's k-tile]
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -1308,26 +1324,34 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
         dkT[kt] = z4; dvT[kt] = z4;
         KT[kt] = tr4(Kb + kt * 16 * IR + troff);
     }
-#pragma unroll 1
-    for (int qt = 0; qt < MT; ++qt) {
-        const int query = qt * 16 + q.c16;
-        bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qb + qt * 16 * IR + rcol);
-        bf16x4 bdo = *reinterpret_cast<const bf16x4*>(dOb + qt * 16 * IR + rcol2);
-        if (q.g >= 2) { bq = zero4(); bdo = zero4(); }
-        const float lqn = -lse_h[query], dl = dlt_h[query];
-        // (Round 5 tried to take dP - delta out of the VALU — this loop's longest unit — by starting the dP product's accumulator at
-        //  -delta, a per-lane splat: 320.2 us against 315.5 with the 4 v_sub per tile, profiles/r05_e_planar_delta_ab.txt.  A zero
-        //  accumulator is an inline constant of the MFMA; a splat has to be copied into four accumulator registers per tile.)
-        const bf16x4 QT = tr4(Qb + qt * 16 * IR + troff);
-        const bf16x4 dOT = tr4(dOb + qt * 16 * IR + troff);
-        f32x4 dqT = z4;
+    // NQ query tiles in hand (round 6): with one, a wave's (score MFMA -> exp -> dS -> convert -> LDS transposition -> dk / dv MFMA)
+    // chain is serial per tile — 539 cycles per tile against ~180 of issue with two waves per SIMD —; with two, the chains of the two
+    // tiles are independent, the K / V row fragments of a key tile are read once for both, and each has its own transposition tile pair.
+    auto qtiles = [&](auto nq_tag, int qt0) {
+        constexpr int NQ = decltype(nq_tag)::value;
+        bf16x4 bq[NQ], bdo[NQ], QT[NQ], dOT[NQ], Bp[NQ], Bds[NQ];
+        float lqn[NQ], dl[NQ];
+        f32x4 dqT[NQ];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            const int qt = qt0 + n, query = qt * 16 + q.c16;
+            bq[n] = *reinterpret_cast<const bf16x4*>(Qb + qt * 16 * IR + rcol);
+            bdo[n] = *reinterpret_cast<const bf16x4*>(dOb + qt * 16 * IR + rcol2);
+            if (q.g >= 2) { bq[n] = zero4(); bdo[n] = zero4(); }
+            lqn[n] = -lse_h[query]; dl[n] = dlt_h[query];
+            // (Round 5 tried to take dP - delta out of the VALU — this loop's longest unit — by starting the dP product's accumulator at
+            //  -delta, a per-lane splat: 320.2 us against 315.5 with the 4 v_sub per tile, profiles/r05_e_planar_delta_ab.txt.  A zero
+            //  accumulator is an inline constant of the MFMA; a splat has to be copied into four accumulator registers per tile.)
+            QT[n] = tr4(Qb + qt * 16 * IR + troff);
+            dOT[n] = tr4(dOb + qt * 16 * IR + troff);
+            dqT[n] = z4; Bp[n] = zero4(); Bds[n] = zero4();
+        }
         // Software pipeline over the key tiles: the transposed operands of tile kt-1 (LDS write -> transpose read, ~200
         // cycles of latency) are consumed after the score MFMAs of tile kt have been issued, and those MFMAs' own
         // latency is covered by the dk/dv MFMAs of tile kt-1.
         // (Round 5 measured two deeper orders — the dk/dv products pinned behind this tile's softmax arithmetic, and the score / dP
         //  products issued one tile ahead: 325.2 -> 325.3 / 321.5 / 322.1 us, profiles/r05_n_core_order_ab.txt.  The loop is not
         //  waiting for the transposition round trip.)
-        bf16x4 Bp = zero4(), Bds = zero4();
         // K / V row fragments one tile ahead as well: their LDS latency is off the per-tile dependency chain
         bf16x4 Kn = *reinterpret_cast<const bf16x4*>(Kb + rcol);
         bf16x4 Vn = *reinterpret_cast<const bf16x4*>(Vb + rcol2);
@@ -1338,47 +1362,73 @@ __device__ __forceinline__ void attn_head_bwd(bf16_t* Qb, bf16_t* Kb, bf16_t* Vb
                 Kn = *reinterpret_cast<const bf16x4*>(Kb + (kt + 1) * 16 * IR + rcol);
                 Vn = *reinterpret_cast<const bf16x4*>(Vb + (kt + 1) * 16 * IR + rcol2);
             }
-            const f32x4 s = mfma16k16(Kf, bq, z4);
-            const f32x4 dp = mfma16k16(Vf, bdo, z4);
-            f32x4 pv, ds;
+            f32x4 s[NQ], dp[NQ], pv[NQ], ds[NQ];
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                s[n] = mfma16k16(Kf, bq[n], z4);
+                dp[n] = mfma16k16(Vf, bdo[n], z4);
+            }
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
 #pragma unroll
 #ifdef HS_EXPERIMENT_NOEXP      /* timing experiment only (scripts/phase_timing.py): what the exps cost */
-            for (int r = 0; r < 4; ++r) pv[r] = fmaf(s[r], sc, lqn);
+                for (int r = 0; r < 4; ++r) pv[n][r] = fmaf(s[n][r], sc, lqn[n]);
 #else
-            for (int r = 0; r < 4; ++r) {
-                const float e = fmaf(s[r], sc, lqn);
-                pv[r] = __builtin_amdgcn_exp2f((kt >= KCL && clamp_from <= kt) ? fminf(e, 0.f) : e);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const float e = fmaf(s[n][r], sc, lqn[n]);
+                    pv[n][r] = __builtin_amdgcn_exp2f((kt >= KCL && clamp_from <= kt) ? fminf(e, 0.f) : e);
+                }
 #endif
-            // No key mask in here (rounds 1-2 masked the last tile only — wrong for 65..96-token sequences, found in round 3 by the
-            // 64-band case of test_fused_decoder_matches_layerwise_decoder — and the general per-tile form compiled to 8 selects
-            // per tile on ALL tiles, a quarter of this loop's VALU work): the caller zeroes the K and V image rows past Ts, so a
-            // padded key has s = 0, dP = 0 and a finite (clamped, see KCL) garbage P / dS that meets K = 0 in dq and is dropped
-            // from dk / dv below.
+                // No key mask in here (rounds 1-2 masked the last tile only — wrong for 65..96-token sequences, found in round 3 by the
+                // 64-band case of test_fused_decoder_matches_layerwise_decoder — and the general per-tile form compiled to 8 selects
+                // per tile on ALL tiles, a quarter of this loop's VALU work): the caller zeroes the K and V image rows past Ts, so a
+                // padded key has s = 0, dP = 0 and a finite (clamped, see KCL) garbage P / dS that meets K = 0 in dq and is dropped
+                // from dk / dv below.
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ds[r] = pv[r] * (dp[r] - dl);
-            if (kt > 0) {                       // previous tile's transposed operands, a VALU phase after their reads were issued
-                dkT[kt - 1] = mfma16k16(QT, Bds, dkT[kt - 1]);
-                dvT[kt - 1] = mfma16k16(dOT, Bp, dvT[kt - 1]);
+                for (int r = 0; r < 4; ++r) ds[n][r] = pv[n][r] * (dp[n][r] - dl[n]);
             }
-            const bf16x4 pb = cvt4(pv), dsb = cvt4(ds);
-            dqT = mfma16k16(KT[kt], dsb, dqT);
-            bf16_t* tp = T;                     // one tile pair per wave: LDS executes a wave's accesses in order
-            bf16_t* td = tp + 16 * TTS;
-            st4(tp + tw, pb);
-            st4(td + tw, dsb);
-            asm volatile("" ::: "memory");
-            Bp = tr4(tp + trd);
-            Bds = tr4(td + trd);
-        }
-        dkT[MT - 1] = mfma16k16(QT, Bds, dkT[MT - 1]);
-        dvT[MT - 1] = mfma16k16(dOT, Bp, dvT[MT - 1]);
-        if (q.g < 2) {
-            bf16x4 v;
+            if (kt > 0) {                       // previous tile's transposed operands, a VALU phase after their reads were issued
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dqT[r] * scale);
-            st4(Qb + qt * 16 * IR + wcol, v);
+                for (int n = 0; n < NQ; ++n) {
+                    dkT[kt - 1] = mfma16k16(QT[n], Bds[n], dkT[kt - 1]);
+                    dvT[kt - 1] = mfma16k16(dOT[n], Bp[n], dvT[kt - 1]);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                const bf16x4 pb = cvt4(pv[n]), dsb = cvt4(ds[n]);
+                dqT[n] = mfma16k16(KT[kt], dsb, dqT[n]);
+                bf16_t* tp = T + n * TT_PAIR;       // one tile pair per wave and query tile in hand: LDS executes a wave's accesses in order
+                bf16_t* td = tp + 16 * TTS;
+                st4(tp + tw, pb);
+                st4(td + tw, dsb);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                Bp[n] = tr4(T + n * TT_PAIR + trd);
+                Bds[n] = tr4(T + n * TT_PAIR + 16 * TTS + trd);
+            }
         }
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            dkT[MT - 1] = mfma16k16(QT[n], Bds[n], dkT[MT - 1]);
+            dvT[MT - 1] = mfma16k16(dOT[n], Bp[n], dvT[MT - 1]);
+            if (q.g < 2) {
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dqT[n][r] * scale);
+                st4(Qb + (qt0 + n) * 16 * IR + wcol, v);
+            }
+        }
+    };
+    if constexpr (HS_DEC_CORE_NQ == 2) {
+#pragma unroll 1
+        for (int qt = 0; qt + 1 < MT; qt += 2) qtiles(std::integral_constant<int, 2>{}, qt);
+        if constexpr (MT & 1) qtiles(std::integral_constant<int, 1>{}, MT - 1);
+    } else {
+#pragma unroll 1
+        for (int qt = 0; qt < MT; ++qt) qtiles(std::integral_constant<int, 1>{}, qt);
     }
     if (q.g < 2) {
 #pragma unroll
@@ -1444,6 +1494,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         const int n = (int)((blockIdx.x >> 3) % (HS_DEC_STG_N > 1 ? HS_DEC_STG_N : 1)) * HS_DEC_STG_ATTN;
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
     }
+    if (HS_DEC_PRIO > 0 && q.wave >= 4) __builtin_amdgcn_s_setprio(HS_DEC_PRIO);      // static priority for the younger half (round 6)
     f32x4 accP[2], accQ[3][2];         // dWp: n-tile = wave>>1; dWq|dWk|dWv: 12 n-tiles x 4 k-tiles, 3 x 2 per wave
 #pragma unroll
     for (int a = 0; a < 2; ++a) accP[a] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1633,7 +1684,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             }
         }
         // attention backward, one head per wave, dq/dk/dv written in place over q/k/v
-        // (a half-tile start stagger of waves 4-7, MI355X_MICROARCH.md "two waves per SIMD" item 9, measured neutral here)
+        // (a half-tile start stagger of waves 4-7, MI355X_MICROARCH.md "two waves per SIMD" item 9, measured neutral in round 1;
+        //  HS_DEC_CORE_STG = the same as a knob, in units of 64 clocks, re-measured in round 6: profiles/EXPERIMENTS.md)
+        if (HS_DEC_CORE_STG > 0 && q.wave >= 4) __builtin_amdgcn_s_sleep(HS_DEC_CORE_STG);
         attn_head_bwd<MT>(Qb, Kb, Vb, Ob, lse + q.wave * R, dlt + q.wave * R, TT + q.wave * TT_WAVE, q.wave, p.Ts, q);
         lds_barrier();
         PH(5)
