@@ -289,10 +289,27 @@ class _Watchdog:
             if self.done:
                 return
             self.done = True
-            self.line["watchdog"] = (f"the legs after the timed region did not finish within {seconds:g} s: line printed without them "
-                                     f"(have: {sorted(k for k in self.line if k.startswith(('comm', 'dp_', 'roofline_', 'cpu_')))})")
-            self._emit()
-        os._exit(0)
+            # the main thread may still be filling the dict (a slow leg, not a hung one): snapshot it, and fall back to the contract
+            # fields if even that keeps failing — a line must come out
+            snap = None
+            for _ in range(5):
+                try:
+                    snap = dict(self.line)
+                    snap["watchdog"] = (f"the legs after the timed region did not finish within {seconds:g} s: line printed without them "
+                                        f"(have: {sorted(k for k in snap if k.startswith(('comm', 'dp_', 'roofline_', 'cpu_')))})")
+                    text = json.dumps(snap)
+                    break
+                except RuntimeError:
+                    snap = None
+            if snap is None:
+                keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                        "dtype", "data")
+                text = json.dumps({**{k: self.line.get(k) for k in keys}, "watchdog": f"legs after the timed region hung ({seconds:g} s); partial line"})
+            C.CDLL(None).fflush(None)
+            print(text, flush=True)
+        # a process that has used the GPU and gives up exits NON-ZERO (the line above is incomplete, other ranks may still be
+        # blocked in a collective); never re-exec
+        os._exit(3)
 
     def finish(self):
         with self.lock:
@@ -791,7 +808,7 @@ def main():
         # step (no 8-GPU node has run this path yet).  One more step in deterministic mode (bit-reproducible local gradients):
         #   (1) with the reducer: bucketed all-reduces launched from inside the backward on the reducer's stream;
         #   (2) the SAME step (RNG streams restored) with the reducer detached, then ONE plain all-reduce of the whole flat
-        #       buffer after a device synchronise, / world;
+        #       buffer after a device synchronise (the step keeps folding 1 / world into dLoss, so SUM is the mean on both legs);
         # (1) must equal (2) up to the summation order inside the collective, on every rank, and every rank must hold
         # bit-identical reduced gradients, the same grid sequence and the same list of collectives (hsimae_amd/parallel.py).
         from hsimae_amd.parallel import verify_step
@@ -803,13 +820,16 @@ def main():
         g_b, launched_v, grid_v = model._flat_grad.clone(), list(red.launched), (model.len_t, model.len_l)
         random.setstate(rng[0]); torch.set_rng_state(rng[1]); torch.cuda.set_rng_state(rng[2], dev)
         model._reducer = None
+        # detached, but with the SAME 1 / world folded into the bf16 dL/dpred: for a world that is not a power of two a division
+        # after the all-reduce would move every bf16 rounding of the backward (1e-3 relative against rtol 2e-6: ADVICE r05)
+        model._world_override = world
         step(); torch.cuda.synchronize()
         g_ref = model._flat_grad.clone()
+        model._world_override = None
         model._reducer = red
         model.deterministic = prev_det
         if world > 1:
-            dist.all_reduce(g_ref)
-        g_ref /= world                                # (detached, the step does not fold 1 / world into dLoss)
+            dist.all_reduce(g_ref)                    # SUM of pre-scaled gradients = the mean, as the bucketed path computes it
         verify = verify_step(g_b, g_ref, grids + [grid_v], launched_v, lv)
         del g_b, g_ref
 

@@ -114,11 +114,18 @@ class CubeParams(C.Structure):
                 ("out", vp), ("sn", i64), ("sb", i64), ("sh", i64), ("sw", i64)]
 
 
+class BuildInfo(C.Structure):
+    _fields_ = [("abi_version", i32), ("variant_bits", C.c_uint32), ("kernel_source_hash", C.c_uint64), ("flags_hash", C.c_uint64),
+                ("default_flags", i32), ("reserved", i32)]
+
+
 BUCKET_CB = C.CFUNCTYPE(None, i32, i64, i64, vp)
 
 # name -> (restype, argtypes); also the list the CPU test checks against include/hsimae_hip.h
 SYMBOLS = {
     "hsimae_version": (C.c_int, []),
+    "hsimae_build_info": (C.c_int, [C.POINTER(BuildInfo)]),
+    "hsimae_variant_name": (C.c_char_p, [C.c_int]),
     "hsimae_strerror": (C.c_char_p, [C.c_int]),
     "hsimae_two_streams_active": (C.c_int, []),
     "hsimae_effective_precision": (C.c_int, [C.POINTER(Config)]),
@@ -161,7 +168,7 @@ SYMBOLS = {
     "hsimae_decode_backward": (C.c_int, [C.POINTER(Config), C.POINTER(IO), vp, vp, vp, BUCKET_CB, vp, vp]),
 }
 
-ABI_VERSION = 104       # HSIMAE_VERSION of include/hsimae_hip.h these ctypes structs mirror (a CPU test compares the two)
+ABI_VERSION = 105       # HSIMAE_VERSION of include/hsimae_hip.h these ctypes structs mirror (a CPU test compares the two)
 PREC_BF16, PREC_FP8 = 0, 1
 A_BF16, A_F32, A_F32_LN = 0, 1, 2
 E_BF16, E_F32, E_RES_F32, E_POS_F32, E_SWIGLU, E_SWIGLU_BWD, E_LN_BWD = 0, 1, 2, 3, 4, 5, 6
@@ -185,8 +192,34 @@ def load() -> C.CDLL:
         if got != ABI_VERSION:          # a stale .so next to newer bindings: struct layouts would silently disagree
             raise RuntimeError(f"{LIB_PATH} answers ABI version {got}, these bindings were written for {ABI_VERSION}: "
                                "rebuild it with `python -m hsimae_amd.build --force`")
+        info = _query_build_info(lib)
+        if info["variant"] and os.environ.get("HSIMAE_ALLOW_VARIANT") != "1":
+            # a timing-ablation / instrumented build computes wrong results on purpose: it must never pass for the product
+            raise RuntimeError(f"{LIB_PATH} is a variant build ({', '.join(info['variant'])}): its kernels are instrumented or compute "
+                               "wrong results on purpose (timing ablations).  Set HSIMAE_ALLOW_VARIANT=1 to load it for an experiment.")
         _lib = lib
     return _lib
+
+
+def _query_build_info(lib) -> dict:
+    bi = BuildInfo()
+    rc = lib.hsimae_build_info(C.byref(bi))
+    if rc != 0:
+        raise RuntimeError(f"hsimae_build_info failed with code {rc}")
+    names = []
+    for b in range(32):
+        if bi.variant_bits >> b & 1:
+            n = lib.hsimae_variant_name(b)
+            names.append(n.decode() if n else f"bit{b}")
+    return {"path": LIB_PATH, "abi_version": bi.abi_version, "variant_bits": bi.variant_bits, "variant": names,
+            "kernel_source_hash": f"{bi.kernel_source_hash:016x}", "flags_hash": f"{bi.flags_hash:016x}",
+            "default_flags": bool(bi.default_flags)}
+
+
+def build_info() -> dict:
+    """What the loaded library was built from (hsimae_build_info): ABI version, variant bits and their names, the hash of the
+    kernel sources and of the hipcc flag list, whether that list is build.py's default (no tuning knob overridden)."""
+    return _query_build_info(load())
 
 
 def check(code: int, what: str = "hsimae") -> None:

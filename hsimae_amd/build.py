@@ -13,7 +13,24 @@ UNITS = ["gemm", "gemm_dma", "attn", "attn_wide", "wgrad", "elem", "pack", "fuse
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # HSIMAE_HIPCC_EXTRA: extra hipcc flags for experiments (e.g. "-Xclang -target-feature -Xclang -packed-fp32-ops",
 # which removes the v_pk_*_f32 forms: measured neutral on the step, so not the default)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-fvisibility=hidden"] + os.environ.get("HSIMAE_HIPCC_EXTRA", "").split()
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-fvisibility=hidden"]
+FLAGS = BASE_FLAGS + os.environ.get("HSIMAE_HIPCC_EXTRA", "").split()
+
+
+def flags_hash(flags: list[str]) -> str:
+    """16 hex digits over the hipcc flag list: names the object directory (a flag change recompiles: the mtime check alone did
+    not notice one) and is compiled into the library (hsimae_build_info().flags_hash)."""
+    import hashlib
+    return hashlib.sha256(" ".join(flags).encode()).hexdigest()[:16]
+
+
+def unit_flags(unit: str, flags: list[str]) -> list[str]:
+    """Flags of one translation unit: `flags` + what hsimae_build_info() reports (api.hip only: the flag-list hash, whether the
+    list is the default one, the kernel-source hash)."""
+    if unit != "api":
+        return list(flags)
+    return list(flags) + [f"-DHS_BUILD_FLAGS_HASH=0x{flags_hash(flags)}ULL", f"-DHS_BUILD_DEFAULT_FLAGS={int(flags == BASE_FLAGS)}",
+                          f"-DHS_KERNEL_SOURCE_HASH=0x{kernel_source_hash()}ULL"]
 
 
 def kernel_source_hash() -> str:
@@ -40,13 +57,21 @@ def _stale(target: str, deps: list[str]) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "plan.h"),
             os.path.join(HERE, "..", "include", "hsimae_hip.h")]
-    objdir = os.path.join(HERE, "build")
+    # one object directory per flag list, so that a changed HSIMAE_HIPCC_EXTRA never links objects of another build
+    objdir = os.path.join(HERE, "build", flags_hash(FLAGS))
     os.makedirs(objdir, exist_ok=True)
+    srchash = kernel_source_hash()
 
     def compile_one(u: str) -> str:
-        src, obj = os.path.join(CSRC, u + ".hip"), os.path.join(objdir, u + ".o")
+        src = os.path.join(CSRC, u + ".hip")
+        # api.o carries the kernel-source hash: its name changes with ANY source, so it is rebuilt whenever the hash it reports would be stale
+        obj = os.path.join(objdir, (f"api_{srchash}.o" if u == "api" else u + ".o"))
+        if u == "api":
+            for old in os.listdir(objdir):
+                if old.startswith("api_") and old != os.path.basename(obj):
+                    os.remove(os.path.join(objdir, old))
         if force or _stale(obj, [src] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + unit_flags(u, FLAGS) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -56,11 +81,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, UNITS))
-    if force or _stale(LIB, objs):
+    stamp = os.path.join(HERE, "build", "linked_from")
+    linked = open(stamp).read() if os.path.exists(stamp) else ""
+    if force or _stale(LIB, objs) or linked != objdir:          # (objects of another flag list may be OLDER than the library)
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        with open(stamp, "w") as fh:
+            fh.write(objdir)
     return LIB
 
 

@@ -460,9 +460,48 @@ int make_ctx(const hsimae_config* cfg, const hsimae_io* io, Ctx& c, bool need_ws
 }  // namespace
 
 // ====================================================================== C ABI
+extern "C" unsigned hs_variant_bits_gemm();
+extern "C" unsigned hs_variant_bits_gemm_dma();
+extern "C" unsigned hs_variant_bits_attn();
+extern "C" unsigned hs_variant_bits_attn_wide();
+extern "C" unsigned hs_variant_bits_wgrad();
+extern "C" unsigned hs_variant_bits_elem();
+extern "C" unsigned hs_variant_bits_pack();
+extern "C" unsigned hs_variant_bits_fused_dec();
+extern "C" unsigned hs_variant_bits_fused_enc();
+extern "C" unsigned hs_variant_bits_loader();
+#ifndef HS_KERNEL_SOURCE_HASH
+#define HS_KERNEL_SOURCE_HASH 0ULL
+#endif
+#ifndef HS_BUILD_FLAGS_HASH
+#define HS_BUILD_FLAGS_HASH 0ULL
+#endif
+#ifndef HS_BUILD_DEFAULT_FLAGS
+#define HS_BUILD_DEFAULT_FLAGS 0
+#endif
+
 extern "C" {
 
 int hsimae_version(void) { return HSIMAE_VERSION; }
+
+int hsimae_build_info(hsimae_build_info_t* out) {
+    if (!out) return HSIMAE_ENULL;
+    out->abi_version = HSIMAE_VERSION;
+    out->variant_bits = hs_variant_bits() | hs_variant_bits_gemm() | hs_variant_bits_gemm_dma() | hs_variant_bits_attn() | hs_variant_bits_attn_wide() | hs_variant_bits_wgrad() | hs_variant_bits_elem() | hs_variant_bits_pack() | hs_variant_bits_fused_dec() | hs_variant_bits_fused_enc() | hs_variant_bits_loader();
+    out->kernel_source_hash = HS_KERNEL_SOURCE_HASH;
+    out->flags_hash = HS_BUILD_FLAGS_HASH;
+    out->default_flags = HS_BUILD_DEFAULT_FLAGS;
+    out->reserved = 0;
+    return HSIMAE_OK;
+}
+const char* hsimae_variant_name(int bit) {
+    switch (bit) {
+#define HS_X(b, name) case b: return #name;
+        HS_VARIANT_TABLE(HS_X)
+#undef HS_X
+        default: return nullptr;
+    }
+}
 
 int hsimae_two_streams_active(void) { return side().ok ? 1 : 0; }
 int hsimae_effective_precision(const hsimae_config* cfg) {

@@ -1911,3 +1911,5 @@ int hs_attn_block_bwd(const hs_bf16* qkv, const hs_bf16* u, const hs_bf16* wqkv,
     if (rc) return Ts <= 16 ? launch_blk128_bwd<1, 2, true>(a, s) : launch_blk128_bwd<2, 2, true>(a, s);
     return Ts <= 16 ? launch_blk128_bwd<1, 2, false>(a, s) : launch_blk128_bwd<2, 2, false>(a, s);
 }
+
+HS_UNIT_VARIANT_BITS(attn)

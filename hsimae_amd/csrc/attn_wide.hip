@@ -780,3 +780,5 @@ int hs_attn_block256_fwd(const float* x, const float* n1w, const float* n1b, con
     a.lse = lse; a.x1 = x1; a.rowscale = rowscale; a.Ts = Ts; a.nsamples = nsamples; a.mode = mode; a.len_l = len_l;
     return Ts <= 16 ? launch_blk256<1, 2>(a, s) : launch_blk256<2, 2>(a, s);
 }
+
+HS_UNIT_VARIANT_BITS(attn_wide)

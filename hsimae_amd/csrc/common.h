@@ -14,6 +14,43 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define HS_WAVE 64
 
+// Variant bits of hsimae_build_info() (include/hsimae_hip.h): every compile-time switch that makes a kernel compute wrong results
+// on purpose (timing ablations) or instruments it.  Each translation unit reports the bits IT was compiled with
+// (HS_UNIT_VARIANT_BITS at its end), api.hip ORs them; tests/test_host_cpu.py greps the sources for HS_ABL_* / HS_EXP_* /
+// HS_EXPERIMENT_* / HS_PHASE_TIMING tokens and fails if one is missing from this table.
+#define HS_VARIANT_TABLE(X) \
+    X(0, HS_ABL_DW2) X(1, HS_ABL_DEC_REREAD) X(2, HS_ABL_FWD_NOLOAD) X(3, HS_ABL_WSTREAM) X(4, HS_ABL_FWD_NOSTORE) \
+    X(5, HS_EXP_NO_COMMIT) X(6, HS_EXPERIMENT_NOEXP) X(7, HS_PHASE_TIMING)
+static inline unsigned hs_variant_bits() {
+    unsigned b = 0;
+#ifdef HS_ABL_DW2
+    b |= 1u << 0;
+#endif
+#ifdef HS_ABL_DEC_REREAD
+    b |= 1u << 1;
+#endif
+#ifdef HS_ABL_FWD_NOLOAD
+    b |= 1u << 2;
+#endif
+#ifdef HS_ABL_WSTREAM
+    b |= 1u << 3;
+#endif
+#ifdef HS_ABL_FWD_NOSTORE
+    b |= 1u << 4;
+#endif
+#ifdef HS_EXP_NO_COMMIT
+    b |= 1u << 5;
+#endif
+#ifdef HS_EXPERIMENT_NOEXP
+    b |= 1u << 6;
+#endif
+#ifdef HS_PHASE_TIMING
+    b |= 1u << 7;
+#endif
+    return b;
+}
+#define HS_UNIT_VARIANT_BITS(unit) extern "C" unsigned hs_variant_bits_##unit() { return hs_variant_bits(); }
+
 // Error codes of the C ABI (include/hsimae_hip.h)
 #define HS_OK 0
 #define HS_EDIMS (-1)

@@ -748,3 +748,5 @@ int hs_adamw(float* p, const float* g, float* m, float* v, const unsigned char* 
                        b2, eps, wd, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
     return (int)hipGetLastError();
 }
+
+HS_UNIT_VARIANT_BITS(elem)

@@ -2036,3 +2036,5 @@ int hs_dec_block_fwd(const float* x, float* x1, float* x2, hs_bf16* o, float* ls
     if (mt <= 7) return launch_fwd<7>(a, s);
     return HS_EUNSUPPORTED;
 }
+
+HS_UNIT_VARIANT_BITS(fused_dec)

@@ -825,3 +825,5 @@ int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs
     if (M <= 0) return HS_OK;
     return launch_bwd(mk_bwd(x1, dy, dx1, u2, dh13, g, dyb, dx1b, M, b, g_n2w, g_n2b, rs_mlp, rs_attn, det, plane_rows), M, d, s);
 }
+
+HS_UNIT_VARIANT_BITS(fused_enc)

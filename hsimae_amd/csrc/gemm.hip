@@ -944,3 +944,5 @@ int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s) {
 #undef CASE
     return HS_EUNSUPPORTED;
 }
+
+HS_UNIT_VARIANT_BITS(gemm)

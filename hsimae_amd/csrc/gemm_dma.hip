@@ -318,3 +318,5 @@ int hs_lnbwd_dma(const GemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL(lnbwd_dma_kernel, dim3(nchunks < 512 ? nchunks : 512), dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
+
+HS_UNIT_VARIANT_BITS(gemm_dma)

@@ -55,3 +55,5 @@ int hs_cube_gather(const CubeParams& p, hipStream_t s) {
     else hipLaunchKernelGGL(cube_gather_kernel<float>, dim3(p.N), dim3(256), 0, s, p);
     return (int)hipGetLastError();
 }
+
+HS_UNIT_VARIANT_BITS(loader)

@@ -89,3 +89,5 @@ int hs_pack(const PackDesc* descs_dev, int ndesc, int max_elems, hipStream_t s) 
     hipLaunchKernelGGL(pack_kernel, dim3(gx, ndesc), dim3(256), 0, s, descs_dev, ndesc);
     return (int)hipGetLastError();
 }
+
+HS_UNIT_VARIANT_BITS(pack)

@@ -547,3 +547,5 @@ int hs_wgrad(const WgradParams& p, hipStream_t s) {
     }
     return (int)hipGetLastError();
 }
+
+HS_UNIT_VARIANT_BITS(wgrad)

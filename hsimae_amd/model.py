@@ -276,6 +276,7 @@ class HSIMAE(nn.Module):
         self._packed_version = -1
         self._anchor = None
         self._reducer = None
+        self._world_override = None     # see _dp_world
         self._grads_home = [False, False]
         self.want_recons = True
         self.len_t = self.len_l = None
@@ -501,7 +502,7 @@ class HSIMAE(nn.Module):
             pred_img = torch.empty(N, 1, imgs.shape[2], 9, 9, dtype=torch.float32, device=dev)
             mask_img = torch.empty_like(pred_img)
         latent = torch.empty(N, K, self.dim, dtype=torch.float32, device=dev) if want_latent else None
-        world = self._reducer.world_size if self._reducer is not None else 1
+        world = self._dp_world()
         io = _lib.IO(
             x=imgs.data_ptr(), sn=imgs.stride(0), sb=imgs.stride(2), sh=imgs.stride(3), sw=imgs.stride(4),
             N=N, len_t=self.len_t, len_l=self.len_l, noise1=n1.data_ptr(), noise2=n2.data_ptr(),
@@ -646,7 +647,7 @@ class HSIMAE(nn.Module):
             lat = x.detach().to(torch.float32).contiguous()
             ids = ids_restore.to(device=dev, dtype=torch.int32).contiguous()
             pred = torch.empty(N, T * L, 72, dtype=torch.float32, device=dev)
-            world = self._reducer.world_size if self._reducer is not None else 1
+            world = self._dp_world()
             io = _lib.IO(N=N, len_t=self.len_t, len_l=self.len_l, params=self._flat.data_ptr(), wpk=self._wpk.data_ptr(),
                          workspace=(ws.data_ptr() + 255) // 256 * 256, workspace_bytes=nbytes, grad_scale=1.0 / world,
                          ids_restore=ids.data_ptr(), bucket_stream=None)
@@ -683,7 +684,7 @@ class HSIMAE(nn.Module):
             dpred = torch.empty(N * TL, 96, dtype=torch.bfloat16, device=dev) if want_grad else None
             # data parallel: the reducer SUMs the ranks' gradients, so dLoss/dpred carries the 1/world of the mean
             # (hsimae_forward folds the same factor in through hsimae_io.grad_scale)
-            world = self._reducer.world_size if self._reducer is not None else 1
+            world = self._dp_world()
             p = _lib.LossParams(x=imgs.data_ptr(), sn=imgs.stride(0), sb=imgs.stride(2), sh=imgs.stride(3), sw=imgs.stride(4),
                                 N=N, T=T, pred=pr.data_ptr(), mask=mk.data_ptr(), norm_pix=int(bool(self.norm_pix_loss)),
                                 inv_scale=(1.0 / (72.0 * sum_mask * world)) if want_grad else 0.0, partial=partial.data_ptr(),
@@ -759,6 +760,13 @@ class HSIMAE(nn.Module):
         return mask, self.unpatchify(pred)
 
     # ------------------------------------------------------------------ data parallel (not in the reference)
+    def _dp_world(self) -> int:
+        """The 1/world folded into dLoss/dpred: the reducer's world size; with the reducer detached, `_world_override` (bench.py's
+        self-check runs the SAME arithmetic — same bf16 roundings — without the bucketed collectives) or 1."""
+        if self._reducer is not None:
+            return self._reducer.world_size
+        return self._world_override or 1
+
     def enable_data_parallel(self, process_group=None, bucket_bytes=4 << 20, broadcast=True, force_collectives=False):
         """One process per GPU: average gradients over the group with bucketed RCCL all-reduce launched from
         inside the backward schedule (overlapped with the remaining backward kernels)."""

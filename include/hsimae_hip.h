@@ -51,9 +51,21 @@ extern "C" {
 /* ABI version of this header; hsimae_version() returns the value the loaded library was built with, and a binder must
  * refuse a library that answers differently (hsimae_amd/_lib.py does).  104 (round 5): HSIMAE_ENOFORWARD, schedule recorded
  * by the forward; 103 -> 104 also covers round 4's incompatible change of the weight-gradient parameter block (t[8] -> t[16]), which had
- * shipped without a bump. */
-#define HSIMAE_VERSION 104
+ * shipped without a bump.  105 (round 6): hsimae_build_info. */
+#define HSIMAE_VERSION 105
 int hsimae_version(void);
+/* What the loaded library was built from (round 6).  `variant_bits` has one bit per compile-time switch that makes a kernel
+ * compute WRONG results on purpose (timing ablations: HS_ABL_*, HS_EXP_*, HS_EXPERIMENT_*) or adds instrumentation
+ * (HS_PHASE_TIMING), OR-ed over every translation unit of the library; hsimae_variant_name(bit) names bit 0..31 (NULL: unused).
+ * A binder must refuse a library with any bit set unless the caller asked for a variant (hsimae_amd/_lib.py:
+ * HSIMAE_ALLOW_VARIANT=1).  `kernel_source_hash` = the first 64 bits of hsimae_amd.build.kernel_source_hash() at build time,
+ * `flags_hash` = the same of the hipcc flag list (0: built by hand, outside hsimae_amd/build.py); `default_flags` = 1 when that
+ * list is build.py's own, i.e. no tuning knob (-DHS_*) was overridden either. */
+typedef struct {
+    int32_t abi_version; uint32_t variant_bits; uint64_t kernel_source_hash; uint64_t flags_hash; int32_t default_flags; int32_t reserved;
+} hsimae_build_info_t;
+int hsimae_build_info(hsimae_build_info_t* out);
+const char* hsimae_variant_name(int bit);
 const char* hsimae_strerror(int code);
 /* 1 if the library runs the two axis stacks of the encoder on two streams on the CURRENT device (the side stream is created
  * on first use; HSIMAE_TWO_STREAMS=0 or a failed hipStreamCreate give 0).  The order in which hsimae_backward reports gradient

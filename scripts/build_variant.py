@@ -17,7 +17,7 @@ procs = []
 for u in B.UNITS:
     obj = os.path.join(out, u + ".o")
     objs.append(obj)
-    procs.append(subprocess.Popen([B.HIPCC] + B.FLAGS + flags + ["-c", os.path.join(B.CSRC, u + ".hip"), "-o", obj],
+    procs.append(subprocess.Popen([B.HIPCC] + B.unit_flags(u, B.FLAGS + flags) + ["-c", os.path.join(B.CSRC, u + ".hip"), "-o", obj],
                                   stderr=subprocess.DEVNULL))
 for p in procs:
     assert p.wait() == 0

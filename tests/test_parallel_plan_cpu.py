@@ -171,7 +171,7 @@ def test_loader_shards_cover_the_global_batches_with_a_ragged_tail(world):
         assert all(len(shards[r][bi]) == per for r in range(world))
 
 
-@pytest.mark.parametrize("world,fault,field", [(2, "", None), (8, "", None), (2, "order", "same_collective_order"),
+@pytest.mark.parametrize("world,fault,field", [(2, "", None), (3, "", None), (8, "", None), (2, "order", "same_collective_order"),
                                                (8, "grad", "same_reduced_gradients"), (2, "grid", "same_grid_sequence")])
 def test_bench_verify_detects_divergent_ranks(world, fault, field):
     """`bench.py --verify`: the self-check a multi-rank run carries in its JSON line.  On gloo ranks with
@@ -212,18 +212,30 @@ def test_verify_step_flags_a_bucketed_result_that_differs_from_the_plain_collect
 
 def test_bench_watchdog_prints_the_line_when_the_legs_after_the_timed_region_hang():
     """`bench.py`'s rank 0 owes the driver ONE JSON line.  The comm / self-check / replay legs run after the timed region; if one
-    hangs (a collective another rank never entered), the watchdog prints the line with what it holds and ends the process."""
+    hangs (a collective another rank never entered), the watchdog prints the line with what it holds and ends the process
+    with a NON-ZERO status (the line is incomplete and the process has used the GPU: rc 0 would tell the driver the run was whole)."""
     code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
             "line = {'metric': 'm', 'value': 1.0, 'comm': {'buckets': 5}}\n"
             "w = bench._Watchdog(0.3, line)\n"
             "time.sleep(30)\n"                      # the hung leg
             "print('never')\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 0, r.stderr[-400:]
+    assert r.returncode == 3, (r.returncode, r.stderr[-400:])
     out = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(out) == 1 and "never" not in r.stdout
     d = json.loads(out[0])
     assert d["value"] == 1.0 and "did not finish" in d["watchdog"] and "comm" in d["watchdog"]
+    # a SLOW leg (not a hung one) that keeps adding keys while the timer fires: a line still comes out
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "line = {'metric': 'm', 'value': 2.0}\n"
+            "w = bench._Watchdog(0.3, line)\n"
+            "t0 = time.time(); i = 0\n"
+            "while time.time() - t0 < 20:\n"
+            "    line['k%%d' %% (i %% 5000)] = i; i += 1\n"
+            "    if i %% 5000 == 0: [line.pop('k%%d' %% j) for j in range(5000)]\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert r.returncode == 3 and len(out) == 1 and json.loads(out[0])["value"] == 2.0 and "watchdog" in json.loads(out[0])
     # the normal end: finish() prints once, the timer is cancelled, nothing follows
     code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
             "w = bench._Watchdog(0.3, {'metric': 'm'}); w.line['extra'] = 1; w.finish(); w.finish(); time.sleep(0.8)\n") % ROOT
