@@ -88,14 +88,30 @@ uint32_t sched_from_env() {
     if (!off("HSIMAE_FUSED_ATTN_BLOCK256_BWD")) b |= SC_ATTN_BLOCK256_BWD;
     return b;
 }
-struct SchedRec { uint32_t enc = 0, dec = 0; bool has_enc = false, has_dec = false; };
+struct SchedRec { uint32_t enc = 0, dec = 0; bool has_enc = false, has_dec = false; uint64_t gen = 0; };
 std::mutex g_sched_mu;
 std::unordered_map<const void*, SchedRec> g_sched;          // keyed by the workspace arena the forward filled
+uint64_t g_sched_gen = 0;
 void record_sched(const void* ws, bool enc, bool dec, uint32_t bits) {
     std::lock_guard<std::mutex> lk(g_sched_mu);
-    if (g_sched.size() > 4096) g_sched.clear();             // (a process that leaks arenas: start over rather than grow)
+    // A process that keeps handing new arena addresses (caching allocator churn): drop the OLDEST half — never the entry being
+    // recorded, and not the recent ones, whose backward may still be pending (clearing the whole map made a live
+    // arena's backward fail with HSIMAE_ENOFORWARD)
+    if (g_sched.size() > 4096 && g_sched.find(ws) == g_sched.end()) {
+        std::vector<uint64_t> gens;
+        gens.reserve(g_sched.size());
+        for (auto& kv : g_sched) gens.push_back(kv.second.gen);
+        std::nth_element(gens.begin(), gens.begin() + gens.size() / 2, gens.end());
+        const uint64_t cut = gens[gens.size() / 2];
+        for (auto it = g_sched.begin(); it != g_sched.end();) it = it->second.gen < cut ? g_sched.erase(it) : std::next(it);
+    }
     SchedRec& r = g_sched[ws];
-    if (enc) { r.enc = bits; r.has_enc = true; }
+    r.gen = ++g_sched_gen;
+    if (enc) {
+        r.enc = bits; r.has_enc = true;
+        // an encoder-only forward re-fills the arena: a decoder record of an EARLIER pass no longer describes what is in it
+        if (!dec) r.has_dec = false;
+    }
     if (dec) { r.dec = bits; r.has_dec = true; }
 }
 int lookup_sched(const void* ws, bool need_enc, bool need_dec, uint32_t& enc, uint32_t& dec) {
@@ -309,7 +325,7 @@ int block_bwd(const BlkP& P, uint32_t sc, const BlkOff& o, float* grads, const f
     const bool fmlp = !f8u && fused_mlp_enabled(d, h, sc);
     // g / dh1 / dh3 as 64-column planes (include/hsimae_hip.h, hsimae_wgrad_task): needs whole 32-row DMA chunks and 32-bit offsets
     const int hp64 = rup(hp, 64);
-    const bool planar = fmlp && (sc & SC_PLANAR) && M % 32 == 0 && (M + 64) * 2 * (int64_t)hp64 * 2 < (1ll << 32);
+    const bool planar = fmlp && (sc & SC_PLANAR) && M % 32 == 0 && (M + kPlanePadRows) * 2 * (int64_t)(hp64 + 256) * 2 < (1ll << 32);
     const int prow = planar ? (int)M + HS_PLANE_PAD_ROWS : 0;       // rows per plane (plan.h: the arena reserves kPlanePadRows)
     if (fmlp) {
         // recompute u2 / h1 / h3 / g inside the tile; emits dx1 and the wgrad operands u2, dh1|dh3, g, bf16 dY and dx1

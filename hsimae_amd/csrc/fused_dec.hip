@@ -87,6 +87,9 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases(unsign
 #ifndef HS_DEC_CORE_NQ
 #define HS_DEC_CORE_NQ 1
 #endif
+#ifndef HS_DEC_REGEO
+#define HS_DEC_REGEO 1      /* dec_bwd_attn: lane geometry re-derived per phase instead of kept alive across the sample loop */
+#endif
 #ifndef HS_DEC_CORE_STG
 #define HS_DEC_CORE_STG 0   /* waves 4-7 enter the attention core this many x 64 clocks late (half a tile period = 4) */
 #endif
@@ -424,6 +427,38 @@ __device__ __forceinline__ const T* launder(const T* p) {
     const __attribute__((address_space(1))) T* g = (const __attribute__((address_space(1))) T*)p;
     asm volatile("" : "+s"(g));
     return (const T*)g;
+}
+// Global addressing of the persistent backward kernels (round 6): a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane BYTE
+// offset, which is the `global_load ... v_off, s[base]` form — one VGPR per access instead of a 64-bit VGPR pair per row group —
+// and the lane offsets are re-derived from an opaque copy of threadIdx.x where they are used.  Left to itself hipcc computes every
+// row group's 64-bit address once, keeps the pairs alive across the whole sample loop and spills them (11 registers in
+// dec_bwd_attn_kernel<7>); the reload of one of them sat in the MIDDLE of the next sample's prefetch burst, and a scratch reload
+// is a vector-memory load: its s_waitcnt vmcnt(0) waited for the ten HBM loads just issued — the "issue" time of that burst in
+// the round-5 phase stamps (33 us per launch) was this wait.
+__device__ __forceinline__ int fresh_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+template <class T>
+__device__ __forceinline__ const T* at_bytes(const T* base, unsigned byte_off) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ T* at_bytes(T* base, unsigned byte_off) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
+}
+// One sample's rows as a raw buffer: `bytes` = the sample's extent (0 for a sample past the batch), so lanes whose row is past
+// the sequence read ZEROS and their stores are dropped by the bounds check — no exec-masked branch around the accesses (with the
+// branches hipcc's wait-count pass fell back to s_waitcnt vmcnt(0) where a counted wait would have left a prefetch in flight).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void bld8(__amdgpu_buffer_rsrc_t r, unsigned bo, float* o) {
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)bo, 0, 0));
+    const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)bo + 16, 0, 0));
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+__device__ __forceinline__ void bst8(__amdgpu_buffer_rsrc_t r, unsigned bo, const float* v) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, f32x4{v[0], v[1], v[2], v[3]}), r, (int)bo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, f32x4{v[4], v[5], v[6], v[7]}), r, (int)bo + 16, 0, 0);
 }
 __device__ __forceinline__ DecW launder_w(const DecW& a) {
     DecW w = a;
@@ -820,9 +855,15 @@ struct GeoB : Geo4 {
     int ft;        // swz of the row 4 g + q4 (+ 16 k): transpose reads
     int pc;        // wrow(c16) - the lane's weight row inside a 16-row n-tile (+ 8 for odd n-tiles, + 32 per tile pair)
 };
-__device__ __forceinline__ GeoB geob() {
+// tid: threadIdx.x, or an opaque copy of it (fresh_tid()) when the caller wants the geometry RE-DERIVED at this point instead of
+// kept alive (and spilled) across the phases of a persistent loop
+__device__ __forceinline__ GeoB geob(int tid = -1) {
     GeoB q;
-    static_cast<Geo4&>(q) = geo();
+    if (tid < 0) static_cast<Geo4&>(q) = geo();
+    else {
+        q.lane = tid & 63; q.c16 = q.lane & 15; q.g = q.lane >> 4;
+        q.wave = __builtin_amdgcn_readfirstlane(tid >> 6); q.wm = q.wave >> 1; q.wn = q.wave & 1;
+    }
     q.q4 = q.c16 >> 2; q.p4 = q.c16 & 3;
     q.fr = swz(q.c16); q.ft = swz(4 * q.g + q.q4);
     q.pc = 4 * (q.c16 >> 3) + (q.c16 & 3) + 16 * ((q.c16 >> 2) & 1);
@@ -950,10 +991,12 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
     float* XS = reinterpret_cast<float*>(Gc);            // fp32 staging aliases Gc|DH1|DH3 (dead once the chunk loop is done)
     bf16_t* WL = DH3 + IMG;                              // W1 | W3 as row-major bf16 [192][LW] (rows past h zero, row k at wrow(k)), resident
     float* BL = reinterpret_cast<float*>(WL + 2 * WRB);  // b1 | b3, zero-padded to 192
-    const GeoB q = geob();
+    GeoB q = geob();                  // re-derived at every phase of the sample loop (HS_DEC_REGEO, see at_bytes)
     const int mt0 = q.wm * L::MH;
-    const int c8 = (threadIdx.x & 7) * 8;
-    const int wide = ((threadIdx.x & 7) ^ swz(threadIdx.x >> 3)) << 3;   // this thread's 16-byte chunk in the wide layout (row = tid >> 3 + 64 i)
+    int c8 = (threadIdx.x & 7) * 8;
+    int wide = ((threadIdx.x & 7) ^ swz(threadIdx.x >> 3)) << 3;   // this thread's 16-byte chunk in the wide layout (row = tid >> 3 + 64 i)
+    auto regeo = [&]() { if (HS_DEC_REGEO) q = geob(fresh_tid()); };
+    auto rewide = [&]() { if (HS_DEC_REGEO) { const int t = fresh_tid(); wide = ((t & 7) ^ swz(t >> 3)) << 3; c8 = (t & 7) * 8; } };
     // The weights are the same for every sample this workgroup walks: stage W1 and W3 once, row-major.  The gate
     // products read them as 16-byte row pieces and the data gradient (which needs the transposed operand) reads the
     // same image with transpose reads, so the per-sample body fetches only the W2^T fragments from L2.
@@ -971,6 +1014,11 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
         const int m = i / HPD, o = i % HPD;
         BL[i] = o < p.w.h ? (m == 0 ? p.w.w1b[o] : p.w.w3b[o]) : 0.f;
     }
+    // LayerNorm-2 gamma | beta in LDS too (round 6): read from global per sample, the epilogue's gamma load was a vector-memory load
+    // YOUNGER than whatever the iteration had prefetched, and its wait drained the prefetch (one in-order counter)
+    float* NL = BL + 2 * HPD;
+    if (threadIdx.x < 2 * D) NL[threadIdx.x] = threadIdx.x < D ? p.w.n2w[threadIdx.x] : p.w.n2b[threadIdx.x - D];
+    lds_barrier();                                       // the first sample's LayerNorm reads NL before the loop's first barrier
 
     if (HS_DEC_STG_N > 1) {
         const int n = (int)((blockIdx.x >> 3) % (HS_DEC_STG_N > 1 ? HS_DEC_STG_N : 1)) * HS_DEC_STG_MLP;
@@ -1014,12 +1062,14 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
     auto fetch_sample = [&](int smp) {
         const bool valid = smp < p.nsamples;
         const size_t nb = (size_t)smp * p.Ts;
+        const int rbytes = valid ? p.Ts * D * 4 : 0;     // (rows_rsrc: lanes past the sequence / the batch read zeros)
+        const __amdgpu_buffer_rsrc_t xr = rows_rsrc(p.x1 + nb * D, rbytes), yr = rows_rsrc(p.dy + nb * D, rbytes);
+        const int tid = fresh_tid();
+        const unsigned lo = (unsigned)((tid >> 3) * D + (tid & 7) * 8) * 4u;
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
-            const int row = (threadIdx.x + NT_ * i) >> 3;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { fa[i][e] = 0.f; dya[i][e] = 0.f; }
-            if (valid && row < p.Ts) { ld8(p.x1 + (nb + row) * D + c8, fa[i]); ld8(p.dy + (nb + row) * D + c8, dya[i]); }
+            const unsigned bo = lo + (unsigned)(i * (NT_ / 8) * D * 4);
+            bld8(xr, bo, fa[i]); bld8(yr, bo, dya[i]);
         }
     };
     if (HS_DEC_MLP_PREFETCH) fetch_sample(blockIdx.x);
@@ -1031,9 +1081,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
         const bf16_t* w2T = launder(p.w2T);
         Fr<2> f2;                                      // W2^T fragments of the next hidden chunk (the only global weights)
         f2.load(w2T, 2, q.wn * 2, 0, q);
-        const float* n2w = launder(p.w.n2w);
-        const float* n2b = launder(p.w.n2b);
+        const float* n2w = NL + wl;
+        const float* n2b = NL + D + wl;
         if (!HS_DEC_MLP_PREFETCH) fetch_sample(sample);
+        rewide();
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pc = threadIdx.x + NT_ * i;
@@ -1057,6 +1108,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
         }
         lds_barrier();
         PH(0)
+        regeo();
         f32x4 du2[L::MH][2];
 #pragma unroll
         for (int mi = 0; mi < L::MH; ++mi) { du2[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f}; du2[mi][1] = du2[mi][0]; }
@@ -1113,6 +1165,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             if (c < 2) f2.load(w2T, 2, (c + 1) * 4 + q.wn * 2, 0, q);
             lds_barrier();
         PH(1)
+            regeo();
             // weight gradients of this hidden chunk: 12 (n-tile) x 4 (k-tile) output tiles, 3 x 2 per wave; on the even waves the
             // dO^T fragment also meets a tile of ones: the column sums of dY / dh1 / dh3 = this sample's bias-gradient addends
             f32x4 accb[3];
@@ -1155,6 +1208,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                 }
             }
             PH(2)
+            regeo();
             // data gradient through W1 / W3 (this chunk's 64 hidden rows are the contraction index: transpose reads of the images)
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2) {          // (spelled out: two helper calls here cost 170 B/lane of scratch)
@@ -1175,7 +1229,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             }
             lds_barrier();
         PH(5)
+            regeo();
         }
+        rewide();
         acc_to_xs<L::MH, true>(XS, mt0, MT, q, du2);
         asm volatile("" :: "v"(touch0), "v"(touch1));
         float xe[NPW][8], dye[NPW][8];                // L2-hot re-reads for the LayerNorm backward, in flight over the barrier
@@ -1184,7 +1240,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             const int row = (threadIdx.x + NT_ * i) >> 3;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { xe[i][e] = 0.f; dye[i][e] = 0.f; }
-            if (row < p.Ts) { ld8(p.x1 + (rb + row) * D + c8, xe[i]); ld8(p.dy + (rb + row) * D + c8, dye[i]); }
+            {
+                const unsigned bo = (unsigned)(row * D + c8) * 4u;
+                bld8(rows_rsrc(p.x1 + rb * D, p.Ts * D * 4), bo, xe[i]); bld8(rows_rsrc(p.dy + rb * D, p.Ts * D * 4), bo, dye[i]);
+            }
         }
         if (HS_DEC_MLP_PREFETCH) {                    // next sample's rows: younger than the re-reads above, so the epilogue does not wait for them
             __builtin_amdgcn_sched_barrier(0);
@@ -1219,7 +1278,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                     dgam[e] += du[e] * xh[e];
                     dbet[e] += du[e];
                 }
-                if (row < p.Ts) st8(p.dx1 + (rb + row) * D + c8, o);
+                bst8(rows_rsrc(p.dx1 + rb * D, p.Ts * D * 4), (unsigned)(row * D + c8) * 4u, o);     // (rows past Ts: dropped by the bounds check)
             }
         }
         lds_barrier();
@@ -1472,10 +1531,12 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     bf16_t* WQ = TT + 8 * TT_WAVE;                                // Wq|Wk|Wv row-major bf16 [192][LW] (row k at wrow(k)), resident
     bf16_t* WP = WQ + 3 * D * LW;                                 // Wp row-major bf16 [64][LW], resident
     float* CB = reinterpret_cast<float*>(WP + D * LW);            // bq|bk|bv (192), LN1 gamma (64), beta (64)
-    const GeoB q = geob();
-    const int wide = ((threadIdx.x & 7) ^ swz(threadIdx.x >> 3)) << 3;   // this thread's 16-byte chunk in the wide layout (row = tid >> 3 + 64 i)
+    GeoB q = geob();                  // re-derived at every phase of the sample loop (HS_DEC_REGEO, see at_bytes above)
+    int wide = ((threadIdx.x & 7) ^ swz(threadIdx.x >> 3)) << 3;   // this thread's 16-byte chunk in the wide layout (row = tid >> 3 + 64 i)
     const int mt0 = q.wm * L::MH;
-    const int c8 = (threadIdx.x & 7) * 8;
+    int c8 = (threadIdx.x & 7) * 8;
+    auto regeo = [&]() { if (HS_DEC_REGEO) q = geob(fresh_tid()); };
+    auto rewide = [&]() { if (HS_DEC_REGEO) { const int t = fresh_tid(); wide = ((t & 7) ^ swz(t >> 3)) << 3; c8 = (t & 7) * 8; } };
     // Weights staged once per workgroup (see dec_bwd_mlp_kernel): q|k|v read them as row pieces, the data gradients
     // (dO = dx1 Wp, du = dq Wq + dk Wk + dv Wv) read the same images with transpose reads.
     for (int i = threadIdx.x; i < 4 * D * 8; i += NT_) {
@@ -1521,28 +1582,22 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     auto fetch_sample = [&](int smp, int part = -1) {               // every load of a sample in flight before the first use
         const bool valid = smp < p.nsamples;
         const size_t nb = (size_t)smp * p.Ts;
+        const int rbytes = valid ? p.Ts * D * 4 : 0;                 // (rows_rsrc: lanes past the sequence / the batch read zeros)
+        const __amdgpu_buffer_rsrc_t xr = rows_rsrc(p.x + nb * D, rbytes), d1r = rows_rsrc(p.dx1 + nb * D, rbytes);
+        const __amdgpu_buffer_rsrc_t orr = rows_rsrc(p.o + nb * D, rbytes >> 1);
+        const int tid = fresh_tid();
+        const unsigned lo = (unsigned)((tid >> 3) * D + (tid & 7) * 8) * 4u;      // byte offset of this lane's 8 floats in row group 0
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
-            const int row = (threadIdx.x + NT_ * i) >> 3;
-            const bool ok = valid && row < p.Ts;
-            if (part < 0 || part == 0) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) fa[i][e] = 0.f;
-                if (ok) ld8(p.x + (nb + row) * D + c8, fa[i]);
-            }
-            if (part < 0 || part == 1) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d1a[i][e] = 0.f;
-                if (ok) ld8(p.dx1 + (nb + row) * D + c8, d1a[i]);
-            }
-            if (part < 0 || part == 2) {
-                ova[i] = zero8();
-                if (ok) ova[i] = *reinterpret_cast<const bf16x8*>(p.o + (nb + row) * D + c8);
-            }
+            const unsigned bo = lo + (unsigned)(i * (NT_ / 8) * D * 4);
+            if (part < 0 || part == 0) bld8(xr, bo, fa[i]);
+            if (part < 0 || part == 1) bld8(d1r, bo, d1a[i]);
+            if (part < 0 || part == 2) ova[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(orr, (int)(bo >> 1), 0, 0));
         }
         if (part < 0 || part == 2) {
-            l4a = f32x4{1e30f, 1e30f, 1e30f, 1e30f};      // rows past Ts: exp2(s - 1e30) = 0
-            if (valid && (threadIdx.x >> 1) < p.Ts) l4a = *reinterpret_cast<const f32x4*>(p.lse_g + (nb + (threadIdx.x >> 1)) * 8 + (threadIdx.x & 1) * 4);
+            // (rows past Ts read 0 here; they become 1e30 — exp2(s - 1e30) = 0 — where the table is written to LDS: a select at this
+            //  point would be a USE of the load, and hipcc waits for it with vmcnt(0), i.e. for the whole prefetch burst)
+            l4a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rows_rsrc(p.lse_g + nb * 8, valid ? p.Ts * 32 : 0), tid * 16, 0, 0));
         }
     };
     fetch_sample(blockIdx.x);
@@ -1557,6 +1612,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         // x, dx1, O and logsumexp of this sample are in registers already: fetch_sample() ran in front of the PREVIOUS sample's
         // LayerNorm-backward epilogue, so the HBM round trip is under that epilogue instead of exposed here (17 % of the kernel
         // before).  Works since the kernel no longer spills: scratch reloads share vmcnt with these loads and used to drain them.
+        rewide();
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pc = threadIdx.x + NT_ * i;
@@ -1583,10 +1639,11 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         if (threadIdx.x < 2 * R) {                     // logsumexp [row][8 heads] -> [head][row]
             const int row = threadIdx.x >> 1, h4 = (threadIdx.x & 1) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) lse[(h4 + e) * R + row] = l4a[e];
+            for (int e = 0; e < 4; ++e) lse[(h4 + e) * R + row] = row < p.Ts ? l4a[e] : 1e30f;
         }
         lds_barrier();
         PH(0)
+        regeo();
         // q | k | v, all row-major.  Operands swapped (here and in the dO / du products below): a lane owns 4 consecutive columns
         // of one token, so tiles reach the images as 8-byte writes, the bias is one 16-byte LDS read and delta needs no 8-lane sums
 #pragma unroll
@@ -1610,6 +1667,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
             }
         }
         PH(1)
+        regeo();
         // dO = dx1 * Wp ; dWp += dx1^T * O
         f32x4 dO[L::MH][2];
 #pragma unroll
@@ -1633,6 +1691,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         }
         dbpw += r4 == 0 ? accb[0] : (r4 == 1 ? accb[1] : (r4 == 2 ? accb[2] : accb[3]));
         PH(2)
+        regeo();
         // delta[head][row] = sum_keys P dP = sum_d dO[row][d] O[row][d] over the head's 8 columns (8 adjacent lanes)
         // (a lane holds 4 of a head's 8 columns of one token: 4 products in the lane + the lane group next door, g ^ 1)
         bf16x4 dOb16[L::MH][2];
@@ -1687,6 +1746,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         // (a half-tile start stagger of waves 4-7, MI355X_MICROARCH.md "two waves per SIMD" item 9, measured neutral in round 1;
         //  HS_DEC_CORE_STG = the same as a knob, in units of 64 clocks, re-measured in round 6: profiles/EXPERIMENTS.md)
         if (HS_DEC_CORE_STG > 0 && q.wave >= 4) __builtin_amdgcn_s_sleep(HS_DEC_CORE_STG);
+        regeo();
         attn_head_bwd<MT>(Qb, Kb, Vb, Ob, lse + q.wave * R, dlt + q.wave * R, TT + q.wave * TT_WAVE, q.wave, p.Ts, q);
         lds_barrier();
         PH(5)
@@ -1698,6 +1758,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         fetch_sample(sample + (int)gridDim.x);          // ~4 us (du + dWqkv + epilogue) ahead of its use
         __builtin_amdgcn_sched_barrier(0);
         PH2(0)
+        regeo();
         // du = dq Wq + dk Wk + dv Wv ; dWq|dWk|dWv += d{q,k,v}^T u
         f32x4 du[L::MH][2];
 #pragma unroll
@@ -1707,6 +1768,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         mm_cols<L::MH>(Kb, WQl + D * LW, mt0, q, du);
         mm_cols<L::MH>(Vb, WQl + 2 * D * LW, mt0, q, du);
         PH2(1)
+        regeo();
         f32x4 accqb[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) accqb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1742,6 +1804,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
         for (int t = 0; t < 3; ++t) dbqw[t] += r4 == 0 ? accqb[t][0] : (r4 == 1 ? accqb[t][1] : (r4 == 2 ? accqb[t][2] : accqb[t][3]));
         PH2(2)
+        regeo(); rewide();
         acc_to_xs<L::MH, true>(XS, mt0, MT, q, du);
         float xe[NPW][8], d1e[NPW][8];                // L2-hot re-reads for the LayerNorm backward, in flight over the barrier
 #pragma unroll
@@ -1750,7 +1813,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
 #pragma unroll
             for (int e = 0; e < 8; ++e) { xe[i][e] = 0.f; d1e[i][e] = 0.f; }
 #ifndef HS_ABL_DEC_REREAD   /* timing ablation (variant builds only): what the epilogue's second read of x and dx1 costs */
-            if (row < p.Ts) { ld8(p.x + (rb + row) * D + c8, xe[i]); ld8(p.dx1 + (rb + row) * D + c8, d1e[i]); }
+            {
+                const unsigned bo = (unsigned)(row * D + c8) * 4u;
+                bld8(rows_rsrc(p.x + rb * D, p.Ts * D * 4), bo, xe[i]); bld8(rows_rsrc(p.dx1 + rb * D, p.Ts * D * 4), bo, d1e[i]);
+            }
 #endif
         }
         PH2(3)
@@ -1783,7 +1849,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
                     dgam[e] += dv[e] * xh[e];
                     dbet[e] += dv[e];
                 }
-                if (row < p.Ts) st8(p.dx + (rb + row) * D + c8, o);
+                bst8(rows_rsrc(p.dx + rb * D, p.Ts * D * 4), (unsigned)(row * D + c8) * 4u, o);      // (rows past Ts: dropped by the bounds check)
             }
         }
         lds_barrier();
@@ -1954,7 +2020,7 @@ template <int MT>
 int launch_bwd(const DecBwdMlpArgs& a, const DecBwdAttnArgs& b, hipStream_t s) {
     using L = DL<MT>;
     constexpr int IMG = L::IMGB;
-    constexpr int LDS_A = 5 * IMG + 2 * WRB * 2 + 2 * HPD * 4;
+    constexpr int LDS_A = 5 * IMG + 2 * WRB * 2 + 2 * HPD * 4 + 2 * D * 4;      // images, W1 | W3, b1 | b3, LayerNorm-2 gamma | beta
     static_assert(3 * IMG >= L::R * LX * 4, "fp32 staging tile must fit over Gc|DH1|DH3");
     static_assert(LDS_A - 5 * IMG >= 16 * IR * 2, "image overrun of the unguarded du2 product must stay inside the allocation");
     constexpr int LDS_B = L::BWD_ATTN_LDS;

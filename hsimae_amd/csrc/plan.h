@@ -207,6 +207,8 @@ inline void pack_descs(const Geo& g, const PLayout& L, const WLayout& W, const f
 #define HS_PLANE_PAD_ROWS 48
 #endif
 constexpr int kPlanePadRows = 64;          // what the arena reserves per plane (>= HS_PLANE_PAD_ROWS)
+static_assert(HS_PLANE_PAD_ROWS <= kPlanePadRows && HS_PLANE_PAD_ROWS % 16 == 0,
+              "a -DHS_PLANE_PAD_ROWS variant must stay inside the rows the arena reserves per plane (ADVICE r05)");
 struct BlkBuf { hs_bf16* u; hs_bf16* qkv; float* lse; hs_bf16* o; float* x1; hs_bf16* u2; hs_bf16* h13; hs_bf16* g; float* x2; };
 
 struct Scr { float* G1; float* du; hs_bf16* dh13; hs_bf16* dob; hs_bf16* dqkv; hs_bf16* g0b; hs_bf16* g1b; float* slab; };   // per-stream backward scratch (g0b/g1b: bf16 dY / dx1; slab: weight-gradient partials)

@@ -488,7 +488,9 @@ int hs_wgrad(const WgradParams& p, hipStream_t s) {
         // planar operands: padded width a multiple of 64, whole 32-row DMA chunks (a row past M would be the next plane's row 0)
         if (p.t[i].dO_plane_rows && (p.t[i].ldo % 64 || p.t[i].dO_f32 || p.M % DC || p.t[i].dO_plane_rows < p.M)) return HS_EDIMS;
         if (p.t[i].A_plane_rows && (p.t[i].lda % 64 || p.M % DC || p.t[i].A_plane_rows < p.M)) return HS_EDIMS;
-        if ((int64_t)std::max(p.t[i].dO_plane_rows, p.t[i].A_plane_rows) * std::max(p.t[i].ldo, p.t[i].lda) * 2 >= (1ll << 32)) return HS_EDIMS;
+        // 32-bit byte offsets: an edge tile's lanes address plane index (n0 + 255) / 64, i.e. up to 256 columns past ld, and rely on
+        // the buffer bounds check to return zeros there — which holds only while that offset does not wrap
+        if ((int64_t)std::max(p.t[i].dO_plane_rows, p.t[i].A_plane_rows) * (std::max(p.t[i].ldo, p.t[i].lda) + 256) * 2 >= (1ll << 32)) return HS_EDIMS;
         any_planar = any_planar || p.t[i].dO_plane_rows || p.t[i].A_plane_rows;
     }
     const int tiles = wg_tiles(p, 128);
