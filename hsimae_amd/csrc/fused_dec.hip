@@ -87,8 +87,16 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases(unsign
 #ifndef HS_DEC_CORE_NQ
 #define HS_DEC_CORE_NQ 1
 #endif
+// Lane geometry (GeoB and what is derived from it) re-derived from an opaque copy of threadIdx.x instead of kept alive across the
+// sample loop: 0 = never, 1 = on entry to and exit from the attention core of dec_bwd_attn only, 2 = at every phase.
+// Measured (profiles/r06_c_decoder_ab.txt, one box): with every phase re-deriving, dec_bwd_mlp 227 -> 240 us and dec_bwd_attn 312 ->
+// 320 us (the ~30 VALU instructions per call are not free in kernels whose waves wait on VALU issue); without any, the
+// two-query-tile core spills again.
 #ifndef HS_DEC_REGEO
-#define HS_DEC_REGEO 1      /* dec_bwd_attn: lane geometry re-derived per phase instead of kept alive across the sample loop */
+#define HS_DEC_REGEO 1
+#endif
+#ifndef HS_DEC_REGEO_MLP
+#define HS_DEC_REGEO_MLP 0
 #endif
 #ifndef HS_DEC_CORE_STG
 #define HS_DEC_CORE_STG 0   /* waves 4-7 enter the attention core this many x 64 clocks late (half a tile period = 4) */
@@ -995,8 +1003,8 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
     const int mt0 = q.wm * L::MH;
     int c8 = (threadIdx.x & 7) * 8;
     int wide = ((threadIdx.x & 7) ^ swz(threadIdx.x >> 3)) << 3;   // this thread's 16-byte chunk in the wide layout (row = tid >> 3 + 64 i)
-    auto regeo = [&]() { if (HS_DEC_REGEO) q = geob(fresh_tid()); };
-    auto rewide = [&]() { if (HS_DEC_REGEO) { const int t = fresh_tid(); wide = ((t & 7) ^ swz(t >> 3)) << 3; c8 = (t & 7) * 8; } };
+    auto regeo = [&]() { if (HS_DEC_REGEO_MLP) q = geob(fresh_tid()); };
+    auto rewide = [&]() { if (HS_DEC_REGEO_MLP) { const int t = fresh_tid(); wide = ((t & 7) ^ swz(t >> 3)) << 3; c8 = (t & 7) * 8; } };
     // The weights are the same for every sample this workgroup walks: stage W1 and W3 once, row-major.  The gate
     // products read them as 16-byte row pieces and the data gradient (which needs the transposed operand) reads the
     // same image with transpose reads, so the per-sample body fetches only the W2^T fragments from L2.
@@ -1535,8 +1543,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
     int wide = ((threadIdx.x & 7) ^ swz(threadIdx.x >> 3)) << 3;   // this thread's 16-byte chunk in the wide layout (row = tid >> 3 + 64 i)
     const int mt0 = q.wm * L::MH;
     int c8 = (threadIdx.x & 7) * 8;
-    auto regeo = [&]() { if (HS_DEC_REGEO) q = geob(fresh_tid()); };
-    auto rewide = [&]() { if (HS_DEC_REGEO) { const int t = fresh_tid(); wide = ((t & 7) ^ swz(t >> 3)) << 3; c8 = (t & 7) * 8; } };
+    auto regeo = [&]() { if (HS_DEC_REGEO >= 2) q = geob(fresh_tid()); };
+    auto regeo_core = [&]() { if (HS_DEC_REGEO >= 1) q = geob(fresh_tid()); };
+    auto rewide = [&]() { if (HS_DEC_REGEO >= 2) { const int t = fresh_tid(); wide = ((t & 7) ^ swz(t >> 3)) << 3; c8 = (t & 7) * 8; } };
     // Weights staged once per workgroup (see dec_bwd_mlp_kernel): q|k|v read them as row pieces, the data gradients
     // (dO = dx1 Wp, du = dq Wq + dk Wk + dv Wv) read the same images with transpose reads.
     for (int i = threadIdx.x; i < 4 * D * 8; i += NT_) {
@@ -1746,7 +1755,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         // (a half-tile start stagger of waves 4-7, MI355X_MICROARCH.md "two waves per SIMD" item 9, measured neutral in round 1;
         //  HS_DEC_CORE_STG = the same as a knob, in units of 64 clocks, re-measured in round 6: profiles/EXPERIMENTS.md)
         if (HS_DEC_CORE_STG > 0 && q.wave >= 4) __builtin_amdgcn_s_sleep(HS_DEC_CORE_STG);
-        regeo();
+        regeo_core();
         attn_head_bwd<MT>(Qb, Kb, Vb, Ob, lse + q.wave * R, dlt + q.wave * R, TT + q.wave * TT_WAVE, q.wave, p.Ts, q);
         lds_barrier();
         PH(5)
@@ -1758,7 +1767,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         fetch_sample(sample + (int)gridDim.x);          // ~4 us (du + dWqkv + epilogue) ahead of its use
         __builtin_amdgcn_sched_barrier(0);
         PH2(0)
-        regeo();
+        regeo_core();
         // du = dq Wq + dk Wk + dv Wv ; dWq|dWk|dWv += d{q,k,v}^T u
         f32x4 du[L::MH][2];
 #pragma unroll

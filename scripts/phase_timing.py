@@ -22,8 +22,8 @@ def build_variant() -> str:
     for u in B.UNITS:
         obj = os.path.join(tmp, u + ".o")
         timed = u in ("fused_dec", "fused_enc", "gemm")
-        flags = B.FLAGS + (["-DHS_PHASE_TIMING"] + os.environ.get("HS_EXTRA_FLAGS", "").split() if timed else [])
-        src_obj = os.path.join(B.HERE, "build", u + ".o")
+        flags = B.unit_flags(u, B.FLAGS + (["-DHS_PHASE_TIMING"] + os.environ.get("HS_EXTRA_FLAGS", "").split() if timed else []))
+        src_obj = os.path.join(B.HERE, "build", B.flags_hash(B.FLAGS), u + ".o")
         if not timed and os.path.exists(src_obj):
             shutil.copy(src_obj, obj)
         else:
@@ -35,7 +35,10 @@ def build_variant() -> str:
 
 
 def main():
-    lib_path = build_variant()
+    # PHASE_LIB: a library built beforehand with -DHS_PHASE_TIMING (python scripts/build_variant.py <name> -DHS_PHASE_TIMING ...): no
+    # compile on the GPU box.  The loader refuses instrumented builds unless asked (hsimae_build_info, round 6).
+    os.environ["HSIMAE_ALLOW_VARIANT"] = "1"
+    lib_path = os.environ.get("PHASE_LIB") or build_variant()
     import hsimae_amd._lib as L
     L.LIB_PATH = lib_path
     import torch

@@ -182,7 +182,7 @@ def test_huge_fp8_against_oracle(grid):
     # (18, 3): the spatial stack attends over 3 tokens, its q / k weight gradients are nearly zero — RMS-relative error is
     # measured on rounding noise there (0.030 in bf16 on these inputs)
     assert res["bf16"][0] <= 1e-4 and res["bf16"][1] <= 3.5e-2
-    assert res["fp8"][0] <= 2e-3, "stated fp8 loss tolerance"
+    assert res["fp8"][0] <= 2e-4, "stated fp8 loss tolerance (measured 1.8e-5 ... 3.2e-5; 2e-3 until round 6)"
     assert res["fp8"][1] <= 0.12
 
 

@@ -119,3 +119,31 @@ def test_backward_on_a_workspace_no_forward_filled_is_refused():
     assert lib.hsimae_backward(C.byref(cfg), C.byref(io_), scratch.data_ptr(), _lib.BUCKET_CB(0), None, stream) == 0
     torch.cuda.synchronize()
     st.release()
+
+
+def test_encoder_only_forward_invalidates_an_older_decoder_record():
+    """the record of an arena is per pass.  hsimae_decode leaves a decoder record for its arena; an encoder-only forward
+    that re-fills the SAME arena (the pool hands it out again) must drop it, so a later hsimae_decode_backward on that arena
+    without a fresh decode is refused (HSIMAE_ENOFORWARD) instead of walking activations the encoder pass has overwritten."""
+    m, bands = make("base")
+    N, grid = 4, (2, 7)
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(N, 1, bands, 9, 9, generator=g).to(DEV)
+    noise = (torch.rand(N, 6, generator=g), torch.rand(N, 9, generator=g))
+    with torch.no_grad():
+        lat, _, ids_restore, _ = m.forward_encoder(x, 0.75, noise=noise, grid=grid)
+        pred, st = m._run_decode(lat, ids_restore)
+    io_dec, ws_ptr = st["io"], st["io"].workspace
+    st.release()
+    _, _, _, st2 = m._run_forward(x, 0.75, noise, grid, want_latent=True, encoder_only=True)
+    if st2["io"].workspace != ws_ptr:
+        pytest.skip("the pool did not hand the decoder's arena to the encoder-only pass")
+    lib, cfg = _lib.load(), m._config()
+    dpred = torch.zeros_like(pred).reshape(-1, 72)
+    dlat = torch.empty_like(lat)
+    scratch = torch.zeros_like(m._flat)
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = lib.hsimae_decode_backward(C.byref(cfg), C.byref(io_dec), dpred.data_ptr(), dlat.data_ptr(), scratch.data_ptr(), _lib.BUCKET_CB(0), None, stream)
+    assert rc == -5, rc
+    torch.cuda.synchronize()
+    st2.release()
