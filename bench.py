@@ -267,6 +267,15 @@ def decoder_block_replay(model, N, Ts, peak_tflops, iters=10):
             "compulsory_bytes": {"fwd": float(M) * (4 * 4 * d + 2 * 2 * d + 2 * 32), "bwd": float(M) * (6 * 4 * d + 2 * d + 32)}}
 
 
+def _build_info():
+    from hsimae_amd import _lib
+    from hsimae_amd.build import kernel_source_hash
+    b = _lib.build_info()
+    return {"variant": b["variant"], "variant_bits": b["variant_bits"], "default_flags": b["default_flags"], "flags_hash": b["flags_hash"],
+            "kernel_source_hash": b["kernel_source_hash"], "matches_sources": b["kernel_source_hash"] == kernel_source_hash(),
+            "lib": os.path.relpath(b["path"], os.path.dirname(os.path.abspath(__file__)))}
+
+
 class _Watchdog:
     """Rank 0's guarantee of ONE JSON line: `finish()` prints the complete line; if it has not been called `seconds` after the timed
     region ended, a timer thread prints what the line holds by then (the contract fields are all there) and ends the process."""
@@ -759,6 +768,9 @@ def main():
                                    f"mask 0.75, {opdesc}",
                        "per_gpu_batch": N, "global_batch": N * world, "parallelism": f"dp{world}"},
             "per_gpu": round(value / world, 1), "loss": round(last_loss, 6),
+            # what the loaded library was built from (hsimae_build_info): an ablation / instrumented build names its switches here (and the
+            # loader refuses it unless HSIMAE_ALLOW_VARIANT=1); default_flags false = a tuning knob was overridden at build time
+            "build": _build_info(),
             "gflop_per_patch": round(fl / 1e9, 4),
             "roofline": {"bound": "mfma", "achieved": round(step_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(step_tflops / peak, 4),

@@ -63,8 +63,7 @@ class PackDesc(C.Structure):
 class AttnParams(C.Structure):
     _fields_ = [("qkv", vp), ("ld", i32), ("d", i32), ("heads", i32), ("hd", i32), ("Ts", i32), ("nsamples", i32),
                 ("mode", i32), ("len_l", i32), ("o", vp), ("ldo", i32), ("lse", vp), ("dout", vp), ("lddo", i32),
-                ("dqkv", vp), ("proj_w", vp), ("proj_b", vp), ("xres", vp), ("x1", vp), ("projT_w", vp), ("rowscale", vp),
-                ("kv_off", i32)]
+                ("dqkv", vp), ("kv_off", i32)]
 
 
 class MlpWeights(C.Structure):

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhsimae_hip.so")
-UNITS = ["gemm", "gemm_dma", "attn", "attn_wide", "wgrad", "elem", "pack", "fused_dec", "fused_enc", "loader", "api"]
+UNITS = ["gemm", "attn", "attn_wide", "wgrad", "elem", "pack", "fused_dec", "fused_enc", "loader", "api"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # HSIMAE_HIPCC_EXTRA: extra hipcc flags for experiments (e.g. "-Xclang -target-feature -Xclang -packed-fp32-ops",
 # which removes the v_pk_*_f32 forms: measured neutral on the step, so not the default)

@@ -84,7 +84,7 @@ uint32_t sched_from_env() {
     if (!off("HSIMAE_ATTN_BWD_RECOMPUTE")) b |= SC_RECOMPUTE;
     if (!off("HSIMAE_WGRAD_SLAB")) b |= SC_WGRAD_SLAB;
     if (!off("HSIMAE_DEC_SLAB")) b |= SC_DEC_SLAB;
-    if (!off("HSIMAE_WGRAD_PLANAR") && hs_wgrad_dma_enabled()) b |= SC_PLANAR;
+    if (!off("HSIMAE_WGRAD_PLANAR")) b |= SC_PLANAR;
     if (!off("HSIMAE_FUSED_ATTN_BLOCK256_BWD")) b |= SC_ATTN_BLOCK256_BWD;
     return b;
 }
@@ -274,17 +274,12 @@ int block_fwd(const BlkP& P, uint32_t sc, const float* x_in, const BlkBuf& b, in
     AttnParams a; std::memset(&a, 0, sizeof(a));
     a.qkv = b.qkv; a.ld = 3 * dp; a.d = d; a.heads = heads; a.hd = d / heads; a.Ts = Ts; a.nsamples = nsamples;
     a.mode = mode; a.len_l = len_l; a.o = b.o; a.ldo = dp; a.lse = b.lse; a.kv_off = dp;
-    if (!f8u && hs_attn_proj_fusable(a)) {    // proj + residual inside the attention kernel (x1 = x + o Wp^T + b)
-        a.proj_w = P.p; a.proj_b = P.pb; a.xres = x_in; a.x1 = b.x1; a.rowscale = rs_a;
-        CK(hs_attn_fwd(a, s));
-    } else {
-        CK(hs_attn_fwd(a, s));
-        p = gp();
-        p.A = b.o; p.lda = dp; p.M = (int)M; p.N = dp; p.K = dp; p.n_valid = d; p.W = P.p; p.bias = P.pb;
-        p.res = x_in; p.ldr = dp; p.out = b.x1; p.ldo = dp; p.out_rowscale = rs_a;
-        w8(p, P.p8);
-        CK(hs_gemm(p, A_BF16, E_RES_F32, s));
-    }
+    CK(hs_attn_fwd(a, s));
+    p = gp();
+    p.A = b.o; p.lda = dp; p.M = (int)M; p.N = dp; p.K = dp; p.n_valid = d; p.W = P.p; p.bias = P.pb;
+    p.res = x_in; p.ldr = dp; p.out = b.x1; p.ldo = dp; p.out_rowscale = rs_a;
+    w8(p, P.p8);
+    CK(hs_gemm(p, A_BF16, E_RES_F32, s));
     }
     if (!f8u && fused_mlp_enabled(d, h, sc)) return hs_enc_mlp_fwd(b.x1, res2, b.x2, (int)M, d, mlp_ptrs(P, h), s, rs_m);
     p = gp();
@@ -411,8 +406,6 @@ int block_bwd(const BlkP& P, uint32_t sc, const BlkOff& o, float* grads, const f
         CK(hs_attn_block_bwd(rc ? nullptr : b.qkv, b.u, P.qkv, P.bqkv, b.o, b.lse, w.g1b, G1, x_in, P.n1w, P.pT, P.qkvT, w.dqkv, dx_out,
                              grads + o.n1w, grads + o.n1b, grads, reinterpret_cast<long long*>(det_acc), Ts, nsamples, mode, len_l,
                              accumulate, s));
-    } else if (fuse_pb && fmlp && hs_attn_proj_fusable(a)) {    // dO = dx1 Wp inside the attention backward (dx1 = the bf16 copy from enc_mlp_bwd)
-        a.dout = w.g1b; a.projT_w = P.pT;
     } else {
         p = gp();
         p.A = w.g1b; p.lda = dp; p.M = (int)M; p.N = dp; p.K = dp; p.n_valid = dp;  // (the bf16 copy carries the DropPath factor)
@@ -433,7 +426,7 @@ int block_bwd(const BlkP& P, uint32_t sc, const BlkOff& o, float* grads, const f
         p.out = dx_out; p.ldo = d; p.res = G1; p.ldr = d; p.lnx = x_in; p.gamma = P.n1w; p.accumulate = accumulate;
         p.dgamma = grads + o.n1w; p.dbeta = grads + o.n1b; p.det_base = grads; p.det_acc = det_acc;
         if (d != 128) w8(p, P.qkvT8);
-        CK(hs_gemm(p, A_BF16, E_LN_BWD, s));       // d = 128, K = 384: the persistent LDS-DMA kernel of gemm_dma.hip; d = 256 / 512: k-outer
+        CK(hs_gemm(p, A_BF16, E_LN_BWD, s));       // d = 128: row-panel kernel with the LN backward as its epilogue; d = 256 / 512: k-outer
     } else {
         p.out = w.du; p.ldo = dp;
         w8(p, P.qkvT8);
@@ -477,7 +470,6 @@ int make_ctx(const hsimae_config* cfg, const hsimae_io* io, Ctx& c, bool need_ws
 
 // ====================================================================== C ABI
 extern "C" unsigned hs_variant_bits_gemm();
-extern "C" unsigned hs_variant_bits_gemm_dma();
 extern "C" unsigned hs_variant_bits_attn();
 extern "C" unsigned hs_variant_bits_attn_wide();
 extern "C" unsigned hs_variant_bits_wgrad();
@@ -503,7 +495,7 @@ int hsimae_version(void) { return HSIMAE_VERSION; }
 int hsimae_build_info(hsimae_build_info_t* out) {
     if (!out) return HSIMAE_ENULL;
     out->abi_version = HSIMAE_VERSION;
-    out->variant_bits = hs_variant_bits() | hs_variant_bits_gemm() | hs_variant_bits_gemm_dma() | hs_variant_bits_attn() | hs_variant_bits_attn_wide() | hs_variant_bits_wgrad() | hs_variant_bits_elem() | hs_variant_bits_pack() | hs_variant_bits_fused_dec() | hs_variant_bits_fused_enc() | hs_variant_bits_loader();
+    out->variant_bits = hs_variant_bits() | hs_variant_bits_gemm() | hs_variant_bits_attn() | hs_variant_bits_attn_wide() | hs_variant_bits_wgrad() | hs_variant_bits_elem() | hs_variant_bits_pack() | hs_variant_bits_fused_dec() | hs_variant_bits_fused_enc() | hs_variant_bits_loader();
     out->kernel_source_hash = HS_KERNEL_SOURCE_HASH;
     out->flags_hash = HS_BUILD_FLAGS_HASH;
     out->default_flags = HS_BUILD_DEFAULT_FLAGS;

@@ -34,309 +34,10 @@
 #define HS_BB_WQ_RESIDENT 1   /* blk128_bwd_kernel<RC>: forward Wqkv fragments resident (1) or streamed from L2 per group (0) */
 #endif
 #ifndef HS_NT_E
-#define HS_NT_E 0      /* dqkv of attn128_bwd */
+#define HS_NT_E 0      /* dq|dk|dv rows of blk128_bwd as streaming stores */
 #endif
 
 namespace {
-
-template <int HD>
-__device__ __forceinline__ bf16x8 frag_row(const bf16_t* base, int row, int g) {
-    // row-major [token][HD] image: A/B fragment element j = feature 8g + j of token `row`
-    if (g * 8 < HD) return *reinterpret_cast<const bf16x8*>(base + row * HD + g * 8);
-    return zero8();
-}
-
-template <int HD>
-__device__ __forceinline__ bf16x8 frag_tr(const bf16_t* base, int vst, int drow, int ta, int tb, int g) {
-    // transposed [feature][token] image: element j<4 = token 16*ta + 4g + j, j>=4 = token 16*tb + 4g + (j-4)
-    if (drow < HD) {
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(base + drow * vst + ta * 16 + g * 4);
-        const u32x2 hi = *reinterpret_cast<const u32x2*>(base + drow * vst + tb * 16 + g * 4);
-        u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-        return __builtin_bit_cast(bf16x8, v);
-    }
-    return zero8();
-}
-
-__device__ __forceinline__ bf16x8 pack_pair(f32x4 a, f32x4 b) {
-    bf16x8 r;
-    r[0] = (bf16_t)a[0]; r[1] = (bf16_t)a[1]; r[2] = (bf16_t)a[2]; r[3] = (bf16_t)a[3];
-    r[4] = (bf16_t)b[0]; r[5] = (bf16_t)b[1]; r[6] = (bf16_t)b[2]; r[7] = (bf16_t)b[3];
-    return r;
-}
-
-__device__ __forceinline__ float group_max(float v) {   // over the 4 lane groups sharing lane&15
-    return rows_max(v);
-}
-__device__ __forceinline__ float group_sum(float v) {
-    return rows_sum(v);
-}
-
-template <int HD, int NT>
-struct Lay {
-    static constexpr int NTP = (NT + 1) & ~1;            // key tiles rounded to pairs (K = 32 per MFMA)
-    static constexpr int ROWS = NTP * 16;
-    static constexpr int VST = ROWS + 8;                  // transposed-image row stride (elements)
-    static constexpr int RM = ROWS * HD;                  // row-major image elements
-    static constexpr int TR = HD * VST;                   // transposed image elements
-    static constexpr int FWD_WAVE = (2 * RM + TR) * 2;                      // Qr Kr Vt
-    static constexpr int BWD_WAVE = (4 * RM + 3 * TR) * 2 + 2 * ROWS * 4;   // Qr Kr Vr dOr Qt Kt dOt lse delta
-    static constexpr int CLS = ROWS * 4;
-};
-
-template <int HD, int NT>
-__device__ __forceinline__ void fill_cls(int* cls, const AttnParams& p) {
-    using L = Lay<HD, NT>;
-    for (int i = threadIdx.x; i < L::ROWS; i += 256) {
-        int c = -1;
-        if (i < p.Ts) c = (p.mode == 1) ? i / p.len_l : (p.mode == 2) ? i % p.len_l : 0;
-        cls[i] = c;
-    }
-}
-
-// Load one head's [Ts][HD] slice (16-B pieces) into a row-major and/or transposed LDS image.
-template <int HD>
-__device__ __forceinline__ void load_slice(const bf16_t* src, int ld, int Ts, int lane, bf16_t* rowmajor,
-                                           bf16_t* transposed, int vst) {
-    constexpr int PPT = HD / 8;
-    for (int idx = lane; idx < Ts * PPT; idx += 64) {
-        const int tok = idx / PPT, pc = idx % PPT;
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)tok * ld + pc * 8);
-        if (rowmajor) *reinterpret_cast<bf16x8*>(rowmajor + tok * HD + pc * 8) = v;
-        if (transposed) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) transposed[(pc * 8 + e) * vst + tok] = v[e];
-        }
-    }
-}
-
-template <int HD, int NT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
-    using L = Lay<HD, NT>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int hgroups = (p.heads + 3) / 4;
-    const int sample = blockIdx.x / hgroups, head = (blockIdx.x % hgroups) * 4 + wave;
-    const bool active = head < p.heads;
-    int* cls = reinterpret_cast<int*>(smem);
-    bf16_t* Qr = reinterpret_cast<bf16_t*>(smem + L::CLS + wave * L::FWD_WAVE);
-    bf16_t* Kr = Qr + L::RM;
-    bf16_t* Vt = Kr + L::RM;
-
-    // zero the wave's region (pads must be finite zeros), then fill
-    for (int i = lane; i < L::FWD_WAVE / 16; i += 64)
-        reinterpret_cast<u32x4*>(Qr)[i] = u32x4{0u, 0u, 0u, 0u};
-    fill_cls<HD, NT>(cls, p);
-    lds_barrier();
-    const size_t row_base = (size_t)sample * p.Ts;
-    if (active) {
-        const bf16_t* base = p.qkv + row_base * p.ld + head * HD;
-        load_slice<HD>(base, p.ld, p.Ts, lane, Qr, nullptr, 0);
-        load_slice<HD>(base + KVO(p), p.ld, p.Ts, lane, Kr, nullptr, 0);
-        load_slice<HD>(base + 2 * KVO(p), p.ld, p.Ts, lane, nullptr, Vt, L::VST);
-    }
-    lds_barrier();
-    if (!active) return;
-
-    const int c16 = lane & 15, g = lane >> 4;
-    const float sc = rsqrtf((float)HD) * 1.4426950408889634f;   // hd^-0.5 * log2(e)
-
-    for (int qt = 0; qt < NT; ++qt) {
-        const int query = qt * 16 + c16;
-        if (qt * 16 >= p.Ts) break;
-        const int qcls = cls[query];
-        const bf16x8 bq = frag_row<HD>(Qr, query, g);
-        f32x4 s[NT];
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            const bf16x8 ak = frag_row<HD>(Kr, kt * 16 + c16, g);
-            s[kt] = mfma16(ak, bq, f32x4{0.f, 0.f, 0.f, 0.f});
-        }
-        float m = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
-            const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
-                s[kt][r] = ok ? s[kt][r] * sc : -INFINITY;
-                m = fmaxf(m, s[kt][r]);
-            }
-        }
-        m = group_max(m);
-        if (m == -INFINITY) m = 0.f;
-        float lsum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = exp2f(s[kt][r] - m);
-                s[kt][r] = e;
-                lsum += e;
-            }
-        lsum = group_sum(lsum);
-        const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int pp = 0; pp < L::NTP / 2; ++pp) {
-            const int ta = 2 * pp, tb = 2 * pp + 1;
-            const bf16x8 bp = pack_pair(s[ta], tb < NT ? s[tb < NT ? tb : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
-            const bf16x8 av = frag_tr<HD>(Vt, L::VST, c16, ta, tb, g);
-            o = mfma16(av, bp, o);
-        }
-        if (query < p.Ts) {
-            if (g * 4 < HD) {
-                bf16x4 ov;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
-                *reinterpret_cast<bf16x4*>(p.o + (row_base + query) * p.ldo + head * HD + g * 4) = ov;
-            }
-            if (g == 0 && p.lse) p.lse[(row_base + query) * p.heads + head] = m + log2f(fmaxf(lsum, 1e-30f));
-        }
-    }
-}
-
-template <int HD, int NT>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
-    using L = Lay<HD, NT>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int hgroups = (p.heads + 3) / 4;
-    const int sample = blockIdx.x / hgroups, head = (blockIdx.x % hgroups) * 4 + wave;
-    const bool active = head < p.heads;
-    int* cls = reinterpret_cast<int*>(smem);
-    bf16_t* Qr = reinterpret_cast<bf16_t*>(smem + L::CLS + wave * L::BWD_WAVE);
-    bf16_t* Kr = Qr + L::RM;
-    bf16_t* Vr = Kr + L::RM;
-    bf16_t* dOr = Vr + L::RM;
-    bf16_t* Qt = dOr + L::RM;
-    bf16_t* Kt = Qt + L::TR;
-    bf16_t* dOt = Kt + L::TR;
-    float* lse = reinterpret_cast<float*>(dOt + L::TR);
-    float* delta = lse + L::ROWS;
-
-    for (int i = lane; i < L::BWD_WAVE / 16; i += 64)
-        reinterpret_cast<u32x4*>(Qr)[i] = u32x4{0u, 0u, 0u, 0u};
-    fill_cls<HD, NT>(cls, p);
-    lds_barrier();
-    const size_t row_base = (size_t)sample * p.Ts;
-    if (active) {
-        const bf16_t* base = p.qkv + row_base * p.ld + head * HD;
-        load_slice<HD>(base, p.ld, p.Ts, lane, Qr, Qt, L::VST);
-        load_slice<HD>(base + KVO(p), p.ld, p.Ts, lane, Kr, Kt, L::VST);
-        load_slice<HD>(base + 2 * KVO(p), p.ld, p.Ts, lane, Vr, nullptr, 0);
-        load_slice<HD>(p.dout + row_base * p.lddo + head * HD, p.lddo, p.Ts, lane, dOr, dOt, L::VST);
-        for (int tok = lane; tok < p.Ts; tok += 64) {
-            const bf16_t* orow = p.o + (row_base + tok) * p.ldo + head * HD;
-            const bf16_t* drow = p.dout + (row_base + tok) * p.lddo + head * HD;
-            float acc = 0.f;
-#pragma unroll
-            for (int e = 0; e < HD; e += 8) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(orow + e);
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(drow + e);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc += bf2f(a[i]) * bf2f(b[i]);
-            }
-            delta[tok] = acc;
-            lse[tok] = p.lse[(row_base + tok) * p.heads + head];
-        }
-    }
-    lds_barrier();
-    if (!active) return;
-
-    const int c16 = lane & 15, g = lane >> 4;
-    const float scale = rsqrtf((float)HD);
-    const float sc = scale * 1.4426950408889634f;
-    bf16_t* dq_base = p.dqkv + row_base * p.ld + head * HD;
-
-    // ---- pass A: S^T orientation (key on rows, query on the lane) -> dQ
-    for (int qt = 0; qt < NT; ++qt) {
-        if (qt * 16 >= p.Ts) break;
-        const int query = qt * 16 + c16;
-        const int qcls = cls[query];
-        const float lq = lse[query], dl = delta[query];
-        const bf16x8 bq = frag_row<HD>(Qr, query, g);
-        const bf16x8 bdo = frag_row<HD>(dOr, query, g);
-        f32x4 ds[NT];
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            const bf16x8 ak = frag_row<HD>(Kr, kt * 16 + c16, g);
-            const bf16x8 av = frag_row<HD>(Vr, kt * 16 + c16, g);
-            const f32x4 s = mfma16(ak, bq, f32x4{0.f, 0.f, 0.f, 0.f});
-            const f32x4 dp = mfma16(av, bdo, f32x4{0.f, 0.f, 0.f, 0.f});
-            const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
-            const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls) && (qcls >= 0);
-                const float pr = ok ? exp2f(s[r] * sc - lq) : 0.f;
-                ds[kt][r] = pr * (dp[r] - dl) * scale;
-            }
-        }
-        f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int pp = 0; pp < L::NTP / 2; ++pp) {
-            const int ta = 2 * pp, tb = 2 * pp + 1;
-            const bf16x8 b = pack_pair(ds[ta], tb < NT ? ds[tb < NT ? tb : 0] : f32x4{0.f, 0.f, 0.f, 0.f});
-            const bf16x8 a = frag_tr<HD>(Kt, L::VST, c16, ta, tb, g);
-            dq = mfma16(a, b, dq);
-        }
-        if (query < p.Ts && g * 4 < HD) {
-            bf16x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)dq[r];
-            *reinterpret_cast<bf16x4*>(dq_base + (size_t)query * p.ld + g * 4) = v;
-        }
-    }
-
-    // ---- pass B: S orientation (query on rows, key on the lane) -> dK, dV
-    for (int kt = 0; kt < NT; ++kt) {
-        if (kt * 16 >= p.Ts) break;
-        const int key = kt * 16 + c16;
-        const int kcls = cls[key];
-        const bf16x8 bk = frag_row<HD>(Kr, key, g);
-        const bf16x8 bv = frag_row<HD>(Vr, key, g);
-        f32x4 pr[NT], ds[NT];
-#pragma unroll
-        for (int qt = 0; qt < NT; ++qt) {
-            const bf16x8 aq = frag_row<HD>(Qr, qt * 16 + c16, g);
-            const bf16x8 ado = frag_row<HD>(dOr, qt * 16 + c16, g);
-            const f32x4 s = mfma16(aq, bk, f32x4{0.f, 0.f, 0.f, 0.f});
-            const f32x4 dp = mfma16(ado, bv, f32x4{0.f, 0.f, 0.f, 0.f});
-            const int4 qc = *reinterpret_cast<const int4*>(cls + qt * 16 + g * 4);
-            const f32x4 lq = *reinterpret_cast<const f32x4*>(lse + qt * 16 + g * 4);
-            const f32x4 dl = *reinterpret_cast<const f32x4*>(delta + qt * 16 + g * 4);
-            const int qcl[4] = {qc.x, qc.y, qc.z, qc.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = (qcl[r] >= 0) && (qcl[r] == kcls);
-                const float pv = ok ? exp2f(s[r] * sc - lq[r]) : 0.f;
-                pr[qt][r] = pv;
-                ds[qt][r] = pv * (dp[r] - dl[r]) * scale;
-            }
-        }
-        f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int pp = 0; pp < L::NTP / 2; ++pp) {
-            const int ta = 2 * pp, tb = 2 * pp + 1;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            const bf16x8 bds = pack_pair(ds[ta], tb < NT ? ds[tb < NT ? tb : 0] : z);
-            const bf16x8 bp = pack_pair(pr[ta], tb < NT ? pr[tb < NT ? tb : 0] : z);
-            const bf16x8 aq = frag_tr<HD>(Qt, L::VST, c16, ta, tb, g);
-            const bf16x8 ado = frag_tr<HD>(dOt, L::VST, c16, ta, tb, g);
-            dk = mfma16(aq, bds, dk);
-            dv = mfma16(ado, bp, dv);
-        }
-        if (key < p.Ts && g * 4 < HD) {
-            bf16x4 vk, vv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { vk[r] = (bf16_t)dk[r]; vv[r] = (bf16_t)dv[r]; }
-            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + KVO(p) + g * 4) = vk;
-            *reinterpret_cast<bf16x4*>(dq_base + (size_t)key * p.ld + 2 * KVO(p) + g * 4) = vv;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Head dim 16 (every encoder attention): second-generation kernels.
@@ -476,7 +177,7 @@ __global__ __launch_bounds__(64 * HPW) void attn16_fwd_kernel(AttnParams p) {
             }
         }
         }
-        m = group_max(m);
+        m = rows_max(m);
         if (m == -INFINITY) m = 0.f;
         float lsum = 0.f;
 #pragma unroll
@@ -487,7 +188,7 @@ __global__ __launch_bounds__(64 * HPW) void attn16_fwd_kernel(AttnParams p) {
                 s[kt][r] = e;
                 lsum += e;
             }
-        lsum = group_sum(lsum);
+        lsum = rows_sum(lsum);
         const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
         f32x4 o = z4;                                           // o^T[d = 4g + r][query c16]
 #pragma unroll
@@ -662,279 +363,7 @@ __global__ __launch_bounds__(64 * HPW) void attn16_bwd_kernel(AttnParams p) {
     store16_wg<NT, HD, HPW>(dq_base + 2 * KVO(p), p.ld, p.Ts, nheads, img0 + 2 * L::IMG, WSTR);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// d = 128 (8 heads of 16), sequences of at most 32 tokens (every masked encoder attention of Base): third generation.
-// One workgroup = one SAMPLE, 8 waves = 8 heads.  The sample's q|k|v rows (and dO, O in the backward) are contiguous
-// in HBM (27 x 768 B): they are staged into full-row LDS images with fully coalesced 16-byte loads, each wave works on
-// its 16 columns of the images, results are written back in place and leave as whole rows.  The per-head kernels
-// above fetch 32-byte pieces at a 768-byte stride (one request per row per matrix per wave) and write 8-byte pieces.
-constexpr int FS = 128 + 8;        // full-row image stride (elements)
-
-template <int NT>
-struct LayF {
-    static constexpr int ROWS = NT * 16;
-    static constexpr int IMG = ROWS * FS;
-    static constexpr int FWD = ROWS * 4 + 3 * IMG * 2 + ROWS * 8 * 4;                                   // cls | Q K V | lse
-    // cls | Q K V dO | dX, later the per-wave transposition tiles T (dX is dead once dO = dX Wp is formed) | lse delta:
-    // 49 KB at NT = 2, three workgroups per CU
-    static constexpr int XT = (IMG * 2 > 8 * 2 * 16 * RS16 * 2) ? IMG * 2 : 8 * 2 * 16 * RS16 * 2;
-    static constexpr int BWD = ROWS * 4 + 4 * IMG * 2 + XT + 2 * 8 * ROWS * 4;
-};
-
-template <int NT, class P>
-__device__ __forceinline__ void fill_cls_f(int* cls, const P& p) {
-    for (int i = threadIdx.x; i < NT * 16; i += 512) {
-        int c = -1;
-        if (i < p.Ts) c = (p.mode == 1) ? i / p.len_l : (p.mode == 2) ? i % p.len_l : 0;
-        cls[i] = c;
-    }
-}
-
-template <int NT>
-__global__ __launch_bounds__(512) void attn128_fwd_kernel(AttnParams p) {
-    using L = LayF<NT>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int* cls = reinterpret_cast<int*>(smem);
-    bf16_t* Qf = reinterpret_cast<bf16_t*>(smem + L::ROWS * 4);
-    bf16_t* Kf = Qf + L::IMG;
-    bf16_t* Vf = Kf + L::IMG;
-    float* lse_s = reinterpret_cast<float*>(Vf + L::IMG);       // [ROWS][8]
-    const size_t row_base = (size_t)blockIdx.x * p.Ts;
-    // output projection fused in (proj_w != NULL): this wave's n-tile of Wp, fetched now, used after the attention
-    bf16x8 bw[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bw[ks] = p.proj_w ? *reinterpret_cast<const bf16x8*>(p.proj_w + ((size_t)(head * 4 + ks) * 64 + lane) * 8) : zero8();
-    fill_cls_f<NT>(cls, p);
-    for (int idx = threadIdx.x; idx < L::ROWS * 48; idx += 512) {
-        const int row = idx / 48, pc = idx - row * 48;
-        bf16x8 v = zero8();
-        if (row < p.Ts) v = *reinterpret_cast<const bf16x8*>(p.qkv + (row_base + row) * p.ld + pc * 8);
-        *reinterpret_cast<bf16x8*>(Qf + (pc >> 4) * L::IMG + row * FS + (pc & 15) * 8) = v;
-    }
-    lds_barrier();
-    const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3, hc = head * 16;
-    const float sc = 0.25f * 1.4426950408889634f;
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    for (int qt = 0; qt < NT; ++qt) {
-        if (qt * 16 >= p.Ts) break;
-        const int query = qt * 16 + c16;
-        const int qcls = cls[query];
-        const bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qf + query * FS + hc + 4 * g);
-        f32x4 s[NT];
-        float m = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (kt * 16 + c16) * FS + hc + 4 * g);
-            s[kt] = mfma_k16(ak, bq, z4);
-            const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
-            const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
-                s[kt][r] = ok ? s[kt][r] * sc : -INFINITY;
-                m = fmaxf(m, s[kt][r]);
-            }
-        }
-        m = group_max(m);
-        if (m == -INFINITY) m = 0.f;
-        float lsum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(s[kt][r] - m);
-                s[kt][r] = e;
-                lsum += e;
-            }
-        lsum = group_sum(lsum);
-        const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
-        f32x4 o = z4;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-            o = mfma_k16(tr4(Vf + (kt * 16 + 4 * g + q4) * FS + hc + 4 * p4), cvt4(s[kt]), o);
-        bf16x4 ov;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)(o[r] * inv);
-        // in place over this head's q columns of the finished query tile (no other wave reads them)
-        *reinterpret_cast<bf16x4*>(Qf + query * FS + hc + 4 * g) = ov;
-        if (g == 0) lse_s[query * 8 + head] = m + __builtin_amdgcn_logf(fmaxf(lsum, 1e-30f));
-    }
-    lds_barrier();
-    for (int idx = threadIdx.x; idx < p.Ts * 16; idx += 512) {
-        const int row = idx >> 4, pc = idx & 15;
-        *reinterpret_cast<bf16x8*>(p.o + (row_base + row) * p.ldo + pc * 8) = *reinterpret_cast<const bf16x8*>(Qf + row * FS + pc * 8);
-    }
-    for (int idx = threadIdx.x; idx < p.Ts * 2; idx += 512)
-        *reinterpret_cast<float4*>(p.lse + row_base * 8 + idx * 4) = *reinterpret_cast<const float4*>(lse_s + idx * 4);
-    if (!p.proj_w) return;
-    // x1 = xres + O Wp^T + bp (Models.py:216, 304): wave = 16 output columns, A = the O image (full rows, in Qf)
-    constexpr int XS_ = 132;
-    float* XT = reinterpret_cast<float*>(Kf);                   // fp32 staging over the K | V images (dead by now)
-    static_assert(2 * L::IMG * 2 >= L::ROWS * XS_ * 4, "fp32 staging tile must fit over K|V");
-    const float pb = p.proj_b[hc + c16];
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) {
-        f32x4 acc = {pb, pb, pb, pb};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            acc = mfma16(*reinterpret_cast<const bf16x8*>(Qf + (mt * 16 + c16) * FS + ks * 32 + g * 8), bw[ks], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) XT[(mt * 16 + 4 * g + r) * XS_ + hc + c16] = acc[r];
-    }
-    lds_barrier();
-    for (int idx = threadIdx.x; idx < p.Ts * 32; idx += 512) {
-        const int row = idx >> 5, c4 = (idx & 31) * 4;
-        float4 t = *reinterpret_cast<const float4*>(XT + row * XS_ + c4);
-        const float4 x = *reinterpret_cast<const float4*>(p.xres + (row_base + row) * 128 + c4);
-        if (p.rowscale) {                                       // DropPath: x + scale * attn(x)
-            const float q = p.rowscale[row_base + row];
-            t.x *= q; t.y *= q; t.z *= q; t.w *= q;
-        }
-        *reinterpret_cast<float4*>(p.x1 + (row_base + row) * 128 + c4) = make_float4(t.x + x.x, t.y + x.y, t.z + x.z, t.w + x.w);
-    }
-}
-
-template <int NT>
-__global__ __launch_bounds__(512) void attn128_bwd_kernel(AttnParams p) {
-    using L = LayF<NT>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, head = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int* cls = reinterpret_cast<int*>(smem);
-    bf16_t* Qf = reinterpret_cast<bf16_t*>(smem + L::ROWS * 4);
-    bf16_t* Kf = Qf + L::IMG;
-    bf16_t* Vf = Kf + L::IMG;
-    bf16_t* Df = Vf + L::IMG;
-    bf16_t* Xf = Df + L::IMG;                                   // dx1 rows (fused projection gradient only), then T
-    float* lse_s = reinterpret_cast<float*>(reinterpret_cast<char*>(Xf) + L::XT);       // [8][ROWS]
-    float* dlt_s = lse_s + 8 * L::ROWS;                         // [8][ROWS]
-    bf16_t* Tp = Xf + head * (2 * 16 * RS16);                   // this wave's P / dS transposition tiles (alias dX)
-    bf16_t* Td = Tp + 16 * RS16;
-    const size_t row_base = (size_t)blockIdx.x * p.Ts;
-    fill_cls_f<NT>(cls, p);
-    for (int idx = threadIdx.x; idx < L::ROWS * 48; idx += 512) {
-        const int row = idx / 48, pc = idx - row * 48;
-        bf16x8 v = zero8();
-        if (row < p.Ts) v = *reinterpret_cast<const bf16x8*>(p.qkv + (row_base + row) * p.ld + pc * 8);
-        *reinterpret_cast<bf16x8*>(Qf + (pc >> 4) * L::IMG + row * FS + (pc & 15) * 8) = v;
-    }
-    const bool fuse_proj = p.projT_w != nullptr;
-    bf16x8 bw[4];                                                         // this wave's n-tile (= its head's 16 columns) of Wp^T
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bw[ks] = fuse_proj ? *reinterpret_cast<const bf16x8*>(p.projT_w + ((size_t)(head * 4 + ks) * 64 + lane) * 8) : zero8();
-    for (int idx = threadIdx.x; idx < L::ROWS * 16; idx += 512) {       // dO rows + delta = rowsum(dO * O) per head
-        const int row = idx >> 4, pc = idx & 15;
-        bf16x8 d = zero8(), o = zero8();
-        if (row < p.Ts) {
-            d = *reinterpret_cast<const bf16x8*>(p.dout + (row_base + row) * p.lddo + pc * 8);
-            o = *reinterpret_cast<const bf16x8*>(p.o + (row_base + row) * p.ldo + pc * 8);
-        }
-        if (fuse_proj) {                                                 // `dout` is dx1: dO = dx1 Wp comes below; O waits in Df
-            *reinterpret_cast<bf16x8*>(Xf + row * FS + pc * 8) = d;
-            *reinterpret_cast<bf16x8*>(Df + row * FS + pc * 8) = o;
-        } else {
-            *reinterpret_cast<bf16x8*>(Df + row * FS + pc * 8) = d;
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc += bf2f(d[i]) * bf2f(o[i]);
-            acc = lanes_sum<2>(acc);                               // the head's two 8-column pieces are adjacent lanes
-            if (!(pc & 1)) dlt_s[(pc >> 1) * L::ROWS + row] = acc;
-        }
-    }
-    for (int idx = threadIdx.x; idx < L::ROWS * 8; idx += 512) {
-        const int row = idx >> 3, h = idx & 7;
-        lse_s[h * L::ROWS + row] = row < p.Ts ? p.lse[(row_base + row) * 8 + h] : 1e30f;       // past Ts: exp2(s - 1e30) = 0
-    }
-    lds_barrier();
-
-    const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3, hc = head * 16;
-    const float scale = 0.25f, sc = 0.25f * 1.4426950408889634f;
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    const int troff = (4 * g + q4) * FS + hc + 4 * p4;
-    const int ttoff = (4 * g + q4) * RS16 + 4 * p4;
-    if (fuse_proj) {
-        // dO[:, this head's 16 columns] = dx1 Wp (autograd of Models.py:216): only this wave ever touches these columns
-        // of Df, so O is read, delta formed and dO written in place without a workgroup barrier
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) {
-            f32x4 acc = z4;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                acc = mfma16(*reinterpret_cast<const bf16x8*>(Xf + (mt * 16 + c16) * FS + ks * 32 + g * 8), bw[ks], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = mt * 16 + 4 * g + r;
-                bf16_t* cell = Df + row * FS + hc + c16;
-                const bf16_t dob = (bf16_t)acc[r];
-                float v = bf2f(dob) * bf2f(*cell);
-                v = lanes_sum<16>(v);
-                if (c16 == 0) dlt_s[head * L::ROWS + row] = v;
-                *cell = dob;
-            }
-        }
-        lds_barrier();                    // every wave is done with dX before any wave's tiles overwrite it (also orders own writes)
-    }
-    const float* lse_h = lse_s + head * L::ROWS;
-    const float* dlt_h = dlt_s + head * L::ROWS;
-    f32x4 dkT[NT], dvT[NT];
-    bf16x4 KT[NT];
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) { dkT[kt] = z4; dvT[kt] = z4; KT[kt] = tr4(Kf + kt * 16 * FS + troff); }
-    for (int qt = 0; qt < NT; ++qt) {
-        if (qt * 16 >= p.Ts) break;
-        const int query = qt * 16 + c16;
-        const int qcls = cls[query];
-        const bf16x4 bq = *reinterpret_cast<const bf16x4*>(Qf + query * FS + hc + 4 * g);
-        const bf16x4 bdo = *reinterpret_cast<const bf16x4*>(Df + query * FS + hc + 4 * g);
-        const float lqn = -lse_h[query], dl = dlt_h[query];
-        const bf16x4 QT = tr4(Qf + qt * 16 * FS + troff);
-        const bf16x4 DT = tr4(Df + qt * 16 * FS + troff);
-        f32x4 dqT = z4;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            const bf16x4 ak = *reinterpret_cast<const bf16x4*>(Kf + (kt * 16 + c16) * FS + hc + 4 * g);
-            const bf16x4 av = *reinterpret_cast<const bf16x4*>(Vf + (kt * 16 + c16) * FS + hc + 4 * g);
-            const f32x4 s = mfma_k16(ak, bq, z4);
-            const f32x4 dp = mfma_k16(av, bdo, z4);
-            const int4 kc = *reinterpret_cast<const int4*>(cls + kt * 16 + g * 4);
-            const int kcl[4] = {kc.x, kc.y, kc.z, kc.w};
-            f32x4 pv, ds;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = (kcl[r] >= 0) && (kcl[r] == qcls);
-                pv[r] = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc, lqn)) : 0.f;
-                ds[r] = pv[r] * (dp[r] - dl);
-            }
-            const bf16x4 pb = cvt4(pv), dsb = cvt4(ds);
-            dqT = mfma_k16(KT[kt], dsb, dqT);
-            *reinterpret_cast<bf16x4*>(Tp + c16 * RS16 + 4 * g) = pb;
-            *reinterpret_cast<bf16x4*>(Td + c16 * RS16 + 4 * g) = dsb;
-            asm volatile("" ::: "memory");
-            const bf16x4 Bp = tr4(Tp + ttoff), Bds = tr4(Td + ttoff);
-            dkT[kt] = mfma_k16(QT, Bds, dkT[kt]);
-            dvT[kt] = mfma_k16(DT, Bp, dvT[kt]);
-        }
-        bf16x4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(dqT[r] * scale);
-        *reinterpret_cast<bf16x4*>(Qf + query * FS + hc + 4 * g) = v;       // dq in place (this head's columns, finished tile)
-    }
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {                                        // dk, dv in place: every read of K / V is done
-        const int key = kt * 16 + c16;
-        bf16x4 vk, vv;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { vk[r] = (bf16_t)(dkT[kt][r] * scale); vv[r] = (bf16_t)dvT[kt][r]; }
-        *reinterpret_cast<bf16x4*>(Kf + key * FS + hc + 4 * g) = vk;
-        *reinterpret_cast<bf16x4*>(Vf + key * FS + hc + 4 * g) = vv;
-    }
-    lds_barrier();
-    for (int idx = threadIdx.x; idx < p.Ts * 48; idx += 512) {
-        const int row = idx / 48, pc = idx - row * 48;
-        HS_NT(HS_NT_E, reinterpret_cast<bf16x8*>(p.dqkv + (row_base + row) * p.ld + pc * 8),
-              *reinterpret_cast<const bf16x8*>(Qf + (pc >> 4) * L::IMG + row * FS + (pc & 15) * 8));
-    }
-}
+constexpr int FS = 128 + 8;        // full-row image stride (elements) of the padded (HS_BF_SWZ = 0) layout of blk128_fwd_kernel
 
 // ---------------------------------------------------------------------------------------------------------------
 // The attention half of an encoder Block in ONE persistent kernel (d = 128, 8 heads, <= 32 tokens per sample):
@@ -1158,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
                         m = fmaxf(m, sv[kt][r]);
                     }
                 }
-                m = group_max(m);
+                m = rows_max(m);
                 if (m == -INFINITY) m = 0.f;
                 float lsum = 0.f;
 #pragma unroll
@@ -1169,7 +598,7 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
                         sv[kt][r] = e;
                         lsum += e;
                     }
-                lsum = group_sum(lsum);
+                lsum = rows_sum(lsum);
                 const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
                 f32x4 o = z4;
 #pragma unroll
@@ -1749,23 +1178,6 @@ int launch_blk128_bwd(const Blk128BwdArgs& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <int NT, bool BWD>
-int launch_attn128(const AttnParams& p, hipStream_t s) {
-    using L = LayF<NT>;
-    const size_t lds = BWD ? L::BWD : L::FWD;
-    static bool attr_set = false;
-    if constexpr (BWD) {
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn128_bwd_kernel<NT>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-        hipLaunchKernelGGL((attn128_bwd_kernel<NT>), dim3(p.nsamples), dim3(512), lds, s, p);
-    } else {
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn128_fwd_kernel<NT>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-        hipLaunchKernelGGL((attn128_fwd_kernel<NT>), dim3(p.nsamples), dim3(512), lds, s, p);
-    }
-    return (int)hipGetLastError();
-}
-
 template <int NT, bool BWD, int HD = 16, int HPW = 4>
 int launch_attn16(const AttnParams& p, hipStream_t s) {
     using L = Lay16<NT, HD, HPW>;
@@ -1794,67 +1206,27 @@ int launch_attn16(const AttnParams& p, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <int HD, int NT, bool BWD>
-int launch_attn(const AttnParams& p, hipStream_t s) {
-    using L = Lay<HD, NT>;
-    const int hgroups = (p.heads + 3) / 4;
-    const size_t lds = L::CLS + 4 * (size_t)(BWD ? L::BWD_WAVE : L::FWD_WAVE);
-    if (lds > 160 * 1024) return HS_EUNSUPPORTED;
-    static bool attr_set = false;
-    if constexpr (BWD) {
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<HD, NT>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-        hipLaunchKernelGGL((attn_bwd_kernel<HD, NT>), dim3(p.nsamples * hgroups), dim3(256), lds, s, p);
-    } else {
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<HD, NT>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, NT>), dim3(p.nsamples * hgroups), dim3(256), lds, s, p);
-    }
-    return (int)hipGetLastError();
-}
-
+// Stand-alone attention (the layer-at-a-time schedule of every width; at d = 128 the fused attention half, blk128_fwd / blk128_bwd,
+// is what a default pass runs).  One kernel family since round 6: per-head workgroups (attn16_*), head dim 16 as it is and head
+// dim 8 zero-extended to the K = 16 MFMA.  The first-generation kernels (head dim as the padded K = 32 contraction, images stored
+// twice) and the whole-sample d = 128 kernels with the projection fused in (attn128_*: superseded by blk128_*) were removed with
+// their switches (HSIMAE_ATTN16_V2, _ATTN8_V2, _ATTN128_V3, _FUSED_PROJ): git history at 96065d4.
 template <bool BWD>
 int dispatch(const AttnParams& p, hipStream_t s) {
     if (p.nsamples <= 0) return HS_OK;
     if (p.d != p.heads * p.hd || p.ld % 8 || p.ldo % 4) return HS_EDIMS;
+    if (BWD && !p.lse) return HS_EUNSUPPORTED;               // the backward needs the forward's logsumexp
     const int nt = (p.Ts + 15) / 16;
-    static int v2 = -1;                      // HSIMAE_ATTN16_V2=0: first-generation head-dim-16 kernels (A/B tests)
-    if (v2 < 0) { const char* e = getenv("HSIMAE_ATTN16_V2"); v2 = !(e && e[0] == '0'); }
-    if ((p.proj_w || p.projT_w) && !hs_attn_proj_fusable(p)) return HS_EUNSUPPORTED;
-    static int v3 = -1;                      // HSIMAE_ATTN128_V3=0: per-head kernels also at d = 128
-    if (v3 < 0) { const char* e = getenv("HSIMAE_ATTN128_V3"); v3 = !(e && e[0] == '0'); }
-    if (v2 && v3 && p.lse && p.d == 128 && p.heads == 8 && p.hd == 16 && nt <= 2 && p.ld == 384 && p.ldo == 128 &&
-        (!BWD || p.lddo == 128)) {
-        if (nt <= 1) return launch_attn128<1, BWD>(p, s);
-        return launch_attn128<2, BWD>(p, s);
-    }
-    if (p.hd == 16 && v2 && p.lse) {
+    if (p.hd == 16) {
         if (nt <= 1) return launch_attn16<1, BWD>(p, s);
         if (nt <= 2) return launch_attn16<2, BWD>(p, s);
         if (nt <= 3) return launch_attn16<3, BWD>(p, s);
         if (nt <= 4) return launch_attn16<4, BWD>(p, s);
         if (nt <= 7) return launch_attn16<7, BWD>(p, s);
-    }
-    static int v8 = -1;                      // HSIMAE_ATTN8_V2=0: first-generation kernels at head dim 8
-    if (v8 < 0) { const char* e = getenv("HSIMAE_ATTN8_V2"); v8 = !(e && e[0] == '0'); }
-    if (p.hd == 8 && v2 && v8 && p.lse) {    // the second-generation kernels with the head dim zero-extended to 16
+    } else if (p.hd == 8) {                                   // head dim zero-extended to 16
         if (nt <= 4) return launch_attn16<4, BWD, 8, 4>(p, s);
         if (nt <= 7) return launch_attn16<7, BWD, 8, 4>(p, s);
         if (nt <= 14) return launch_attn16<14, BWD, 8, 4>(p, s);
-    }
-    if (p.hd == 16) {
-        if (nt <= 1) return launch_attn<16, 1, BWD>(p, s);
-        if (nt <= 2) return launch_attn<16, 2, BWD>(p, s);
-        if (nt <= 3) return launch_attn<16, 3, BWD>(p, s);
-        if (nt <= 4) return launch_attn<16, 4, BWD>(p, s);
-        if (nt <= 7) return launch_attn<16, 7, BWD>(p, s);
-    } else if (p.hd == 8) {
-        if (nt <= 1) return launch_attn<8, 1, BWD>(p, s);
-        if (nt <= 2) return launch_attn<8, 2, BWD>(p, s);
-        if (nt <= 3) return launch_attn<8, 3, BWD>(p, s);
-        if (nt <= 4) return launch_attn<8, 4, BWD>(p, s);
-        if (nt <= 7) return launch_attn<8, 7, BWD>(p, s);
-        if (nt <= 14) return launch_attn<8, 14, BWD>(p, s);
     }
     return HS_EUNSUPPORTED;
 }
@@ -1862,13 +1234,9 @@ int dispatch(const AttnParams& p, hipStream_t s) {
 }  // namespace
 
 int hs_attn_fwd(const AttnParams& p, hipStream_t s) { return dispatch<false>(p, s); }
+// shape predicate of the fused attention half at d = 128 (blk128_fwd / blk128_bwd): 8 heads of 16, <= 32 tokens, unpadded rows
 bool hs_attn_proj_fusable(const AttnParams& p) {
-    static int v3 = -1;
-    if (v3 < 0) {
-        const char* e = getenv("HSIMAE_ATTN128_V3"); const char* e2 = getenv("HSIMAE_ATTN16_V2"); const char* e3 = getenv("HSIMAE_FUSED_PROJ");
-        v3 = !(e && e[0] == '0') && !(e2 && e2[0] == '0') && !(e3 && e3[0] == '0');
-    }
-    return v3 && p.lse && p.d == 128 && p.heads == 8 && p.hd == 16 && p.Ts <= 32 && p.ld == 384 && p.ldo == 128;
+    return p.lse && p.d == 128 && p.heads == 8 && p.hd == 16 && p.Ts <= 32 && p.ld == 384 && p.ldo == 128;
 }
 int hs_attn_bwd(const AttnParams& p, hipStream_t s) { return dispatch<true>(p, s); }
 

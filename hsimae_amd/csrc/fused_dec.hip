@@ -85,7 +85,7 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases(unsign
 #define HS_DEC_PRIO 0
 #endif
 #ifndef HS_DEC_CORE_NQ
-#define HS_DEC_CORE_NQ 1
+#define HS_DEC_CORE_NQ 2      /* measured (profiles/r06_d_decoder_ab.txt): 308 -> 299 us per launch with two; the core is then ~75 % issue-bound */
 #endif
 // Lane geometry (GeoB and what is derived from it) re-derived from an opaque copy of threadIdx.x instead of kept alive across the
 // sample loop: 0 = never, 1 = on entry to and exit from the attention core of dec_bwd_attn only, 2 = at every phase.

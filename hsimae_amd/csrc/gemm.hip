@@ -901,7 +901,6 @@ int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s) {
     if (p.M <= 0) return HS_OK;
     if (p.K % 32 || p.N % 16 || p.lda % 8 || p.ldo % 8) return HS_EDIMS;
     if ((epi == E_F32 || epi == E_RES_F32 || epi == E_POS_F32) && p.n_valid % 8) return HS_EDIMS;
-    if (akind == A_F32_LN && epi == E_BF16 && !g_force_bm && p.prec != HSIMAE_PREC_FP8 && hs_lnqkv_supported(p)) return hs_lnqkv(p, s);   // persistent LN1 + q|k|v (gemm_dma.hip)
 #define CASE(AK, EP) \
     if (akind == AK && epi == EP) return launch_kc<AK, EP>(p, s);
     CASE(A_F32_LN, E_BF16)
@@ -935,7 +934,6 @@ int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s) {
         if (p.prec == HSIMAE_PREC_FP8) return HS_EUNSUPPORTED;
         if (p.N != 128 || p.n_valid != 128 || !p.lnx || !p.res || !p.gamma || !p.dgamma || !p.dbeta || p.ldr % 4 || p.ldo % 4)
             return HS_EUNSUPPORTED;
-        if (hs_lnbwd_dma_supported(p)) return hs_lnbwd_dma(p, s);      // persistent, LDS-DMA fed (gemm_dma.hip)
         return launch_kc<A_BF16, E_LN_BWD>(p, s);
     }
     CASE(A_F32, E_SWIGLU_BWD)

@@ -23,14 +23,10 @@ typedef hsimae_cube_params CubeParams;
 
 int hs_gemm(const GemmParams& p, int akind, int epi, hipStream_t s);
 int hs_gemm_tiled(const GemmParams& p, int akind, int epi, int bm, int kc, hipStream_t s);   // tile sweep hook
-bool hs_lnbwd_dma_supported(const GemmParams& p);     // persistent LDS-DMA form of (A_BF16, E_LN_BWD) at N = 128, K = 384
-int hs_lnbwd_dma(const GemmParams& p, hipStream_t s);
-bool hs_lnqkv_supported(const GemmParams& p);          // persistent form of (A_F32_LN, E_BF16) at K = 128, N = 384
-int hs_lnqkv(const GemmParams& p, hipStream_t s);
 int hs_pack(const PackDesc* descs_dev, int ndesc, int max_elems, hipStream_t s);
 int hs_attn_fwd(const AttnParams& p, hipStream_t s);
 int hs_attn_bwd(const AttnParams& p, hipStream_t s);
-bool hs_attn_proj_fusable(const AttnParams& p);      // proj_w / projT_w fusion available for this shape (d=128, 8 heads, Ts<=32)
+bool hs_attn_proj_fusable(const AttnParams& p);      // shape predicate of the fused attention half (d = 128, 8 heads of 16, Ts <= 32, unpadded rows)
 int hs_wgrad(const WgradParams& p, hipStream_t s);
 int hs_ln_bwd(const LnBwdParams& p, hipStream_t s);
 int hs_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int M, int d, hipStream_t s, int ldx = 0, int ldo = 0);
@@ -104,7 +100,6 @@ int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, 
 int hs_enc_mlp_bwd(const float* x1, const float* dy, float* dx1, hs_bf16* u2, hs_bf16* dh13, hs_bf16* g, hs_bf16* dyb,
                    hs_bf16* dx1b, int M, int d, const EncMlpPtrs& b, float* g_n2w, float* g_n2b, hipStream_t s,
                    const float* rs_mlp = nullptr, const float* rs_attn = nullptr, HsDet det = HsDet{nullptr, nullptr}, int plane_rows = 0);
-bool hs_wgrad_dma_enabled();      // the LDS-DMA weight-gradient kernel is not switched off (HSIMAE_WGRAD_DMA=0): planar operands need it
 
 int hs_adamw(float* p, const float* g, float* m, float* v, const unsigned char* group, int64_t n, float lr, float b1, float b2,
              float eps, float wd, int step, hipStream_t s);

@@ -473,12 +473,6 @@ __global__ __launch_bounds__(512) void wgrad_slab_reduce_kernel(WgradParams p) {
 
 }  // namespace
 
-bool hs_wgrad_dma_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("HSIMAE_WGRAD_DMA"); on = !(e && e[0] == '0'); }
-    return on != 0;
-}
-
 int hs_wgrad(const WgradParams& p, hipStream_t s) {
     if (p.ntasks <= 0 || p.M <= 0) return HS_OK;
     if (p.ntasks > 16 || p.msplit < 1) return HS_EDIMS;
@@ -494,21 +488,16 @@ int hs_wgrad(const WgradParams& p, hipStream_t s) {
         any_planar = any_planar || p.t[i].dO_plane_rows || p.t[i].A_plane_rows;
     }
     const int tiles = wg_tiles(p, 128);
-    // all operands bf16 and addressable with 32-bit buffer offsets -> LDS-DMA kernel (HSIMAE_WGRAD_DMA=0 disables it)
-    static int dma_ok = -1, big_ok = -1, ds_env = -1;
-    if (dma_ok < 0) {
-        const char* e = getenv("HSIMAE_WGRAD_DMA"); dma_ok = !(e && e[0] == '0');
-        e = getenv("HSIMAE_WGRAD_BIG"); big_ok = !(e && e[0] == '0');
-        e = getenv("HSIMAE_WGRAD_DS");
-        ds_env = e ? atoi(e) : 0;
-        if (ds_env < 3 || ds_env > 6) ds_env = 0;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WT<false>::STAGE_ELEMS * 2);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * WT<false>::STAGE_ELEMS * 2);
+    // all operands bf16 and addressable with 32-bit buffer offsets -> LDS-DMA kernels; fp32 dO (the layer-at-a-time schedule) or larger
+    // extents -> the register-staged wgrad_kernel.  (The switches that forced the older choice — HSIMAE_WGRAD_DMA, _WGRAD_BIG, _WGRAD_DS —
+    // and the ring depths nobody ran went in round 6.)
+    static bool attrs = false;
+    if (!attrs) {
+        attrs = true;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * WT<false>::STAGE_ELEMS * 2);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WT<true>::STAGE_ELEMS * 2);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_dma_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WT<true>::STAGE_ELEMS * 2);
     }
-    bool dma = dma_ok != 0, big = big_ok != 0;
+    bool dma = true, big = true;
     for (int i = 0; i < p.ntasks; ++i) {
         const WgradTask& t = p.t[i];
         if (t.dO_f32 || (int64_t)(p.M + DC) * t.ldo * 2 >= (1ll << 32) || (int64_t)(p.M + DC) * t.lda * 2 >= (1ll << 32)) dma = false;
@@ -529,20 +518,16 @@ int hs_wgrad(const WgradParams& p, hipStream_t s) {
         // 35.70 -> 35.27 ms per step); with few slices per tile (Huge: 52 tiles x 4) the atomics are uncontended and the extra
         // 64 MB pass costs more than it saves (48.86 -> 49.06 ms): atomics there
         if (total > 256 || q.msplit < 8) q.slab = nullptr;
-        if (ds_env == 3) hipLaunchKernelGGL((wgrad_dma_kernel<3, true>), grid, dim3(512), 3 * WT<true>::STAGE_ELEMS * 2, s, q);
-        else hipLaunchKernelGGL((wgrad_dma_kernel<4, true>), grid, dim3(512), 4 * WT<true>::STAGE_ELEMS * 2, s, q);
+        hipLaunchKernelGGL((wgrad_dma_kernel<4, true>), grid, dim3(512), 4 * WT<true>::STAGE_ELEMS * 2, s, q);
         if (q.slab) hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(t256 * 128), dim3(512), 0, s, q);
         return (int)hipGetLastError();
     }
     const dim3 grid((p.msplit & 7) == 0 ? 8 * tiles * (p.msplit / 8) : 8 * ((tiles + 7) / 8) * p.msplit);      // decode_wg
     if (dma) {
         // ring depth: a launch of at most one workgroup per CU has the LDS to itself (6 stages = 96 KB); larger
-        // launches keep 3 stages so that three workgroups fit a CU.  HSIMAE_WGRAD_DS=3..6 forces one.
+        // launches keep 3 stages so that three workgroups fit a CU
         constexpr int SB = WT<false>::STAGE_ELEMS * 2;
-        const int ds = ds_env ? ds_env : (grid.x <= 256 ? 6 : 3);
-        if (ds == 3) hipLaunchKernelGGL((wgrad_dma_kernel<3, false>), grid, dim3(256), 3 * SB, s, p);
-        else if (ds == 4) hipLaunchKernelGGL((wgrad_dma_kernel<4, false>), grid, dim3(256), 4 * SB, s, p);
-        else if (ds == 5) hipLaunchKernelGGL((wgrad_dma_kernel<5, false>), grid, dim3(256), 5 * SB, s, p);
+        if (grid.x > 256) hipLaunchKernelGGL((wgrad_dma_kernel<3, false>), grid, dim3(256), 3 * SB, s, p);
         else hipLaunchKernelGGL((wgrad_dma_kernel<6, false>), grid, dim3(256), 6 * SB, s, p);
     } else {
         hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, p);

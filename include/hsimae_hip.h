@@ -51,7 +51,8 @@ extern "C" {
 /* ABI version of this header; hsimae_version() returns the value the loaded library was built with, and a binder must
  * refuse a library that answers differently (hsimae_amd/_lib.py does).  104 (round 5): HSIMAE_ENOFORWARD, schedule recorded
  * by the forward; 103 -> 104 also covers round 4's incompatible change of the weight-gradient parameter block (t[8] -> t[16]), which had
- * shipped without a bump.  105 (round 6): hsimae_build_info. */
+ * shipped without a bump.  105 (round 6): hsimae_build_info; hsimae_attn_params lost the fused-projection fields
+ * (proj_w .. rowscale) with the whole-sample d = 128 attention kernels they drove (superseded by the fused attention half). */
 #define HSIMAE_VERSION 105
 int hsimae_version(void);
 /* What the loaded library was built from (round 6).  `variant_bits` has one bit per compile-time switch that makes a kernel
@@ -280,15 +281,6 @@ typedef struct {
     float* lse;
     const hs_bf16* dout; int32_t lddo;
     hs_bf16* dqkv;
-    /* optional fusion of the output projection + residual (Models.py:216, 304), forward, d = 128 / 8 heads / Ts <= 32
-       only: x1 = xres + o * Wp^T + bp.  proj_w: packed [128][128] image; NULL = attention only. */
-    const hs_bf16* proj_w; const float* proj_b; const float* xres; float* x1;
-    /* optional fusion of the projection's data gradient, backward, same shapes: dout is then taken as
-       dO = dx1 * Wp with dx1 the bf16 [rows][128] gradient of x1 (Models.py:216 backward) and projT_w the packed
-       transposed image; NULL = dout is dO itself. */
-    const hs_bf16* projT_w;
-    /* optional per-row factor [rows] on the fused projection branch (DropPath): x1 = xres + rowscale * (o Wp^T + bp) */
-    const float* rowscale;
     /* column offset of k (and 2x: of v) inside a qkv / dqkv row when rows are stored wider than d (storage width); 0 = d */
     int32_t kv_off;
 } hsimae_attn_params;

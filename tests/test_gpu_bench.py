@@ -28,6 +28,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     # per-kernel and per-group evidence: the dominant encoder kernels, the decoder group and one fused decoder Block
     for k in ("roofline_kernel", "roofline_kernel_hbm", "roofline_decoder", "roofline_decoder_block", "encoder_mfma_frac", "step_ms"):
         assert k in d, k
+    # the line says what library produced it (VERDICT r05 "Next round" 5): the shipped one, built from these sources, no variant switch
+    b = d["build"]
+    assert b["variant"] == [] and b["variant_bits"] == 0 and b["default_flags"] is True and b["matches_sources"] is True
     blk = d["roofline_decoder_block"]
     assert 50 < blk["fwd_us"] < 1000 and 100 < blk["bwd_us"] < 3000 and 0 < blk["frac"] < 1
 

@@ -87,7 +87,8 @@ def compare(m, loss, ref_loss, ref_grads, named_keys, tag, loss_gate=1e-4, named
 # std = 0.02 is the reference's weight scale (Models.py:452), where the loss barely depends on the network (~1.01); std = 0.08 is the
 # non-degenerate regime (VERDICT r05 weak spot 1 / "Next round" 4a): activations that are not LayerNorm noise through the
 # full-size weight-gradient reductions.  Its loss gate is 1e-3 (rounding the WEIGHTS to bf16 alone moves the loss by 1-4e-4 there:
-# test_c1_base48_against_oracle_loss_latent_grads), the gradient gates are the same.
+# test_c1_base48_against_oracle_loss_latent_grads), the gradient gates are the same.  Measured (profiles/r06_d_new_parity_tests.txt):
+# loss 1.07e-4, named tensors worst 9.3e-3 RMS-rel (a LayerNorm weight) / 3.4e-3 on the norm, every other tensor <= 1.33e-2.
 @pytest.mark.parametrize("grid,std,loss_gate", [((3, 9), 0.02, 1e-4), ((9, 3), 0.02, 1e-4), ((9, 3), 0.08, 1e-3)])
 def test_c2_n4096_loss_and_gradients_against_the_oracle(grid, std, loss_gate):
     cfg = O.OracleConfig(bands=96)
@@ -149,6 +150,7 @@ def test_huge_fp8_n1024_against_the_mx_operand_oracle():
     loss.backward()
     torch.cuda.synchronize()
     ref_loss, ref_grads = oracle_in_chunks(state, cfg, x, n1, n2, grid, chunk=64, operands=O.operands_mx8)
-    # gates: N = 6 measured loss 1e-6, encoder gradients median 0.002 / worst 0.022-0.036 (a decoder q bias) against this oracle
+    # measured (profiles/r06_d_new_parity_tests.txt): loss 1.4e-7, named tensors worst 4.8e-4 RMS-rel / 1.8e-4 on the norm, every other
+    # tensor <= 2.6e-3 (a decoder q weight) — gated at ~5x that
     compare(m, loss.item(), ref_loss, ref_grads, NAMED_HUGE, f"Huge fp8 N=1024 grid {grid} vs MX-operand oracle",
-            loss_gate=2e-5, named_gate=1.5e-2, norm_gate=1e-2, other_gate=6e-2)
+            loss_gate=2e-5, named_gate=3e-3, norm_gate=1e-3, other_gate=1.5e-2)
