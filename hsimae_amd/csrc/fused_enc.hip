@@ -34,6 +34,16 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases_enc(un
 #ifndef HS_NT_B
 #define HS_NT_B 0      /* u2 / dY copy / dx1 / dx1 copy */
 #endif
+// enc_mlp_bwd, planar operands (round 6): the chunk's g / dh1 / dh3 pieces leave AFTER the chunk's data-gradient products, as
+// unconditional bounds-checked buffer stores.  On gfx950 loads and stores share one in-order counter: with the stores in front of
+// the du2 products (rounds 2-5) every wait for a W1^T | W3^T fragment also waited for all but the last few operand stores of the
+// chunk — their trip to HBM — and the conditional store loop (1.5 iterations per thread) made hipcc's wait-count pass assume the
+// worst at the next chunk's first fragment use (s_waitcnt vmcnt(0)).  Behind the products the stores have a whole chunk of
+// arithmetic to drain under, and every wave issues the same six store instructions (lanes with nothing to store address past the
+// buffer's extent), so the next chunk's waits are counted ones that leave them in flight.
+#ifndef HS_MLPB_LATE_STORES
+#define HS_MLPB_LATE_STORES 1
+#endif
 
 // Forward kernel occupancy knobs (round 3, profiles/r03_d_variants.txt).  Default: the panel's fp32 copy stays in LDS for the
 // residual (XR) and three workgroups share a CU.  Without the copy (residual re-read from L2 in the store loop) a workgroup
@@ -115,11 +125,12 @@ struct MG {
     static constexpr bool PERSIST = D <= 128 && HS_MLP_FWD_PERSIST;   // forward kernel walks panels with the next one's rows prefetched
     static constexpr int LDS_FWD_IMG = R * LU * 2 + 2 * R * LC * 2;
     static constexpr int LDS_FWD = (LDS_FWD_IMG > R * LX * 4 ? LDS_FWD_IMG : R * LX * 4) + (KEEP_XR ? R * LX * 4 : 0);
-    static constexpr int LDS_BWD = 2 * R * LU * 2 + 3 * R * LC * 2;
+    static constexpr int LDS_BWD_IMG = 2 * R * LU * 2 + 3 * R * LC * 2;
+    static constexpr int LDS_BWD = LDS_BWD_IMG + 2 * NCH * 64 * 4;       // + b1 | b3, zero-padded to whole chunks (round 6)
     // backward: the fp32 tile of du2 goes over the dY panel + chunk images when they are large enough (D = 128), else
     // over the whole arena (the U2 panel is dead by then)
     static constexpr bool XS_AT_DY = R * LU * 2 + 3 * R * LC * 2 >= R * LX * 4;
-    static_assert(LDS_BWD >= R * LX * 4, "the arena must hold the fp32 staging tile");
+    static_assert(LDS_BWD_IMG >= R * LX * 4, "the arena must hold the fp32 staging tile");
     static_assert(2 * R * LU * 2 >= 2 * NTH * 8 * 4, "reduction scratch must fit in the two panels");
 };
 
@@ -444,7 +455,31 @@ struct EncMlpBwdArgs {
     int plane_rows;                  // > 0: g / dh1 / dh3 as 64-column planes [plane][plane_rows][64] (include/hsimae_hip.h, hsimae_wgrad_task)
 };
 
-template <int D, int HPE>
+// LATE: planar operands stored behind the chunk's data-gradient products (HS_MLPB_LATE_STORES above) — a compile-time choice, so
+// that the wait-count pass sees ONE order of loads and stores per instantiation
+// The panel's rows as raw buffers (round 6): a wave-uniform base + a 32-bit lane byte offset per access, rows past M read as zeros and
+// their stores are dropped by the bounds check — no 64-bit per-row-group addresses (24 registers at D = 256, where the prologue sits at
+// the 256-register limit) and no exec-masked branches around the accesses.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const void* base, long long rows, int row_bytes) {
+    const long long b = rows > 0 ? rows * row_bytes : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)b, 0x00020000);
+}
+__device__ __forceinline__ void bld8(__amdgpu_buffer_rsrc_t r, unsigned bo, float* o) {
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)bo, 0, 0));
+    const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)bo + 16, 0, 0));
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+typedef __attribute__((ext_vector_type(4))) unsigned int u32q;
+__device__ __forceinline__ void bst8f(__amdgpu_buffer_rsrc_t r, unsigned bo, const float* v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32q, f32x4{v[0], v[1], v[2], v[3]}), r, (int)bo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32q, f32x4{v[4], v[5], v[6], v[7]}), r, (int)bo + 16, 0, 0);
+}
+__device__ __forceinline__ void bst8h(__amdgpu_buffer_rsrc_t r, unsigned bo, bf16x8 v, int aux) {
+    if (aux) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32q, v), r, (int)bo, 0, 2);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32q, v), r, (int)bo, 0, 0);
+}
+
+template <int D, int HPE, bool LATE_ST = false>
 __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     using G = MG<D, HPE>;
     constexpr int R = G::R;
@@ -461,6 +496,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
     const EncMlpW& w = p.w;
     const int nt_h = HPE / 16;
     const int c8 = (threadIdx.x % LPR) * 8;
+    constexpr bool late_stores = LATE_ST;
 
     PH_DECL
     // column-split decomposition (see FrN): wave w owns n-tile w of every 64-column hidden chunk and the output
@@ -470,22 +506,24 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
     f1.template load<false>(w.w1, KSD, q.wave, 0, nt_h, q.lane);
     f3.template load<false>(w.w3, KSD, q.wave, 0, nt_h, q.lane);
     f2.template load<false>(w.w2T, KSD, q.wave, 0, nt_h, q.lane);
-    constexpr bool BPF = D == 128;                      // bias prefetch: at the other widths the 8 registers spill
-    [[maybe_unused]] Bias13 bn;                         // biases of the NEXT chunk (see Bias13)
-    if constexpr (BPF) bn.load(w.w1b, w.w3b, q.wave * 16 + q.g * 4, w.h);
+    // b1 | b3 staged once per panel in LDS (round 6): fetched from global per chunk they were vector-memory loads used at once — an
+    // s_waitcnt vmcnt(0) at the head of every chunk, which on gfx950 also waits for the previous chunk's operand stores
+    float* BL = reinterpret_cast<float*>(smem + G::LDS_BWD_IMG);        // [2][NCH * 64]
     {
         float gm[8], bt[8];
         ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
         // all of the panel's loads first: one exposed HBM round trip instead of one per row group
         constexpr int NI = R * LPR / NTH;
         float fa[NI][8], dya[NI][8];
+        const long long left = (long long)p.M - row0;                         // rows of this panel inside the matrix
+        const __amdgpu_buffer_rsrc_t xr = panel_rsrc(p.x1 + (size_t)row0 * D, left, D * 4), yr = panel_rsrc(p.dy + (size_t)row0 * D, left, D * 4);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int row = (threadIdx.x + NTH * i) / LPR;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { fa[i][e] = 0.f; dya[i][e] = 0.f; }
-            if (row0 + row < p.M) { ld8(p.x1 + (size_t)(row0 + row) * D + c8, fa[i]); ld8(p.dy + (size_t)(row0 + row) * D + c8, dya[i]); }
+            const unsigned bo = (unsigned)(((threadIdx.x + NTH * i) / LPR) * D + c8) * 4u;
+            bld8(xr, bo, fa[i]); bld8(yr, bo, dya[i]);
         }
+        const __amdgpu_buffer_rsrc_t ur = panel_rsrc(p.u2 ? p.u2 + (size_t)row0 * D : nullptr, p.u2 ? left : 0, D * 2);
+        const __amdgpu_buffer_rsrc_t ybr = panel_rsrc(p.u2 ? p.dyb + (size_t)row0 * D : nullptr, p.u2 ? left : 0, D * 2);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int pc = threadIdx.x + NTH * i, row = pc / LPR;
@@ -511,12 +549,22 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
             }
             const bf16x8 dyb8 = cvt8(dyv);
             *reinterpret_cast<bf16x8*>(DYb + row * LU + (((c8 >> 3) ^ swzp<D>(row)) << 3)) = dyb8;
-            if (ok && p.u2) {                     // (NULL operands: data path only — the caller takes its weight gradients elsewhere)
-                HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.u2 + (size_t)(row0 + row) * D + c8), ub);     // wgrad operands
+            {                                     // wgrad operands (NULL operands = an empty buffer: data path only — the caller takes
+                                                  // its weight gradients elsewhere; rows past M: dropped by the bounds check)
+                const unsigned bo = (unsigned)(row * D + c8) * 2u;
+                bst8h(ur, bo, ub, HS_NT_B);
 #ifndef HS_ABL_DW2          /* timing ablation (variant builds only): what "dW2 kept on chip" could save at most — see DESIGN 7.2 */
-                HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.dyb + (size_t)(row0 + row) * D + c8), dyb8);
+                bst8h(ybr, bo, dyb8, HS_NT_B);
 #endif
             }
+        }
+    }
+    {   // (staged behind the panel's prologue: in front of it the loads competed with the panel's rows for the last registers at D = 256)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        for (int i = tid; i < 2 * NCH * 64; i += NTH) {
+            const int m = i / (NCH * 64), o = i % (NCH * 64);
+            BL[i] = o < w.h ? (m == 0 ? w.w1b[o] : w.w3b[o]) : 0.f;
         }
     }
     lds_barrier();
@@ -535,14 +583,9 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
         {
             // operands swapped as in the forward kernel: a lane owns 4 consecutive hidden columns of one row
             f32x4 h1[MT4], h3[MT4], dg[MT4];
-            if constexpr (BPF) {
-#pragma unroll
-                for (int mt = 0; mt < MT4; ++mt) { h1[mt] = bn.b1; h3[mt] = bn.b3; dg[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            } else {
+            {
                 const int col = nt * 16 + q.g * 4;
-                f32x4 b1, b3;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { b1[r] = col + r < w.h ? w.w1b[col + r] : 0.f; b3[r] = col + r < w.h ? w.w3b[col + r] : 0.f; }
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(BL + col), b3 = *reinterpret_cast<const f32x4*>(BL + NCH * 64 + col);
 #pragma unroll
                 for (int mt = 0; mt < MT4; ++mt) { h1[mt] = b1; h3[mt] = b3; dg[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
@@ -569,7 +612,6 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                     f3.load(w.w3, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
                     f2.load(w.w2T, KSD, (c + 1) * 4 + q.wave, 0, nt_h, q.lane);
                 }
-                if constexpr (BPF) bn.load(w.w1b, w.w3b, ((c + 1) * 4 + q.wave) * 16 + q.g * 4, w.h);
             }
 #endif
 #pragma unroll
@@ -611,7 +653,7 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
         wb0.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * cw, D / 16, q.lane);
         if constexpr (!LATE) wb1.template load<false>(w.w13T, 2 * KSH, q.wave * NJO, KSH + 2 * cw + 1, D / 16, q.lane);
         // weight-gradient operands of this chunk to HBM (row-contiguous 16-B stores), columns < 352 only
-        if (p.dh13) {
+        if (!late_stores && p.dh13) {
             const int ncol = (c * 64 + 64 <= HPE) ? 64 : HPE - c * 64;       // 64 or 32
             for (int pc = threadIdx.x; pc < R * 8; pc += NTH) {
                 const int row = pc >> 3, k8 = (pc & 7) * 8;
@@ -656,6 +698,26 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                 }
             }
         }
+        if (late_stores && p.dh13) {
+            const int ncol = (c * 64 + 64 <= HPE) ? 64 : HPE - c * 64;       // 64 or 32
+            const unsigned plane = (unsigned)p.plane_rows * 64u * 2u;          // bytes per 64-column plane
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(p.g, 0, (int)(NCH * plane), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(p.dh13, 0, (int)(2 * NCH * plane), 0x00020000);
+            typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));              // opaque: the lane offsets below are derived here, per chunk, not hoisted and kept (spilled) across the kernel
+#pragma unroll
+            for (int it = 0; it < (R * 8 + NTH - 1) / NTH; ++it) {
+                const int pc = tid + it * NTH, row = pc >> 3, k8 = (pc & 7) * 8;
+                const bool ok = pc < R * 8 && row0 + row < p.M && k8 < ncol;
+                const int lrow = ok ? row : 0;
+                const int lo = lrow * LC + (((k8 >> 3) ^ swzc<D>(lrow)) << 3);
+                const unsigned po = ok ? (unsigned)c * plane + ((unsigned)(row0 + row) * 64u + (unsigned)k8) * 2u : 0xffffff00u;    // past the extent: dropped
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, *reinterpret_cast<const bf16x8*>(Gc + lo)), rg, (int)po, 0, HS_NT_A ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, *reinterpret_cast<const bf16x8*>(DH1 + lo)), rd, (int)po, 0, HS_NT_A ? 2 : 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, *reinterpret_cast<const bf16x8*>(DH3 + lo)), rd, (int)(ok ? po + NCH * plane : po), 0, HS_NT_A ? 2 : 0);
+            }
+        }
         lds_barrier();
         PH(3)
     }
@@ -673,12 +735,14 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
         ld8(w.n2w + c8, gm);
         constexpr int NI = R * LPR / NTH;
         float xa[NI][8], dya[NI][8];
+        const long long left = (long long)p.M - row0;
+        const __amdgpu_buffer_rsrc_t xr = panel_rsrc(p.x1 + (size_t)row0 * D, left, D * 4), yr = panel_rsrc(p.dy + (size_t)row0 * D, left, D * 4);
+        const __amdgpu_buffer_rsrc_t dxr = panel_rsrc(p.dx1 + (size_t)row0 * D, left, D * 4);
+        const __amdgpu_buffer_rsrc_t dbr = panel_rsrc(p.dx1b ? p.dx1b + (size_t)row0 * D : nullptr, p.dx1b ? left : 0, D * 2);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {                 // L2-hot re-reads, all in flight at once
-            const int row = (threadIdx.x + NTH * i) / LPR;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { xa[i][e] = 0.f; dya[i][e] = 0.f; }
-            if (row0 + row < p.M) { ld8(p.x1 + (size_t)(row0 + row) * D + c8, xa[i]); ld8(p.dy + (size_t)(row0 + row) * D + c8, dya[i]); }
+            const unsigned bo = (unsigned)(((threadIdx.x + NTH * i) / LPR) * D + c8) * 4u;
+            bld8(xr, bo, xa[i]); bld8(yr, bo, dya[i]);
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -705,13 +769,13 @@ __global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(Enc
                     dgam[e] += du[e] * xh[e];
                     dbet[e] += du[e];
                 }
-                st8(p.dx1 + (size_t)(row0 + row) * D + c8, o);
+                bst8f(dxr, (unsigned)(row * D + c8) * 4u, o);
                 if (p.rs_attn) {
                     const float rs = p.rs_attn[row0 + row];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] *= rs;
                 }
-                if (p.dx1b) HS_NT(HS_NT_B, reinterpret_cast<bf16x8*>(p.dx1b + (size_t)(row0 + row) * D + c8), cvt8(o));
+                bst8h(dbr, (unsigned)(row * D + c8) * 2u, cvt8(o), HS_NT_B);
             }
         }
     }
@@ -754,7 +818,8 @@ static void set_attrs() {
     static bool done = false;
     if (done) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_fwd_kernel<D, HP>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_FWD);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel<D, HP>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_BWD);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel<D, HP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_BWD);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel<D, HP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_BWD);
     done = true;
 }
 
@@ -791,22 +856,21 @@ int hs_enc_mlp_fwd(const float* x1, const float* res2, float* x2, int M, int d, 
     return launch_fwd(a, M, d, s);
 }
 
+template <int D, int HP>
+static void launch_bwd_t(const EncMlpBwdArgs& a, int M, hipStream_t s) {
+    constexpr int R = MG<D, HP>::R;
+    set_attrs<D, HP>();
+    // planar operands whose extent fits a raw buffer's 32-bit range: the late-store instantiation (HS_MLPB_LATE_STORES)
+    const bool late = HS_MLPB_LATE_STORES && a.dh13 && a.plane_rows > 0 && (size_t)2 * MG<D, HP>::NCH * a.plane_rows * 128 < 0xffffff00u;
+    if (late) hipLaunchKernelGGL((enc_mlp_bwd_kernel<D, HP, true>), dim3((M + R - 1) / R), dim3(NTH), (MG<D, HP>::LDS_BWD), s, a);
+    else hipLaunchKernelGGL((enc_mlp_bwd_kernel<D, HP, false>), dim3((M + R - 1) / R), dim3(NTH), (MG<D, HP>::LDS_BWD), s, a);
+}
+
 static int launch_bwd(const EncMlpBwdArgs& a, int M, int d, hipStream_t s) {
-    if (d == 128) {
-        constexpr int R = MG<128, 352>::R;
-        set_attrs<128, 352>();
-        hipLaunchKernelGGL((enc_mlp_bwd_kernel<128, 352>), dim3((M + R - 1) / R), dim3(NTH), (MG<128, 352>::LDS_BWD), s, a);
-    } else if (d == 256) {
-        constexpr int R = MG<256, 704>::R;
-        set_attrs<256, 704>();
-        hipLaunchKernelGGL((enc_mlp_bwd_kernel<256, 704>), dim3((M + R - 1) / R), dim3(NTH), (MG<256, 704>::LDS_BWD), s, a);
-    } else if (d == 64) {
-        constexpr int R = MG<64, 192>::R;
-        set_attrs<64, 192>();
-        hipLaunchKernelGGL((enc_mlp_bwd_kernel<64, 192>), dim3((M + R - 1) / R), dim3(NTH), (MG<64, 192>::LDS_BWD), s, a);
-    } else {
-        return HS_EUNSUPPORTED;
-    }
+    if (d == 128) launch_bwd_t<128, 352>(a, M, s);
+    else if (d == 256) launch_bwd_t<256, 704>(a, M, s);
+    else if (d == 64) launch_bwd_t<64, 192>(a, M, s);
+    else return HS_EUNSUPPORTED;
     return (int)hipGetLastError();
 }
 
