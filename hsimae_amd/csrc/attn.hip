@@ -33,6 +33,12 @@
 #ifndef HS_BB_WQ_RESIDENT
 #define HS_BB_WQ_RESIDENT 1   /* blk128_bwd_kernel<RC>: forward Wqkv fragments resident (1) or streamed from L2 per group (0) */
 #endif
+#ifndef HS_BF_EARLY_WAIT
+#define HS_BF_EARLY_WAIT 1     /* blk128_fwd_kernel: the same in front of its output stores */
+#endif
+#ifndef HS_BB_EARLY_WAIT
+#define HS_BB_EARLY_WAIT 1     /* blk128_bwd_kernel: one explicit vmcnt(0) in front of the LayerNorm epilogue (see there) */
+#endif
 #ifndef HS_NT_E
 #define HS_NT_E 0      /* dq|dk|dv rows of blk128_bwd as streaming stores */
 #endif
@@ -507,6 +513,7 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
             }
     }
     PHB_DECL
+    if (HS_BF_EARLY_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);       // the first group's rows (wanted at once): no load pending on EITHER way into the loop head
     for (int first = blockIdx.x * SPW; first < p.nsamples; first += gridDim.x * SPW) {
         // global row of image row i (slot-major), or -1
         auto grow = [&](int irow) -> int64_t {
@@ -622,6 +629,9 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
         PHB(4)
         lds_barrier();
         PHB(5)
+        // (as in blk128_bwd_kernel, HS_BB_EARLY_WAIT: the next group's x rows — issued in front of the q|k|v products — are waited for
+        //  HERE, explicitly, so that the group's o / x1 stores below are not what the next iteration's first vmcnt wait drains)
+        if (HS_BF_EARLY_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);
         int64_t orow[MTT];
 #pragma unroll
         for (int mt = 0; mt < MTT; ++mt) orow[mt] = grow(mt * 16 + c16);
@@ -880,6 +890,7 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
     }
 #endif
     PHB_DECL
+    if (HS_BB_EARLY_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);       // the resident weight fragments: no load pending on EITHER way into the loop head
     for (int first = blockIdx.x * SPW; first < p.nsamples; first += gridDim.x * SPW) {
 #if !HS_BB_WQ_RESIDENT
         // RC: this group's 12 fragments of Wqkv (n-tiles head, 8 + head, 16 + head), in flight across the barrier.  The image
@@ -1106,6 +1117,13 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
         PHB(6)
         lds_barrier();                                            // du tile complete; every read of the images is done
         PHB(7)
+        // One explicit wait for everything in flight — this group's epilogue rows, the next group's inputs (issued a phase or more
+        // ago) and the dq|dk|dv row stores — BEFORE the first dx store (round 6).  gfx950 counts loads and stores in one in-order
+        // counter and the accesses here sit under per-row predicates, so hipcc fell back to s_waitcnt vmcnt(0) in front of the second
+        // pass's arithmetic and again in front of commit(): each waited for the dx stores issued just before it, i.e. for their
+        // trip to HBM (2 x ~1 us per 11-us group).  A builtin wait is visible to the wait-count pass: after it nothing older than
+        // the dx stores is pending, and they drain under the next group's first phases.
+        if (HS_BB_EARLY_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), lgkmcnt / expcnt untouched
         // ---- LayerNorm-1 backward + residual gradient, wide layout (as lnbwd_dma_kernel's epilogue)
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {

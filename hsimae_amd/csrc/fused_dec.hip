@@ -98,6 +98,9 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases(unsign
 #ifndef HS_DEC_REGEO_MLP
 #define HS_DEC_REGEO_MLP 0
 #endif
+#ifndef HS_DEC_PRELOOP_WAIT
+#define HS_DEC_PRELOOP_WAIT 1
+#endif
 #ifndef HS_DEC_CORE_STG
 #define HS_DEC_CORE_STG 0   /* waves 4-7 enter the attention core this many x 64 clocks late (half a tile period = 4) */
 #endif
@@ -1080,7 +1083,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             bld8(xr, bo, fa[i]); bld8(yr, bo, dya[i]);
         }
     };
-    if (HS_DEC_MLP_PREFETCH) fetch_sample(blockIdx.x);
+    if (HS_DEC_MLP_PREFETCH) { fetch_sample(blockIdx.x); if (HS_DEC_PRELOOP_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70); }
     for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {
         const size_t rb = (size_t)sample * p.Ts;
         const int wl = launder_i(0);                   // keeps the LDS weight reads inside the sample loop (no LICM + spill)
@@ -1610,6 +1613,10 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         }
     };
     fetch_sample(blockIdx.x);
+    // (the first sample's rows are wanted at once: waited for HERE, with a builtin the wait-count pass can see, no load is pending on
+    //  either way into the loop head — otherwise the merged state makes the loop's first use of a prefetched row an s_waitcnt vmcnt(0),
+    //  which on the back edge drains the previous sample's dx stores: attn.hip HS_BB_EARLY_WAIT)
+    if (HS_DEC_PRELOOP_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);
     PH_DECL
     PH2_DECL
     for (int sample = blockIdx.x; sample < p.nsamples; sample += gridDim.x) {

@@ -861,7 +861,9 @@ static void launch_bwd_t(const EncMlpBwdArgs& a, int M, hipStream_t s) {
     constexpr int R = MG<D, HP>::R;
     set_attrs<D, HP>();
     // planar operands whose extent fits a raw buffer's 32-bit range: the late-store instantiation (HS_MLPB_LATE_STORES)
-    const bool late = HS_MLPB_LATE_STORES && a.dh13 && a.plane_rows > 0 && (size_t)2 * MG<D, HP>::NCH * a.plane_rows * 128 < 0xffffff00u;
+    // (D >= 256 only: at D = 128 the kernel sits on its HBM bytes either way — 136.4 / 137.2 us late against 136.9 / 135.4 early,
+    //  Large 381.1 / 374.9 against 381.7 / 380.6 and 390.2 / 389.1 before this round: profiles/r06_f_enc_mlp_bwd_ab.txt)
+    const bool late = HS_MLPB_LATE_STORES && D >= 256 && a.dh13 && a.plane_rows > 0 && (size_t)2 * MG<D, HP>::NCH * a.plane_rows * 128 < 0xffffff00u;
     if (late) hipLaunchKernelGGL((enc_mlp_bwd_kernel<D, HP, true>), dim3((M + R - 1) / R), dim3(NTH), (MG<D, HP>::LDS_BWD), s, a);
     else hipLaunchKernelGGL((enc_mlp_bwd_kernel<D, HP, false>), dim3((M + R - 1) / R), dim3(NTH), (MG<D, HP>::LDS_BWD), s, a);
 }
