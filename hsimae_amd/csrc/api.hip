@@ -318,6 +318,7 @@ int block_bwd(const BlkP& P, uint32_t sc, const BlkOff& o, float* grads, const f
     const bool f8u = f8 && (sc & SC_FP8_UNFUSED);
     auto w8 = [&](GemmParams& q, const BlkP::I8& a) { if (f8) { q.prec = HSIMAE_PREC_FP8; q.W8 = a.w; q.S8 = a.s; } };
     const bool fmlp = !f8u && fused_mlp_enabled(d, h, sc);
+    bool g1b_done = false;
     // g / dh1 / dh3 as 64-column planes (include/hsimae_hip.h, hsimae_wgrad_task): needs whole 32-row DMA chunks and 32-bit offsets
     const int hp64 = rup(hp, 64);
     const bool planar = fmlp && (sc & SC_PLANAR) && M % 32 == 0 && (M + kPlanePadRows) * 2 * (int64_t)(hp64 + 256) * 2 < (1ll << 32);
@@ -337,6 +338,7 @@ int block_bwd(const BlkP& P, uint32_t sc, const BlkOff& o, float* grads, const f
         if (wide_ln_fused(d, dp, f8, sc)) {   // LayerNorm-2 backward as the epilogue of the k-outer GEMM (the whole row is on chip)
             p.out = G1; p.ldo = dp; p.res = G0; p.ldr = dp; p.lnx = b.x1; p.gamma = P.n2w; p.accumulate = 0;
             p.dgamma = grads + o.n2w; p.dbeta = grads + o.n2b; p.det_base = grads; p.det_acc = det_acc;
+            if (!rs_a) { p.u_out = w.g1b; p.ldu = dp; g1b_done = true; }      // bf16 copy of dx1 from the epilogue (no DropPath factor to fold in)
             CK(hs_gemm(p, A_BF16, E_LN_BWD, s));
         } else {
             p.out = w.du; p.ldo = dp;
@@ -348,7 +350,7 @@ int block_bwd(const BlkP& P, uint32_t sc, const BlkOff& o, float* grads, const f
         // bf16 copies of dY / dx1 (with the DropPath factors folded in) so that the weight gradients below take the
         // LDS-DMA kernel: 666 -> ~300 us per block at D = 256
         CK(hs_rows_to_bf16(G0, w.g0b, M, dp, rs_m, s));
-        CK(hs_rows_to_bf16(G1, w.g1b, M, dp, rs_a, s));
+        if (!g1b_done) CK(hs_rows_to_bf16(G1, w.g1b, M, dp, rs_a, s));
     }
     // All weight / bias gradients of the block: 7 tasks for the batched weight-gradient kernel (every operand is a bf16 buffer on the
     // fused path, so no launch below reads G0 / G1, which the LayerNorm-1 backward overwrites with dx when the caller runs in place).

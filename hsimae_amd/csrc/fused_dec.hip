@@ -1837,6 +1837,9 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_attn_kernel(DecBwdAttnArgs p) 
         }
         PH2(3)
         lds_barrier();
+        // (both row groups' re-reads — and the next sample's rows, issued a phase ago — waited for once, before the first dx store:
+        //  a wait for the second group's rows behind the first group's stores would be an s_waitcnt vmcnt(0) that drains them)
+        if (HS_DEC_PRELOOP_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);
         PH2(4)
         PH(6)
 #pragma unroll

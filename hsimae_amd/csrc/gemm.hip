@@ -668,6 +668,9 @@ __global__ __launch_bounds__(256, (EPI == E_LN_BWD || BM <= 64) ? 2 : 1) void ge
                         for (int e = 0; e < 8; ++e) v[e] += rstd * (du[e] * gm[c][e] - a - xr[c][e] * b);
                         *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
                         *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        // optional bf16 copy of the result (u_out / ldu, round 6): the weight-gradient operand the caller otherwise
+                        // makes with a rows_to_bf16 pass over the rows just written (1.18 ms of the Huge step for both copies)
+                        if (p.u_out) *reinterpret_cast<bf16x8*>(p.u_out + (size_t)row * p.ldu + c * 128 + c8) = cvt8(v);
                     }
                 }
             }
