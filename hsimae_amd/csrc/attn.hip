@@ -374,7 +374,7 @@ constexpr int FS = 128 + 8;        // full-row image stride (elements) of the pa
 // ---------------------------------------------------------------------------------------------------------------
 // The attention half of an encoder Block in ONE persistent kernel (d = 128, 8 heads, <= 32 tokens per sample):
 //   u = LN1(x);  q|k|v = u Wqkv^T + b;  o = softmax(q k^T / 4) v per head;  x1 = x + rs * (o Wp^T + bp)
-// (Models.py:303-304 with Attention.forward :192-219).  Replaces lnqkv_kernel + attn128_fwd_kernel: q|k|v never make
+// (Models.py:303-304 with Attention.forward :192-219).  Replaced lnqkv_kernel + attn128_fwd_kernel (rounds 1-3; removed in round 6): q|k|v never make
 // the round trip through HBM between the two (they are still written once, for the backward) and x is read once
 // (it is both the LayerNorm input and the residual).  One workgroup walks samples; wave h owns head h end to end:
 // its 48 columns of Wqkv and its 16 columns of Wp stay in registers for the whole launch, its q / k / v columns go
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(512, 2) void blk128_fwd_kernel(Blk128Args p) {
         }
         PHB(3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // own writes before own reads (only this wave touches these columns)
-        // ---- attention of this head (as attn128_fwd_kernel) slot by slot, O into its own image
+        // ---- attention of this head (one head per wave) slot by slot, O into its own image
 #pragma unroll
         for (int slot = 0; slot < SPW; ++slot) {
             const int r0 = slot * ROWS;
@@ -705,7 +705,7 @@ int launch_blk128(const Blk128Args& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------
 // The attention half of an encoder Block, BACKWARD, in one persistent kernel (d = 128, 8 heads, <= 32 tokens; round 4):
 //   dO = dx1 Wp;  dq|dk|dv = attention backward per head;  du = dq|dk|dv Wqkv;  dx = dx1 + LayerNorm1-backward(du; x),  dgamma / dbeta
-// (autograd of Models.py:303-304 with Attention.forward :192-219).  Replaces attn128_bwd_kernel + lnbwd_dma_kernel: dq|dk|dv
+// (autograd of Models.py:303-304 with Attention.forward :192-219).  Replaced attn128_bwd_kernel + lnbwd_dma_kernel (rounds 1-3; removed in round 6): dq|dk|dv
 // are written once (the q / k / v weight gradients' operand) and not read back, x and dx1 are read once.  Mirror image of
 // blk128_fwd_kernel: wave h owns head h in the attention and output columns 16 h .. 16 h + 15 of both products, whose weight
 // slices (4 + 12 packed fragments = 64 registers) stay in registers for the whole launch; two samples per iteration; the next
@@ -974,7 +974,7 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // own writes before own reads
-        // ---- attention backward of this head (as attn128_bwd_kernel), slot by slot; dq, dk, dv in place
+        // ---- attention backward of this head (single pass, see attn16_bwd_kernel), slot by slot; dq, dk, dv in place
         const float* lse_h = lse_s + head * RT;
 #if !HS_BB_DELTA_PDP
         const float* dlt_h = dlt_s + head * RT;
@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(512) void blk128_bwd_kernel(Blk128BwdArgs p) {
         // trip to HBM (2 x ~1 us per 11-us group).  A builtin wait is visible to the wait-count pass: after it nothing older than
         // the dx stores is pending, and they drain under the next group's first phases.
         if (HS_BB_EARLY_WAIT) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), lgkmcnt / expcnt untouched
-        // ---- LayerNorm-1 backward + residual gradient, wide layout (as lnbwd_dma_kernel's epilogue)
+        // ---- LayerNorm-1 backward + residual gradient, wide layout (16 lanes per row)
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int irow = ps * 32 + (tx >> 4);

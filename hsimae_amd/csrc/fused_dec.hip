@@ -1177,6 +1177,11 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             lds_barrier();
         PH(1)
             regeo();
+            if (HS_DEC_MLP_PREFETCH == 2 && c == 2) {     // next sample's rows a whole weight-gradient + du2 phase + epilogue ahead of their use
+                __builtin_amdgcn_sched_barrier(0);
+                fetch_sample(sample + (int)gridDim.x);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // weight gradients of this hidden chunk: 12 (n-tile) x 4 (k-tile) output tiles, 3 x 2 per wave; on the even waves the
             // dO^T fragment also meets a tile of ones: the column sums of dY / dh1 / dh3 = this sample's bias-gradient addends
             f32x4 accb[3];
@@ -1256,7 +1261,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
                 bld8(rows_rsrc(p.x1 + rb * D, p.Ts * D * 4), bo, xe[i]); bld8(rows_rsrc(p.dy + rb * D, p.Ts * D * 4), bo, dye[i]);
             }
         }
-        if (HS_DEC_MLP_PREFETCH) {                    // next sample's rows: younger than the re-reads above, so the epilogue does not wait for them
+        if (HS_DEC_MLP_PREFETCH == 1) {               // next sample's rows: younger than the re-reads above, so the epilogue does not wait for them
             __builtin_amdgcn_sched_barrier(0);
             fetch_sample(sample + (int)gridDim.x);
             __builtin_amdgcn_sched_barrier(0);

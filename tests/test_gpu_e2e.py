@@ -413,7 +413,7 @@ def test_public_sub_entry_points_against_oracle(bands, grid):
 @pytest.mark.parametrize("bands,grid,N", [(48, (2, 7), 37), (96, (3, 9), 24), (96, (9, 3), 24)])
 def test_fused_attention_half_matches_separate_kernels(bands, grid, N):
     """blk128_fwd_kernel (LN1 -> q|k|v -> attention -> projection + residual in one persistent launch) against
-    lnqkv_kernel + attn128_fwd_kernel on the same inputs: loss, predictions and every gradient (the backward consumes
+    the layer-at-a-time kernels (LN + q|k|v GEMM, attn16_fwd, projection GEMM) on the same inputs: loss, predictions and every gradient (the backward consumes
     the u / qkv / o / lse / x1 the forward saved, so it checks those too)."""
     cfg = O.OracleConfig(bands=bands)
     m = build(cfg, O.init_state(cfg, seed=13, std=0.06))
@@ -451,7 +451,7 @@ def test_fused_attention_half_matches_separate_kernels(bands, grid, N):
                                               (96, (3, 9), 24, True)])
 def test_fused_attention_half_backward_matches_separate_kernels(bands, grid, N, det):
     """blk128_bwd_kernel (dO = dx1 Wp -> attention backward -> du = dq|dk|dv Wqkv -> LayerNorm-1 backward + residual, dgamma /
-    dbeta, in one persistent launch) against attn128_bwd_kernel + lnbwd_dma_kernel: every gradient (the q / k / v weight
+    dbeta, in one persistent launch) against the layer-at-a-time kernels (dO GEMM, attn16_bwd, du GEMM with the LayerNorm backward as its epilogue): every gradient (the q / k / v weight
     gradients read the dq|dk|dv rows the kernel writes, everything upstream reads its dx), both axis-class modes and the
     whole-sample fusion blocks, odd sample counts (pairs of samples per iteration), 14-token sequences (one key tile), the block
     whose dx accumulates into the other stack's, and the deterministic commit path of dgamma / dbeta.  Three schedules:
