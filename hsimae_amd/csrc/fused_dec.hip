@@ -70,8 +70,13 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases(unsign
 #ifndef HS_DEC_STG_MLP
 #define HS_DEC_STG_MLP 0
 #endif
+// dec_bwd_mlp: when the next sample's x1 / dY rows are requested.  0 = at the top of its own iteration (rounds 2-5: the prologue wait
+// was 21 % of the kernel); 1 = in front of the epilogue (round 5 with spills: 214 -> 220 us; round 6 without: 224 -> 221 us — half a
+// round trip of lead time); 2 = at the start of the LAST hidden chunk's weight-gradient phase, a weight-gradient + du2 phase + epilogue
+// ahead (round 6, default: 224.8 / 224.7 / 228.4 -> 215.8 / 214.2 / 215.5 us, profiles/r06_i_dec_mlp_prefetch2_ab.txt; no spill in
+// the loop); 3 = a chunk earlier still: 31 registers spilled, not measured.
 #ifndef HS_DEC_MLP_PREFETCH
-#define HS_DEC_MLP_PREFETCH 0      /* dec_bwd_mlp: 1 = x1 / dY rows one sample ahead (round-5 experiment, measured SLOWER: see the kernel) */
+#define HS_DEC_MLP_PREFETCH 2
 #endif
 #ifndef HS_TOUCH_A
 #define HS_TOUCH_A 0
@@ -1177,7 +1182,7 @@ __global__ __launch_bounds__(512, 2) void dec_bwd_mlp_kernel(DecBwdMlpArgs p) {
             lds_barrier();
         PH(1)
             regeo();
-            if (HS_DEC_MLP_PREFETCH == 2 && c == 2) {     // next sample's rows a whole weight-gradient + du2 phase + epilogue ahead of their use
+            if ((HS_DEC_MLP_PREFETCH == 2 && c == 2) || (HS_DEC_MLP_PREFETCH == 3 && c == 1)) {     // next sample's rows a whole weight-gradient + du2 phase + epilogue ahead of their use (3: a chunk more)
                 __builtin_amdgcn_sched_barrier(0);
                 fetch_sample(sample + (int)gridDim.x);
                 __builtin_amdgcn_sched_barrier(0);
