@@ -37,7 +37,7 @@ __device__ __forceinline__ unsigned word_of(int it, int wg, int idx) { return (u
 
 // WRITE: panels are written; BAR: the group barrier runs; FR: 32nds of every panel each workgroup reads back (0: none);
 // REL: agent-scope release fence (buffer_wbl2) in front of the arrival = placement-independent form
-template <bool WRITE, bool BAR, int FR, bool REL>
+template <bool WRITE, bool BAR, int FR, bool REL, bool CHECK = true>
 __global__ __launch_bounds__(NT) void exch(unsigned char* ring, unsigned* counters, int iters, int panel_bytes, unsigned* stale,
                                            unsigned* xcc_out, unsigned* tmo) {
     const int b = blockIdx.x, grp = b % GROUPS, mem = b / GROUPS;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(NT) void exch(unsigned char* ring, unsigned* counte
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     if (i0 + u * NT < total)
-                        for (int e = 0; e < 4; ++e) bad += (WRITE && BAR) ? (w[u][e] != word_of(it, wg[u], vi[u] * 4 + e)) : (w[u][e] == 0x9e3779b9u);
+                        for (int e = 0; e < 4; ++e) bad += !CHECK ? (w[u][e] == 0x9e3779b9u) : (WRITE && BAR) ? (w[u][e] != word_of(it, wg[u], vi[u] * 4 + e)) : (w[u][e] == 0x9e3779b9u);
             }
         }
     }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NT) void exch(unsigned char* ring, unsigned* counte
 
 struct Res { float us_iter; unsigned stale, tmo; bool grouped; };
 
-template <bool WRITE, bool BAR, int FR, bool REL>
+template <bool WRITE, bool BAR, int FR, bool REL, bool CHECK = true>
 Res run(unsigned char* ring, unsigned* counters, int iters, int panel_bytes, unsigned* dflags, unsigned* xcc) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
     // warm-up launch, then the timed one; counters zeroed before each (epochs count within a launch)
@@ -109,7 +109,7 @@ Res run(unsigned char* ring, unsigned* counters, int iters, int panel_bytes, uns
         CHECK(hipMemsetAsync(counters, 0, GROUPS * 256, 0));
         CHECK(hipMemsetAsync(dflags, 0, 16, 0));
         if (rep == 1) CHECK(hipEventRecord(a, 0));
-        hipLaunchKernelGGL((exch<WRITE, BAR, FR, REL>), dim3(256), dim3(NT), 0, 0, ring, counters, iters, panel_bytes, dflags, xcc, dflags + 1);
+        hipLaunchKernelGGL((exch<WRITE, BAR, FR, REL, CHECK>), dim3(256), dim3(NT), 0, 0, ring, counters, iters, panel_bytes, dflags, xcc, dflags + 1);
         if (rep == 1) CHECK(hipEventRecord(b, 0));
     }
     CHECK(hipEventSynchronize(b));
@@ -128,13 +128,16 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&ring, (size_t)GROUPS * 2 * MEMBERS * (128 << 10)));
     CHECK(hipMemset(ring, 0, (size_t)GROUPS * 2 * MEMBERS * (128 << 10)));
     CHECK(hipMalloc(&counters, GROUPS * 256)); CHECK(hipMalloc(&dflags, 16)); CHECK(hipMalloc(&xcc, 1024));
-    if (mode != 0) {          // one configuration (panel 32 KB = 1-MB halves, 2-MB ring per XCD) for the PMC passes
-        const int pb = 32 << 10;
+    if (mode != 0) {          // one configuration for the PMC passes: panel 32 KB = 1-MB halves, 2-MB ring per XCD (modes 1-5);
+                              // modes 6 / 7: panel 128 KB (one 48-row panel of enc_mlp_bwd per CU: 4-MB halves), write + barrier / + read 8/32
+        const int pb = mode >= 6 ? (128 << 10) : (32 << 10);
         Res r = mode == 1 ? run<true, false, 0, false>(ring, counters, iters, pb, dflags, xcc)
               : mode == 2 ? run<true, true, 0, false>(ring, counters, iters, pb, dflags, xcc)
               : mode == 3 ? run<true, true, 1, false>(ring, counters, iters, pb, dflags, xcc)
               : mode == 4 ? run<true, true, 8, false>(ring, counters, iters, pb, dflags, xcc)
-                          : run<true, true, 8, true>(ring, counters, iters, pb, dflags, xcc);
+              : mode == 5 ? run<true, true, 8, true>(ring, counters, iters, pb, dflags, xcc)
+              : mode == 6 ? run<true, true, 0, false>(ring, counters, iters, pb, dflags, xcc)
+                          : run<true, true, 8, false>(ring, counters, iters, pb, dflags, xcc);
         printf("mode %d panel %d KB: %.2f us/iter, ring bytes x iterations = %.1f MB written, stale %u, timeouts %u, grouped %d\n", mode, pb >> 10,
                r.us_iter, 256.0 * pb * iters / 1e6, r.stale, r.tmo, (int)r.grouped);
         return 0;
@@ -146,7 +149,7 @@ int main(int argc, char** argv) {
         r = run<false, true, 0, true>(ring, counters, iters, 16 << 10, dflags, xcc);
         printf("barrier alone with an agent release fence before the arrival: %.2f us per barrier\n", r.us_iter);
     }
-    for (int kb : {8, 16, 32, 64}) {
+    for (int kb : {8, 16, 32, 64, 128}) {       // 128 KB = the operands of ONE 48-row panel of enc_mlp_bwd (126 KB): 8 MB per XCD for the two halves
         const int pb = kb << 10;
         const double ringmb = 2.0 * MEMBERS * pb / 1048576.0;
         Res w = run<true, false, 0, false>(ring, counters, iters, pb, dflags, xcc);
@@ -162,6 +165,10 @@ int main(int argc, char** argv) {
         printf("   + read 8/32 of every panel      %7.2f us/iter  stale words %u  (L2 -> CU %5.2f TB/s)\n", f8.us_iter, f8.stale, 256.0 * 8 * pb / f8.us_iter / 1e6);
         printf("   + read ALL of every panel       %7.2f us/iter  stale words %u  (L2 -> CU %5.2f TB/s)\n", f32.us_iter, f32.stale, 256.0 * 32 * pb / f32.us_iter / 1e6);
         printf("   8/32 with release fence         %7.2f us/iter  stale words %u\n", r8.us_iter, r8.stale);
+        Res n8 = run<true, true, 8, false, false>(ring, counters, iters, pb, dflags, xcc);
+        Res n32 = run<true, true, 32, false, false>(ring, counters, iters, pb, dflags, xcc);
+        printf("   8/32, words folded not checked  %7.2f us/iter  (L2 -> CU %5.2f TB/s);  ALL: %7.2f us/iter (%5.2f TB/s)\n", n8.us_iter, 256.0 * 8 * pb / n8.us_iter / 1e6,
+               n32.us_iter, 256.0 * 32 * pb / n32.us_iter / 1e6);
     }
     return 0;
 }
