@@ -67,8 +67,11 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases(unsign
 #ifndef HS_DEC_STG_ATTN
 #define HS_DEC_STG_ATTN 5
 #endif
+// (round 6: with the next sample's rows requested early, HS_DEC_MLP_PREFETCH = 2, the stagger pays in dec_bwd_mlp too — 213.8 / 214.1 /
+//  214.8 us without, 208.4 / 206.6 / 208.5 at 4, 209.4 / 208.1 / 209.1 at 5, 209.2 / 207.6 / 208.9 at 6; dec_bwd_attn is flat between
+//  3 and 8: profiles/r06_k_dec_stagger_resweep.txt, r06_l_dec_stagger_combos.txt)
 #ifndef HS_DEC_STG_MLP
-#define HS_DEC_STG_MLP 0
+#define HS_DEC_STG_MLP 4
 #endif
 // dec_bwd_mlp: when the next sample's x1 / dY rows are requested.  0 = at the top of its own iteration (rounds 2-5: the prologue wait
 // was 21 % of the kernel); 1 = in front of the epilogue (round 5 with spills: 214 -> 220 us; round 6 without: 224 -> 221 us — half a

@@ -461,7 +461,7 @@ struct EncMlpBwdArgs {
 // their stores are dropped by the bounds check — no 64-bit per-row-group addresses (24 registers at D = 256, where the prologue sits at
 // the 256-register limit) and no exec-masked branches around the accesses.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const void* base, long long rows, int row_bytes) {
-    const long long b = rows > 0 ? rows * row_bytes : 0;
+    const long long b = rows > 0 ? (rows < 4096 ? rows : 4096) * row_bytes : 0;      // (a panel is <= 64 rows: the extent never nears 2^31)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)b, 0x00020000);
 }
 __device__ __forceinline__ void bld8(__amdgpu_buffer_rsrc_t r, unsigned bo, float* o) {
