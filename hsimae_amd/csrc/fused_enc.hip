@@ -44,9 +44,6 @@ extern "C" __attribute__((visibility("default"))) int hsimae_debug_phases_enc(un
 #ifndef HS_MLPB_LATE_STORES
 #define HS_MLPB_LATE_STORES 1
 #endif
-#ifndef HS_MLPB_KEEP_ROWS
-#define HS_MLPB_KEEP_ROWS 0      /* 1: enc_mlp_bwd<128,352> keeps x-hat / dY / 1/sigma in registers, two workgroups per CU (see KEEP_R) */
-#endif
 
 // Forward kernel occupancy knobs (round 3, profiles/r03_d_variants.txt).  Default: the panel's fp32 copy stays in LDS for the
 // residual (XR) and three workgroups share a CU.  Without the copy (residual re-read from L2 in the store loop) a workgroup
@@ -482,11 +479,8 @@ __device__ __forceinline__ void bst8h(__amdgpu_buffer_rsrc_t r, unsigned bo, bf1
     else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32q, v), r, (int)bo, 0, 0);
 }
 
-// KEEP_R (round 6 experiment, HS_MLPB_KEEP_ROWS): x-hat, 1 / sigma and dY of the panel stay in registers from the prologue to the
-// LayerNorm epilogue (51 registers at D = 128) instead of being re-read there (113 MB of the kernel's 615 per launch at C2) — which
-// takes the kernel from three workgroups per CU to two
-template <int D, int HPE, bool LATE_ST = false, bool KEEP_R = false>
-__global__ __launch_bounds__(NTH, (KEEP_R ? 2 : MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
+template <int D, int HPE, bool LATE_ST = false>
+__global__ __launch_bounds__(NTH, (MG<D, HPE>::WPC)) void enc_mlp_bwd_kernel(EncMlpBwdArgs p) {
     using G = MG<D, HPE>;
     constexpr int R = G::R;
     constexpr int LU = G::LU, LC = G::LC, LX = G::LX, NCH = G::NCH, KSD = G::KSD, KSH = G::KSH, LPR = G::LPR;
@@ -515,8 +509,6 @@ __global__ __launch_bounds__(NTH, (KEEP_R ? 2 : MG<D, HPE>::WPC)) void enc_mlp_b
     // b1 | b3 staged once per panel in LDS (round 6): fetched from global per chunk they were vector-memory loads used at once — an
     // s_waitcnt vmcnt(0) at the head of every chunk, which on gfx950 also waits for the previous chunk's operand stores
     float* BL = reinterpret_cast<float*>(smem + G::LDS_BWD_IMG);        // [2][NCH * 64]
-    constexpr int NIK = KEEP_R ? R * LPR / NTH : 1;
-    [[maybe_unused]] float xk[NIK][8], dyk[NIK][8], rk[NIK];          // KEEP_R: x-hat, dY (unscaled), 1 / sigma of this thread's row pieces
     {
         float gm[8], bt[8];
         ld8(w.n2w + c8, gm); ld8(w.n2b + c8, bt);
@@ -543,11 +535,6 @@ __global__ __launch_bounds__(NTH, (KEEP_R ? 2 : MG<D, HPE>::WPC)) void enc_mlp_b
 #pragma unroll
             for (int e = 0; e < 8; ++e) { f[e] -= mean; v += f[e] * f[e]; }
             const float rstd = rsqrtf(redrow<LPR>(v) * (1.f / D) + 1e-5f);
-            if constexpr (KEEP_R) {
-                rk[i] = rstd;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { xk[i][e] = f[e] * rstd; dyk[i][e] = dyv[e]; }
-            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = f[e] * rstd * gm[e] + bt[e];
             const bf16x8 ub = cvt8(f);
@@ -752,12 +739,10 @@ __global__ __launch_bounds__(NTH, (KEEP_R ? 2 : MG<D, HPE>::WPC)) void enc_mlp_b
         const __amdgpu_buffer_rsrc_t xr = panel_rsrc(p.x1 + (size_t)row0 * D, left, D * 4), yr = panel_rsrc(p.dy + (size_t)row0 * D, left, D * 4);
         const __amdgpu_buffer_rsrc_t dxr = panel_rsrc(p.dx1 + (size_t)row0 * D, left, D * 4);
         const __amdgpu_buffer_rsrc_t dbr = panel_rsrc(p.dx1b ? p.dx1b + (size_t)row0 * D : nullptr, p.dx1b ? left : 0, D * 2);
-        if constexpr (!KEEP_R) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {                 // L2-hot re-reads, all in flight at once
-                const unsigned bo = (unsigned)(((threadIdx.x + NTH * i) / LPR) * D + c8) * 4u;
-                bld8(xr, bo, xa[i]); bld8(yr, bo, dya[i]);
-            }
+        for (int i = 0; i < NI; ++i) {                 // L2-hot re-reads, all in flight at once
+            const unsigned bo = (unsigned)(((threadIdx.x + NTH * i) / LPR) * D + c8) * 4u;
+            bld8(xr, bo, xa[i]); bld8(yr, bo, dya[i]);
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -767,23 +752,14 @@ __global__ __launch_bounds__(NTH, (KEEP_R ? 2 : MG<D, HPE>::WPC)) void enc_mlp_b
             float (&xh)[8] = xa[i];
             float (&dyv)[8] = dya[i];
             ld8(XS + row * LX + c8, du);
-            float rstd;
-            if constexpr (KEEP_R) {
-                rstd = rk[i < NIK ? i : 0];
+            const float mean = redrow<LPR>(xh[0] + xh[1] + xh[2] + xh[3] + xh[4] + xh[5] + xh[6] + xh[7]) * (1.f / D);
+            float v = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { xh[e] = xk[i < NIK ? i : 0][e]; dyv[e] = dyk[i < NIK ? i : 0][e]; }
-            } else {
-                const float mean = redrow<LPR>(xh[0] + xh[1] + xh[2] + xh[3] + xh[4] + xh[5] + xh[6] + xh[7]) * (1.f / D);
-                float v = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { xh[e] -= mean; v += xh[e] * xh[e]; }
-                rstd = rsqrtf(redrow<LPR>(v) * (1.f / D) + 1e-5f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xh[e] *= rstd;
-            }
+            for (int e = 0; e < 8; ++e) { xh[e] -= mean; v += xh[e] * xh[e]; }
+            const float rstd = rsqrtf(redrow<LPR>(v) * (1.f / D) + 1e-5f);
             float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { t[e] = du[e] * gm[e]; a += t[e]; b += t[e] * xh[e]; }
+            for (int e = 0; e < 8; ++e) { xh[e] *= rstd; t[e] = du[e] * gm[e]; a += t[e]; b += t[e] * xh[e]; }
             a = redrow<LPR>(a) * (1.f / D); b = redrow<LPR>(b) * (1.f / D);
             if (ok) {
                 float o[8];
@@ -844,8 +820,6 @@ static void set_attrs() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_fwd_kernel<D, HP>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_FWD);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel<D, HP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_BWD);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel<D, HP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_BWD);
-    if constexpr (D == 128 && HS_MLPB_KEEP_ROWS)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_mlp_bwd_kernel<D, HP, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MG<D, HP>::LDS_BWD);
     done = true;
 }
 
@@ -890,10 +864,6 @@ static void launch_bwd_t(const EncMlpBwdArgs& a, int M, hipStream_t s) {
     // (D >= 256 only: at D = 128 the kernel sits on its HBM bytes either way — 136.4 / 137.2 us late against 136.9 / 135.4 early,
     //  Large 381.1 / 374.9 against 381.7 / 380.6 and 390.2 / 389.1 before this round: profiles/r06_f_enc_mlp_bwd_ab.txt)
     const bool late = HS_MLPB_LATE_STORES && D >= 256 && a.dh13 && a.plane_rows > 0 && (size_t)2 * MG<D, HP>::NCH * a.plane_rows * 128 < 0xffffff00u;
-    if constexpr (D == 128 && HS_MLPB_KEEP_ROWS) {
-        hipLaunchKernelGGL((enc_mlp_bwd_kernel<D, HP, false, true>), dim3((M + R - 1) / R), dim3(NTH), (MG<D, HP>::LDS_BWD), s, a);
-        return;
-    }
     if (late) hipLaunchKernelGGL((enc_mlp_bwd_kernel<D, HP, true>), dim3((M + R - 1) / R), dim3(NTH), (MG<D, HP>::LDS_BWD), s, a);
     else hipLaunchKernelGGL((enc_mlp_bwd_kernel<D, HP, false>), dim3((M + R - 1) / R), dim3(NTH), (MG<D, HP>::LDS_BWD), s, a);
 }
