@@ -696,7 +696,7 @@ int launch_blk128(const Blk128Args& a, hipStream_t s) {
     // persistent, one 8-wave workgroup per CU: the weights (64 registers) + the attention state need ~156 registers;
     // forced to 128 (two workgroups per CU) the kernel spills 24-68 of them and is 20 % slower.  HSIMAE_BLK128_WGS overrides.
     static int wgs = 0;
-    if (!wgs) { const char* e = getenv("HSIMAE_BLK128_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 1) wgs = 256; }
+    if (!wgs) wgs = 256;
     const int groups = (a.nsamples + SPW - 1) / SPW;
     hipLaunchKernelGGL((blk128_fwd_kernel<NT, SPW>), dim3(groups < wgs ? groups : wgs), dim3(512), (size_t)L::TOTAL, s, a);
     return (int)hipGetLastError();
@@ -1190,7 +1190,7 @@ int launch_blk128_bwd(const Blk128BwdArgs& a, hipStream_t s) {
     if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk128_bwd_kernel<NT, SPW, RC>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::TOTAL); attr_set = true; }
     static int wgs = 0;
-    if (!wgs) { const char* e = getenv("HSIMAE_BLK128_BWD_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 1) wgs = 256; }
+    if (!wgs) wgs = 256;
     const int groups = (a.nsamples + SPW - 1) / SPW;
     hipLaunchKernelGGL((blk128_bwd_kernel<NT, SPW, RC>), dim3(groups < wgs ? groups : wgs), dim3(512), (size_t)L::TOTAL, s, a);
     return (int)hipGetLastError();
@@ -1273,9 +1273,7 @@ int hs_attn_block_fwd(const float* x, const float* n1w, const float* n1b, const 
     Blk128Args a;
     a.x = x; a.n1w = n1w; a.n1b = n1b; a.wqkv = wqkv; a.bqkv = bqkv; a.wp = wp; a.pb = pb; a.u = u; a.qkv = qkv; a.o = o;
     a.lse = lse; a.x1 = x1; a.rowscale = rowscale; a.Ts = Ts; a.nsamples = nsamples; a.mode = mode; a.len_l = len_l;
-    static int spw = 0;                       // samples in hand per iteration (HSIMAE_BLK128_SPW = 1 | 2; 3 measured 0.5 % slower than 2)
-    if (!spw) { const char* e = getenv("HSIMAE_BLK128_SPW"); spw = (e && e[0] == '1') ? 1 : 2; }
-    if (spw == 1) return Ts <= 16 ? launch_blk128<1, 1>(a, s) : launch_blk128<2, 1>(a, s);
+    // two samples in hand per iteration (one: 84 instead of 74 us in round 3; three measured 0.5 % slower than two)
     return Ts <= 16 ? launch_blk128<1, 2>(a, s) : launch_blk128<2, 2>(a, s);
 }
 

@@ -724,7 +724,7 @@ int launch_blk256_bwd(const Blk256BwdArgs& a, hipStream_t s) {
     if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk256_bwd_kernel<NT, SPW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::TOTAL); attr_set = true; }
     static int wgs = 0;                       // persistent, one 16-wave workgroup per CU (HSIMAE_BLK256_BWD_WGS overrides)
-    if (!wgs) { const char* e = getenv("HSIMAE_BLK256_BWD_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 1) wgs = 256; }
+    if (!wgs) wgs = 256;
     const int groups = (a.nsamples + SPW - 1) / SPW;
     hipLaunchKernelGGL((blk256_bwd_kernel<NT, SPW>), dim3(groups < wgs ? groups : wgs), dim3(NTHW), (size_t)L::TOTAL, s, a);
     return (int)hipGetLastError();
@@ -737,7 +737,7 @@ int launch_blk256(const Blk256Args& a, hipStream_t s) {
     if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blk256_fwd_kernel<NT, SPW>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::TOTAL); attr_set = true; }
     static int wgs = 0;                       // persistent, one 16-wave workgroup per CU (HSIMAE_BLK256_WGS overrides)
-    if (!wgs) { const char* e = getenv("HSIMAE_BLK256_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 1) wgs = 256; }
+    if (!wgs) wgs = 256;
     const int groups = (a.nsamples + SPW - 1) / SPW;
     hipLaunchKernelGGL((blk256_fwd_kernel<NT, SPW>), dim3(groups < wgs ? groups : wgs), dim3(NTHW), (size_t)L::TOTAL, s, a);
     return (int)hipGetLastError();

@@ -2029,7 +2029,7 @@ int launch_fwd(const DecFwdArgs& a, hipStream_t s) {
         attr_set = true;
     }
     static int wgs = 0;                       // workgroups: 2 per CU walking the samples (HSIMAE_DEC_FWD_WGS overrides)
-    if (!wgs) { const char* e = getenv("HSIMAE_DEC_FWD_WGS"); wgs = e ? atoi(e) : 512; if (wgs < 1) wgs = 512; }
+    if (!wgs) wgs = 512;
     hipLaunchKernelGGL((dec_block_fwd_kernel<MT>), dim3(a.nsamples < wgs ? a.nsamples : wgs), dim3(256), L::FWD_TOTAL, s, a);
     return (int)hipGetLastError();
 }

@@ -828,7 +828,7 @@ static int fwd_grid(int M) {
     const int panels = (M + MG<D, HP>::R - 1) / MG<D, HP>::R;
     if (!MG<D, HP>::PERSIST) return panels;
     static int slots = 0;                     // resident workgroups: WPCF per CU (HSIMAE_MLP_FWD_WGS overrides)
-    if (!slots) { const char* e = getenv("HSIMAE_MLP_FWD_WGS"); slots = e ? atoi(e) : 256 * MG<D, HP>::WPCF; if (slots < 1) slots = 256 * MG<D, HP>::WPCF; }
+    if (!slots) slots = 256 * MG<D, HP>::WPCF;
     return panels < slots ? panels : slots;
 }
 

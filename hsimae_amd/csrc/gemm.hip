@@ -805,25 +805,12 @@ int launch(const GemmParams& p, hipStream_t s) {
 // wherever the weight image is small enough that streaming it once per 64 rows instead of once per 128 costs less than
 // the overlap gains: q|k|v at d = 256 235 -> 175 us, gate backward 461 -> 216 us; they lose at d = 512 when K is deep
 // (w2 303 -> 355 us).  256-deep A chunks pay only together with 64-row panels (alone: 1.3-1.7x slower).
-// HSIMAE_GEMM_WIDE=0 keeps the 128-row / 128-deep form everywhere (A/B runs).
-static int wide_mode() {
-    static int m = -1;
-    if (m < 0) { const char* e = getenv("HSIMAE_GEMM_WIDE"); m = e ? atoi(e) : 1; }
-    return m;
-}
+// (The A/B switches of this family — HSIMAE_GEMM_WIDE, _GEMM_KO_BM, _GEMM_KOUTER, _GEMM_F8_BM — went in round 6; hsimae_gemm_tiled
+//  still forces a tile shape for sweeps.)
+static int wide_mode() { return 1; }
 static thread_local int g_force_bm = 0, g_force_kc = 0;       // hsimae_gemm_tiled (tile sweeps): 0 = the shape rule below
-// HSIMAE_GEMM_KO_BM=32|64: panel height of the k-outer products (A/B runs; default below)
-static int ko_bm() {
-    static int m = -1;
-    if (m < 0) { const char* e = getenv("HSIMAE_GEMM_KO_BM"); m = e ? atoi(e) : 0; }
-    return m;
-}
-// HSIMAE_GEMM_KOUTER=0: never the k-outer schedule (A/B runs)
-static bool k_outer() {
-    static int m = -1;
-    if (m < 0) { const char* e = getenv("HSIMAE_GEMM_KOUTER"); m = !(e && e[0] == '0'); }
-    return m != 0;
-}
+static int ko_bm() { return 0; }          // panel height of the k-outer products: the shape rule below
+static bool k_outer() { return true; }
 static bool small_weights(const GemmParams& p, bool dual) {
     const int64_t nk = (int64_t)p.N * p.K;
     if (p.K < 256) return false;
@@ -845,13 +832,10 @@ int launch_f8(const GemmParams& p, hipStream_t s) {
         // 76.8 ms, and a deeper fragment prefetch there does not help: 87.8 ms)
         bool bm64 = true;
         (void)nk;
-        static int env_bm = -1;                   // HSIMAE_GEMM_F8_BM=64|128: force the panel height of the fp8 GEMMs (A/B runs)
-        if (env_bm < 0) { const char* e = getenv("HSIMAE_GEMM_F8_BM"); env_bm = e ? atoi(e) : 0; }
-        if (env_bm) bm64 = env_bm == 64;
         if (g_force_bm) bm64 = g_force_bm == 64;
         if constexpr (AK != A_F32_LN && EPI != E_SWIGLU) {
             // deep K (several 512-chunks) and at most 4 n-chunks: k outer on 64-row panels, every chunk quantised once
-            if (k_outer() && p.K > 512 && p.N > 128 && p.N <= 512 && g_force_bm != 128 && env_bm != 128) {
+            if (k_outer() && p.K > 512 && p.N > 128 && p.N <= 512 && g_force_bm != 128) {
                 if constexpr (AK == A_BF16) {         // register-prefetched A chunks: 32-row panels keep them at 32 registers
                     if (ko_bm() != 64) return p.N <= 256 ? launch<AK, EPI, 512, 32, 1, 2>(p, s) : launch<AK, EPI, 512, 32, 1, 4>(p, s);
                 }

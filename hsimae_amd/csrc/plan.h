@@ -287,9 +287,8 @@ inline void carve(const Geo& g, int N, int K, char* base, Ws& w) {
 inline int wgrad_msplit(int tiles, int64_t M, int concurrent = 1) {
     const int chunks = (int)((M + 63) / 64);
     // the kernel holds 2 workgroups per CU (196 registers: 64 accumulators + the prefetched next chunk): keep the
-    // launch to one resident wave of workgroups (HSIMAE_WGRAD_WGS overrides the 512 for experiments)
-    static int budget = 0;
-    if (!budget) { const char* e = getenv("HSIMAE_WGRAD_WGS"); budget = e ? std::max(8, atoi(e)) : 512; }
+    // launch to one resident wave of workgroups
+    const int budget = 512;
     // `concurrent` launches resident at once (the forked axis stacks) share the budget as long as each still gets whole
     // groups of 8 row slices: slice ms runs on XCD ms % 8, so fewer than 8 slices leave XCDs idle (D = 256: 52 tiles,
     // sharing made the step 13 % slower; D = 128: 13 tiles, 2 % faster).

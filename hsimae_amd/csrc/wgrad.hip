@@ -510,7 +510,7 @@ int hs_wgrad(const WgradParams& p, hipStream_t s) {
         WgradParams q = p;
         const int t256 = wg_tiles(p, 256), nchunks = (p.M + DC - 1) / DC;
         static int wgs = 0;
-        if (!wgs) { const char* e = getenv("HSIMAE_WGRAD_BIG_WGS"); wgs = e ? atoi(e) : 256; if (wgs < 8) wgs = 256; }
+        if (!wgs) wgs = 256;
         q.msplit = std::max(1, std::min(wgs / std::max(1, t256), nchunks));
         const int total = t256 * q.msplit;
         const dim3 grid(8 * ((total + 7) / 8));
