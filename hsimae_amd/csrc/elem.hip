@@ -396,14 +396,11 @@ __global__ __launch_bounds__(LSN) void loss_sample_kernel(LossParams p) {
     if (p.sw == 1 && p.sh == 9 && p.sb == 81 && (p.sn & 3) == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0) {
         for (int e = threadIdx.x; e < E / 4; e += LSN) reinterpret_cast<float4*>(X)[e] = reinterpret_cast<const float4*>(base)[e];
     } else if (p.sb == 1) {                         // band-fastest cubes (the loader's layout): bands are the contiguous axis
-        // (ij, b) = (e / B, e % B) by increments: B is a run-time value, and a division per element was a fifth of this kernel's
-        // VALU instructions (it is 95 % VALU-bound)
-        int ij = (int)threadIdx.x / B, b = (int)threadIdx.x - ij * B;
-        const int dq = LSN / B, dr = LSN - dq * B;
         for (int e = threadIdx.x; e < E; e += LSN) {
+            // (round 6 tried (e / B, e % B) by increments instead of a division by the run-time B per element: 162.5 -> 169 us, the
+            //  carry branch costs more than the division; reverted)
+            const int ij = e / B, b = e - ij * B;
             X[b * 81 + ij] = base[(int64_t)b + (int64_t)(ij / 9) * p.sh + (int64_t)(ij % 9) * p.sw];
-            b += dr; ij += dq;
-            if (b >= B) { b -= B; ++ij; }
         }
     } else {
         for (int e = threadIdx.x; e < E; e += LSN) {
